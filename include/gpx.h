@@ -1,0 +1,137 @@
+/*
+ * gpx.h -- C-ABI of libgpx.so: the MI355X (gfx950) GP-posterior + acquisition engine.
+ *
+ * The reference (mwhoffman/pybo) has NO native boundary: its GP arithmetic is a set of Python
+ * method calls on a duck-typed `model` object (the un-vendored `reggie` package).  Each entry point
+ * below therefore cites the *call site in pybo* whose work it performs; the Python model/policy/
+ * solver plugins in pybo_amd/ bind these through ctypes.
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = GPX_OK, negative = error class;
+ *     gpx_last_error(h) returns a NUL-terminated description (handle-local; NULL handle ->
+ *     thread-local string of the last failed gpx_create).
+ *   - caller owns every host buffer; arrays are row-major C-contiguous float64 / int64.
+ *   - `_dev` variants take DEVICE pointers (e.g. torch.Tensor.data_ptr()) valid on the handle's
+ *     device; they enqueue on the handle's stream and are synchronous on return only where an
+ *     output lands in a host buffer (top-k, status).
+ *   - a handle is not re-entrant; distinct handles may be driven from distinct threads.
+ *   - no C++ exception crosses this boundary.
+ */
+#ifndef GPX_H
+#define GPX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gpx_handle gpx_handle;
+
+enum gpx_status {
+    GPX_OK = 0,
+    GPX_EARG = -1,    /* bad argument */
+    GPX_ENOTPD = -2,  /* K + sn2*I not positive definite; see gpx_fail_pivot */
+    GPX_EHIP = -3,    /* HIP runtime error */
+    GPX_EOOM = -4,    /* device allocation failed */
+    GPX_ESTATE = -5   /* call order error (e.g. sweep before fit) */
+};
+
+/* covariance functions; parametrisation (sn2, rho, ell[d], bias) = the arguments of
+ * reggie.make_gp(sn2, rho, ell, bias)                       [pybo/bayesopt.py:98-105] */
+enum gpx_kernel {
+    GPX_KERN_SE_ARD = 0,   /* rho * exp(-r2/2),                      r2 = sum_k ((x_k-z_k)/ell_k)^2 */
+    GPX_KERN_MATERN52 = 1, /* rho * (1 + sqrt5 r + 5 r2/3) exp(-sqrt5 r) */
+    GPX_KERN_MATERN32 = 2, /* rho * (1 + sqrt3 r) exp(-sqrt3 r) */
+    GPX_KERN_MATERN12 = 3  /* rho * exp(-r) */
+};
+
+/* acquisition functions evaluated by the sweep */
+enum gpx_acq {
+    GPX_ACQ_EI = 0,   /* model.get_improvement(target, X)  [pybo/policies/simple.py:25]  params = {target} */
+    GPX_ACQ_PI = 1,   /* model.get_tail(target, X)         [pybo/policies/simple.py:39]  params = {target} */
+    GPX_ACQ_UCB = 2,  /* mu + sqrt(beta*s2)                [pybo/policies/simple.py:62-73] params = {beta} */
+    GPX_ACQ_MEAN = 3  /* posterior mean                    [pybo/recommenders.py:19-25]  no params */
+};
+
+/* ---- lifetime --------------------------------------------------------------------------- */
+/* `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL for a
+ * library-owned stream. */
+int gpx_create(int device, void *stream, gpx_handle **out);
+int gpx_destroy(gpx_handle *h);
+const char *gpx_last_error(const gpx_handle *h);
+int gpx_version(void);
+/* options: "chunk" = candidate columns per sweep chunk (multiple of 128);
+ *          "tile_order" = blockIdx->tile mapping of the sweep kernel (0 default). */
+int gpx_set_option(gpx_handle *h, const char *name, int64_t value);
+
+/* ---- GP fit = model.add_data(X, Y)            [pybo/bayesopt.py:114,258,269] ------------- */
+/* Gram build K = k(X,X) + sn2 I, Cholesky K = R^T R, triangular inverse T = R^-T,
+ * a = T (y - bias).  X is (N,d), y is (N,), ell is (d,) on the HOST in both variants. */
+int gpx_fit(gpx_handle *h, const double *X, int64_t N, int64_t d, const double *y, int kernel_id,
+            const double *ell, double rho, double sn2, double bias);
+int gpx_fit_dev(gpx_handle *h, const double *dX, int64_t N, int64_t d, const double *dy,
+                int kernel_id, const double *ell, double rho, double sn2, double bias);
+/* 0-based index of the failing pivot of the last GPX_ENOTPD fit, else -1. */
+int64_t gpx_fail_pivot(const gpx_handle *h);
+
+/* introspection for parity tests (host outputs):
+ *   which = 0: L (N,N) lower Cholesky factor, row-major        (K + sn2 I = L L^T)
+ *   which = 1: T = L^-1 (N,N) lower, row-major
+ *   which = 2: K + sn2 I, upper triangle only (lower part returned as 0); only valid after
+ *              gpx_fit_stage(..., stop_after_gram=1) since the factorisation consumes it */
+int gpx_get_matrix(gpx_handle *h, int which, double *out);
+/* a = L^-1 (y - bias) (N,) and alpha = (K + sn2 I)^-1 (y - bias) (N,) */
+int gpx_get_vectors(gpx_handle *h, double *a, double *alpha);
+/* debugging/parity: run the fit but stop after the Gram build (stage=1) or Cholesky (stage=2) */
+int gpx_fit_stage(gpx_handle *h, const double *X, int64_t N, int64_t d, const double *y,
+                  int kernel_id, const double *ell, double rho, double sn2, double bias, int stage);
+
+/* posterior (latent) mean at the N observed points, closed form y - sn2*alpha.
+ * = model.predict(X_obs)[0]                     [pybo/policies/simple.py:21,35]            */
+int gpx_mean_at_obs(gpx_handle *h, double *mu_host, double *mu_max);
+
+/* ---- posterior moments = model.predict(X, grad) [pybo/policies/simple.py:64] ------------- */
+/* Xc (M,d) -> mu (M,), s2 (M,) latent variance; dmu, ds2 (M,d) optional (NULL to skip). */
+int gpx_predict(gpx_handle *h, const double *Xc, int64_t M, double *mu, double *s2, double *dmu,
+                double *ds2);
+
+/* ---- acquisition sweep + top-k = the batched index call and argsort of the solver
+ *      finit = f(xgrid); idx = argsort(finit)[::-1]       [pybo/solvers/lbfgs.py:50-51] ---- */
+/* Evaluates acq over M candidates, returns the k best (value desc, then index asc) in host
+ * buffers top_val[k], top_idx[k] (indices are LOCAL to Xc; add your shard offset).  acq_all, mu,
+ * s2 (each (M,), host in gpx_sweep / device in gpx_sweep_dev) are optional (NULL to skip). */
+int gpx_sweep(gpx_handle *h, int acq_id, const double *params, int nparams, const double *Xc,
+              int64_t M, int64_t k, double *top_val, int64_t *top_idx, double *acq_all, double *mu,
+              double *s2);
+int gpx_sweep_dev(gpx_handle *h, int acq_id, const double *params, int nparams, const double *dXc,
+                  int64_t M, int64_t k, double *top_val, int64_t *top_idx, double *d_acq_all,
+                  double *d_mu, double *d_s2);
+
+/* ---- Thompson sampling = model.sample_f(n, rng).get(X)   [pybo/policies/simple.py:44-48] -- */
+/* S random-Fourier-feature posterior draws f_s(x) = bias + sum_j theta[s][j] cos(W[s][j].x + b[s][j])
+ * (the sqrt(2 rho/n) factor is folded into theta by the caller).  W (S,n,d), b (S,n), theta (S,n)
+ * on the host.  For each draw returns the k best candidates: top_val (S,k), top_idx (S,k).
+ * vals_all (S,M) optional. */
+int gpx_rff_sweep(gpx_handle *h, const double *W, const double *b, const double *theta, int64_t S,
+                  int64_t n, int64_t d, double bias, const double *Xc, int64_t M, int64_t k,
+                  double *top_val, int64_t *top_idx, double *vals_all);
+int gpx_rff_sweep_dev(gpx_handle *h, const double *W, const double *b, const double *theta,
+                      int64_t S, int64_t n, int64_t d, double bias, const double *dXc, int64_t M,
+                      int64_t k, double *top_val, int64_t *top_idx, double *d_vals_all);
+/* feature Gram for the weight posterior: Phi = cos(X_obs W^T + b) (N,n) on the device's X_obs;
+ * returns A = Phi^T Phi (n,n) and v = Phi^T (y - bias) (n,) in host buffers. */
+int gpx_rff_gram(gpx_handle *h, const double *W, const double *b, int64_t n, double *A, double *v);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+/* Stage timers in milliseconds accumulated since the last reset (HIP events on the handle's
+ * stream): [0] gram [1] cholesky [2] trtri [3] alpha [4] cross_gram [5] sweep_trmm [6] acq_topk
+ * [7] rff [8] number of sweep_trmm launches [9] sweep_trmm algorithmic flop [10] h2d/d2h copies.
+ * Synchronises the stream.  Returns the number of slots written (<= n). */
+int gpx_timers(gpx_handle *h, double *out, int n, int reset);
+int gpx_sync(gpx_handle *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPX_H */

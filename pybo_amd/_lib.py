@@ -1,0 +1,250 @@
+"""
+ctypes binding of libgpx.so (include/gpx.h).  This is the ONLY way pybo_amd reaches the GP arithmetic:
+there is no CPU fallback -- if the shared library is missing, or no HIP device is present, the first use
+raises.  (The CPU restatement under oracle/ is test infrastructure and is never imported from here.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libgpx.so')
+
+# every symbol include/gpx.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+_D = C.POINTER(C.c_double)
+_I = C.POINTER(C.c_int64)
+_i64 = C.c_int64
+_dbl = C.c_double
+SYMBOLS = {
+    'gpx_create': (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
+    'gpx_destroy': (C.c_int, [_P]),
+    'gpx_last_error': (C.c_char_p, [_P]),
+    'gpx_version': (C.c_int, []),
+    'gpx_set_option': (C.c_int, [_P, C.c_char_p, _i64]),
+    'gpx_fit': (C.c_int, [_P, _P, _i64, _i64, _P, C.c_int, _P, _dbl, _dbl, _dbl]),
+    'gpx_fit_dev': (C.c_int, [_P, _P, _i64, _i64, _P, C.c_int, _P, _dbl, _dbl, _dbl]),
+    'gpx_fail_pivot': (_i64, [_P]),
+    'gpx_get_matrix': (C.c_int, [_P, C.c_int, _P]),
+    'gpx_get_vectors': (C.c_int, [_P, _P, _P]),
+    'gpx_fit_stage': (C.c_int, [_P, _P, _i64, _i64, _P, C.c_int, _P, _dbl, _dbl, _dbl, C.c_int]),
+    'gpx_mean_at_obs': (C.c_int, [_P, _P, _P]),
+    'gpx_predict': (C.c_int, [_P, _P, _i64, _P, _P, _P, _P]),
+    'gpx_sweep': (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _i64, _i64, _P, _P, _P, _P, _P]),
+    'gpx_sweep_dev': (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _i64, _i64, _P, _P, _P, _P, _P]),
+    'gpx_rff_sweep': (C.c_int, [_P, _P, _P, _P, _i64, _i64, _i64, _dbl, _P, _i64, _i64, _P, _P, _P]),
+    'gpx_rff_sweep_dev': (C.c_int, [_P, _P, _P, _P, _i64, _i64, _i64, _dbl, _P, _i64, _i64, _P, _P, _P]),
+    'gpx_rff_gram': (C.c_int, [_P, _P, _P, _i64, _P, _P]),
+    'gpx_timers': (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    'gpx_sync': (C.c_int, [_P]),
+}
+
+GPX_OK, GPX_EARG, GPX_ENOTPD, GPX_EHIP, GPX_EOOM, GPX_ESTATE = 0, -1, -2, -3, -4, -5
+KERNELS = {'se': 0, 'matern5': 1, 'matern3': 2, 'matern1': 3}
+ACQ = {'ei': 0, 'pi': 1, 'ucb': 2, 'mean': 3}
+TIMER_NAMES = ['gram', 'cholesky', 'trtri', 'alpha', 'cross_gram', 'sweep_trmm', 'acq_topk', 'rff',
+               'sweep_trmm_launches', 'sweep_trmm_flop', 'copies']
+TOPK_MAX = 64
+
+_lib = None
+
+
+class GpxError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, 'libgpx error %d: %s' % (code, msg))
+        self.code = code
+
+
+def load():
+    """Load libgpx.so (once) and set the prototypes.  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError('pybo_amd: %s not found -- build it with `python __graft_entry__.py` '
+                              '(or pybo_amd/csrc/build.sh); there is no CPU fallback.' % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_P)
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+class Engine(object):
+    """One gpx handle = one (device, model).  Thin, stateless-in-Python wrapper over the C-ABI."""
+
+    def __init__(self, device=0, stream=None):
+        self._lib = load()
+        h = _P()
+        rc = self._lib.gpx_create(int(device), _P(stream) if stream else None, C.byref(h))
+        if rc != GPX_OK:
+            raise GpxError(rc, (self._lib.gpx_last_error(None) or b'').decode())
+        self._h = h
+        self.device = int(device)
+        self.N = 0
+        self.d = 0
+
+    def close(self):
+        if getattr(self, '_h', None):
+            self._lib.gpx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != GPX_OK:
+            msg = (self._lib.gpx_last_error(self._h) or b'').decode()
+            if rc == GPX_ENOTPD:
+                raise np.linalg.LinAlgError(msg)
+            raise GpxError(rc, msg)
+
+    def set_option(self, name, value):
+        self._check(self._lib.gpx_set_option(self._h, name.encode(), int(value)))
+
+    # -- fit -----------------------------------------------------------------------------------
+    def fit(self, X, y, kernel, ell, rho, sn2, bias, stage=3):
+        X = _f64(X)
+        if X.ndim != 2:
+            raise ValueError('X must be (N, d)')
+        y = _f64(y).reshape(-1)
+        N, d = X.shape
+        if len(y) != N:
+            raise ValueError('X and y disagree on N')
+        ell = _f64(np.broadcast_to(np.asarray(ell, dtype=float), (d,)))
+        kid = KERNELS[kernel] if isinstance(kernel, str) else int(kernel)
+        if stage == 3:
+            rc = self._lib.gpx_fit(self._h, _ptr(X), N, d, _ptr(y), kid, _ptr(ell), rho, sn2, bias)
+        else:
+            rc = self._lib.gpx_fit_stage(self._h, _ptr(X), N, d, _ptr(y), kid, _ptr(ell), rho, sn2, bias,
+                                         int(stage))
+        self._check(rc)
+        self.N, self.d = N, d
+
+    def fit_dev(self, dX_ptr, N, d, dy_ptr, kernel, ell, rho, sn2, bias):
+        ell = _f64(np.broadcast_to(np.asarray(ell, dtype=float), (d,)))
+        kid = KERNELS[kernel] if isinstance(kernel, str) else int(kernel)
+        self._check(self._lib.gpx_fit_dev(self._h, _P(dX_ptr), N, d, _P(dy_ptr), kid, _ptr(ell), rho, sn2,
+                                          bias))
+        self.N, self.d = N, d
+
+    def fail_pivot(self):
+        return int(self._lib.gpx_fail_pivot(self._h))
+
+    def get_matrix(self, which):
+        out = np.empty((self.N, self.N))
+        self._check(self._lib.gpx_get_matrix(self._h, {'L': 0, 'T': 1, 'K': 2}[which], _ptr(out)))
+        return out
+
+    def get_vectors(self):
+        a = np.empty(self.N)
+        alpha = np.empty(self.N)
+        self._check(self._lib.gpx_get_vectors(self._h, _ptr(a), _ptr(alpha)))
+        return a, alpha
+
+    def mean_at_obs(self):
+        mu = np.empty(self.N)
+        mx = C.c_double()
+        self._check(self._lib.gpx_mean_at_obs(self._h, _ptr(mu), C.byref(mx)))
+        return mu, mx.value
+
+    # -- posterior / sweep -----------------------------------------------------------------------
+    def predict(self, Xc, grad=False):
+        Xc = _f64(Xc).reshape(-1, self.d)
+        M = len(Xc)
+        mu = np.empty(M)
+        s2 = np.empty(M)
+        if grad:
+            dmu = np.empty((M, self.d))
+            ds2 = np.empty((M, self.d))
+            self._check(self._lib.gpx_predict(self._h, _ptr(Xc), M, _ptr(mu), _ptr(s2), _ptr(dmu), _ptr(ds2)))
+            return mu, s2, dmu, ds2
+        self._check(self._lib.gpx_predict(self._h, _ptr(Xc), M, _ptr(mu), _ptr(s2), None, None))
+        return mu, s2
+
+    def sweep(self, acq, param, Xc, k=0, want_all=True, want_moments=False):
+        """Host-buffer sweep.  Returns dict(top_val, top_idx, acq, mu, s2)."""
+        Xc = _f64(Xc).reshape(-1, self.d)
+        M = len(Xc)
+        aid = ACQ[acq] if isinstance(acq, str) else int(acq)
+        params = _f64([0.0 if param is None else param])
+        tv = np.empty(k)
+        ti = np.empty(k, dtype=np.int64)
+        out = np.empty(M) if want_all else None
+        mu = np.empty(M) if want_moments else None
+        s2 = np.empty(M) if want_moments else None
+        self._check(self._lib.gpx_sweep(self._h, aid, _ptr(params), 1, _ptr(Xc), M, k,
+                                        _ptr(tv) if k else None, _ptr(ti) if k else None, _ptr(out),
+                                        _ptr(mu), _ptr(s2)))
+        return dict(top_val=tv, top_idx=ti, acq=out, mu=mu, s2=s2)
+
+    def sweep_dev(self, acq, param, dXc_ptr, M, k, d_acq=None, d_mu=None, d_s2=None):
+        aid = ACQ[acq] if isinstance(acq, str) else int(acq)
+        params = _f64([0.0 if param is None else param])
+        tv = np.empty(k)
+        ti = np.empty(k, dtype=np.int64)
+        self._check(self._lib.gpx_sweep_dev(self._h, aid, _ptr(params), 1, _P(dXc_ptr), M, k,
+                                            _ptr(tv) if k else None, _ptr(ti) if k else None,
+                                            _P(d_acq) if d_acq else None, _P(d_mu) if d_mu else None,
+                                            _P(d_s2) if d_s2 else None))
+        return tv, ti
+
+    # -- Thompson --------------------------------------------------------------------------------
+    def rff_gram(self, W, b):
+        W = _f64(W)
+        b = _f64(b)
+        n = len(b)
+        A = np.empty((n, n))
+        v = np.empty(n)
+        self._check(self._lib.gpx_rff_gram(self._h, _ptr(W), _ptr(b), n, _ptr(A), _ptr(v)))
+        return A, v
+
+    def rff_sweep(self, W, b, theta, bias, Xc, k=0, want_all=True):
+        W = _f64(W)
+        S, n, d = W.shape
+        b = _f64(b).reshape(S, n)
+        theta = _f64(theta).reshape(S, n)
+        Xc = _f64(Xc).reshape(-1, d)
+        M = len(Xc)
+        tv = np.empty((S, k))
+        ti = np.empty((S, k), dtype=np.int64)
+        out = np.empty((S, M)) if want_all else None
+        self._check(self._lib.gpx_rff_sweep(self._h, _ptr(W), _ptr(b), _ptr(theta), S, n, d, bias, _ptr(Xc), M,
+                                            k, _ptr(tv) if k else None, _ptr(ti) if k else None, _ptr(out)))
+        return dict(top_val=tv, top_idx=ti, vals=out)
+
+    def rff_sweep_dev(self, W, b, theta, bias, dXc_ptr, M, k):
+        W = _f64(W)
+        S, n, d = W.shape
+        b = _f64(b).reshape(S, n)
+        theta = _f64(theta).reshape(S, n)
+        tv = np.empty((S, k))
+        ti = np.empty((S, k), dtype=np.int64)
+        self._check(self._lib.gpx_rff_sweep_dev(self._h, _ptr(W), _ptr(b), _ptr(theta), S, n, d, bias,
+                                                _P(dXc_ptr), M, k, _ptr(tv), _ptr(ti), None))
+        return tv, ti
+
+    # -- measurement -----------------------------------------------------------------------------
+    def timers(self, reset=False):
+        out = np.zeros(len(TIMER_NAMES))
+        self._lib.gpx_timers(self._h, _ptr(out), len(out), 1 if reset else 0)
+        return dict(zip(TIMER_NAMES, out.tolist()))
+
+    def sync(self):
+        self._check(self._lib.gpx_sync(self._h))

@@ -1,0 +1,597 @@
+// api.hip -- the C-ABI of libgpx.so (see include/gpx.h for the contract and the pybo call sites each
+// entry point stands in for).  Host-side orchestration only: allocation, chunking, launch order,
+// HIP-event timers.  No exception leaves this file.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+#include "gpx_internal.h"
+
+using namespace gpx;
+
+static thread_local std::string g_create_err;
+
+#define HIPCHK(h, call)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            char buf_[512];                                                                 \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                                   \
+            (h)->err = buf_;                                                                \
+            return (e_ == hipErrorOutOfMemory) ? GPX_EOOM : GPX_EHIP;                       \
+        }                                                                                   \
+    } while (0)
+
+static int fail(gpx_handle* h, int code, const char* msg) {
+    h->err = msg;
+    return code;
+}
+
+template <typename T>
+static int ensure(gpx_handle* h, T*& p, int64_t& cap, int64_t need) {
+    if (need <= cap && p) return GPX_OK;
+    if (p) HIPCHK(h, hipFree(p));
+    p = nullptr;
+    cap = 0;
+    HIPCHK(h, hipMalloc((void**)&p, (size_t)need * sizeof(T)));
+    cap = need;
+    return GPX_OK;
+}
+
+// ---- timers -----------------------------------------------------------------------------------
+static hipEvent_t ev_get(gpx_handle* h) {
+    if (!h->pool.empty()) {
+        hipEvent_t e = h->pool.back();
+        h->pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+struct Span {
+    gpx_handle* h;
+    EventPair p;
+    Span(gpx_handle* h_, int slot) : h(h_) {
+        p.a = ev_get(h);
+        p.b = ev_get(h);
+        p.slot = slot;
+        hipEventRecord(p.a, h->stream);
+    }
+    ~Span() {
+        hipEventRecord(p.b, h->stream);
+        h->pending.push_back(p);
+    }
+};
+static void harvest(gpx_handle* h) {
+    hipStreamSynchronize(h->stream);
+    for (auto& p : h->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) h->tacc[p.slot] += ms;
+        h->pool.push_back(p.a);
+        h->pool.push_back(p.b);
+    }
+    h->pending.clear();
+}
+
+// ---- lifetime ---------------------------------------------------------------------------------
+extern "C" int gpx_version(void) { return 100; }
+
+extern "C" const char* gpx_last_error(const gpx_handle* h) {
+    return h ? h->err.c_str() : g_create_err.c_str();
+}
+
+extern "C" int gpx_create(int device, void* stream, gpx_handle** out) {
+    if (!out) { g_create_err = "gpx_create: out is NULL"; return GPX_EARG; }
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_err = std::string("gpx_create: no HIP device (") + hipGetErrorString(e) + ")";
+        return GPX_EHIP;
+    }
+    if (device < 0 || device >= ndev) { g_create_err = "gpx_create: bad device index"; return GPX_EARG; }
+    gpx_handle* h = new (std::nothrow) gpx_handle();
+    if (!h) { g_create_err = "gpx_create: out of host memory"; return GPX_EOOM; }
+    h->device = device;
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e);
+        delete h;
+        return GPX_EHIP;
+    }
+    if (stream) {
+        h->stream = (hipStream_t)stream;
+    } else {
+        if ((e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)) != hipSuccess) {
+            g_create_err = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+            delete h;
+            return GPX_EHIP;
+        }
+        h->own_stream = true;
+    }
+    if (hipMalloc((void**)&h->dflag, 64) != hipSuccess || hipMalloc((void**)&h->dscal, 16 * 8) != hipSuccess ||
+        hipMalloc((void**)&h->dinvell, DMAX * 8) != hipSuccess) {
+        g_create_err = "gpx_create: device allocation failed";
+        delete h;
+        return GPX_EOOM;
+    }
+    *out = h;
+    return GPX_OK;
+}
+
+extern "C" int gpx_destroy(gpx_handle* h) {
+    if (!h) return GPX_OK;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    for (auto& p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (auto e : h->pool) hipEventDestroy(e);
+    void* ptrs[] = {h->dXs, h->dXraw, h->dy, h->dS, h->dR, h->dT, h->dU, h->da, h->dalpha, h->dinvell,
+                    h->dflag, h->dscal, h->dKs, h->dQp, h->dXc, h->dout, h->dblkv, h->dblki,
+                    h->dtopv, h->drff, h->dgrad};  // dPp, dtopi alias dQp, dtopv
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    if (h->own_stream) hipStreamDestroy(h->stream);
+    delete h;
+    return GPX_OK;
+}
+
+extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
+    if (!h || !name) return GPX_EARG;
+    if (!strcmp(name, "chunk")) {
+        if (value < 128 || value % 128) return fail(h, GPX_EARG, "chunk must be a positive multiple of 128");
+        h->chunk = value;
+        return GPX_OK;
+    }
+    if (!strcmp(name, "tile_order")) {
+        if (value < 0 || value > 1) return fail(h, GPX_EARG, "tile_order must be 0 or 1");
+        h->tile_order = (int)value;
+        return GPX_OK;
+    }
+    return fail(h, GPX_EARG, "unknown option");
+}
+
+extern "C" int gpx_sync(gpx_handle* h) {
+    if (!h) return GPX_EARG;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return GPX_OK;
+}
+
+extern "C" int gpx_timers(gpx_handle* h, double* out, int n, int reset) {
+    if (!h) return GPX_EARG;
+    harvest(h);
+    const int m = std::min(n, (int)T_COUNT);
+    for (int i = 0; i < m; ++i) out[i] = h->tacc[i];
+    if (reset)
+        for (int i = 0; i < T_COUNT; ++i) h->tacc[i] = 0;
+    return m;
+}
+
+// ---- fit --------------------------------------------------------------------------------------
+static int check_fit_args(gpx_handle* h, const void* X, int64_t N, int64_t d, const void* y, int kid,
+                          const double* ell, double rho, double sn2) {
+    if (!h) return GPX_EARG;
+    if (!X || !y || !ell) return fail(h, GPX_EARG, "fit: NULL pointer");
+    if (N < 1) return fail(h, GPX_EARG, "fit: N must be >= 1");
+    if (d < 1 || d > DMAX) return fail(h, GPX_EARG, "fit: d must be in [1, 64]");
+    if (kid < GPX_KERN_SE_ARD || kid > GPX_KERN_MATERN12) return fail(h, GPX_EARG, "fit: unknown kernel id");
+    if (!(rho > 0) || !(sn2 >= 0)) return fail(h, GPX_EARG, "fit: need rho > 0 and sn2 >= 0");
+    for (int64_t k = 0; k < d; ++k)
+        if (!(ell[k] > 0)) return fail(h, GPX_EARG, "fit: length-scales must be positive");
+    return GPX_OK;
+}
+
+static int alloc_model(gpx_handle* h, int64_t Np, int64_t d) {
+    if (Np > h->cap_np) {
+        double** mats[] = {&h->dS, &h->dR, &h->dT, &h->dU};
+        for (auto m : mats) {
+            if (*m) HIPCHK(h, hipFree(*m));
+            *m = nullptr;
+        }
+        double** vecs[] = {&h->dy, &h->da, &h->dalpha, &h->dXs, &h->dXraw};
+        for (auto v : vecs) {
+            if (*v) HIPCHK(h, hipFree(*v));
+            *v = nullptr;
+        }
+        h->cap_np = 0;
+        for (auto m : mats) {
+            HIPCHK(h, hipMalloc((void**)m, (size_t)Np * Np * 8));
+            // never-written regions (e.g. the upper off-diagonal blocks of T) are never read by a
+            // kernel either, but keep them defined for introspection
+            HIPCHK(h, hipMemsetAsync(*m, 0, (size_t)Np * Np * 8, h->stream));
+        }
+        HIPCHK(h, hipMalloc((void**)&h->dy, (size_t)Np * 8));
+        HIPCHK(h, hipMalloc((void**)&h->da, (size_t)Np * 8));
+        HIPCHK(h, hipMalloc((void**)&h->dalpha, (size_t)Np * 8));
+        HIPCHK(h, hipMalloc((void**)&h->dXs, (size_t)Np * DMAX * 8));
+        HIPCHK(h, hipMalloc((void**)&h->dXraw, (size_t)Np * DMAX * 8));
+        h->cap_np = Np;
+    }
+    (void)d;
+    return GPX_OK;
+}
+
+// core: dX (N,d), dy (N,) device pointers; stage 1 = stop after Gram, 2 = after Cholesky, 3 = full
+static int fit_core(gpx_handle* h, const double* dX, int64_t N, int64_t d, const double* dy, int kid,
+                    const double* ell, double rho, double sn2, double bias, int stage) {
+    HIPCHK(h, hipSetDevice(h->device));
+    const int64_t Np = (N + NB - 1) / NB * NB;
+    h->fitted = false;
+    h->stage = 0;
+    h->fail_pivot = -1;
+    int rc = alloc_model(h, Np, d);
+    if (rc) return rc;
+    h->N = N; h->Np = Np; h->d = d; h->kernel_id = kid;
+    h->rho = rho; h->sn2 = sn2; h->bias = bias;
+    h->ell.assign(ell, ell + d);
+    double inv[DMAX];
+    for (int64_t k = 0; k < d; ++k) inv[k] = 1.0 / ell[k];
+    hipStream_t s = h->stream;
+    HIPCHK(h, hipMemcpyAsync(h->dinvell, inv, (size_t)d * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipStreamSynchronize(s));  // inv[] is a stack buffer
+    HIPCHK(h, hipMemcpyAsync(h->dXraw, dX, (size_t)N * d * 8, hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, hipMemsetAsync(h->dy, 0, (size_t)Np * 8, s));
+    HIPCHK(h, hipMemcpyAsync(h->dy, dy, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
+    {
+        Span sp(h, T_GRAM);
+        launch_scale_x(s, h->dXraw, N, Np, (int)d, h->dinvell, h->dXs);
+        launch_gram_sym(s, h->dXs, N, Np, (int)d, kid, rho, sn2, h->dS);
+    }
+    h->stage = 1;
+    if (stage >= 2) {
+        {
+            Span sp(h, T_CHOL);
+            launch_cholesky(h);
+        }
+        int flag = 0;
+        HIPCHK(h, hipMemcpyAsync(&flag, h->dflag, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+        if (flag != 0) {
+            h->fail_pivot = (int64_t)flag - 1;
+            char buf[160];
+            snprintf(buf, sizeof buf, "fit: K + sn2*I is not positive definite (pivot %lld)",
+                     (long long)h->fail_pivot);
+            return fail(h, GPX_ENOTPD, buf);
+        }
+        h->stage = 2;
+    }
+    if (stage >= 3) {
+        {
+            Span sp(h, T_TRTRI);
+            launch_trtri(h);
+        }
+        {
+            Span sp(h, T_ALPHA);
+            launch_alpha(h);
+        }
+        h->stage = 3;
+        h->fitted = true;
+    }
+    HIPCHK(h, hipGetLastError());
+    return GPX_OK;
+}
+
+extern "C" int gpx_fit_dev(gpx_handle* h, const double* dX, int64_t N, int64_t d, const double* dy,
+                           int kernel_id, const double* ell, double rho, double sn2, double bias) {
+    int rc = check_fit_args(h, dX, N, d, dy, kernel_id, ell, rho, sn2);
+    if (rc) return rc;
+    return fit_core(h, dX, N, d, dy, kernel_id, ell, rho, sn2, bias, 3);
+}
+
+static int fit_host(gpx_handle* h, const double* X, int64_t N, int64_t d, const double* y, int kid,
+                    const double* ell, double rho, double sn2, double bias, int stage) {
+    int rc = check_fit_args(h, X, N, d, y, kid, ell, rho, sn2);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    rc = ensure(h, h->dXc, h->cap_xc, N * d + N);
+    if (rc) return rc;
+    {
+        Span sp(h, T_COPY);
+        HIPCHK(h, hipMemcpyAsync(h->dXc, X, (size_t)N * d * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->dXc + N * d, y, (size_t)N * 8, hipMemcpyHostToDevice, h->stream));
+    }
+    return fit_core(h, h->dXc, N, d, h->dXc + N * d, kid, ell, rho, sn2, bias, stage);
+}
+
+extern "C" int gpx_fit(gpx_handle* h, const double* X, int64_t N, int64_t d, const double* y, int kernel_id,
+                       const double* ell, double rho, double sn2, double bias) {
+    return fit_host(h, X, N, d, y, kernel_id, ell, rho, sn2, bias, 3);
+}
+
+extern "C" int gpx_fit_stage(gpx_handle* h, const double* X, int64_t N, int64_t d, const double* y,
+                             int kernel_id, const double* ell, double rho, double sn2, double bias,
+                             int stage) {
+    if (stage < 1 || stage > 3) return h ? fail(h, GPX_EARG, "fit_stage: stage must be 1..3") : GPX_EARG;
+    return fit_host(h, X, N, d, y, kernel_id, ell, rho, sn2, bias, stage);
+}
+
+extern "C" int64_t gpx_fail_pivot(const gpx_handle* h) { return h ? h->fail_pivot : -1; }
+
+extern "C" int gpx_get_matrix(gpx_handle* h, int which, double* out) {
+    if (!h || !out) return GPX_EARG;
+    if (which < 0 || which > 2) return fail(h, GPX_EARG, "get_matrix: which must be 0..2");
+    if ((which == 2 && h->stage != 1) || (which == 0 && h->stage < 2) || (which == 1 && h->stage < 3))
+        return fail(h, GPX_ESTATE, "get_matrix: the requested matrix is not available at this stage");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int64_t N = h->N, Np = h->Np;
+    int rc = ensure(h, h->dout, h->cap_out, N * N);
+    if (rc) return rc;
+    if (which == 0) {
+        launch_transpose_lower(h->stream, h->dR, Np, h->dout, N);  // L = R^T
+        HIPCHK(h, hipMemcpyAsync(out, h->dout, (size_t)N * N * 8, hipMemcpyDeviceToHost, h->stream));
+    } else {
+        const double* src = (which == 1) ? h->dT : h->dS;
+        HIPCHK(h, hipMemcpy2DAsync(out, (size_t)N * 8, src, (size_t)Np * 8, (size_t)N * 8, (size_t)N,
+                                   hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (which == 2) {  // only the upper 128-block triangle was built: blank the rest
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t j = 0; j < i; ++j) out[i * N + j] = 0.0;
+    }
+    if (which == 1) {  // T is lower triangular; blocks above the diagonal are never written
+        for (int64_t i = 0; i < N; ++i)
+            for (int64_t j = i + 1; j < N; ++j) out[i * N + j] = 0.0;
+    }
+    return GPX_OK;
+}
+
+extern "C" int gpx_get_vectors(gpx_handle* h, double* a, double* alpha) {
+    if (!h) return GPX_EARG;
+    if (!h->fitted) return fail(h, GPX_ESTATE, "get_vectors: model is not fitted");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (a) HIPCHK(h, hipMemcpyAsync(a, h->da, (size_t)h->N * 8, hipMemcpyDeviceToHost, h->stream));
+    if (alpha) HIPCHK(h, hipMemcpyAsync(alpha, h->dalpha, (size_t)h->N * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return GPX_OK;
+}
+
+extern "C" int gpx_mean_at_obs(gpx_handle* h, double* mu_host, double* mu_max) {
+    if (!h) return GPX_EARG;
+    if (!h->fitted) return fail(h, GPX_ESTATE, "mean_at_obs: model is not fitted");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int64_t N = h->N;
+    std::vector<double> al((size_t)N), yy((size_t)N);
+    HIPCHK(h, hipMemcpyAsync(al.data(), h->dalpha, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(yy.data(), h->dy, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // latent posterior mean at the observed inputs: K alpha + bias = y - sn2 * alpha
+    double mx = -HUGE_VAL;
+    for (int64_t i = 0; i < N; ++i) {
+        const double m = yy[i] - h->sn2 * al[i];
+        if (mu_host) mu_host[i] = m;
+        if (m > mx) mx = m;
+    }
+    if (mu_max) *mu_max = mx;
+    return GPX_OK;
+}
+
+// ---- sweep ------------------------------------------------------------------------------------
+static int sweep_core(gpx_handle* h, int acq_id, const double* params, int nparams, const double* dXc,
+                      int64_t M, int64_t k, double* top_val, int64_t* top_idx, double* d_acq,
+                      double* d_mu, double* d_s2) {
+    if (!h->fitted) return fail(h, GPX_ESTATE, "sweep: model is not fitted");
+    if (!dXc || M < 1) return fail(h, GPX_EARG, "sweep: need M >= 1 candidates");
+    if (acq_id < GPX_ACQ_EI || acq_id > GPX_ACQ_MEAN) return fail(h, GPX_EARG, "sweep: unknown acquisition id");
+    if (acq_id != GPX_ACQ_MEAN && (nparams < 1 || !params)) return fail(h, GPX_EARG, "sweep: missing acquisition parameter");
+    if (k < 0 || k > TOPK_MAX) return fail(h, GPX_EARG, "sweep: k must be in [0, 64]");
+    if (k > 0 && (!top_val || !top_idx)) return fail(h, GPX_EARG, "sweep: NULL top-k output");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int64_t Np = h->Np;
+    const int nP = (int)(Np / NB);
+    const int64_t chunk = std::min<int64_t>(h->chunk, (M + TBH - 1) / TBH * TBH);
+    int rc;
+    if ((rc = ensure(h, h->dKs, h->cap_ks, Np * chunk))) return rc;
+    if ((rc = ensure(h, h->dQp, h->cap_part, (int64_t)nP * chunk * 2))) return rc;
+    h->dPp = h->dQp + (int64_t)nP * chunk;
+    if (!d_acq) {
+        if ((rc = ensure(h, h->dout, h->cap_out, M))) return rc;
+        d_acq = h->dout;
+    }
+    const double p0 = (acq_id == GPX_ACQ_MEAN) ? 0.0 : params[0];
+
+    for (int64_t m0 = 0; m0 < M; m0 += chunk) {
+        const int64_t valid = std::min(chunk, M - m0);
+        const int64_t cols = (valid + TBH - 1) / TBH * TBH;
+        {
+            Span sp(h, T_XGRAM);
+            launch_cross_gram(s, h->dXs, Np, h->N, (int)h->d, dXc, m0, M, cols, h->dinvell, h->kernel_id,
+                              h->rho, h->dKs, chunk);
+        }
+        {
+            Span sp(h, T_TRMM);
+            launch_sweep_trmm(s, h->dU, Np, h->dKs, chunk, cols, h->da, h->dQp, h->dPp, chunk,
+                              h->tile_order);
+        }
+        h->tacc[T_NLAUNCH] += 1.0;
+        // algorithmic work of this launch: sum over row blocks mt of 2*128*128*(mt+1)*128 per
+        // candidate tile = Np*(Np+128) flop per candidate column
+        h->tacc[T_FLOP] += (double)Np * (double)(Np + TBH) * (double)cols;
+        {
+            Span sp(h, T_ACQ);
+            launch_acq(s, h->dQp, h->dPp, chunk, nP, m0, valid, h->rho, h->bias, acq_id, p0, d_acq, d_mu,
+                       d_s2);
+        }
+    }
+    if (k > 0) {
+        const int64_t nblk = topk_blocks(M);
+        if ((rc = ensure(h, h->dblkv, h->cap_blk, nblk * k))) return rc;
+        if (!h->dblki || h->cap_blki < nblk * k) {
+            if (h->dblki) HIPCHK(h, hipFree(h->dblki));
+            h->dblki = nullptr;
+            HIPCHK(h, hipMalloc((void**)&h->dblki, (size_t)nblk * k * 8));
+            h->cap_blki = nblk * k;
+        }
+        if ((rc = ensure(h, h->dtopv, h->cap_top, (int64_t)TOPK_MAX * 2))) return rc;
+        h->dtopi = reinterpret_cast<int64_t*>(h->dtopv + TOPK_MAX);
+        {
+            Span sp(h, T_ACQ);
+            launch_topk(s, d_acq, M, (int)k, h->dblkv, h->dblki, nblk, h->dtopv, h->dtopi);
+        }
+        HIPCHK(h, hipMemcpyAsync(top_val, h->dtopv, (size_t)k * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(top_idx, h->dtopi, (size_t)k * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+    }
+    HIPCHK(h, hipGetLastError());
+    return GPX_OK;
+}
+
+extern "C" int gpx_sweep_dev(gpx_handle* h, int acq_id, const double* params, int nparams, const double* dXc,
+                             int64_t M, int64_t k, double* top_val, int64_t* top_idx, double* d_acq_all,
+                             double* d_mu, double* d_s2) {
+    if (!h) return GPX_EARG;
+    return sweep_core(h, acq_id, params, nparams, dXc, M, k, top_val, top_idx, d_acq_all, d_mu, d_s2);
+}
+
+extern "C" int gpx_sweep(gpx_handle* h, int acq_id, const double* params, int nparams, const double* Xc,
+                         int64_t M, int64_t k, double* top_val, int64_t* top_idx, double* acq_all, double* mu,
+                         double* s2) {
+    if (!h) return GPX_EARG;
+    if (!h->fitted) return fail(h, GPX_ESTATE, "sweep: model is not fitted");
+    if (!Xc || M < 1) return fail(h, GPX_EARG, "sweep: need M >= 1 candidates");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    const int64_t d = h->d;
+    // staging: [Xc (M*d)] [acq M] [mu M] [s2 M]
+    if ((rc = ensure(h, h->dXc, h->cap_xc, M * d + 3 * M))) return rc;
+    double* dX = h->dXc;
+    double* dacq = dX + M * d;
+    double* dmu = dacq + M;
+    double* ds2 = dmu + M;
+    {
+        Span sp(h, T_COPY);
+        HIPCHK(h, hipMemcpyAsync(dX, Xc, (size_t)M * d * 8, hipMemcpyHostToDevice, h->stream));
+    }
+    rc = sweep_core(h, acq_id, params, nparams, dX, M, k, top_val, top_idx, dacq, mu ? dmu : nullptr,
+                    s2 ? ds2 : nullptr);
+    if (rc) return rc;
+    {
+        Span sp(h, T_COPY);
+        if (acq_all) HIPCHK(h, hipMemcpyAsync(acq_all, dacq, (size_t)M * 8, hipMemcpyDeviceToHost, h->stream));
+        if (mu) HIPCHK(h, hipMemcpyAsync(mu, dmu, (size_t)M * 8, hipMemcpyDeviceToHost, h->stream));
+        if (s2) HIPCHK(h, hipMemcpyAsync(s2, ds2, (size_t)M * 8, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return GPX_OK;
+}
+
+extern "C" int gpx_predict(gpx_handle* h, const double* Xc, int64_t M, double* mu, double* s2, double* dmu,
+                           double* ds2) {
+    if (!h) return GPX_EARG;
+    if (!mu || !s2) return fail(h, GPX_EARG, "predict: mu and s2 outputs are required");
+    if (dmu || ds2) {
+        if (!dmu || !ds2) return fail(h, GPX_EARG, "predict: pass both gradient outputs or neither");
+        return gpx::predict_grad_host(h, Xc, M, mu, s2, dmu, ds2);
+    }
+    return gpx_sweep(h, GPX_ACQ_MEAN, nullptr, 0, Xc, M, 0, nullptr, nullptr, nullptr, mu, s2);
+}
+
+// ---- Thompson / RFF ---------------------------------------------------------------------------
+static int rff_core(gpx_handle* h, const double* W, const double* b, const double* theta, int64_t S,
+                    int64_t n, int64_t d, double bias, const double* dXc, int64_t M, int64_t k,
+                    double* top_val, int64_t* top_idx, double* d_vals) {
+    if (!W || !b || !theta || !dXc) return fail(h, GPX_EARG, "rff_sweep: NULL pointer");
+    if (S < 1 || n < 1 || d < 1 || d > DMAX || M < 1) return fail(h, GPX_EARG, "rff_sweep: bad sizes");
+    if (k < 0 || k > TOPK_MAX) return fail(h, GPX_EARG, "rff_sweep: k must be in [0, 64]");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int rc;
+    const int64_t npar = S * n * d + 2 * S * n;
+    if ((rc = ensure(h, h->drff, h->cap_rff, npar))) return rc;
+    double* dW = h->drff;
+    double* db = dW + S * n * d;
+    double* dth = db + S * n;
+    HIPCHK(h, hipMemcpyAsync(dW, W, (size_t)S * n * d * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(db, b, (size_t)S * n * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(dth, theta, (size_t)S * n * 8, hipMemcpyHostToDevice, s));
+    if (!d_vals) {
+        if ((rc = ensure(h, h->dout, h->cap_out, S * M))) return rc;
+        d_vals = h->dout;
+    }
+    {
+        Span sp(h, T_RFF);
+        launch_rff_eval(s, dW, db, dth, (int)S, (int)n, (int)d, bias, dXc, M, d_vals);
+    }
+    if (k > 0) {
+        const int64_t nblk = topk_blocks(M);
+        if ((rc = ensure(h, h->dblkv, h->cap_blk, nblk * k))) return rc;
+        if (!h->dblki || h->cap_blki < nblk * k) {
+            if (h->dblki) HIPCHK(h, hipFree(h->dblki));
+            h->dblki = nullptr;
+            HIPCHK(h, hipMalloc((void**)&h->dblki, (size_t)nblk * k * 8));
+            h->cap_blki = nblk * k;
+        }
+        if ((rc = ensure(h, h->dtopv, h->cap_top, std::max<int64_t>((int64_t)TOPK_MAX * 2, S * k * 2)))) return rc;
+        double* tv = h->dtopv;
+        int64_t* ti = reinterpret_cast<int64_t*>(h->dtopv + S * k);
+        {
+            Span sp(h, T_RFF);
+            for (int64_t q = 0; q < S; ++q)
+                launch_topk(s, d_vals + q * M, M, (int)k, h->dblkv, h->dblki, nblk, tv + q * k, ti + q * k);
+        }
+        HIPCHK(h, hipMemcpyAsync(top_val, tv, (size_t)S * k * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(top_idx, ti, (size_t)S * k * 8, hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(h, hipStreamSynchronize(s));
+    HIPCHK(h, hipGetLastError());
+    return GPX_OK;
+}
+
+extern "C" int gpx_rff_sweep_dev(gpx_handle* h, const double* W, const double* b, const double* theta,
+                                 int64_t S, int64_t n, int64_t d, double bias, const double* dXc, int64_t M,
+                                 int64_t k, double* top_val, int64_t* top_idx, double* d_vals_all) {
+    if (!h) return GPX_EARG;
+    return rff_core(h, W, b, theta, S, n, d, bias, dXc, M, k, top_val, top_idx, d_vals_all);
+}
+
+extern "C" int gpx_rff_sweep(gpx_handle* h, const double* W, const double* b, const double* theta, int64_t S,
+                             int64_t n, int64_t d, double bias, const double* Xc, int64_t M, int64_t k,
+                             double* top_val, int64_t* top_idx, double* vals_all) {
+    if (!h) return GPX_EARG;
+    if (!Xc || M < 1 || d < 1) return fail(h, GPX_EARG, "rff_sweep: bad candidates");
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure(h, h->dXc, h->cap_xc, M * d))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->dXc, Xc, (size_t)M * d * 8, hipMemcpyHostToDevice, h->stream));
+    if ((rc = ensure(h, h->dout, h->cap_out, S * M))) return rc;
+    rc = rff_core(h, W, b, theta, S, n, d, bias, h->dXc, M, k, top_val, top_idx, h->dout);
+    if (rc) return rc;
+    if (vals_all) {
+        HIPCHK(h, hipMemcpyAsync(vals_all, h->dout, (size_t)S * M * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+    }
+    return GPX_OK;
+}
+
+extern "C" int gpx_rff_gram(gpx_handle* h, const double* W, const double* b, int64_t n, double* A, double* v) {
+    if (!h) return GPX_EARG;
+    if (h->stage < 1) return fail(h, GPX_ESTATE, "rff_gram: no data on the device (fit first)");
+    if (!W || !b || !A || !v || n < 1) return fail(h, GPX_EARG, "rff_gram: bad arguments");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int64_t d = h->d, Np = h->Np;
+    int rc;
+    // layout: [W n*d][b n][A n*n][v n][Ft n*Np]
+    const int64_t need = n * d + n + n * n + n + n * Np;
+    if ((rc = ensure(h, h->drff, h->cap_rff, need))) return rc;
+    double* dW = h->drff;
+    double* db = dW + n * d;
+    double* dA = db + n;
+    double* dv = dA + n * n;
+    double* dFt = dv + n;
+    HIPCHK(h, hipMemcpyAsync(dW, W, (size_t)n * d * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(db, b, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    {
+        Span sp(h, T_RFF);
+        launch_rff_gram(s, h->dXraw, dFt, h->N, (int)d, dW, db, (int)n, h->dy, h->bias, dA, dv);
+    }
+    HIPCHK(h, hipMemcpyAsync(A, dA, (size_t)n * n * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(v, dv, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    HIPCHK(h, hipGetLastError());
+    return GPX_OK;
+}

@@ -1,0 +1,133 @@
+// gemm_core.h -- fp64 MFMA tile engine for gfx950 (CDNA4), shared by the Cholesky trailing update,
+// the triangular inversion and the posterior sweep.
+//
+// One workgroup (256 threads = 4 wave64, arranged 2x2) produces a 128x128 fp64 tile
+//     D(m,n) = sum_{k in [k_lo,k_hi)} A(m,k) * B(k,n)
+// with BOTH operands supplied "k-major":  A(m,k) = A[k*lda + m],  B(k,n) = B[k*ldb + n].
+// That is the layout every caller is arranged to have (upper Cholesky factor R row-major, U = R^-1
+// row-major, cross-Gram Ks[obs][candidate]), so every global load is a full 1 KiB row per wave and
+// every LDS store is lane-linear; no transposes on the load path.
+//
+// Per wave: a 64x64 sub-tile = 4x4 v_mfma_f64_16x16x4_f64 accumulators (16 x 8 VGPR = 128 VGPR).
+// Operand fragments (one f64 per lane: A[m = lane&15][k = lane>>4], B[k = lane>>4][n = lane&15])
+// come from LDS with ds_read_b64; the row pitch of 144 f64 (= 288 dwords = 32 mod 64 banks) makes
+// the two 32-lane groups of a ds_read_b64 hit disjoint bank halves -> conflict-free.
+// Result layout (f64 MFMA, NOT the f32 map): D[row = (lane>>4) + 4*r][col = lane&15], r = 0..3.
+//
+// K is stepped 16 at a time through a 2-deep LDS ring (register-staged: the global loads of step
+// t+1 are issued before the 64 MFMAs of step t and written to the other LDS buffer after them;
+// one barrier per step).  fp64 MFMA is 64 cycles/instruction/SIMD, so one k-step is ~4096 matrix
+// cycles per wave against 8 x 16-B global loads and 8 ds_write_b128 per thread.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gpx {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int TB = 128;           // tile edge (BM = BN)
+constexpr int BK = 16;            // k per pipeline step
+constexpr int LDT = TB + 16;      // LDS row pitch in f64
+constexpr int GEMM_THREADS = 256;
+constexpr int GEMM_LDS_F64 = 2 * 2 * BK * LDT;        // [buf][A|B][BK][LDT]
+constexpr int GEMM_LDS_BYTES = GEMM_LDS_F64 * 8;      // 73,728 B -> 2 workgroups per CU
+
+__device__ __forceinline__ void acc_zero(d4 (&acc)[4][4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+}
+
+// A, B already point at (k = 0, m = tile origin) / (k = 0, n = tile origin).
+// k_lo, k_hi are multiples of BK; all 256 threads of the workgroup must call this.
+__device__ __forceinline__ void gemm_tile_128(d4 (&acc)[4][4], const double* __restrict__ A,
+                                              int64_t lda, const double* __restrict__ B,
+                                              int64_t ldb, int k_lo, int k_hi, double* smem) {
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    double* As = smem;                  // [2][BK][LDT]
+    double* Bs = smem + 2 * BK * LDT;   // [2][BK][LDT]
+
+    // global->LDS staging map: wave w loads row (w + 4p) of the k-slab, lane -> 16-B chunk
+    const int lrow = w;
+    const int lcol = lane * 2;
+    d2 ra[4], rb[4];
+
+    const int nk = (k_hi - k_lo) / BK;
+    if (nk <= 0) return;
+
+    const double* Ap = A + (int64_t)(k_lo + lrow) * lda + lcol;
+    const double* Bp = B + (int64_t)(k_lo + lrow) * ldb + lcol;
+
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        ra[p] = *reinterpret_cast<const d2*>(Ap + (int64_t)(4 * p) * lda);
+        rb[p] = *reinterpret_cast<const d2*>(Bp + (int64_t)(4 * p) * ldb);
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        *reinterpret_cast<d2*>(As + (lrow + 4 * p) * LDT + lcol) = ra[p];
+        *reinterpret_cast<d2*>(Bs + (lrow + 4 * p) * LDT + lcol) = rb[p];
+    }
+    __syncthreads();
+
+    const int fr = lane & 15;   // fragment row/col within a 16x16 MFMA tile
+    const int fk = lane >> 4;   // fragment k within the 4-deep MFMA
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            Ap += (int64_t)BK * lda;
+            Bp += (int64_t)BK * ldb;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                ra[p] = *reinterpret_cast<const d2*>(Ap + (int64_t)(4 * p) * lda);
+                rb[p] = *reinterpret_cast<const d2*>(Bp + (int64_t)(4 * p) * ldb);
+            }
+        }
+        const double* as = As + buf * BK * LDT + wm * 64 + fr;
+        const double* bs = Bs + buf * BK * LDT + wn * 64 + fr;
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            const int kr = kk * 4 + fk;
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = as[kr * LDT + i * 16];
+                b[i] = bs[kr * LDT + i * 16];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            const int nb = buf ^ 1;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                *reinterpret_cast<d2*>(As + nb * BK * LDT + (lrow + 4 * p) * LDT + lcol) = ra[p];
+                *reinterpret_cast<d2*>(Bs + nb * BK * LDT + (lrow + 4 * p) * LDT + lcol) = rb[p];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// element coordinates of accumulator register acc[i][j][r] inside the 128x128 tile
+__device__ __forceinline__ int acc_row(int i, int r) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    return (w >> 1) * 64 + i * 16 + (lane >> 4) + 4 * r;
+}
+__device__ __forceinline__ int acc_col(int j) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    return (w & 1) * 64 + j * 16 + (lane & 15);
+}
+
+}  // namespace gpx

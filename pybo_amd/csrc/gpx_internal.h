@@ -1,0 +1,125 @@
+// gpx_internal.h -- handle layout and host-side launcher prototypes (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/gpx.h"
+
+namespace gpx {
+
+constexpr int NB = 128;       // factorisation block = GEMM tile edge
+constexpr int TBH = 128;      // host-side copy of the GEMM tile edge (gemm_core.h TB)
+constexpr int DMAX = 64;      // max input dimension staged in LDS
+constexpr int TOPK_MAX = 64;  // max k of the device top-k
+
+enum Timer {
+    T_GRAM = 0, T_CHOL, T_TRTRI, T_ALPHA, T_XGRAM, T_TRMM, T_ACQ, T_RFF, T_NLAUNCH, T_FLOP, T_COPY,
+    T_COUNT
+};
+
+struct EventPair { hipEvent_t a, b; int slot; };
+
+}  // namespace gpx
+
+struct gpx_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // model state
+    bool fitted = false;
+    int stage = 0;               // 0 none, 1 gram, 2 chol, 3 full
+    int64_t N = 0, Np = 0, d = 0;
+    int kernel_id = 0;
+    double rho = 1, sn2 = 0, bias = 0;
+    std::vector<double> ell;
+    int64_t fail_pivot = -1;
+
+    // device buffers (capacity tracked in elements)
+    int64_t cap_np = 0, cap_d = 0;
+    double* dXs = nullptr;    // (Np, d) observed points scaled by 1/ell, padded rows = 0
+    double* dXraw = nullptr;  // (N, d) observed points as given
+    double* dy = nullptr;     // (Np,) y (padded 0)
+    double* dS = nullptr;     // (Np,Np) working Gram matrix (upper), later trtri workspace
+    double* dR = nullptr;     // (Np,Np) upper Cholesky factor, row-major: K = R^T R
+    double* dT = nullptr;     // (Np,Np) T = R^-T (lower), row-major
+    double* dU = nullptr;     // (Np,Np) U = R^-1 = T^T (upper), row-major
+    double* da = nullptr;     // (Np,) a = T (y - bias)
+    double* dalpha = nullptr; // (Np,) alpha = U a
+    double* dinvell = nullptr;// (DMAX,) 1/ell
+    int* dflag = nullptr;     // [0] = failing pivot + 1 (0 = ok)
+    double* dscal = nullptr;  // small scalar scratch (16 doubles)
+
+    // sweep workspace
+    int64_t chunk = 65536;    // candidate columns per chunk (multiple of 128)
+    int tile_order = 0;
+    int64_t cap_ks = 0;       // elements of dKs
+    double* dKs = nullptr;    // (Np, chunk) cross-Gram chunk
+    double* dQp = nullptr;    // (Np/128, chunk) per-row-block partials of colsum(V^2)
+    double* dPp = nullptr;    // (Np/128, chunk) per-row-block partials of V^T a
+    int64_t cap_part = 0;
+    double* dXc = nullptr;    // staging for host candidates (M, d)
+    int64_t cap_xc = 0;
+    double* dout = nullptr;   // staging for host outputs 3*(M) (acq, mu, s2)
+    int64_t cap_out = 0;
+    double* dblkv = nullptr;  // per-block top-k values
+    int64_t* dblki = nullptr; // per-block top-k indices
+    int64_t cap_blk = 0;
+    int64_t cap_blki = 0;
+    double* dtopv = nullptr;  // final top-k (S*k)
+    int64_t* dtopi = nullptr;
+    int64_t cap_top = 0;
+    double* drff = nullptr;   // RFF parameter staging
+    int64_t cap_rff = 0;
+    double* dgrad = nullptr;  // predict-with-gradient scratch
+    int64_t cap_grad = 0;
+
+    // timers
+    std::vector<gpx::EventPair> pending;
+    std::vector<hipEvent_t> pool;
+    double tacc[gpx::T_COUNT] = {0};
+};
+
+namespace gpx {
+
+// launchers (kernels_fit.hip)
+void launch_scale_x(hipStream_t s, const double* X, int64_t n, int64_t np, int d, const double* invell,
+                    double* Xs);
+void launch_gram_sym(hipStream_t s, const double* Xs, int64_t N, int64_t Np, int d, int kernel_id,
+                     double rho, double sn2, double* S);
+void launch_cholesky(gpx_handle* h);   // S -> R, diag blocks of T/U; sets dflag
+void launch_trtri(gpx_handle* h);      // R, diag blocks -> T, U (uses S as workspace)
+void launch_alpha(gpx_handle* h);      // a = T (y - bias); alpha = U a
+void launch_transpose_lower(hipStream_t s, const double* R, int64_t Np, double* out, int64_t N);
+
+// launchers (kernels_sweep.hip)
+void launch_cross_gram(hipStream_t s, const double* Xs, int64_t Np, int64_t N, int d, const double* Xc,
+                       int64_t m0, int64_t M, int64_t cols, const double* invell, int kernel_id,
+                       double rho, double* Ks, int64_t ldk);
+void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double* Ks, int64_t ldk,
+                       int64_t cols, const double* a, double* Qp, double* Pp, int64_t ldp,
+                       int tile_order);
+// reduce partials, form mu/s2/acq for columns [0,cols) of this chunk -> global candidate m0+..
+void launch_acq(hipStream_t s, const double* Qp, const double* Pp, int64_t ldp, int nrb, int64_t m0,
+                int64_t cols_valid, double rho, double bias, int acq_id, double p0, double* acq_out,
+                double* mu_out, double* s2_out);
+// block-local top-k over vals[0..M) then merge -> topv/topi (k entries)
+void launch_topk(hipStream_t s, const double* vals, int64_t M, int k, double* blkv, int64_t* blki,
+                 int64_t nblk, double* topv, int64_t* topi);
+int64_t topk_blocks(int64_t M);
+
+// predict with gradients (small M path)
+int predict_grad_host(gpx_handle* h, const double* Xc, int64_t M, double* mu, double* s2, double* dmu,
+                      double* ds2);
+
+// launchers (kernels_rff.hip)
+void launch_rff_eval(hipStream_t s, const double* W, const double* b, const double* theta, int S, int n,
+                     int d, double bias, const double* Xc, int64_t M, double* vals /* (S,M) */);
+void launch_rff_gram(hipStream_t s, const double* Xraw, const double* Ft_scratch, int64_t N, int d,
+                     const double* W, const double* b, int n, const double* y, double bias, double* A,
+                     double* v);
+
+}  // namespace gpx

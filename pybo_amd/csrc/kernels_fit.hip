@@ -1,0 +1,390 @@
+// kernels_fit.hip -- GP fit on gfx950:  Gram build, blocked Cholesky (K = R^T R, R upper row-major),
+// recursive triangular inversion (T = R^-T lower, U = R^-1 upper), a = T (y - bias), alpha = U a.
+//
+// Replaces the work behind `model.add_data(X, Y)` [pybo/bayesopt.py:114,258,269]; the arithmetic
+// itself lives in the un-vendored `reggie` package, so it is restated from Rasmussen & Williams
+// Alg. 2.1 (oracle/gp_ref.py is the CPU statement of the same maths).
+//
+// Storage: everything is (Np, Np) row-major with Np = N rounded up to 128; padding rows/columns carry
+// the identity so every tile is full and no kernel has bounds checks.  We factor the UPPER triangle:
+// with R row-major, both GEMM operands of the trailing update  S_IJ -= R_pI^T R_pJ  are k-major
+// (see gemm_core.h), which is what keeps the loads coalesced without any transpose.
+#include "gemm_core.h"
+#include "gpx_internal.h"
+
+namespace gpx {
+
+// ------------------------------------------------------------------------------------------------
+// covariance functions of the squared scaled distance r2
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double kern_eval(int kid, double r2, double rho) {
+    switch (kid) {
+        case GPX_KERN_SE_ARD:
+            return rho * exp(-0.5 * r2);
+        case GPX_KERN_MATERN52: {
+            const double s = 2.23606797749978969641 * sqrt(r2);
+            return rho * (1.0 + s + (5.0 / 3.0) * r2) * exp(-s);
+        }
+        case GPX_KERN_MATERN32: {
+            const double s = 1.73205080756887729353 * sqrt(r2);
+            return rho * (1.0 + s) * exp(-s);
+        }
+        default:
+            return rho * exp(-sqrt(r2));
+    }
+}
+
+// Xs[i][k] = X[i][k] / ell[k] for i < n, 0 for n <= i < np
+__global__ void k_scale_x(const double* __restrict__ X, int64_t n, int64_t np, int d,
+                          const double* __restrict__ invell, double* __restrict__ Xs) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= np * d) return;
+    const int64_t i = idx / d;
+    const int k = (int)(idx - i * d);
+    Xs[idx] = (i < n) ? X[idx] * invell[k] : 0.0;
+}
+
+void launch_scale_x(hipStream_t s, const double* X, int64_t n, int64_t np, int d, const double* invell,
+                    double* Xs) {
+    const int64_t tot = np * d;
+    hipLaunchKernelGGL(k_scale_x, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, X, n, np, d,
+                       invell, Xs);
+}
+
+// ------------------------------------------------------------------------------------------------
+// R1: symmetric Gram build, upper 128-block triangle, 64x64 tile per workgroup, 4x4 per thread.
+// HBM-write bound: 8 B per element, X tiles staged in LDS (coordinate-major so a wave's lanes read
+// consecutive addresses).
+// ------------------------------------------------------------------------------------------------
+constexpr int GT = 64;
+constexpr int GDC = 16;  // coordinates staged per pass
+
+__global__ __launch_bounds__(256) void k_gram_sym(const double* __restrict__ Xs, int64_t N, int64_t Np,
+                                                  int d, int kid, double rho, double sn2,
+                                                  double* __restrict__ S) {
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if ((bi >> 1) > (bj >> 1)) return;  // below the 128-block diagonal: never read
+    __shared__ double xi[GDC][GT];
+    __shared__ double xj[GDC][GT];
+    const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
+    const int64_t i0 = (int64_t)bi * GT, j0 = (int64_t)bj * GT;
+    double r2[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) r2[a][b] = 0.0;
+
+    for (int k0 = 0; k0 < d; k0 += GDC) {
+        const int kc = min(GDC, d - k0);
+        __syncthreads();
+        for (int e = t; e < GT * kc; e += 256) {
+            const int row = e / kc, k = e - row * kc;
+            xi[k][row] = Xs[(i0 + row) * d + k0 + k];
+            xj[k][row] = Xs[(j0 + row) * d + k0 + k];
+        }
+        __syncthreads();
+        for (int k = 0; k < kc; ++k) {
+            double a4[4], b4[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) a4[a] = xi[k][ty * 4 + a];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) b4[b] = xj[k][tx * 4 + b];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const double df = a4[a] - b4[b];
+                    r2[a][b] = fma(df, df, r2[a][b]);
+                }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int64_t gi = i0 + ty * 4 + a;
+        d4 o;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int64_t gj = j0 + tx * 4 + b;
+            double v;
+            if (gi < N && gj < N) {
+                v = kern_eval(kid, r2[a][b], rho);
+                if (gi == gj) v += sn2;
+            } else {
+                v = (gi == gj) ? 1.0 : 0.0;
+            }
+            o[b] = v;
+        }
+        *reinterpret_cast<d4*>(S + gi * Np + j0 + tx * 4) = o;
+    }
+}
+
+void launch_gram_sym(hipStream_t s, const double* Xs, int64_t N, int64_t Np, int d, int kernel_id,
+                     double rho, double sn2, double* S) {
+    const unsigned g = (unsigned)(Np / GT);
+    hipLaunchKernelGGL(k_gram_sym, dim3(g, g), dim3(256), 0, s, Xs, N, Np, d, kernel_id, rho, sn2, S);
+}
+
+// ------------------------------------------------------------------------------------------------
+// R2a: diagonal-block factorisation + inversion, one workgroup, whole 128x128 block in LDS.
+// Right-looking Cholesky on the upper triangle (rows of R); the same row operations applied to the
+// identity give T_pp = R_pp^-T in the strict lower triangle (Gauss-Jordan style), so one LDS array
+// holds both.  One barrier per pivot: row j is scaled one step late, while nobody reads it.
+// ------------------------------------------------------------------------------------------------
+constexpr int PD_LD = NB + 1;
+
+__global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, double* __restrict__ R,
+                                                    double* __restrict__ T, double* __restrict__ U,
+                                                    int64_t Np, int p, int* __restrict__ flag) {
+    __shared__ double M[NB * PD_LD];
+    if (*flag != 0) return;  // an earlier panel already failed
+    const int t = threadIdx.x;
+    const int64_t p0 = (int64_t)p * NB;
+    for (int e = t; e < NB * NB; e += 256) {
+        const int r = e >> 7, c = e & 127;
+        M[r * PD_LD + c] = (c >= r) ? S[(p0 + r) * Np + p0 + c] : 0.0;
+    }
+    __syncthreads();
+
+    const int tr = t >> 4, tc = t & 15;
+    double d_prev = 1.0, inv_prev = 1.0;
+    for (int j = 0; j < NB; ++j) {
+        const double piv = M[j * PD_LD + j];
+        if (!(piv > 0.0) || !(piv < 1.0e300)) {  // also catches NaN
+            if (t == 0) *flag = (int)(p0 + j) + 1;
+            return;  // uniform: every thread read the same pivot
+        }
+        const double dj = sqrt(piv);
+        const double inv = 1.0 / dj;
+        // deferred scaling of row j-1 (nobody reads it any more)
+        if (j > 0 && t < NB) {
+            const int jr = j - 1;
+            const double v = M[jr * PD_LD + t];
+            M[jr * PD_LD + t] = (t == jr) ? d_prev : v * inv_prev;
+        }
+        // rank-1 update of rows r > j: Cholesky part (c >= r) and inverse part (c <= j)
+        for (int r = j + 1 + tr; r < NB; r += 16) {
+            const double mult = M[j * PD_LD + r] * inv;
+#pragma unroll
+            for (int cc = 0; cc < NB / 16; ++cc) {
+                const int c = cc * 16 + tc;
+                if (c >= r || c <= j) {
+                    const double rj = (c == j) ? inv : M[j * PD_LD + c] * inv;
+                    M[r * PD_LD + c] = fma(-mult, rj, M[r * PD_LD + c]);
+                }
+            }
+        }
+        d_prev = dj;
+        inv_prev = inv;
+        __syncthreads();
+    }
+    if (t < NB) {
+        const int jr = NB - 1;
+        const double v = M[jr * PD_LD + t];
+        M[jr * PD_LD + t] = (t == jr) ? d_prev : v * inv_prev;
+    }
+    __syncthreads();
+    // write back: R (upper), T (lower) and U = T^T (upper), zeros elsewhere in the block
+    for (int e = t; e < NB * NB; e += 256) {
+        const int r = e >> 7, c = e & 127;
+        const double m_rc = M[r * PD_LD + c];
+        const double m_cr = M[c * PD_LD + r];
+        const double dinv = 1.0 / M[r * PD_LD + r];
+        const int64_t g = (p0 + r) * Np + p0 + c;
+        R[g] = (c >= r) ? m_rc : 0.0;
+        T[g] = (c < r) ? m_rc : ((c == r) ? dinv : 0.0);
+        U[g] = (c > r) ? m_cr : ((c == r) ? dinv : 0.0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// R2b: panel solve  R_pJ = T_pp S_pJ  (J > p) as a GEMM:  A(m,k) = T_pp(m,k) = U[p0+k][p0+m]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_panel_trsm(const double* __restrict__ U,
+                                                                const double* __restrict__ S,
+                                                                double* __restrict__ R, int64_t Np,
+                                                                int p) {
+    __shared__ __attribute__((aligned(16))) double smem[GEMM_LDS_F64];
+    const int64_t p0 = (int64_t)p * NB;
+    const int64_t j0 = (int64_t)(p + 1 + blockIdx.x) * NB;
+    d4 acc[4][4];
+    acc_zero(acc);
+    gemm_tile_128(acc, U + p0 * Np + p0, Np, S + p0 * Np + j0, Np, 0, NB, smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                R[(p0 + acc_row(i, r)) * Np + j0 + acc_col(j)] = acc[i][j][r];
+}
+
+// ------------------------------------------------------------------------------------------------
+// R2c: trailing update  S_IJ -= R_pI^T R_pJ  for p < I <= J  (the syrk/gemm on fp64 MFMA)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(const double* __restrict__ R,
+                                                                 double* __restrict__ S, int64_t Np,
+                                                                 int p) {
+    const int bi = blockIdx.y, bj = blockIdx.x;
+    if (bi > bj) return;
+    __shared__ __attribute__((aligned(16))) double smem[GEMM_LDS_F64];
+    const int64_t p0 = (int64_t)p * NB;
+    const int64_t i0 = (int64_t)(p + 1 + bi) * NB, j0 = (int64_t)(p + 1 + bj) * NB;
+    d4 acc[4][4];
+    acc_zero(acc);
+    gemm_tile_128(acc, R + p0 * Np + i0, Np, R + p0 * Np + j0, Np, 0, NB, smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double* q = S + (i0 + acc_row(i, r)) * Np + j0 + acc_col(j);
+                *q -= acc[i][j][r];
+            }
+}
+
+void launch_cholesky(gpx_handle* h) {
+    const int64_t Np = h->Np;
+    const int nP = (int)(Np / NB);
+    hipStream_t s = h->stream;
+    hipMemsetAsync(h->dflag, 0, sizeof(int), s);
+    for (int p = 0; p < nP; ++p) {
+        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, s, h->dS, h->dR, h->dT, h->dU, Np, p,
+                           h->dflag);
+        const int rem = nP - 1 - p;
+        if (rem > 0) {
+            hipLaunchKernelGGL(k_panel_trsm, dim3(rem), dim3(GEMM_THREADS), 0, s, h->dU, h->dS, h->dR,
+                               Np, p);
+            hipLaunchKernelGGL(k_syrk_update, dim3(rem, rem), dim3(GEMM_THREADS), 0, s, h->dR, h->dS,
+                               Np, p);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Triangular inversion by recursive doubling.  With diagonal 128-blocks already inverted, level
+// `hb` merges block ranges [r1, r1+hb) and [r1+hb, r1+hb+size2):
+//      T_21 = - T_22 (L_21 T_11),   L_21(m,k) = R[r1+k][r2+m]
+// as two GEMM launches over all groups.  Every operand is k-major: L_21 via R, T_11 via T (row-major
+// lower), T_22 via U = T^T.  GEMM2 stores T_21 and, transposed, U_12, keeping both views current.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_trtri_gemm1(const double* __restrict__ R,
+                                                                 const double* __restrict__ T,
+                                                                 double* __restrict__ W, int64_t Np,
+                                                                 int nP, int hb) {
+    const int g = blockIdx.z, bm = blockIdx.y, bn = blockIdx.x;
+    const int r1 = g * 2 * hb, r2 = r1 + hb;
+    if (r2 >= nP) return;
+    const int size2 = min(hb, nP - r2);
+    if (bm >= size2) return;
+    __shared__ __attribute__((aligned(16))) double smem[GEMM_LDS_F64];
+    const int64_t r1e = (int64_t)r1 * NB, r2e = (int64_t)r2 * NB;
+    const int64_t m0 = r2e + (int64_t)bm * NB, n0 = r1e + (int64_t)bn * NB;
+    d4 acc[4][4];
+    acc_zero(acc);
+    gemm_tile_128(acc, R + r1e * Np + m0, Np, T + r1e * Np + n0, Np, bn * NB, hb * NB, smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W[(m0 + acc_row(i, r)) * Np + n0 + acc_col(j)] = acc[i][j][r];
+}
+
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_trtri_gemm2(const double* __restrict__ W,
+                                                                 double* __restrict__ T,
+                                                                 double* __restrict__ U, int64_t Np,
+                                                                 int nP, int hb) {
+    const int g = blockIdx.z, bm = blockIdx.y, bn = blockIdx.x;
+    const int r1 = g * 2 * hb, r2 = r1 + hb;
+    if (r2 >= nP) return;
+    const int size2 = min(hb, nP - r2);
+    if (bm >= size2) return;
+    __shared__ __attribute__((aligned(16))) double smem[GEMM_LDS_F64];
+    const int64_t r1e = (int64_t)r1 * NB, r2e = (int64_t)r2 * NB;
+    const int64_t m0 = r2e + (int64_t)bm * NB, n0 = r1e + (int64_t)bn * NB;
+    d4 acc[4][4];
+    acc_zero(acc);
+    // A(m,k) = T_22(m,k) = U[r2e+k][m0+m], k <= m  ->  k-blocks [0, bm]
+    gemm_tile_128(acc, U + r2e * Np + m0, Np, W + r2e * Np + n0, Np, 0, (bm + 1) * NB, smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gm = m0 + acc_row(i, r), gn = n0 + acc_col(j);
+                const double v = -acc[i][j][r];
+                T[gm * Np + gn] = v;
+                U[gn * Np + gm] = v;
+            }
+}
+
+void launch_trtri(gpx_handle* h) {
+    const int64_t Np = h->Np;
+    const int nP = (int)(Np / NB);
+    hipStream_t s = h->stream;
+    for (int hb = 1; hb < nP; hb *= 2) {
+        const int ngroups = (nP + 2 * hb - 1) / (2 * hb);
+        dim3 grid((unsigned)hb, (unsigned)hb, (unsigned)ngroups);
+        hipLaunchKernelGGL(k_trtri_gemm1, grid, dim3(GEMM_THREADS), 0, s, h->dR, h->dT, h->dS, Np, nP, hb);
+        hipLaunchKernelGGL(k_trtri_gemm2, grid, dim3(GEMM_THREADS), 0, s, h->dS, h->dT, h->dU, Np, nP, hb);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// R3: a = T (y - bias) and alpha = U a as row-dot matvecs (one wave per row; HBM-read bound).
+// mode 0: out[i] = sum_{j <= i} Mx[i][j] * (v[j] - shift)   (T, lower)
+// mode 1: out[i] = sum_{j >= i} Mx[i][j] * v[j]             (U, upper)
+// Rows >= N (padding) produce 0.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tri_matvec(const double* __restrict__ Mx, int64_t Np, int64_t N,
+                                                    const double* __restrict__ v, double shift,
+                                                    int mode, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Np) return;
+    double acc = 0.0;
+    if (row < N) {
+        const int64_t lo = (mode == 0) ? 0 : row;
+        const int64_t hi = (mode == 0) ? row + 1 : N;
+        const double* mr = Mx + row * Np;
+        for (int64_t j = lo + lane; j < hi; j += 64) acc = fma(mr[j], v[j] - shift, acc);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) out[row] = acc;
+}
+
+void launch_alpha(gpx_handle* h) {
+    const unsigned g = (unsigned)((h->Np + 3) / 4);
+    hipLaunchKernelGGL(k_tri_matvec, dim3(g), dim3(256), 0, h->stream, h->dT, h->Np, h->N, h->dy,
+                       h->bias, 0, h->da);
+    hipLaunchKernelGGL(k_tri_matvec, dim3(g), dim3(256), 0, h->stream, h->dU, h->Np, h->N, h->da, 0.0,
+                       1, h->dalpha);
+}
+
+// out (N,N) row-major = transpose of the leading N x N part of src (Np,Np) keeping only the part
+// that is lower-triangular in `out` (used to hand L = R^T to the parity tests)
+__global__ void k_transpose_lower(const double* __restrict__ src, int64_t Np, double* __restrict__ out,
+                                  int64_t N) {
+    __shared__ double tile[32][33];
+    const int64_t bx = (int64_t)blockIdx.x * 32, by = (int64_t)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t sr = by + r, sc = bx + tx;
+        tile[r][tx] = (sr < N && sc < N) ? src[sr * Np + sc] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t orow = bx + r, ocol = by + tx;  // out[orow][ocol] = src[ocol][orow]
+        if (orow < N && ocol < N) out[orow * N + ocol] = (ocol <= orow) ? tile[tx][r] : 0.0;
+    }
+}
+
+void launch_transpose_lower(hipStream_t s, const double* src, int64_t Np, double* out, int64_t N) {
+    const unsigned g = (unsigned)((N + 31) / 32);
+    hipLaunchKernelGGL(k_transpose_lower, dim3(g, g), dim3(256), 0, s, src, Np, out, N);
+}
+
+}  // namespace gpx

@@ -1,0 +1,352 @@
+// kernels_sweep.hip -- the acquisition sweep on gfx950.
+//
+// Replaces, for M candidates at once, what pybo reaches through `finit = f(xgrid, grad=False)`
+// [pybo/solvers/lbfgs.py:50] -> index(X) [pybo/policies/simple.py:23-25,37-39,62-73] ->
+// model.predict / get_improvement / get_tail (reggie, un-vendored), followed by
+// `np.argsort(finit)[::-1]` [pybo/solvers/lbfgs.py:51] of which only the first nbest are used.
+//
+// Per chunk of candidate columns:
+//   1. k_cross_gram   Ks[k][n] = k(x_k, c_n)                      (HBM-write bound, exp on VALU)
+//   2. k_sweep_trmm   V = T Ks on fp64 MFMA, tile (mt, nt); V never leaves registers: the epilogue
+//                     reduces colsum(V^2) and V^T a per 128-row block into Qp/Pp[mt][n]
+//   3. k_acq          q = sum_mt Qp, p = sum_mt Pp (fixed order -> deterministic),
+//                     mu = bias + p, s2 = max(rho - q, 1e-100), acquisition value
+// then one block-local + one merge top-k pass over all M values.
+#include "gemm_core.h"
+#include "gpx_internal.h"
+
+namespace gpx {
+
+__device__ __forceinline__ double kern_eval_s(int kid, double r2, double rho) {
+    switch (kid) {
+        case GPX_KERN_SE_ARD:
+            return rho * exp(-0.5 * r2);
+        case GPX_KERN_MATERN52: {
+            const double s = 2.23606797749978969641 * sqrt(r2);
+            return rho * (1.0 + s + (5.0 / 3.0) * r2) * exp(-s);
+        }
+        case GPX_KERN_MATERN32: {
+            const double s = 1.73205080756887729353 * sqrt(r2);
+            return rho * (1.0 + s) * exp(-s);
+        }
+        default:
+            return rho * exp(-sqrt(r2));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cross-Gram: tile 64 observed rows x 128 candidate columns, 8x4 outputs per thread
+// ------------------------------------------------------------------------------------------------
+constexpr int XK = 64, XN = 128, XDC = 16;
+
+__global__ __launch_bounds__(256) void k_cross_gram(const double* __restrict__ Xs, int64_t N, int d,
+                                                    const double* __restrict__ Xc, int64_t m0, int64_t M,
+                                                    const double* __restrict__ invell, int kid,
+                                                    double rho, double* __restrict__ Ks, int64_t ldk) {
+    __shared__ double xo[XDC][XK];
+    __shared__ double xc[XDC][XN];
+    const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
+    const int64_t k0 = (int64_t)blockIdx.y * XK;   // observed row origin
+    const int64_t n0 = (int64_t)blockIdx.x * XN;   // chunk-local candidate origin
+    double r2[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) r2[a][b] = 0.0;
+
+    for (int c0 = 0; c0 < d; c0 += XDC) {
+        const int kc = min(XDC, d - c0);
+        __syncthreads();
+        for (int e = t; e < XK * kc; e += 256) {
+            const int row = e / kc, k = e - row * kc;
+            xo[k][row] = Xs[(k0 + row) * d + c0 + k];
+        }
+        for (int e = t; e < XN * kc; e += 256) {
+            const int row = e / kc, k = e - row * kc;
+            const int64_t gm = m0 + n0 + row;
+            xc[k][row] = (gm < M) ? Xc[gm * d + c0 + k] * invell[c0 + k] : 0.0;
+        }
+        __syncthreads();
+        for (int k = 0; k < kc; ++k) {
+            double a8[8], b4[4];
+#pragma unroll
+            for (int a = 0; a < 8; ++a) a8[a] = xo[k][ty * 8 + a];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) b4[b] = xc[k][tx * 4 + b];
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const double df = a8[a] - b4[b];
+                    r2[a][b] = fma(df, df, r2[a][b]);
+                }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const int64_t gk = k0 + ty * 8 + a;
+        d4 o;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int64_t gm = m0 + n0 + tx * 4 + b;
+            o[b] = (gk < N && gm < M) ? kern_eval_s(kid, r2[a][b], rho) : 0.0;
+        }
+        *reinterpret_cast<d4*>(Ks + gk * ldk + n0 + tx * 4) = o;
+    }
+}
+
+void launch_cross_gram(hipStream_t s, const double* Xs, int64_t Np, int64_t N, int d, const double* Xc,
+                       int64_t m0, int64_t M, int64_t cols, const double* invell, int kernel_id,
+                       double rho, double* Ks, int64_t ldk) {
+    dim3 grid((unsigned)(cols / XN), (unsigned)(Np / XK));
+    hipLaunchKernelGGL(k_cross_gram, grid, dim3(256), 0, s, Xs, N, d, Xc, m0, M, invell, kernel_id, rho,
+                       Ks, ldk);
+}
+
+// ------------------------------------------------------------------------------------------------
+// THE dominant kernel: V(m,n) = sum_{k <= m} T(m,k) Ks(k,n),  T(m,k) = U[k][m]  (both k-major).
+// Tile (mt, nt): 128 observed rows x 128 candidates, K-extent (mt+1)*128 (T is lower triangular),
+// N^2 * M flop in total.  Heavy tiles (large mt) are dispatched first.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __restrict__ U, int64_t Np,
+                                                                const double* __restrict__ Ks,
+                                                                int64_t ldk, int NT,
+                                                                const double* __restrict__ avec,
+                                                                double* __restrict__ Qp,
+                                                                double* __restrict__ Pp, int64_t ldp,
+                                                                int order) {
+    __shared__ __attribute__((aligned(16))) double smem[GEMM_LDS_F64];
+    const int nP = (int)(Np / TB);
+    int mt, nt;
+    {
+        const int b = blockIdx.x;
+        if (order == 1) {
+            // XCD-aware: block b runs on XCD b%8 (observed, speed only).  Give each XCD its own
+            // contiguous slice of candidate tiles so the 64 tiles resident on one XCD walk the
+            // SAME mt (shared T rows in that XCD's L2) over neighbouring nt.
+            const int x = b & 7, q = b >> 3;          // q-th block of XCD x
+            const int per = (NT + 7) / 8;             // candidate tiles per XCD
+            const int lm = q / per, ln = q - lm * per;
+            mt = nP - 1 - lm;
+            nt = x * per + ln;
+            if (nt >= NT || mt < 0) return;
+        } else {
+            mt = nP - 1 - b / NT;
+            nt = b - (b / NT) * NT;
+        }
+    }
+    const int64_t m0 = (int64_t)mt * TB, n0 = (int64_t)nt * TB;
+    d4 acc[4][4];
+    acc_zero(acc);
+    gemm_tile_128(acc, U + m0, Np, Ks + n0, ldk, 0, (mt + 1) * TB, smem);
+
+    // epilogue: column sums of V^2 and V*a over this tile's 128 rows
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    double av[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) av[i][r] = avec[m0 + wm * 64 + i * 16 + (lane >> 4) + 4 * r];
+    double qs[4], ps[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double q = 0.0, p = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = acc[i][j][r];
+                q = fma(v, v, q);
+                p = fma(v, av[i][r], p);
+            }
+        q += __shfl_xor(q, 16);
+        p += __shfl_xor(p, 16);
+        q += __shfl_xor(q, 32);
+        p += __shfl_xor(p, 32);
+        qs[j] = q;
+        ps[j] = p;
+    }
+    double* red = smem;  // [2][128][2]; gemm_tile_128 ended on a barrier, LDS is free
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = wn * 64 + j * 16 + lane;
+            red[(wm * TB + c) * 2 + 0] = qs[j];
+            red[(wm * TB + c) * 2 + 1] = ps[j];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < TB) {
+        const int c = threadIdx.x;
+        Qp[(int64_t)mt * ldp + n0 + c] = red[c * 2] + red[(TB + c) * 2];
+        Pp[(int64_t)mt * ldp + n0 + c] = red[c * 2 + 1] + red[(TB + c) * 2 + 1];
+    }
+}
+
+void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double* Ks, int64_t ldk,
+                       int64_t cols, const double* a, double* Qp, double* Pp, int64_t ldp,
+                       int tile_order) {
+    const int NT = (int)(cols / TB);
+    const int nP = (int)(Np / TB);
+    unsigned nblk;
+    if (tile_order == 1) {
+        const int per = (NT + 7) / 8;
+        nblk = (unsigned)(8 * per * nP);
+    } else {
+        nblk = (unsigned)(NT * nP);
+    }
+    hipLaunchKernelGGL(k_sweep_trmm, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
+                       ldp, tile_order);
+}
+
+// ------------------------------------------------------------------------------------------------
+// acquisition values from the reduced partials (one thread per candidate; coalesced over n)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double norm_cdf(double z) { return 0.5 * erfc(-z * 0.70710678118654752440); }
+__device__ __forceinline__ double norm_pdf(double z) {
+    return 0.39894228040143267794 * exp(-0.5 * z * z);
+}
+
+__global__ __launch_bounds__(256) void k_acq(const double* __restrict__ Qp, const double* __restrict__ Pp,
+                                             int64_t ldp, int nrb, int64_t m0, int64_t cols_valid,
+                                             double rho, double bias, int acq_id, double p0,
+                                             double* __restrict__ acq_out, double* __restrict__ mu_out,
+                                             double* __restrict__ s2_out) {
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= cols_valid) return;
+    double q = 0.0, p = 0.0;
+    for (int rb = 0; rb < nrb; ++rb) {
+        q += Qp[(int64_t)rb * ldp + n];
+        p += Pp[(int64_t)rb * ldp + n];
+    }
+    const double mu = bias + p;
+    const double s2 = fmax(rho - q, 1e-100);
+    double val;
+    switch (acq_id) {
+        case GPX_ACQ_EI: {
+            const double s = sqrt(s2);
+            const double dlt = mu - p0;
+            const double z = dlt / s;
+            val = dlt * norm_cdf(z) + s * norm_pdf(z);
+            break;
+        }
+        case GPX_ACQ_PI: {
+            const double z = (mu - p0) / sqrt(s2);
+            val = norm_cdf(z);
+            break;
+        }
+        case GPX_ACQ_UCB:
+            val = mu + sqrt(p0 * s2);
+            break;
+        default:
+            val = mu;
+    }
+    acq_out[m0 + n] = val;
+    if (mu_out) mu_out[m0 + n] = mu;
+    if (s2_out) s2_out[m0 + n] = s2;
+}
+
+void launch_acq(hipStream_t s, const double* Qp, const double* Pp, int64_t ldp, int nrb, int64_t m0,
+                int64_t cols_valid, double rho, double bias, int acq_id, double p0, double* acq_out,
+                double* mu_out, double* s2_out) {
+    const unsigned g = (unsigned)((cols_valid + 255) / 256);
+    hipLaunchKernelGGL(k_acq, dim3(g), dim3(256), 0, s, Qp, Pp, ldp, nrb, m0, cols_valid, rho, bias,
+                       acq_id, p0, acq_out, mu_out, s2_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// top-k: value descending, ties -> lower index; NaN ranks below everything.
+// ------------------------------------------------------------------------------------------------
+constexpr int TK_PER_THREAD = 16;
+constexpr int TK_PER_BLOCK = 256 * TK_PER_THREAD;
+#define GPX_NEG_INF (-__builtin_huge_val())
+#define GPX_IDX_NONE ((int64_t)0x7fffffffffffffffLL)
+
+__device__ __forceinline__ bool better(double av, int64_t ai, double bv, int64_t bi) {
+    return (av > bv) || (av == bv && ai < bi);
+}
+
+// block-wide argmax of (v, i); result broadcast to all threads
+__device__ __forceinline__ void block_argmax(double& v, int64_t& i, double* sv, int64_t* si) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(v, off);
+        const int64_t oi = __shfl_xor((long long)i, off);
+        if (better(ov, oi, v, i)) { v = ov; i = oi; }
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { sv[w] = v; si[w] = i; }
+    __syncthreads();
+    v = sv[0]; i = si[0];
+#pragma unroll
+    for (int ww = 1; ww < 4; ++ww)
+        if (better(sv[ww], si[ww], v, i)) { v = sv[ww]; i = si[ww]; }
+}
+
+__global__ __launch_bounds__(256) void k_topk_block(const double* __restrict__ vals, int64_t M, int k,
+                                                    double* __restrict__ blkv,
+                                                    int64_t* __restrict__ blki) {
+    __shared__ double sv[4];
+    __shared__ int64_t si[4];
+    const int64_t base = (int64_t)blockIdx.x * TK_PER_BLOCK;
+    double v[TK_PER_THREAD];
+#pragma unroll
+    for (int e = 0; e < TK_PER_THREAD; ++e) {
+        const int64_t idx = base + e * 256 + threadIdx.x;
+        double x = (idx < M) ? vals[idx] : GPX_NEG_INF;
+        if (x != x) x = GPX_NEG_INF;
+        v[e] = x;
+    }
+    unsigned used = 0;  // bit e set: element e already emitted
+    for (int it = 0; it < k; ++it) {
+        double bv = GPX_NEG_INF;
+        int64_t bi = GPX_IDX_NONE;
+#pragma unroll
+        for (int e = 0; e < TK_PER_THREAD; ++e) {
+            const int64_t idx = base + e * 256 + threadIdx.x;
+            if (!((used >> e) & 1u) && idx < M && better(v[e], idx, bv, bi)) { bv = v[e]; bi = idx; }
+        }
+        block_argmax(bv, bi, sv, si);
+        if (bi != GPX_IDX_NONE) {
+            const int64_t off = bi - base;
+            if ((int)(off & 255) == (int)threadIdx.x) used |= 1u << (unsigned)(off >> 8);
+        }
+        if (threadIdx.x == 0) {
+            blkv[(int64_t)blockIdx.x * k + it] = bv;
+            blki[(int64_t)blockIdx.x * k + it] = bi;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_topk_merge(double* __restrict__ blkv, int64_t* __restrict__ blki,
+                                                    int64_t n, int k, double* __restrict__ topv,
+                                                    int64_t* __restrict__ topi) {
+    __shared__ double sv[4];
+    __shared__ int64_t si[4];
+    for (int it = 0; it < k; ++it) {
+        double bv = GPX_NEG_INF;
+        int64_t bi = GPX_IDX_NONE;
+        int64_t bpos = -1;
+        for (int64_t e = threadIdx.x; e < n; e += 256) {
+            const int64_t idx = blki[e];
+            if (idx != GPX_IDX_NONE && better(blkv[e], idx, bv, bi)) { bv = blkv[e]; bi = idx; bpos = e; }
+        }
+        const int64_t mine = bi;
+        block_argmax(bv, bi, sv, si);
+        if (bi != GPX_IDX_NONE && mine == bi && bpos >= 0) blki[bpos] = GPX_IDX_NONE;  // consume
+        if (threadIdx.x == 0) { topv[it] = bv; topi[it] = (bi == GPX_IDX_NONE) ? -1 : bi; }
+        __syncthreads();
+    }
+}
+
+int64_t topk_blocks(int64_t M) { return (M + TK_PER_BLOCK - 1) / TK_PER_BLOCK; }
+
+void launch_topk(hipStream_t s, const double* vals, int64_t M, int k, double* blkv, int64_t* blki,
+                 int64_t nblk, double* topv, int64_t* topi) {
+    hipLaunchKernelGGL(k_topk_block, dim3((unsigned)nblk), dim3(256), 0, s, vals, M, k, blkv, blki);
+    hipLaunchKernelGGL(k_topk_merge, dim3(1), dim3(256), 0, s, blkv, blki, nblk * k, k, topv, topi);
+}
+
+}  // namespace gpx
