@@ -119,6 +119,10 @@ int gpx_rff_sweep(gpx_handle *h, const double *W, const double *b, const double 
 int gpx_rff_sweep_dev(gpx_handle *h, const double *W, const double *b, const double *theta,
                       int64_t S, int64_t n, int64_t d, double bias, const double *dXc, int64_t M,
                       int64_t k, double *top_val, int64_t *top_idx, double *d_vals_all);
+/* value f (M,) and gradient g (M,d) of ONE draw at M points (host buffers): the
+ * `f(x[None], grad=True)` calls of the L-BFGS refinement   [pybo/solvers/lbfgs.py:56-58] */
+int gpx_rff_grad(gpx_handle *h, const double *W, const double *b, const double *theta, int64_t n,
+                 int64_t d, double bias, const double *Xc, int64_t M, double *f, double *g);
 /* feature Gram for the weight posterior: Phi = cos(X_obs W^T + b) (N,n) on the device's X_obs;
  * returns A = Phi^T Phi (n,n) and v = Phi^T (y - bias) (n,) in host buffers. */
 int gpx_rff_gram(gpx_handle *h, const double *W, const double *b, int64_t n, double *A, double *v);

@@ -35,6 +35,7 @@ SYMBOLS = {
     'gpx_sweep_dev': (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _i64, _i64, _P, _P, _P, _P, _P]),
     'gpx_rff_sweep': (C.c_int, [_P, _P, _P, _P, _i64, _i64, _i64, _dbl, _P, _i64, _i64, _P, _P, _P]),
     'gpx_rff_sweep_dev': (C.c_int, [_P, _P, _P, _P, _i64, _i64, _i64, _dbl, _P, _i64, _i64, _P, _P, _P]),
+    'gpx_rff_grad': (C.c_int, [_P, _P, _P, _P, _i64, _i64, _dbl, _P, _i64, _P, _P]),
     'gpx_rff_gram': (C.c_int, [_P, _P, _P, _i64, _P, _P]),
     'gpx_timers': (C.c_int, [_P, _P, C.c_int, C.c_int]),
     'gpx_sync': (C.c_int, [_P]),
@@ -129,6 +130,7 @@ class Engine(object):
             raise ValueError('X and y disagree on N')
         ell = _f64(np.broadcast_to(np.asarray(ell, dtype=float), (d,)))
         kid = KERNELS[kernel] if isinstance(kernel, str) else int(kernel)
+        self.N, self.d = N, d
         if stage == 3:
             rc = self._lib.gpx_fit(self._h, _ptr(X), N, d, _ptr(y), kid, _ptr(ell), rho, sn2, bias)
         else:
@@ -180,7 +182,8 @@ class Engine(object):
 
     def sweep(self, acq, param, Xc, k=0, want_all=True, want_moments=False):
         """Host-buffer sweep.  Returns dict(top_val, top_idx, acq, mu, s2)."""
-        Xc = _f64(Xc).reshape(-1, self.d)
+        Xc = _f64(Xc)
+        Xc = Xc.reshape(-1, self.d) if self.d else np.atleast_2d(Xc)
         M = len(Xc)
         aid = ACQ[acq] if isinstance(acq, str) else int(acq)
         params = _f64([0.0 if param is None else param])
@@ -228,6 +231,19 @@ class Engine(object):
         self._check(self._lib.gpx_rff_sweep(self._h, _ptr(W), _ptr(b), _ptr(theta), S, n, d, bias, _ptr(Xc), M,
                                             k, _ptr(tv) if k else None, _ptr(ti) if k else None, _ptr(out)))
         return dict(top_val=tv, top_idx=ti, vals=out)
+
+    def rff_eval_grad(self, W, b, theta, bias, Xc):
+        W = _f64(W)
+        n, d = W.shape
+        b = _f64(b)
+        theta = _f64(theta)
+        Xc = _f64(Xc).reshape(-1, d)
+        M = len(Xc)
+        f = np.empty(M)
+        g = np.empty((M, d))
+        self._check(self._lib.gpx_rff_grad(self._h, _ptr(W), _ptr(b), _ptr(theta), n, d, bias, _ptr(Xc), M,
+                                           _ptr(f), _ptr(g)))
+        return f, g
 
     def rff_sweep_dev(self, W, b, theta, bias, dXc_ptr, M, k):
         W = _f64(W)

@@ -567,6 +567,12 @@ extern "C" int gpx_rff_sweep(gpx_handle* h, const double* W, const double* b, co
     return GPX_OK;
 }
 
+extern "C" int gpx_rff_grad(gpx_handle* h, const double* W, const double* b, const double* theta, int64_t n,
+                            int64_t d, double bias, const double* Xc, int64_t M, double* f, double* g) {
+    if (!h) return GPX_EARG;
+    return gpx::rff_grad_host(h, W, b, theta, n, d, bias, Xc, M, f, g);
+}
+
 extern "C" int gpx_rff_gram(gpx_handle* h, const double* W, const double* b, int64_t n, double* A, double* v) {
     if (!h) return GPX_EARG;
     if (h->stage < 1) return fail(h, GPX_ESTATE, "rff_gram: no data on the device (fit first)");

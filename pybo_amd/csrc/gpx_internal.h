@@ -115,6 +115,9 @@ int64_t topk_blocks(int64_t M);
 int predict_grad_host(gpx_handle* h, const double* Xc, int64_t M, double* mu, double* s2, double* dmu,
                       double* ds2);
 
+int rff_grad_host(gpx_handle* h, const double* W, const double* b, const double* theta, int64_t n, int64_t d,
+                  double bias, const double* Xc, int64_t M, double* f, double* g);
+
 // launchers (kernels_rff.hip)
 void launch_rff_eval(hipStream_t s, const double* W, const double* b, const double* theta, int S, int n,
                      int d, double bias, const double* Xc, int64_t M, double* vals /* (S,M) */);

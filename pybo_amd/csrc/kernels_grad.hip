@@ -1,9 +1,287 @@
-// kernels_grad.hip -- posterior moments WITH input gradients for small candidate batches
-// (the `f(x[None], grad=True)` calls of the L-BFGS refinement, pybo/solvers/lbfgs.py:56-58).
+// kernels_grad.hip -- posterior moments WITH input gradients for small candidate batches, and the
+// gradient of an RFF function sample.  These serve the `f(x[None], grad=True)` calls of the L-BFGS
+// refinement (/root/reference/pybo/solvers/lbfgs.py:56-58) reaching model.predict(X, True)
+// (pybo/policies/simple.py:64-70, pybo/recommenders.py:22) and sample_f(...).get(X, True).
+//
+//   k* = k(X_obs, x)            g = dk/dr2
+//   V  = T k*                   mu = bias + V.a          s2 = rho - V.V
+//   w  = U V = K^-1 k*          dmu/dx_j = sum_i dk_i/dx_j alpha_i      ds2/dx_j = -2 sum_i dk_i/dx_j w_i
+//   dk_i/dx_j = g_i * 2 (x_j - X_ij) / ell_j^2
+//
+// Memory-bound by design: one pass over T and one over U per batch of up to GB candidates (matvecs
+// with GB right-hand sides, one wave per matrix row, coalesced row reads).
+#include <algorithm>
+
 #include "gpx_internal.h"
+
 namespace gpx {
-int predict_grad_host(gpx_handle* h, const double*, int64_t, double*, double*, double*, double*) {
-    h->err = "predict with gradients: not built yet";
-    return GPX_EARG;
+
+constexpr int GB = 8;  // candidates per batch
+
+__device__ __forceinline__ void kern_and_grad(int kid, double r2, double rho, double& k, double& g) {
+    switch (kid) {
+        case GPX_KERN_SE_ARD: {
+            k = rho * exp(-0.5 * r2);
+            g = -0.5 * k;
+            break;
+        }
+        case GPX_KERN_MATERN52: {
+            const double s = 2.23606797749978969641 * sqrt(r2);
+            const double e = rho * exp(-s);
+            k = (1.0 + s + (5.0 / 3.0) * r2) * e;
+            g = -(5.0 / 6.0) * (1.0 + s) * e;
+            break;
+        }
+        case GPX_KERN_MATERN32: {
+            const double s = 1.73205080756887729353 * sqrt(r2);
+            const double e = rho * exp(-s);
+            k = (1.0 + s) * e;
+            g = -1.5 * e;
+            break;
+        }
+        default: {
+            const double r = sqrt(r2);
+            k = rho * exp(-r);
+            g = -0.5 * k / r;
+        }
+    }
 }
+
+// ks[m][i], g[m][i] for i < Np (0 beyond N); grid (Np/256, mb)
+__global__ __launch_bounds__(256) void k_kstar(const double* __restrict__ Xs, int64_t N, int64_t Np, int d,
+                                               const double* __restrict__ Xc, const double* __restrict__ invell,
+                                               int kid, double rho, double* __restrict__ ks,
+                                               double* __restrict__ g) {
+    const int m = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Np) return;
+    double kv = 0.0, gv = 0.0;
+    if (i < N) {
+        double r2 = 0.0;
+        for (int k = 0; k < d; ++k) {
+            const double df = Xs[i * d + k] - Xc[(int64_t)m * d + k] * invell[k];
+            r2 = fma(df, df, r2);
+        }
+        kern_and_grad(kid, r2, rho, kv, gv);
+    }
+    ks[(int64_t)m * Np + i] = kv;
+    g[(int64_t)m * Np + i] = gv;
+}
+
+// out[m][row] = sum_j Mx[row][j] * in[m][j], j in [0,row] (mode 0, lower) or [row,N) (mode 1, upper)
+__global__ __launch_bounds__(256) void k_tri_matvec_multi(const double* __restrict__ Mx, int64_t Np, int64_t N,
+                                                          const double* __restrict__ in, int mb, int mode,
+                                                          double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Np) return;
+    double acc[GB];
+#pragma unroll
+    for (int m = 0; m < GB; ++m) acc[m] = 0.0;
+    if (row < N) {
+        const int64_t lo = (mode == 0) ? 0 : row;
+        const int64_t hi = (mode == 0) ? row + 1 : N;
+        const double* mr = Mx + row * Np;
+        for (int64_t j = lo + lane; j < hi; j += 64) {
+            const double t = mr[j];
+#pragma unroll
+            for (int m = 0; m < GB; ++m)
+                if (m < mb) acc[m] = fma(t, in[(int64_t)m * Np + j], acc[m]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < GB; ++m) {
+        double a = acc[m];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+        if (lane == 0 && m < mb) out[(int64_t)m * Np + row] = a;
+    }
+}
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// grid (d+1, mb).  blockIdx.x < d: gradient component j; blockIdx.x == d: mu and s2.
+// out layout per candidate m: [mu, s2, dmu[0..d), ds2[0..d)]
+__global__ __launch_bounds__(256) void k_grad_reduce(const double* __restrict__ Xs, int64_t N, int64_t Np,
+                                                     int d, const double* __restrict__ Xc,
+                                                     const double* __restrict__ invell,
+                                                     const double* __restrict__ g, const double* __restrict__ V,
+                                                     const double* __restrict__ w, const double* __restrict__ a,
+                                                     const double* __restrict__ alpha, double rho, double bias,
+                                                     double* __restrict__ out) {
+    __shared__ double sh[4];
+    const int j = blockIdx.x, m = blockIdx.y;
+    const int64_t base = (int64_t)m * Np;
+    double* o = out + (int64_t)m * (2 + 2 * d);
+    if (j == d) {
+        double p = 0.0, q = 0.0;
+        for (int64_t i = threadIdx.x; i < N; i += 256) {
+            const double v = V[base + i];
+            p = fma(v, a[i], p);
+            q = fma(v, v, q);
+        }
+        p = block_sum(p, sh);
+        q = block_sum(q, sh);
+        if (threadIdx.x == 0) {
+            o[0] = bias + p;
+            o[1] = fmax(rho - q, 1e-100);
+        }
+        return;
+    }
+    const double cj = Xc[(int64_t)m * d + j] * invell[j];
+    const double two_inv = 2.0 * invell[j];
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t i = threadIdx.x; i < N; i += 256) {
+        const double dk = g[base + i] * (two_inv * (cj - Xs[i * d + j]));
+        s1 = fma(dk, alpha[i], s1);
+        s2 = fma(dk, w[base + i], s2);
+    }
+    s1 = block_sum(s1, sh);
+    s2 = block_sum(s2, sh);
+    if (threadIdx.x == 0) {
+        o[2 + j] = s1;
+        o[2 + d + j] = -2.0 * s2;
+    }
+}
+
+int predict_grad_host(gpx_handle* h, const double* Xc, int64_t M, double* mu, double* s2, double* dmu,
+                      double* ds2) {
+    if (!h->fitted) { h->err = "predict: model is not fitted"; return GPX_ESTATE; }
+    if (!Xc || M < 1) { h->err = "predict: need M >= 1 points"; return GPX_EARG; }
+    if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return GPX_EHIP; }
+    hipStream_t s = h->stream;
+    const int64_t Np = h->Np, N = h->N;
+    const int d = (int)h->d;
+    const int64_t per = 2 + 2 * d;
+    // scratch: [Xc GB*d][ks][g][V][w] (GB*Np each) [out GB*per]
+    const int64_t need = GB * d + 4 * GB * Np + GB * per;
+    if (need > h->cap_grad) {
+        if (h->dgrad) hipFree(h->dgrad);
+        h->dgrad = nullptr;
+        h->cap_grad = 0;
+        if (hipMalloc((void**)&h->dgrad, (size_t)need * 8) != hipSuccess) {
+            h->err = "predict: device allocation failed";
+            return GPX_EOOM;
+        }
+        h->cap_grad = need;
+    }
+    double* dX = h->dgrad;
+    double* dks = dX + GB * d;
+    double* dg = dks + GB * Np;
+    double* dV = dg + GB * Np;
+    double* dw = dV + GB * Np;
+    double* dout = dw + GB * Np;
+    std::vector<double> host((size_t)GB * per);
+    const unsigned rows4 = (unsigned)((Np + 3) / 4);
+    for (int64_t m0 = 0; m0 < M; m0 += GB) {
+        const int mb = (int)std::min<int64_t>(GB, M - m0);
+        if (hipMemcpyAsync(dX, Xc + m0 * d, (size_t)mb * d * 8, hipMemcpyHostToDevice, s) != hipSuccess) {
+            h->err = "predict: H2D copy failed";
+            return GPX_EHIP;
+        }
+        hipLaunchKernelGGL(k_kstar, dim3((unsigned)((Np + 255) / 256), (unsigned)mb), dim3(256), 0, s, h->dXs,
+                           N, Np, d, dX, h->dinvell, h->kernel_id, h->rho, dks, dg);
+        hipLaunchKernelGGL(k_tri_matvec_multi, dim3(rows4), dim3(256), 0, s, h->dT, Np, N, dks, mb, 0, dV);
+        hipLaunchKernelGGL(k_tri_matvec_multi, dim3(rows4), dim3(256), 0, s, h->dU, Np, N, dV, mb, 1, dw);
+        hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)(d + 1), (unsigned)mb), dim3(256), 0, s, h->dXs, N, Np,
+                           d, dX, h->dinvell, dg, dV, dw, h->da, h->dalpha, h->rho, h->bias, dout);
+        if (hipMemcpyAsync(host.data(), dout, (size_t)mb * per * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {
+            h->err = "predict: D2H copy failed";
+            return GPX_EHIP;
+        }
+        for (int m = 0; m < mb; ++m) {
+            const double* o = host.data() + (size_t)m * per;
+            mu[m0 + m] = o[0];
+            s2[m0 + m] = o[1];
+            for (int j = 0; j < d; ++j) {
+                dmu[(m0 + m) * d + j] = o[2 + j];
+                ds2[(m0 + m) * d + j] = o[2 + d + j];
+            }
+        }
+    }
+    if (hipGetLastError() != hipSuccess) { h->err = "predict: kernel launch failed"; return GPX_EHIP; }
+    return GPX_OK;
+}
+
+// ---- RFF sample value + gradient at M points: grid (M), threads over features -------------------
+// out per point: [f, df/dx_0 .. df/dx_{d-1}]
+__global__ __launch_bounds__(256) void k_rff_grad(const double* __restrict__ W, const double* __restrict__ b,
+                                                  const double* __restrict__ theta, int n, int d, double bias,
+                                                  const double* __restrict__ Xc, double* __restrict__ out) {
+    __shared__ double sh[4];
+    const int m = blockIdx.x;
+    const double* x = Xc + (int64_t)m * d;
+    double f = 0.0;
+    for (int j = threadIdx.x; j < n; j += 256) {
+        double z = b[j];
+        for (int k = 0; k < d; ++k) z = fma(W[j * d + k], x[k], z);
+        f = fma(theta[j], cos(z), f);
+    }
+    f = block_sum(f, sh);
+    if (threadIdx.x == 0) out[(int64_t)m * (d + 1)] = bias + f;
+    for (int k = 0; k < d; ++k) {
+        double gk = 0.0;
+        for (int j = threadIdx.x; j < n; j += 256) {
+            double z = b[j];
+            for (int kk = 0; kk < d; ++kk) z = fma(W[j * d + kk], x[kk], z);
+            gk = fma(-theta[j] * sin(z), W[j * d + k], gk);
+        }
+        gk = block_sum(gk, sh);
+        if (threadIdx.x == 0) out[(int64_t)m * (d + 1) + 1 + k] = gk;
+    }
+}
+
+int rff_grad_host(gpx_handle* h, const double* W, const double* b, const double* theta, int64_t n, int64_t d,
+                  double bias, const double* Xc, int64_t M, double* f, double* g) {
+    if (!W || !b || !theta || !Xc || !f || !g || n < 1 || d < 1 || d > DMAX || M < 1) {
+        h->err = "rff_grad: bad arguments";
+        return GPX_EARG;
+    }
+    if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return GPX_EHIP; }
+    hipStream_t s = h->stream;
+    const int64_t need = n * d + 2 * n + M * d + M * (d + 1);
+    if (need > h->cap_grad) {
+        if (h->dgrad) hipFree(h->dgrad);
+        h->dgrad = nullptr;
+        h->cap_grad = 0;
+        if (hipMalloc((void**)&h->dgrad, (size_t)need * 8) != hipSuccess) {
+            h->err = "rff_grad: device allocation failed";
+            return GPX_EOOM;
+        }
+        h->cap_grad = need;
+    }
+    double* dW = h->dgrad;
+    double* db = dW + n * d;
+    double* dth = db + n;
+    double* dX = dth + n;
+    double* dout = dX + M * d;
+    bool ok = hipMemcpyAsync(dW, W, (size_t)n * d * 8, hipMemcpyHostToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(db, b, (size_t)n * 8, hipMemcpyHostToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(dth, theta, (size_t)n * 8, hipMemcpyHostToDevice, s) == hipSuccess &&
+              hipMemcpyAsync(dX, Xc, (size_t)M * d * 8, hipMemcpyHostToDevice, s) == hipSuccess;
+    if (!ok) { h->err = "rff_grad: H2D copy failed"; return GPX_EHIP; }
+    hipLaunchKernelGGL(k_rff_grad, dim3((unsigned)M), dim3(256), 0, s, dW, db, dth, (int)n, (int)d, bias, dX,
+                       dout);
+    std::vector<double> host((size_t)M * (d + 1));
+    if (hipMemcpyAsync(host.data(), dout, host.size() * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) {
+        h->err = "rff_grad: kernel or D2H copy failed";
+        return GPX_EHIP;
+    }
+    for (int64_t m = 0; m < M; ++m) {
+        f[m] = host[(size_t)m * (d + 1)];
+        for (int64_t k = 0; k < d; ++k) g[m * d + k] = host[(size_t)m * (d + 1) + 1 + k];
+    }
+    return GPX_OK;
+}
+
 }  // namespace gpx

@@ -1,0 +1,57 @@
+"""
+Initial designs / candidate generators, same names, signatures and RandomState call sequences as
+/root/reference/pybo/inits/methods.py:17-77, so that a fixed seed yields the same points
+(tests/golden/inits.npz pins init_middle / init_uniform / init_latin bit-for-bit).
+
+init_sobol is the one deliberate difference: the reference drives a 13k-line LGPL direction-number table
+(pybo/inits/sobol.py) that must not be copied; here the sequence comes from scipy.stats.qmc.Sobol
+(Joe-Kuo numbers as well, but a different generator convention), with the same `skip` draw from the rng.
+Candidates are an *input* to the hot path, so bit-parity of this generator is not part of the contract.
+"""
+import numpy as np
+
+from ..utils import rstate
+
+__all__ = ['init_middle', 'init_uniform', 'init_latin', 'init_sobol']
+
+
+def _box(bounds):
+    b = np.array(bounds, dtype=float, ndmin=2)
+    return b[:, 0], b[:, 1] - b[:, 0], len(b)
+
+
+def init_middle(bounds):
+    """The single point at the centre of the box, shape (1, d)."""
+    return np.mean(np.array(bounds, dtype=float, ndmin=2), axis=1)[None, :]
+
+
+def init_uniform(bounds, n=None, rng=None):
+    """n i.i.d. uniform points in the box (n defaults to 3*d).  One `rng.rand(n, d)` call."""
+    rng = rstate(rng)
+    lo, width, d = _box(bounds)
+    n = 3 * d if n is None else n
+    return lo + width * rng.rand(n, d)
+
+
+def init_latin(bounds, n=None, rng=None):
+    """Latin hypercube: one uniform jitter per cell, then an independent shuffle of every column."""
+    rng = rstate(rng)
+    lo, width, d = _box(bounds)
+    n = 3 * d if n is None else n
+    X = lo + width * (np.arange(n)[:, None] + rng.rand(n, d)) / n
+    for k in range(d):
+        X[:, k] = rng.permutation(X[:, k])
+    return X
+
+
+def init_sobol(bounds, n=None, rng=None):
+    """Sobol points; `skip = rng.randint(100, 200)` leading points are discarded as in the reference."""
+    from scipy.stats import qmc
+    rng = rstate(rng)
+    lo, width, d = _box(bounds)
+    n = 3 * d if n is None else n
+    skip = rng.randint(100, 200)
+    eng = qmc.Sobol(d, scramble=False)
+    if skip:
+        eng.fast_forward(skip)
+    return lo + width * eng.random(n)

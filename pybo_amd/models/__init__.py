@@ -1,0 +1,4 @@
+"""Probabilistic models with the protocol pybo expects of `reggie` objects."""
+from .gp import GP, make_gp, RFFSampleDevice      # noqa: F401
+
+__all__ = ['GP', 'make_gp']

@@ -1,0 +1,250 @@
+"""
+Device-backed exact GP with the duck-typed protocol pybo expects from `reggie` models
+(call sites: /root/reference/pybo/bayesopt.py:105-115,258,269; pybo/policies/simple.py:20-64;
+pybo/recommenders.py:22-34):
+
+    make_gp(sn2, rho, ell, bias)   copy()   add_data(X, Y)   predict(X, grad=False)
+    get_improvement(target, X, grad)   get_tail(target, X, grad)   sample_f(n, rng).get(X, grad)
+    params[name].set_prior(kind, *args)   picklable
+
+All GP arithmetic runs in libgpx.so (HIP, gfx950) through pybo_amd._lib.Engine; this file is host
+logic only: data bookkeeping, copy-on-write sharing of the device state between `copy()`s, pickling
+(hyper-parameters + data only, device state rebuilt lazily), and the closed-form elementwise EI/PI
+gradient chain rule on top of device-computed (mu, s2, dmu, ds2).
+There is NO CPU fallback: without the library / a GPU, the first device call raises.
+"""
+import weakref
+
+import numpy as np
+from scipy.special import erfc
+
+from .. import _lib
+from ..utils import rstate
+
+__all__ = ['GP', 'make_gp']
+
+_KERNELS = ('se', 'matern5', 'matern3', 'matern1')
+_ENGINE_POOL = []      # engines whose last owner died; reused so steady-state BO never re-allocates
+
+
+class _DeviceState(object):
+    """A fitted engine shared by a model and its copies (copy-on-write in GP._own_state)."""
+
+    def __init__(self, device):
+        self.engine = None
+        while _ENGINE_POOL and self.engine is None:
+            cand = _ENGINE_POOL.pop()
+            if cand._h and cand.device == device:      # never hand out a closed handle
+                self.engine = cand
+        if self.engine is None:
+            self.engine = _lib.Engine(device)
+        self.nrefs = 1
+
+    def release(self):
+        self.nrefs -= 1
+        if self.nrefs == 0 and self.engine is not None:
+            if self.engine._h and len(_ENGINE_POOL) < 4:
+                _ENGINE_POOL.append(self.engine)
+            self.engine = None
+
+
+class Param(object):
+    """A named hyper-parameter with an optional prior record (priors are stored, not sampled)."""
+
+    def __init__(self, owner, attr):
+        # weak back-reference: a strong one would make every GP part of a reference cycle, and the
+        # cyclic collector runs GP.__del__ and Engine.__del__ in arbitrary order
+        self._owner, self._attr = weakref.proxy(owner), attr
+        self.prior = None
+
+    @property
+    def value(self):
+        return getattr(self._owner, self._attr)
+
+    def set_prior(self, kind, *args):
+        self.prior = (kind,) + tuple(np.array(a, dtype=float) for a in args)
+
+
+class RFFSampleDevice(object):
+    """One RFF posterior function sample; `.get(X, grad=False)` evaluates on the device."""
+
+    def __init__(self, model, W, b, theta):
+        self._model, self.W, self.b, self.theta = model, W, b, theta
+
+    def get(self, X, grad=False):
+        X = np.array(X, ndmin=2, dtype=float)
+        eng = self._model._engine()
+        if grad:
+            return eng.rff_eval_grad(self.W, self.b, self.theta, self._model.bias, X)
+        out = eng.rff_sweep(self.W[None], self.b[None], self.theta[None], self._model.bias, X, k=0)
+        return out['vals'][0]
+
+    def topk(self, xgrid, k):
+        out = self._model._engine().rff_sweep(self.W[None], self.b[None], self.theta[None],
+                                              self._model.bias, xgrid, k=int(k), want_all=False)
+        return out['top_val'][0], out['top_idx'][0]
+
+    __call__ = get
+
+
+class GP(object):
+    def __init__(self, sn2, rho, ell, bias=0.0, kernel='se', device=0):
+        if kernel not in _KERNELS:
+            raise ValueError('unknown kernel {!r}; choose from {}'.format(kernel, _KERNELS))
+        self.sn2 = float(sn2)
+        self.rho = float(rho)
+        self.ell = np.array(ell, dtype=float, ndmin=1)
+        self.bias = float(bias)
+        self.kernel = kernel
+        self.device = int(device)
+        self._X = np.empty((0, len(self.ell)))
+        self._Y = np.empty(0)
+        self._state = None          # _DeviceState, shared with copies
+        self._fitted = False
+        self.params = {'like.sn2': Param(self, 'sn2'), 'kern.rho': Param(self, 'rho'),
+                       'kern.ell': Param(self, 'ell'), 'mean.bias': Param(self, 'bias')}
+
+    # -- bookkeeping ---------------------------------------------------------------------------
+    @property
+    def ndata(self):
+        return len(self._X)
+
+    @property
+    def data(self):
+        return self._X, self._Y
+
+    def __del__(self):
+        st = getattr(self, '_state', None)
+        if st is not None:
+            try:
+                st.release()
+            except Exception:
+                pass
+
+    def __getstate__(self):
+        return dict(sn2=self.sn2, rho=self.rho, ell=self.ell, bias=self.bias, kernel=self.kernel,
+                    device=self.device, X=self._X, Y=self._Y,
+                    priors={k: p.prior for k, p in self.params.items()})
+
+    def __setstate__(self, st):
+        self.__init__(st['sn2'], st['rho'], st['ell'], st['bias'], st['kernel'], st['device'])
+        self._X, self._Y = st['X'], st['Y']
+        for k, pr in st['priors'].items():
+            self.params[k].prior = pr
+
+    def copy(self):
+        """Cheap: hyper-parameters and host data are copied, the fitted device state is shared."""
+        new = GP(self.sn2, self.rho, self.ell.copy(), self.bias, self.kernel, self.device)
+        new._X, new._Y = self._X, self._Y          # arrays are replaced, never mutated in place
+        for k, p in self.params.items():
+            new.params[k].prior = p.prior
+        if self._state is not None and self._fitted:
+            self._state.nrefs += 1
+            new._state, new._fitted = self._state, True
+        return new
+
+    def _own_state(self):
+        """A device state this model may overwrite (fresh one if the current is shared)."""
+        if self._state is not None and self._state.nrefs > 1:
+            self._state.release()
+            self._state = None
+        if self._state is None:
+            self._state = _DeviceState(self.device)
+        return self._state
+
+    def _engine(self):
+        if self.ndata == 0:
+            raise RuntimeError('the model has no data yet')
+        if not self._fitted:
+            st = self._own_state()
+            st.engine.fit(self._X, self._Y, self.kernel, self.ell, self.rho, self.sn2, self.bias)
+            self._fitted = True
+        return self._state.engine
+
+    # -- protocol ------------------------------------------------------------------------------
+    def add_data(self, X, Y):
+        d = len(self.ell)
+        X = np.array(X, dtype=float)
+        X = X.reshape(-1, d)
+        Y = np.array(Y, dtype=float).reshape(-1)
+        if len(X) != len(Y):
+            raise ValueError('X and Y must have the same number of rows')
+        self._X = np.vstack([self._X, X])
+        self._Y = np.hstack([self._Y, Y])
+        self._fitted = False
+        self._engine()              # refit now: a non-PD Gram matrix must surface here (LinAlgError)
+
+    def predict(self, X, grad=False):
+        X = np.array(X, ndmin=2, dtype=float)
+        if self.ndata == 0:
+            M, d = X.shape
+            mu, s2 = np.full(M, self.bias), np.full(M, self.rho)
+            return (mu, s2, np.zeros((M, d)), np.zeros((M, d))) if grad else (mu, s2)
+        eng = self._engine()
+        if not grad and X.shape == self._X.shape and np.array_equal(X, self._X):
+            # posterior mean at the training inputs has the closed form y - sn2*alpha (no N^3 solve);
+            # the variance still needs the sweep.  Used by EI/PI for their target (simple.py:21,35).
+            mu, _ = eng.mean_at_obs()
+            s2 = eng.sweep('mean', None, X, k=0, want_all=False, want_moments=True)['s2']
+            return mu, s2
+        return eng.predict(X, grad=grad)
+
+    def posterior_mean_at_data(self):
+        return self._engine().mean_at_obs()[0]
+
+    def _acq(self, kind, target, X, grad):
+        X = np.array(X, ndmin=2, dtype=float)
+        if self.ndata == 0:
+            raise RuntimeError('the model has no data yet')
+        if not grad:
+            return self._engine().sweep(kind, target, X, k=0)['acq']
+        mu, s2, dmu, ds2 = self._engine().predict(X, grad=True)
+        s = np.sqrt(s2)
+        z = (mu - target) / s
+        cdf = 0.5 * erfc(-z * 0.70710678118654752440)
+        pdf = 0.39894228040143267794 * np.exp(-0.5 * z * z)
+        if kind == 'ei':
+            val = (mu - target) * cdf + s * pdf
+            return val, cdf[:, None] * dmu + (0.5 * pdf / s)[:, None] * ds2
+        dz = dmu / s[:, None] - (0.5 * z / s2)[:, None] * ds2
+        return cdf, pdf[:, None] * dz
+
+    def get_improvement(self, target, X, grad=False):
+        return self._acq('ei', target, X, grad)
+
+    def get_tail(self, target, X, grad=False):
+        return self._acq('pi', target, X, grad)
+
+    def acq_topk(self, kind, param, xgrid, k):
+        """Whole-grid acquisition + top-k on the device: (values (k,), grid indices (k,))."""
+        xgrid = np.array(xgrid, ndmin=2, dtype=float)
+        out = self._engine().sweep(kind, param, xgrid, k=int(k), want_all=False)
+        return out['top_val'], out['top_idx']
+
+    def sample_f(self, n, rng=None):
+        """RFF posterior function sample.  Host draws (order fixed: randn(n,d), [chisquare], rand(n),
+        randn(n)); the O(N n^2) feature Gram runs on the device, the n x n weight posterior on the host."""
+        rng = rstate(rng)
+        d = len(self.ell)
+        W = rng.randn(n, d)
+        if self.kernel != 'se':
+            nu = {'matern5': 2.5, 'matern3': 1.5, 'matern1': 0.5}[self.kernel]
+            u = rng.chisquare(2.0 * nu, size=n)
+            W = W * np.sqrt(2.0 * nu / u)[:, None]
+        W = W / self.ell
+        b = rng.rand(n) * 2.0 * np.pi
+        z = rng.randn(n)
+        sc = np.sqrt(2.0 * self.rho / n)
+        if self.ndata == 0:
+            return RFFSampleDevice(self, W, b, sc * z)
+        A, v = self._engine().rff_gram(W, b)
+        Am = (sc * sc) * A + self.sn2 * np.eye(n)
+        L = np.linalg.cholesky(Am)
+        mean = np.linalg.solve(L.T, np.linalg.solve(L, sc * v))
+        noise = np.sqrt(self.sn2) * np.linalg.solve(L.T, z)
+        return RFFSampleDevice(self, W, b, sc * (mean + noise))
+
+
+def make_gp(sn2, rho, ell, bias=0.0, kernel='se', device=0):
+    """`reggie.make_gp(sn2, rho, ell, bias)` (pybo/bayesopt.py:105) plus kernel family and device."""
+    return GP(sn2, rho, ell, bias, kernel, device)

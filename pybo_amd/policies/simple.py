@@ -1,0 +1,73 @@
+"""
+Acquisition policies EI / PI / UCB / Thompson with pybo's signatures
+`policy(model, bounds, X, **kw[, rng]) -> index`, `index(X, grad=False)`
+(/root/reference/pybo/policies/simple.py:16-74).  Behaviour kept on purpose:
+
+  * EI / PI copy the model, then take `target = max posterior mean at the observed X + xi`
+    (simple.py:20-21, 34-35) -- one `model.predict(X)` per policy call;
+  * UCB's `d` is the NUMBER OF OBSERVATIONS len(X), not the input dimension (simple.py:58-60):
+    beta = xi*2*log(pi^2/(3 delta)) + xi*(4+N)*log(N+1);
+  * Thompson returns ONE posterior function sample's `.get` (simple.py:48); `n` is the number of random
+    Fourier features.
+
+New: when the model is the device-backed `pybo_amd.models.GP`, the returned index also carries
+`index.topk(xgrid, k)` -- the whole-grid evaluation + top-k done on the GPU in one call -- which
+`pybo_amd.solvers.solve_lbfgs` uses instead of `argsort(f(xgrid))` (pybo/solvers/lbfgs.py:50-51).
+Any other model (e.g. a test stub) gets plain closures, exactly as in the reference.
+"""
+import numpy as np
+
+__all__ = ['EI', 'PI', 'UCB', 'Thompson']
+
+
+def _attach_topk(index, model, kind, param):
+    fast = getattr(model, 'acq_topk', None)
+    if fast is not None:
+        index.topk = lambda xgrid, k: fast(kind, param, xgrid, k)
+    return index
+
+
+def EI(model, _, X, xi=0.0):
+    """Expected improvement over (best posterior mean at the data) + xi."""
+    model = model.copy()
+    target = model.predict(X)[0].max() + xi
+
+    def index(X, grad=False):
+        return model.get_improvement(target, X, grad)
+
+    return _attach_topk(index, model, 'ei', target)
+
+
+def PI(model, _, X, xi=0.05):
+    """Probability of improvement over (best posterior mean at the data) + xi."""
+    model = model.copy()
+    target = model.predict(X)[0].max() + xi
+
+    def index(X, grad=False):
+        return model.get_tail(target, X, grad)
+
+    return _attach_topk(index, model, 'pi', target)
+
+
+def Thompson(model, _, __, n=100, rng=None):
+    """Thompson sampling: the index is one posterior function sample (n random features)."""
+    return model.sample_f(n, rng).get
+
+
+def UCB(model, _, X, delta=0.1, xi=0.2):
+    """GP-UCB; `delta` = failure probability of the bound, `xi` scales the exploration term."""
+    model = model.copy()
+    nobs = len(X)
+    a = xi * 2 * np.log(np.pi ** 2 / 3 / delta)
+    b = xi * (4 + nobs)
+    beta = a + b * np.log(nobs + 1)
+
+    def index(X, grad=False):
+        post = model.predict(X, grad=grad)
+        mu, s2 = post[:2]
+        if not grad:
+            return mu + np.sqrt(beta * s2)
+        dmu, ds2 = post[2:]
+        return mu + np.sqrt(beta * s2), dmu + 0.5 * np.sqrt(beta / s2[:, None]) * ds2
+
+    return _attach_topk(index, model, 'ucb', beta)

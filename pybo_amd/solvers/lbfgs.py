@@ -1,0 +1,58 @@
+"""
+Grid sweep + multi-start L-BFGS-B, the solver plugin of pybo
+(/root/reference/pybo/solvers/lbfgs.py:17-68): evaluate the index on a candidate grid in ONE batched
+call, keep the `nbest` best grid points, refine each with L-BFGS-B on the negated index.
+
+Kept from the reference:
+  * default grid = `init_uniform(bounds, ngrid, rng)` (lbfgs.py:45), a user grid through `xgrid=`;
+  * the refinement loop and its negation convention (lbfgs.py:56-62, 68);
+  * SELECTION: the reference picks `result[np.argmin(<generator>)]`, which is always `result[0]`
+    (lbfgs.py:65) -- i.e. the refinement started from the single best grid point.
+    `select='first'` (default) reproduces that; `select='best'` returns the best refined value.
+Changed:
+  * if the index carries `.topk(xgrid, k)` (device-backed models) the grid evaluation and the top-k run
+    on the GPU and only k (value, index) pairs come back; otherwise `f(xgrid)` is ranked on the host
+    with a deterministic order (value descending, then index ascending -- the reference's
+    `argsort(finit)[::-1]` leaves ties unspecified).
+"""
+import numpy as np
+import scipy.optimize
+
+from ..inits import init_uniform
+
+__all__ = ['solve_lbfgs']
+
+
+def _rank_host(finit, k):
+    v = np.where(np.isnan(finit), -np.inf, finit)
+    order = np.lexsort((np.arange(len(v)), -v))
+    return order[:k]
+
+
+def solve_lbfgs(f, bounds, nbest=10, ngrid=10000, xgrid=None, rng=None, select='first'):
+    """Maximise f over the box; returns (xmax, fmax)."""
+    bounds = np.array(bounds, dtype=float, ndmin=2)
+    if xgrid is None:
+        xgrid = init_uniform(bounds, ngrid, rng)
+    else:
+        xgrid = np.array(xgrid, ndmin=2, dtype=float)
+
+    topk = getattr(f, 'topk', None)
+    k = min(int(nbest), len(xgrid))
+    if topk is not None:
+        _, best = topk(xgrid, k)
+        best = np.asarray(best, dtype=int)
+    else:
+        best = _rank_host(np.asarray(f(xgrid, grad=False)), k)
+
+    def negated(x):
+        fx, gx = f(x[None], grad=True)
+        return -fx[0], -gx[0]
+
+    result = [scipy.optimize.fmin_l_bfgs_b(negated, x0, bounds=bounds)[:2] for x0 in xgrid[best]]
+
+    if select == 'best':
+        xmin, fmin = min(result, key=lambda r: r[1])
+    else:
+        xmin, fmin = result[0]
+    return xmin, -fmin

@@ -1,0 +1,37 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def _have_gpu():
+    try:
+        from pybo_amd import _lib
+        import ctypes as C
+        lib = _lib.load()
+        h = C.c_void_p()
+        if lib.gpx_create(0, None, C.byref(h)) == 0:
+            lib.gpx_destroy(h)
+            return True
+    except Exception:
+        pass
+    return False
+
+
+@pytest.fixture(scope='session')
+def gpu_available():
+    return _have_gpu()
+
+
+def pytest_collection_modifyitems(config, items):
+    # `-m gpu` on a box without a GPU (or without the built library) must FAIL loudly, not skip:
+    # a silent skip would read as "parity green".  So nothing is auto-skipped here.
+    pass

@@ -1,0 +1,99 @@
+"""Shared test helpers: the deterministic stub model the golden vectors were captured with
+(tests/golden/make_golden.py defines the same formulas), analytic indices, synthetic problems."""
+import numpy as np
+
+
+class StubModel(object):
+    def __init__(self, log=None):
+        self.log = [] if log is None else log
+
+    def copy(self):
+        self.log.append('copy')
+        return StubModel(self.log)
+
+    @staticmethod
+    def moments(X):
+        X = np.array(X, ndmin=2, dtype=float)
+        t = X.sum(axis=1)
+        mu = np.sin(1.7 * t) + 0.3 * t
+        s2 = 0.2 + 0.1 * np.cos(0.9 * t) ** 2
+        dmu = np.repeat((1.7 * np.cos(1.7 * t) + 0.3)[:, None], X.shape[1], axis=1)
+        ds2 = np.repeat((-0.18 * np.cos(0.9 * t) * np.sin(0.9 * t))[:, None], X.shape[1], axis=1)
+        return mu, s2, dmu, ds2
+
+    def predict(self, X, grad=False):
+        self.log.append('predict:%d' % int(bool(grad)))
+        m = self.moments(X)
+        return m if grad else m[:2]
+
+    def get_improvement(self, target, X, grad=False):
+        self.log.append('get_improvement:%d' % int(bool(grad)))
+        mu = self.moments(X)[0]
+        out = mu - target
+        return (out, np.ones_like(np.array(X, ndmin=2, dtype=float))) if grad else out
+
+    def get_tail(self, target, X, grad=False):
+        self.log.append('get_tail:%d' % int(bool(grad)))
+        mu = self.moments(X)[0]
+        out = 1.0 / (1.0 + np.exp(-(mu - target)))
+        return (out, np.ones_like(np.array(X, ndmin=2, dtype=float))) if grad else out
+
+
+def analytic_index(kind):
+    if kind == 'bimodal2':
+        c1, c2 = np.array([0.8, 0.8]), np.array([0.25, 0.3])
+
+        def f(X, grad=False):
+            X = np.array(X, ndmin=2, dtype=float)
+            e1 = 2.0 * np.exp(-8.0 * ((X - c1) ** 2).sum(1))
+            e2 = 1.5 * np.exp(-6.0 * ((X - c2) ** 2).sum(1))
+            v = e1 + e2
+            if not grad:
+                return v
+            g = e1[:, None] * (-16.0 * (X - c1)) + e2[:, None] * (-12.0 * (X - c2))
+            return v, g
+        return f, np.array([[0.0, 1.0], [0.0, 1.0]])
+    if kind == 'tilted1':
+        def f(X, grad=False):
+            X = np.array(X, ndmin=2, dtype=float)
+            x = X[:, 0]
+            v = np.sin(3.0 * x) + 0.5 * x
+            if not grad:
+                return v
+            return v, (3.0 * np.cos(3.0 * x) + 0.5)[:, None]
+        return f, np.array([[0.0, 4.0]])
+    if kind == 'quad5':
+        c = np.array([0.3, -0.2, 0.6, 0.1, -0.5])
+
+        def f(X, grad=False):
+            X = np.array(X, ndmin=2, dtype=float)
+            v = -((X - c) ** 2 * np.arange(1, 6)).sum(1)
+            if not grad:
+                return v
+            return v, -2.0 * (X - c) * np.arange(1, 6)
+        return f, np.array([[-1.0, 1.0]] * 5)
+    raise KeyError(kind)
+
+
+def branin(X):
+    X = np.array(X, ndmin=2, dtype=float)
+    a, b, c, r, s, t = 1.0, 5.1 / (4 * np.pi ** 2), 5.0 / np.pi, 6.0, 10.0, 1.0 / (8 * np.pi)
+    return a * (X[:, 1] - b * X[:, 0] ** 2 + c * X[:, 0] - r) ** 2 + s * (1 - t) * np.cos(X[:, 0]) + s
+
+
+def synth_problem(N, d, seed=0, noise=1e-2):
+    """Smooth synthetic regression problem in the unit box with moderate conditioning."""
+    rng = np.random.RandomState(seed)
+    X = rng.rand(N, d)
+    y = np.sin(3.0 * X.sum(1)) + 0.5 * np.cos(5.0 * X[:, 0]) + noise * rng.randn(N)
+    ell = 0.3 + 0.2 * rng.rand(d)
+    return X, y, ell
+
+
+def s2_tol(s2_ref, rho):
+    """Stated tolerance for latent variances: |d| <= 1e-6*s2 + 1e-10*rho."""
+    return 1e-6 * np.abs(s2_ref) + 1e-10 * rho
+
+
+def mu_tol(mu_ref, rho):
+    return 1e-6 * np.abs(mu_ref) + 1e-9 * np.sqrt(rho)

@@ -1,0 +1,55 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol
+include/gpx.h declares, and fails LOUDLY when there is no GPU (no silent fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, 'include', 'gpx.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(gpx_[a-z_0-9]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from pybo_amd import _lib
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), 'libgpx.so does not export %s' % n
+    # and the binding table covers the header exactly
+    assert sorted(_lib.SYMBOLS) == names
+
+
+def test_version_and_loud_failure_without_gpu(gpu_available):
+    from pybo_amd import _lib
+    lib = _lib.load()
+    assert lib.gpx_version() >= 100
+    if gpu_available:
+        pytest.skip('a GPU is present; the no-GPU failure path is checked on CPU-only hosts')
+    h = C.c_void_p()
+    rc = lib.gpx_create(0, None, C.byref(h))
+    assert rc == _lib.GPX_EHIP and not h.value
+    assert b'no HIP device' in lib.gpx_last_error(None)
+    with pytest.raises(_lib.GpxError):
+        _lib.Engine(0)
+    # the model object has no CPU path either
+    from pybo_amd import models
+    gp = models.make_gp(1e-3, 1.0, [0.3, 0.3], 0.0)
+    with pytest.raises(_lib.GpxError):
+        gp.add_data(np.random.rand(4, 2), np.random.rand(4))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'pybo_amd')
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', txt, flags=re.M), f

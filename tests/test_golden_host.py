@@ -1,0 +1,152 @@
+"""Host-side plugin logic against golden vectors captured from the reference's own modules
+(tests/golden/make_golden.py imports /root/reference/pybo/{policies/simple,solvers/lbfgs,inits/methods,
+recommenders}.py in the build container; only the vectors travel)."""
+import os
+
+import numpy as np
+import pytest
+
+from pybo_amd import bayesopt, inits, policies, recommenders, solvers
+from helpers import StubModel, analytic_index
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def test_inits_match_reference_bit_for_bit():
+    g = np.load(os.path.join(G, 'inits.npz'))
+    b2 = [[0.0, 1.0], [2.0, 4.0]]
+    b3 = [[-5.0, 10.0], [0.0, 15.0], [1.0, 3.0]]
+    assert np.array_equal(inits.init_middle(b2), g['middle_b2'])
+    assert np.array_equal(inits.init_middle(b3), g['middle_b3'])
+    for name, bounds in (('b2', b2), ('b3', b3)):
+        for seed in (0, 7):
+            for n in (None, 5, 64):
+                key = '%s_s%d_n%s' % (name, seed, n)
+                assert np.array_equal(inits.init_uniform(bounds, n, seed), g['uniform_' + key]), key
+                assert np.array_equal(inits.init_latin(bounds, n, seed), g['latin_' + key]), key
+
+
+def test_init_sobol_is_a_valid_low_discrepancy_design():
+    # by design NOT the reference's LGPL generator (candidates are an input of the hot path)
+    b3 = np.array([[-5.0, 10.0], [0.0, 15.0], [1.0, 3.0]])
+    X = inits.init_sobol(b3, 64, 0)
+    assert X.shape == (64, 3)
+    assert np.all(X >= b3[:, 0]) and np.all(X <= b3[:, 1])
+    u = (X - b3[:, 0]) / (b3[:, 1] - b3[:, 0])
+    # 64 consecutive Sobol points put exactly 16 in each quarter of every axis... up to the skip
+    # offset; check balance loosely
+    for k in range(3):
+        h, _ = np.histogram(u[:, k], bins=4, range=(0, 1))
+        assert h.min() >= 12 and h.max() <= 20
+    assert inits.init_sobol(b3, None, 1).shape == (9, 3)
+
+
+@pytest.mark.parametrize('pname,kw', [('EI', {}), ('EI', {'xi': 0.25}), ('PI', {}), ('PI', {'xi': 0.3}),
+                                      ('UCB', {}), ('UCB', {'delta': 0.05, 'xi': 0.7})])
+def test_policies_match_reference(pname, kw):
+    g = np.load(os.path.join(G, 'policies.npz'))
+    Xobs = [x for x in g['Xobs']]
+    Xq = g['Xq']
+    stub = StubModel()
+    index = getattr(policies, pname)(stub, None, Xobs, **kw)
+    tag = pname + ''.join('_%s%g' % kv for kv in sorted(kw.items()))
+    v = index(Xq)
+    v2, gr = index(Xq, grad=True)
+    np.testing.assert_allclose(v, g[tag + '_val'], rtol=1e-15, atol=0)
+    np.testing.assert_allclose(v2, g[tag + '_val_g'], rtol=1e-15, atol=0)
+    np.testing.assert_allclose(gr, g[tag + '_grad'], rtol=1e-15, atol=0)
+    # same protocol calls in the same order (copy -> predict(X_obs) -> index calls)
+    assert '|'.join(stub.log) == str(g[tag + '_log'])
+
+
+def test_ucb_beta_uses_number_of_observations():
+    g = np.load(os.path.join(G, 'policies.npz'))
+    beta = 0.2 * 2 * np.log(np.pi ** 2 / 0.3) + 0.2 * 7 * np.log(4.0)      # SURVEY F7, N = 3
+    assert abs(beta - 3.3381851359777412) < 1e-14
+    assert abs(float(g['UCB_beta_N3']) - beta) < 1e-12
+    stub = StubModel()
+    Xq = g['Xq'][:, :2]
+    idx = policies.UCB(stub, None, [np.zeros(2)] * 3)
+    mu, s2 = StubModel.moments(Xq)[:2]
+    np.testing.assert_allclose((idx(Xq) - mu) ** 2 / s2, beta, rtol=1e-12)
+
+
+@pytest.mark.parametrize('kind', ['bimodal2', 'tilted1', 'quad5'])
+def test_solver_selection_matches_reference(kind):
+    g = np.load(os.path.join(G, 'solver.npz'))
+    f, bounds = analytic_index(kind)
+    d = len(bounds)
+    for nbest in (1, 3, 10):
+        grid = bounds[:, 0] + (bounds[:, 1] - bounds[:, 0]) * np.random.RandomState(11).rand(200, d)
+        x, fx = solvers.solve_lbfgs(f, bounds, nbest=nbest, xgrid=grid)
+        np.testing.assert_allclose(x, g['%s_nb%d_x' % (kind, nbest)], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(fx, g['%s_nb%d_f' % (kind, nbest)], rtol=1e-12)
+    x, fx = solvers.solve_lbfgs(f, bounds, nbest=4, ngrid=500, rng=5)
+    np.testing.assert_allclose(x, g['%s_rng5_x' % kind], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(fx, g['%s_rng5_f' % kind], rtol=1e-12)
+
+
+def test_solver_reference_selection_quirk_and_fix():
+    # F6: the reference returns the refinement of the single best grid point; with a grid whose best
+    # point sits in the basin of the LOWER peak, 'first' and 'best' differ.
+    f, bounds = analytic_index('bimodal2')
+    grid = np.array([[0.25, 0.3], [0.6, 0.6], [0.1, 0.9]])       # best grid value is at the minor peak
+    x1, f1 = solvers.solve_lbfgs(f, bounds, nbest=3, xgrid=grid)
+    x2, f2 = solvers.solve_lbfgs(f, bounds, nbest=3, xgrid=grid, select='best')
+    assert f2 >= f1
+    np.testing.assert_allclose(x2, [0.8, 0.8], atol=2e-2)
+    np.testing.assert_allclose(x1, [0.25, 0.3], atol=5e-2)
+
+
+def test_solver_uses_device_topk_hook_when_present():
+    f, bounds = analytic_index('bimodal2')
+    calls = []
+
+    def g(X, grad=False):
+        return f(X, grad)
+
+    def topk(xgrid, k):
+        calls.append((len(xgrid), k))
+        v = f(xgrid)
+        order = np.lexsort((np.arange(len(v)), -v))[:k]
+        return v[order], order
+    g.topk = topk
+    grid = np.random.RandomState(0).rand(300, 2)
+    xa, fa = solvers.solve_lbfgs(g, bounds, nbest=5, xgrid=grid)
+    xb, fb = solvers.solve_lbfgs(f, bounds, nbest=5, xgrid=grid)
+    assert calls == [(300, 5)]
+    np.testing.assert_allclose(xa, xb)
+    np.testing.assert_allclose(fa, fb)
+
+
+def test_recommenders_match_reference():
+    g = np.load(os.path.join(G, 'recommenders.npz'))
+    Xobs = g['Xobs']
+    bounds = np.array([[0.0, 1.0]] * 3)
+    np.testing.assert_array_equal(recommenders.best_incumbent(StubModel(), bounds, Xobs), g['incumbent'])
+    np.testing.assert_allclose(recommenders.best_latent(StubModel(), bounds, Xobs), g['latent'], atol=1e-12)
+
+
+def test_get_component_resolution_table():
+    rng = np.random.RandomState(0)
+    gc = bayesopt.get_component
+    assert gc('ei', policies, rng) is policies.EI
+    assert gc('ucb', policies, rng) is policies.UCB
+    th = gc('thompson', policies, rng)                 # has an rng argument -> partial with rng injected
+    assert th.func is policies.Thompson and th.keywords == {'rng': rng}
+    s = gc(('lbfgs', {'nbest': 3}), solvers, rng, lstrip='solve_')
+    assert s.func is solvers.solve_lbfgs and s.keywords == {'nbest': 3, 'rng': rng}
+    assert gc('latent', recommenders, rng, lstrip='best_') is recommenders.best_latent
+    assert gc('incumbent', recommenders, rng, lstrip='best_') is recommenders.best_incumbent
+    f = lambda model, bounds, X: None                   # noqa: E731  any callable passes through
+    assert gc(f, policies, rng) is f
+    with pytest.raises(ValueError):
+        gc('nope', policies, rng)
+    with pytest.raises(ValueError):
+        gc(('ei', {'bogus': 1}), policies, rng)
+    with pytest.raises(ValueError):
+        gc(('thompson', {'rng': 1}), policies, rng)     # rng is never a user kwarg
+    with pytest.raises(ValueError):
+        gc(('ei', 1, 2), policies, rng)
+    with pytest.raises(ValueError):
+        gc('EI', policies, rng)                         # names are lower-case, as in the reference

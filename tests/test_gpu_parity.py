@@ -1,0 +1,321 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on the same seeded inputs.
+Tolerances are the stated ones:
+    L:   |L L^T - K|_F / |K|_F <= 1e-13        mu: |d| <= 1e-6 |mu| + 1e-9 sqrt(rho)
+    s2:  |d| <= 1e-6 s2 + 1e-10 rho            acquisition: 1e-6 relative where value > 1e-12 max
+    selected index identical on tie-free inputs.
+"""
+import pickle
+
+import numpy as np
+import pytest
+
+from oracle import gp_ref
+from helpers import synth_problem, s2_tol, mu_tol, branin
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = ['se', 'matern5', 'matern3', 'matern1']
+
+
+def _engine(**opts):
+    from pybo_amd._lib import Engine
+    e = Engine(0)
+    for k, v in opts.items():
+        e.set_option(k, v)
+    return e
+
+
+def _pair(N, d, kernel='se', sn2=1e-3, rho=1.3, bias=0.2, seed=0, **opts):
+    X, y, ell = synth_problem(N, d, seed=seed)
+    ref = gp_ref.make_gp(sn2, rho, ell, bias, kernel)
+    ref.add_data(X, y)
+    e = _engine(**opts)
+    e.fit(X, y, kernel, ell, rho, sn2, bias)
+    return e, ref, (X, y, ell, rho, sn2, bias)
+
+
+# ---- fit ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('N,d', [(1, 1), (7, 2), (64, 6), (128, 3), (129, 1), (257, 8), (700, 32), (2048, 2)])
+@pytest.mark.parametrize('kernel', ['se', 'matern5'])
+def test_fit_stages_match_oracle(N, d, kernel):
+    X, y, ell = synth_problem(N, d, seed=N)
+    sn2, rho, bias = 1e-3, 1.3, 0.2
+    ref = gp_ref.make_gp(sn2, rho, ell, bias, kernel)
+    ref.add_data(X, y)
+    Kref = ref.gram()
+    e = _engine()
+    e.fit(X, y, kernel, ell, rho, sn2, bias, stage=1)
+    K = e.get_matrix('K')
+    np.testing.assert_allclose(K, np.triu(Kref), rtol=1e-14, atol=1e-15)
+    e.fit(X, y, kernel, ell, rho, sn2, bias, stage=2)
+    L = e.get_matrix('L')
+    assert np.linalg.norm(L @ L.T - Kref) / np.linalg.norm(Kref) <= 1e-13
+    assert np.allclose(L, np.tril(L))
+    np.testing.assert_allclose(L, ref.L, rtol=0, atol=1e-9 * np.abs(ref.L).max())
+    e.fit(X, y, kernel, ell, rho, sn2, bias)
+    T = e.get_matrix('T')
+    assert np.allclose(T, np.tril(T))
+    assert np.max(np.abs(T @ L - np.eye(N))) < 1e-9
+    a, alpha = e.get_vectors()
+    np.testing.assert_allclose(a, ref.a, rtol=0, atol=1e-9 * max(np.abs(ref.a).max(), 1e-300))
+    np.testing.assert_allclose(alpha, ref.alpha(), rtol=0, atol=1e-8 * max(np.abs(ref.alpha()).max(), 1e-300))
+    mo, mx = e.mean_at_obs()
+    np.testing.assert_allclose(mo, ref.predict(X)[0], rtol=0, atol=1e-8)
+    assert mx == mo.max()
+    e.close()
+
+
+def test_refit_with_different_sizes_reuses_the_handle():
+    e = _engine()
+    for N, d in [(300, 3), (50, 3), (513, 2), (300, 5)]:
+        X, y, ell = synth_problem(N, d, seed=N + d)
+        ref = gp_ref.make_gp(1e-3, 1.0, ell, 0.0)
+        ref.add_data(X, y)
+        e.fit(X, y, 'se', ell, 1.0, 1e-3, 0.0)
+        Z = np.random.RandomState(1).rand(77, d)
+        mu, s2 = e.predict(Z)
+        mr, sr = ref.predict(Z)
+        assert np.all(np.abs(mu - mr) <= mu_tol(mr, 1.0))
+        assert np.all(np.abs(s2 - sr) <= s2_tol(sr, 1.0))
+    e.close()
+
+
+def test_not_positive_definite_reports_pivot():
+    from pybo_amd._lib import GpxError
+    X, y, ell = synth_problem(40, 2, seed=3)
+    X = np.vstack([X, X[:5]])          # duplicated rows and no noise: singular
+    y = np.hstack([y, y[:5]])
+    e = _engine()
+    with pytest.raises(np.linalg.LinAlgError):
+        e.fit(X, y, 'se', ell, 1.0, 0.0, 0.0)
+    assert 40 <= e.fail_pivot() < 45
+    with pytest.raises(GpxError):      # nothing usable is left behind
+        e.sweep('mean', None, X[:3], k=0)
+    # the handle recovers
+    e.fit(X, y, 'se', ell, 1.0, 1e-3, 0.0)
+    assert e.fail_pivot() == -1
+    e.close()
+
+
+def test_argument_errors():
+    from pybo_amd._lib import GpxError, GPX_EARG, GPX_ESTATE
+    e = _engine()
+    X, y, ell = synth_problem(10, 2)
+    with pytest.raises(GpxError) as ei:
+        e.sweep('ei', 0.0, X, k=1)
+    assert ei.value.code == GPX_ESTATE
+    for bad in [dict(rho=-1.0), dict(sn2=-1e-3), dict(ell=[0.1, -0.2])]:
+        kw = dict(rho=1.0, sn2=1e-3, ell=ell)
+        kw.update(bad)
+        with pytest.raises(GpxError) as ei:
+            e.fit(X, y, 'se', kw['ell'], kw['rho'], kw['sn2'], 0.0)
+        assert ei.value.code == GPX_EARG
+    e.fit(X, y, 'se', ell, 1.0, 1e-3, 0.0)
+    with pytest.raises(GpxError):
+        e.sweep('ei', 0.0, X, k=65)
+    with pytest.raises(GpxError):
+        e.set_option('chunk', 100)
+    e.close()
+
+
+# ---- sweep ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize('kernel', KERNELS)
+@pytest.mark.parametrize('N,d,M', [(7, 1, 1), (64, 2, 63), (257, 6, 4096), (1000, 8, 777)])
+def test_posterior_moments_match_oracle(kernel, N, d, M):
+    e, ref, (X, y, ell, rho, sn2, bias) = _pair(N, d, kernel, seed=N + M)
+    Z = np.random.RandomState(M).rand(M, d)
+    mu, s2 = e.predict(Z)
+    mr, sr = ref.predict(Z)
+    assert np.all(np.abs(mu - mr) <= mu_tol(mr, rho))
+    assert np.all(np.abs(s2 - sr) <= s2_tol(sr, rho))
+    assert np.all(s2 > 0) and np.all(s2 <= rho * (1 + 1e-12))
+    e.close()
+
+
+@pytest.mark.parametrize('opts', [dict(chunk=128), dict(chunk=256, tile_order=1), dict(chunk=65536, tile_order=1)])
+def test_chunking_and_tile_order_do_not_change_results(opts):
+    e0, ref, (X, y, ell, rho, sn2, bias) = _pair(300, 3, 'matern5', seed=5)
+    e1 = _engine(**opts)
+    e1.fit(X, y, 'matern5', ell, rho, sn2, bias)
+    Z = np.random.RandomState(1).rand(1000, 3)
+    r0 = e0.sweep('ei', 0.5, Z, k=10, want_moments=True)
+    r1 = e1.sweep('ei', 0.5, Z, k=10, want_moments=True)
+    for key in ('acq', 'mu', 's2', 'top_val'):
+        assert np.array_equal(r0[key], r1[key]), key         # bitwise: fixed reduction order
+    assert np.array_equal(r0['top_idx'], r1['top_idx'])
+    e0.close()
+    e1.close()
+
+
+@pytest.mark.parametrize('acq', ['ei', 'pi', 'ucb', 'mean'])
+def test_acquisition_values_and_topk(acq):
+    e, ref, (X, y, ell, rho, sn2, bias) = _pair(400, 4, 'se', seed=11)
+    Z = np.random.RandomState(2).rand(5000, 4)
+    mr, sr = ref.predict(Z)
+    target = ref.mean_at_obs().max() + 0.01
+    beta = 3.7
+    param = {'ei': target, 'pi': target, 'ucb': beta, 'mean': None}[acq]
+    want = {'ei': ref.get_improvement(target, Z), 'pi': ref.get_tail(target, Z),
+            'ucb': mr + np.sqrt(beta * sr), 'mean': mr}[acq]
+    r = e.sweep(acq, param, Z, k=10)
+    got = r['acq']
+    big = np.abs(want) > 1e-12 * np.abs(want).max()
+    np.testing.assert_allclose(got[big], want[big], rtol=1e-6)
+    # the device top-k is exactly the ranking of the device's own values ...
+    np.testing.assert_array_equal(r['top_idx'], gp_ref.topk_desc(got, 10))
+    np.testing.assert_array_equal(r['top_val'], got[r['top_idx']])
+    # ... and on this tie-free input it is the oracle's selection too
+    order = gp_ref.topk_desc(want, 11)
+    gaps = np.abs(np.diff(want[order])) / np.abs(want[order[:-1]])
+    if np.all(gaps > 1e-5):
+        np.testing.assert_array_equal(r['top_idx'], order[:10])
+    else:
+        assert r['top_idx'][0] == order[0]
+    e.close()
+
+
+def test_topk_edge_cases():
+    e, ref, (X, y, ell, rho, sn2, bias) = _pair(50, 2, seed=2)
+    Z = np.random.RandomState(3).rand(5, 2)
+    r = e.sweep('mean', None, Z, k=8)                  # k > M: the tail is (-inf, -1)
+    assert np.array_equal(r['top_idx'][:5], gp_ref.topk_desc(r['acq'], 5))
+    assert np.all(r['top_idx'][5:] == -1) and np.all(np.isneginf(r['top_val'][5:]))
+    # ties: duplicated candidates -> lower index first
+    Zt = np.vstack([Z[2], Z[2], Z[2], Z[0]])
+    r = e.sweep('mean', None, Zt, k=4)
+    v = r['acq']
+    assert v[0] == v[1] == v[2]
+    np.testing.assert_array_equal(r['top_idx'], gp_ref.topk_desc(v, 4))
+    # many blocks (> 4096 candidates per block) and k = 64
+    Zb = np.random.RandomState(4).rand(20000, 2)
+    r = e.sweep('ucb', 2.0, Zb, k=64)
+    np.testing.assert_array_equal(r['top_idx'], gp_ref.topk_desc(r['acq'], 64))
+    e.close()
+
+
+@pytest.mark.parametrize('kernel', ['se', 'matern5', 'matern3'])
+def test_predict_with_gradients(kernel):
+    e, ref, (X, y, ell, rho, sn2, bias) = _pair(300, 5, kernel, seed=21)
+    Z = np.random.RandomState(6).rand(19, 5)          # > one batch of 8
+    mu, s2, dmu, ds2 = e.predict(Z, grad=True)
+    mr, sr, dmr, dsr = ref.predict(Z, grad=True)
+    assert np.all(np.abs(mu - mr) <= mu_tol(mr, rho))
+    assert np.all(np.abs(s2 - sr) <= s2_tol(sr, rho))
+    np.testing.assert_allclose(dmu, dmr, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(ds2, dsr, rtol=1e-6, atol=1e-8)
+    e.close()
+
+
+# ---- Thompson / RFF -------------------------------------------------------------------------------
+@pytest.mark.parametrize('kernel', ['se', 'matern5'])
+def test_rff_paths_match_oracle(kernel):
+    e, ref, (X, y, ell, rho, sn2, bias) = _pair(200, 3, kernel, seed=31)
+    kid = gp_ref.KERNEL_IDS[kernel]
+    S, n = 3, 100
+    Ws, bs, ths, samples = [], [], [], []
+    for s in range(S):
+        smp = ref.sample_f(n, rng=100 + s)
+        samples.append(smp)
+        Ws.append(smp.W); bs.append(smp.b); ths.append(smp.theta)
+    # feature Gram on the device vs numpy
+    C = np.cos(X @ Ws[0].T + bs[0])
+    A, v = e.rff_gram(Ws[0], bs[0])
+    np.testing.assert_allclose(A, C.T @ C, rtol=1e-11, atol=1e-10)
+    np.testing.assert_allclose(v, C.T @ (y - bias), rtol=1e-11, atol=1e-10)
+    # evaluation sweep, S draws at once, with per-draw top-k
+    Z = np.random.RandomState(8).rand(3000, 3)
+    r = e.rff_sweep(np.array(Ws), np.array(bs), np.array(ths), bias, Z, k=5)
+    for s in range(S):
+        want = samples[s].get(Z)
+        np.testing.assert_allclose(r['vals'][s], want, rtol=1e-9, atol=1e-10)
+        np.testing.assert_array_equal(r['top_idx'][s], gp_ref.topk_desc(r['vals'][s], 5))
+        assert r['top_idx'][s][0] == int(np.argmax(want))
+    f, g = e.rff_eval_grad(Ws[1], bs[1], ths[1], bias, Z[:7])
+    fr, gr = samples[1].get(Z[:7], grad=True)
+    np.testing.assert_allclose(f, fr, rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(g, gr, rtol=1e-9, atol=1e-10)
+    e.close()
+
+
+# ---- the model object behind pybo's protocol ---------------------------------------------------------
+def test_model_protocol_matches_oracle_and_is_copy_on_write():
+    from pybo_amd import models
+    X, y, ell = synth_problem(150, 2, seed=41)
+    sn2, rho, bias = 1e-3, 1.1, 0.1
+    gp = models.make_gp(sn2, rho, ell, bias, kernel='matern5')
+    ref = gp_ref.make_gp(sn2, rho, ell, bias, 'matern5')
+    gp.add_data(X[:100], y[:100]); ref.add_data(X[:100], y[:100])
+    gp.add_data(X[100:], y[100:]); ref.add_data(X[100:], y[100:])       # incremental, as the BO loop does
+    gp.add_data(X[0] + 0.01, 0.3); ref.add_data(X[0] + 0.01, 0.3)       # single point, 1-d input
+    Z = np.random.RandomState(1).rand(300, 2)
+    for grad in (False, True):
+        got, want = gp.predict(Z[:20], grad), ref.predict(Z[:20], grad)
+        for a, b in zip(got, want):
+            np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-8)
+        for name in ('get_improvement', 'get_tail'):
+            got, want = getattr(gp, name)(0.6, Z[:20], grad), getattr(ref, name)(0.6, Z[:20], grad)
+            if grad:
+                for a, b in zip(got, want):
+                    np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-8)
+            else:
+                np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-10)
+    # predict at the training inputs takes the closed-form branch: same answer as the generic one
+    mu_c, s2_c = gp.predict(gp.data[0])
+    mu_g, s2_g = ref.predict(ref.X)
+    np.testing.assert_allclose(mu_c, mu_g, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(s2_c, s2_g, rtol=1e-6, atol=1e-10 * rho)
+    # copies share the device state until one of them changes
+    c = gp.copy()
+    assert c._state is gp._state and gp._state.nrefs == 2
+    before = gp.predict(Z[:5])[0]
+    c.add_data(Z[0], 5.0)
+    assert c._state is not gp._state and c.ndata == gp.ndata + 1
+    np.testing.assert_array_equal(gp.predict(Z[:5])[0], before)
+    rc = ref.copy()
+    rc.add_data(Z[0], 5.0)
+    np.testing.assert_allclose(c.predict(Z[:3])[0], rc.predict(Z[:3])[0], rtol=1e-6, atol=1e-8)
+    del c
+    import gc
+    gc.collect()
+    # the released engine is pooled and reused, never a closed one
+    c2 = gp.copy()
+    c2.add_data(Z[1], -1.0)
+    assert c2._state.engine._h
+    # thompson: same rng -> same draw as the oracle's definition
+    s_dev, s_ref = gp.sample_f(64, rng=7), ref.sample_f(64, rng=7)
+    np.testing.assert_allclose(s_dev.theta, s_ref.theta, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(s_dev.get(Z), s_ref.get(Z), rtol=1e-7, atol=1e-8)
+    fa, ga = s_dev.get(Z[:3], grad=True)
+    fb, gb = s_ref.get(Z[:3], grad=True)
+    np.testing.assert_allclose(ga, gb, rtol=1e-6, atol=1e-8)
+    # pickling keeps hyper-parameters + data, not device handles
+    g2 = pickle.loads(pickle.dumps(gp))
+    assert g2._state is None and g2.ndata == gp.ndata
+    np.testing.assert_array_equal(g2.predict(Z[:5])[0], before)
+    g2.params['kern.rho'].set_prior('lognormal', 0.0, 1.0)
+    assert pickle.loads(pickle.dumps(g2)).params['kern.rho'].prior[0] == 'lognormal'
+
+
+@pytest.mark.parametrize('policy', ['ei', 'pi', 'ucb', 'thompson'])
+def test_bo_loop_selects_the_same_points_as_the_cpu_path(policy):
+    """solve_bayesopt with the device model vs the same loop driven by the oracle model: identical
+    plugins, seeds and candidate grids -> the same queried points (within L-BFGS tolerance)."""
+    from pybo_amd import models, solve_bayesopt
+    bounds = np.array([[-5.0, 10.0], [0.0, 15.0]])
+    f = lambda x: float(-branin(x)[0] / 10.0)           # noqa: E731
+    ell = 0.25 * (bounds[:, 1] - bounds[:, 0])
+    X0 = bounds[:, 0] + (bounds[:, 1] - bounds[:, 0]) * np.random.RandomState(0).rand(12, 2)
+    y0 = np.array([f(x) for x in X0])
+    out = {}
+    for name, mk in (('dev', models.make_gp), ('ref', gp_ref.make_gp)):
+        m = mk(1e-4, float(np.var(y0)), ell, float(np.mean(y0)))
+        m.add_data(X0, y0)
+        grid = bounds[:, 0] + (bounds[:, 1] - bounds[:, 0]) * np.random.RandomState(5).rand(4000, 2)
+        # the model already holds data, so seed the trace through the log-free path: niter small
+        xb, mm, info = solve_bayesopt(f, bounds, model=m, niter=4, policy=policy,
+                                      solver=('lbfgs', {'xgrid': grid, 'nbest': 5}),
+                                      recommender='incumbent', rng=3)
+        out[name] = info
+    np.testing.assert_allclose(out['dev'].x, out['ref'].x, rtol=0, atol=2e-4)
+    np.testing.assert_allclose(out['dev'].y, out['ref'].y, rtol=0, atol=2e-4)
+    np.testing.assert_allclose(out['dev'].xbest, out['ref'].xbest, rtol=0, atol=2e-4)

@@ -1,0 +1,173 @@
+"""Pins for the CPU restatement (oracle/gp_ref.py).  The reference offers no golden vectors for the GP
+arithmetic (it lives in the absent `reggie`), so the oracle is pinned by: analytic known answers, an
+independent implementation (scikit-learn), a long-double re-evaluation, finite-difference gradients and
+the statistical identity of the random-feature map.  PARITY AGAINST REGGIE ITSELF REMAINS UNPINNED."""
+import numpy as np
+import pytest
+import scipy.linalg as sla
+
+from oracle import gp_ref
+from helpers import synth_problem
+
+
+def test_single_observation_closed_form():
+    sn2, rho, ell, bias = 0.1, 2.0, [0.5], 0.3
+    gp = gp_ref.make_gp(sn2, rho, ell, bias)
+    gp.add_data([[0.2]], [1.1])
+    x = np.array([[0.2], [0.7], [5.0]])
+    k = rho * np.exp(-0.5 * ((x[:, 0] - 0.2) / 0.5) ** 2)
+    mu, s2 = gp.predict(x)
+    np.testing.assert_allclose(mu, bias + k * (1.1 - bias) / (rho + sn2), rtol=1e-14)
+    np.testing.assert_allclose(s2, rho - k * k / (rho + sn2), rtol=1e-13)
+    # far from the data the prior comes back
+    assert abs(mu[2] - bias) < 1e-12 and abs(s2[2] - rho) < 1e-12
+
+
+@pytest.mark.parametrize('kernel', ['se', 'matern5', 'matern3', 'matern1'])
+def test_interpolation_and_prior_limits(kernel):
+    X, y, ell = synth_problem(40, 2, seed=1, noise=0.0)
+    gp = gp_ref.make_gp(1e-10, 1.5, ell, 0.1, kernel)
+    gp.add_data(X, y)
+    mu, s2 = gp.predict(X)
+    np.testing.assert_allclose(mu, y, atol=1e-5)
+    assert np.all(s2 < 1e-6)
+    np.testing.assert_allclose(gp.mean_at_obs(), mu, atol=1e-7)
+    mu_far, s2_far = gp.predict(X + 100.0)
+    np.testing.assert_allclose(mu_far, 0.1, atol=1e-12)
+    np.testing.assert_allclose(s2_far, 1.5, atol=1e-12)
+
+
+@pytest.mark.parametrize('kernel,skl', [('se', 'rbf'), ('matern5', 2.5), ('matern3', 1.5), ('matern1', 0.5)])
+def test_against_sklearn(kernel, skl):
+    from sklearn.gaussian_process import GaussianProcessRegressor
+    from sklearn.gaussian_process.kernels import RBF, ConstantKernel, Matern
+    X, y, ell = synth_problem(120, 3, seed=2)
+    sn2, rho, bias = 1e-3, 1.7, 0.25
+    base = RBF(length_scale=ell) if skl == 'rbf' else Matern(length_scale=ell, nu=skl)
+    skm = GaussianProcessRegressor(ConstantKernel(rho) * base, alpha=sn2, optimizer=None)
+    skm.fit(X, y - bias)
+    Z = np.random.RandomState(9).rand(200, 3)
+    m_sk, sd_sk = skm.predict(Z, return_std=True)
+    gp = gp_ref.make_gp(sn2, rho, ell, bias, kernel)
+    gp.add_data(X, y)
+    mu, s2 = gp.predict(Z)
+    np.testing.assert_allclose(mu, m_sk + bias, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(s2, sd_sk ** 2, rtol=1e-6, atol=1e-9)
+
+
+def test_against_long_double():
+    X, y, ell = synth_problem(96, 2, seed=3)
+    sn2, rho, bias = 1e-4, 1.2, 0.0
+    gp = gp_ref.make_gp(sn2, rho, ell, bias)
+    gp.add_data(X, y)
+    Z = np.random.RandomState(5).rand(32, 2)
+    mu, s2 = gp.predict(Z)
+    ld = np.longdouble
+    Xl, Zl, elll = X.astype(ld) / ell.astype(ld), Z.astype(ld) / ell.astype(ld), None
+    def k(A, B):
+        r2 = ((A[:, None, :] - B[None, :, :]) ** 2).sum(-1)
+        return ld(rho) * np.exp(-r2 / 2)
+    K = k(Xl, Xl) + ld(sn2) * np.eye(96, dtype=ld)
+    # long-double Cholesky + substitution
+    L = np.zeros_like(K)
+    for j in range(96):
+        L[j, j] = np.sqrt(K[j, j] - (L[j, :j] ** 2).sum())
+        L[j + 1:, j] = (K[j + 1:, j] - L[j + 1:, :j] @ L[j, :j]) / L[j, j]
+    Ks = k(Xl, Zl)
+    V = np.zeros_like(Ks)
+    for i in range(96):
+        V[i] = (Ks[i] - L[i, :i] @ V[:i]) / L[i, i]
+    a = np.zeros(96, dtype=ld)
+    r = y.astype(ld)
+    for i in range(96):
+        a[i] = (r[i] - L[i, :i] @ a[:i]) / L[i, i]
+    mu_l = (V.T @ a).astype(float)
+    s2_l = (ld(rho) - (V * V).sum(0)).astype(float)
+    np.testing.assert_allclose(mu, mu_l, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(s2, s2_l, rtol=1e-7, atol=1e-12)
+
+
+def test_ei_pi_known_answers():
+    gp = gp_ref.make_gp(1e-2, 1.0, [0.4, 0.4], 0.0)
+    X, y, _ = synth_problem(30, 2, seed=4)
+    gp.add_data(X, y)
+    Z = np.random.RandomState(1).rand(50, 2)
+    mu, s2 = gp.predict(Z)
+    s = np.sqrt(s2)
+    # with target == mu:  EI = s / sqrt(2 pi),  PI = 1/2   (evaluate point by point)
+    for i in range(5):
+        ei = gp.get_improvement(mu[i], Z[i:i + 1])[0]
+        pi = gp.get_tail(mu[i], Z[i:i + 1])[0]
+        assert abs(ei - s[i] / np.sqrt(2 * np.pi)) < 1e-12
+        assert abs(pi - 0.5) < 1e-12
+    # EI >= max(mu - t, 0), monotone in target
+    t = 0.3
+    ei = gp.get_improvement(t, Z)
+    assert np.all(ei >= np.maximum(mu - t, 0) - 1e-15)
+    assert np.all(gp.get_improvement(t + 0.1, Z) <= ei + 1e-15)
+
+
+@pytest.mark.parametrize('kernel', ['se', 'matern5', 'matern3'])
+def test_gradients_by_finite_differences(kernel):
+    X, y, ell = synth_problem(60, 3, seed=6)
+    gp = gp_ref.make_gp(1e-3, 1.3, ell, 0.2, kernel)
+    gp.add_data(X, y)
+    Z = np.random.RandomState(2).rand(6, 3)
+    mu, s2, dmu, ds2 = gp.predict(Z, grad=True)
+    ei, dei = gp.get_improvement(0.4, Z, grad=True)
+    pi, dpi = gp.get_tail(0.4, Z, grad=True)
+    h = 1e-6
+    for j in range(3):
+        E = np.zeros(3)
+        E[j] = h
+        mp, sp = gp.predict(Z + E)
+        mm, sm = gp.predict(Z - E)
+        np.testing.assert_allclose(dmu[:, j], (mp - mm) / (2 * h), rtol=2e-6, atol=2e-8)
+        np.testing.assert_allclose(ds2[:, j], (sp - sm) / (2 * h), rtol=2e-5, atol=2e-8)
+        np.testing.assert_allclose(dei[:, j], (gp.get_improvement(0.4, Z + E) - gp.get_improvement(0.4, Z - E)) / (2 * h), rtol=2e-5, atol=2e-8)
+        np.testing.assert_allclose(dpi[:, j], (gp.get_tail(0.4, Z + E) - gp.get_tail(0.4, Z - E)) / (2 * h), rtol=2e-5, atol=2e-8)
+
+
+@pytest.mark.parametrize('kernel', ['se', 'matern5'])
+def test_rff_feature_map_approximates_the_kernel(kernel):
+    rng = np.random.RandomState(0)
+    ell = np.array([0.5, 0.8])
+    n = 40000
+    W, b = gp_ref.rff_draw_spectral(gp_ref.KERNEL_IDS[kernel], n, 2, ell, rng)
+    A = np.random.RandomState(1).rand(5, 2)
+    Phi = np.sqrt(2.0 / n) * np.cos(A @ W.T + b)
+    Kapprox = Phi @ Phi.T
+    K = gp_ref.kernel(gp_ref.KERNEL_IDS[kernel], A, A, ell, 1.0)
+    assert np.max(np.abs(Kapprox - K)) < 0.03
+
+
+def test_rff_posterior_sample_tracks_the_posterior_mean():
+    X, y, ell = synth_problem(50, 1, seed=8, noise=1e-2)
+    gp = gp_ref.make_gp(1e-4, 1.0, ell, 0.0)
+    gp.add_data(X, y)
+    Z = np.linspace(0.05, 0.95, 40)[:, None]
+    mu, s2 = gp.predict(Z)
+    draws = np.array([gp.sample_f(2000, rng=s).get(Z) for s in range(20)])
+    # inside the data the posterior is tight, every draw must be close to the mean
+    assert np.max(np.abs(draws.mean(0) - mu)) < 0.15
+    f, g = gp.sample_f(300, rng=3).get(Z[:4], grad=True)
+    fp = gp.sample_f(300, rng=3).get(Z[:4] + 1e-6)
+    fm = gp.sample_f(300, rng=3).get(Z[:4] - 1e-6)
+    np.testing.assert_allclose(g[:, 0], (fp - fm) / 2e-6, rtol=1e-5, atol=1e-7)
+
+
+def test_topk_rule():
+    v = np.array([1.0, 3.0, np.nan, 3.0, 2.0, -np.inf])
+    assert list(gp_ref.topk_desc(v, 4)) == [1, 3, 4, 0]
+
+
+def test_copy_is_independent_and_not_pd_raises():
+    X, y, ell = synth_problem(10, 2, seed=1)
+    gp = gp_ref.make_gp(1e-3, 1.0, ell, 0.0)
+    gp.add_data(X, y)
+    c = gp.copy()
+    c.add_data(X[:1] + 0.1, y[:1])
+    assert gp.ndata == 10 and c.ndata == 11
+    bad = gp_ref.make_gp(0.0, 1.0, ell, 0.0)
+    with pytest.raises(np.linalg.LinAlgError):
+        bad.add_data(np.vstack([X, X]), np.hstack([y, y]))    # duplicated rows, no noise -> singular
