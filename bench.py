@@ -1,0 +1,283 @@
+#!/usr/bin/env python
+"""
+bench.py -- BO-step wall-clock of the MI355X engine: GP fit + 1e6-candidate acquisition sweep.
+
+One "step" = what one iteration of pybo's loop asks of the model for the configured policy
+(/root/reference/pybo/bayesopt.py:262-269):
+    model.add_data        -> Gram build + Cholesky + triangular inverse + alpha      (gpx_fit_dev)
+    policy(model, ., X)   -> target = max posterior mean at the data (+xi)          (gpx_mean_at_obs)
+    solver(index, bounds) -> index on the whole candidate grid + top-k               (gpx_sweep_dev)
+    [N > 1 ranks]         -> all-gather of the per-rank (value, global index) top-k   (RCCL)
+Inputs (observations, candidates) are resident in HBM before the timed region starts; every rank
+refits redundantly (bitwise-identical factor, zero communication) and sweeps its contiguous candidate
+slice, so the job is STRONG scaling: total work fixed at M candidates.
+
+Launch:  python bench.py [--gpus 1 --steps K --warmup W --workload ns|b|c|d]
+         python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X datasheet fp64 matrix (= fp64 vector) peak, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def hartmann6(X):
+    A = np.array([[10, 3, 17, 3.5, 1.7, 8], [0.05, 10, 17, 0.1, 8, 14], [3, 3.5, 1.7, 10, 17, 8],
+                  [17, 8, 0.05, 10, 0.1, 14]])
+    P = 1e-4 * np.array([[1312, 1696, 5569, 124, 8283, 5886], [2329, 4135, 8307, 3736, 1004, 9991],
+                         [2348, 1451, 3522, 2883, 3047, 6650], [4047, 8828, 8732, 5743, 1091, 381]])
+    c = np.array([1.0, 1.2, 3.0, 3.2])
+    return -(c * np.exp(-(A[None] * (X[:, None, :] - P[None]) ** 2).sum(-1))).sum(-1)
+
+
+def branin(X):
+    a, b, c, r, s, t = 1.0, 5.1 / (4 * np.pi ** 2), 5.0 / np.pi, 6.0, 10.0, 1.0 / (8 * np.pi)
+    return a * (X[:, 1] - b * X[:, 0] ** 2 + c * X[:, 0] - r) ** 2 + s * (1 - t) * np.cos(X[:, 0]) + s
+
+
+def make_workload(name, M):
+    """Synthetic inputs of SURVEY.md 8(d): identical arrays feed the GPU path and the CPU baseline."""
+    from scipy.stats import qmc
+    if name == 'ns':      # north-star target: N=8192, d=8, SE-ARD, EI
+        N, d, seed, kernel, acq = 8192, 8, 2, 'se', 'ei'
+        lo, hi = np.zeros(d), np.ones(d)
+        rng = np.random.RandomState(seed)
+        X = lo + (hi - lo) * rng.rand(N, d)
+        y = -((X - 0.5) ** 2).sum(1) + 1e-3 * rng.randn(N)
+        desc = 'north-star: d=8 synthetic quadratic, N=8192 observed, SE-ARD, EI over 2^20 Sobol candidates'
+    elif name == 'b':     # BASELINE configs[1]
+        N, d, seed, kernel, acq = 2048, 2, 0, 'se', 'ei'
+        lo, hi = np.array([-5.0, 0.0]), np.array([10.0, 15.0])
+        rng = np.random.RandomState(seed)
+        X = lo + (hi - lo) * rng.rand(N, d)
+        y = -branin(X) / 10.0 + 1e-3 * rng.randn(N)
+        desc = 'config B: Branin d=2, N=2048 observed, SE-ARD, EI over 2^20 Sobol candidates'
+    elif name == 'c':     # BASELINE configs[2]
+        N, d, seed, kernel, acq = 8192, 6, 1, 'matern5', 'ucb'
+        lo, hi = np.zeros(d), np.ones(d)
+        rng = np.random.RandomState(seed)
+        X = lo + (hi - lo) * rng.rand(N, d)
+        y = -hartmann6(X) + 1e-3 * rng.randn(N)
+        desc = 'config C: Hartmann-6, N=8192 observed, Matern-5/2, UCB over 2^20 Sobol candidates'
+    elif name == 'd':     # BASELINE configs[3]
+        N, d, seed, kernel, acq = 16384, 32, 3, 'se', 'thompson'
+        lo, hi = -np.ones(d), np.ones(d)
+        rng = np.random.RandomState(seed)
+        X = lo + (hi - lo) * rng.rand(N, d)
+        y = -(X ** 2).sum(1) + 1e-3 * rng.randn(N)
+        desc = 'config D: d=32 quadratic, N=16384 observed, SE-ARD, Thompson (64 RFF draws x 100 features)'
+    else:
+        raise SystemExit('unknown workload %r' % name)
+    ell = 0.25 * (hi - lo)
+    rho, bias = float(np.var(y)), float(np.mean(y))
+    sn2 = 1e-4 * rho
+    Xc = lo + (hi - lo) * qmc.Sobol(d, scramble=False).random(M)
+    return dict(name=name, desc=desc, N=N, d=d, M=M, kernel=kernel, acq=acq, X=X, y=y, ell=ell, rho=rho,
+                sn2=sn2, bias=bias, Xc=Xc)
+
+
+def ucb_beta(nobs, delta=0.1, xi=0.2):
+    """pybo/policies/simple.py:58-66 -- `d` is the number of observations."""
+    return xi * 2 * np.log(np.pi ** 2 / 3 / delta) + xi * (4 + nobs) * np.log(nobs + 1)
+
+
+def cpu_baseline(w, budget_candidates):
+    """Time the CPU restatement (oracle/, numpy+scipy on the host's BLAS threads) on a bounded sample:
+    the fit in full, the sweep on `budget_candidates` of the M candidates, extrapolated linearly."""
+    from oracle import gp_ref
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = len(os.sched_getaffinity(0))
+    t0 = time.perf_counter()
+    ref = gp_ref.make_gp(w['sn2'], w['rho'], w['ell'], w['bias'], w['kernel'])
+    ref.add_data(w['X'], w['y'])
+    t_fit = time.perf_counter() - t0
+    Z = w['Xc'][:budget_candidates]
+    t0 = time.perf_counter()
+    if w['acq'] == 'ei':
+        target = ref.mean_at_obs().max()
+        v = ref.get_improvement(target, Z)
+    elif w['acq'] == 'ucb':
+        mu, s2 = ref.predict(Z)
+        v = mu + np.sqrt(ucb_beta(w['N']) * s2)
+    else:
+        smp = ref.sample_f(100, rng=100)
+        v = smp.get(Z)
+    int(np.argmax(v))
+    t_sw = time.perf_counter() - t0
+    step = t_fit + t_sw * (w['M'] / float(len(Z)))
+    return dict(value=1.0 / step, unit='steps/s', cores=int(threads), kind='port',
+                sample='fit in full (N=%d: %.2f s) + sweep on %d of %d candidates (%.2f s), sweep extrapolated '
+                       'linearly to M; host has %d logical cpus, %d in affinity'
+                       % (w['N'], t_fit, len(Z), w['M'], t_sw, os.cpu_count(), len(os.sched_getaffinity(0))),
+                seconds_per_step=step)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default='ns', choices=['ns', 'b', 'c', 'd'])
+    ap.add_argument('--candidates', type=int, default=1 << 20)
+    ap.add_argument('--topk', type=int, default=10)
+    ap.add_argument('--chunk', type=int, default=0)
+    ap.add_argument('--tile-order', type=int, default=-1)
+    ap.add_argument('--draws', type=int, default=64, help='Thompson draws (workload d)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-candidates', type=int, default=0, help='candidates in the CPU sample (0 = auto)')
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from pybo_amd._lib import Engine
+    from pybo_amd import dist as pdist
+    w = make_workload(args.workload, args.candidates)
+    N, d, M, k = w['N'], w['d'], w['M'], args.topk
+    # contiguous candidate slice of this rank
+    lo_i, hi_i = (M * rank) // world, (M * (rank + 1)) // world
+    dX = torch.from_numpy(w['X']).to(dev)
+    dy = torch.from_numpy(w['y']).to(dev)
+    dXc = torch.from_numpy(np.ascontiguousarray(w['Xc'][lo_i:hi_i])).to(dev)
+    stream = torch.cuda.current_stream(dev)
+    eng = Engine(local, stream.cuda_stream)
+    if args.chunk:
+        eng.set_option('chunk', args.chunk)
+    if args.tile_order >= 0:
+        eng.set_option('tile_order', args.tile_order)
+    Ml = hi_i - lo_i
+
+    thompson = None
+    if w['acq'] == 'thompson':
+        S = args.draws
+        mine = [s for s in range(S) if s % world == rank]      # draws are the sharded unit here
+
+    def step():
+        eng.fit_dev(dX.data_ptr(), N, d, dy.data_ptr(), w['kernel'], w['ell'], w['rho'], w['sn2'], w['bias'])
+        if w['acq'] == 'thompson':
+            # each rank owns S/world posterior draws and sweeps ALL candidates for them
+            Ws, bs, ths = [], [], []
+            for s in mine:
+                rng = np.random.RandomState(100 + s)
+                W = rng.randn(100, d) / w['ell']
+                b = rng.rand(100) * 2 * np.pi
+                z = rng.randn(100)
+                A, v = eng.rff_gram(W, b)
+                sc = np.sqrt(2.0 * w['rho'] / 100)
+                L = np.linalg.cholesky(sc * sc * A + w['sn2'] * np.eye(100))
+                th = sc * (np.linalg.solve(L.T, np.linalg.solve(L, sc * v)) +
+                           np.sqrt(w['sn2']) * np.linalg.solve(L.T, z))
+                Ws.append(W); bs.append(b); ths.append(th)
+            tv, ti = eng.rff_sweep_dev(np.array(Ws), np.array(bs), np.array(ths), w['bias'],
+                                       dXc_full.data_ptr(), M, 1)
+            tv, ti = tv[:, 0], ti[:, 0]
+        else:
+            if w['acq'] == 'ei':
+                _, mx = eng.mean_at_obs()
+                param = mx
+            elif w['acq'] == 'ucb':
+                param = ucb_beta(N)
+            tv, ti = eng.sweep_dev(w['acq'], param, dXc.data_ptr(), Ml, k)
+            ti = ti + lo_i
+        if world > 1:
+            if w['acq'] == 'thompson':      # one (value, index) pair per draw: concatenate all ranks' draws
+                kk = len(tv)
+                tvals = torch.from_numpy(np.ascontiguousarray(tv)).to(dev)
+                tidx = torch.from_numpy(np.ascontiguousarray(ti)).to(dev)
+                allv = torch.empty(world * kk, dtype=torch.float64, device=dev)
+                alli = torch.empty(world * kk, dtype=torch.int64, device=dev)
+                dist.all_gather_into_tensor(allv, tvals)
+                dist.all_gather_into_tensor(alli, tidx)
+                return allv.cpu().numpy(), alli.cpu().numpy()
+            return pdist.gather_topk(tv, ti, k)      # RCCL all-gather + deterministic merge
+        return tv, ti
+
+    if w['acq'] == 'thompson':
+        dXc_full = torch.from_numpy(w['Xc']).to(dev)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        best = step()
+    eng.timers(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        best = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    tm = eng.timers(reset=True)
+
+    if rank == 0:
+        sec = elapsed / args.steps
+        out = {
+            'metric': 'BO-step wall-clock (GP fit + 1e6-candidate acq sweep) at N obs; steps/sec',
+            'value': 1.0 / sec, 'unit': 'steps/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': sec * 1e3, 'seconds_per_step': sec,
+            'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {'workload': w['desc'], 'N': N, 'd': d, 'candidates': M, 'kernel': w['kernel'],
+                       'acquisition': w['acq'], 'topk': k,
+                       'parallelism': 'candidates sharded contiguously over %d rank(s), fit replicated, '
+                                      'all-gather of (value,index) top-k' % world},
+            'selected': {'index': int(best[1][0]), 'value': float(best[0][0])},
+            'stage_ms_per_step_rank0': {kk: tm[kk] / args.steps for kk in
+                                        ('gram', 'cholesky', 'trtri', 'alpha', 'cross_gram', 'sweep_trmm',
+                                         'acq_topk', 'rff') if tm[kk] > 0},
+        }
+        if tm['sweep_trmm'] > 0:
+            launches = tm['sweep_trmm_launches']
+            ach = tm['sweep_trmm_flop'] / (tm['sweep_trmm'] * 1e-3) / 1e12
+            out['roofline'] = {'kernel': 'k_sweep_trmm', 'bound': 'mfma', 'achieved': ach,
+                               'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': ach / FP64_MFMA_PEAK_TFLOPS, 'traffic': None,
+                               'launches': int(launches),
+                               'avg_launch_ms': tm['sweep_trmm'] / max(launches, 1),
+                               'flop_per_launch': tm['sweep_trmm_flop'] / max(launches, 1)}
+        elif tm['cholesky'] > 0:
+            Np = (N + 127) // 128 * 128
+            ach = (Np ** 3 / 3.0) * args.steps / (tm['cholesky'] * 1e-3) / 1e12
+            out['roofline'] = {'kernel': 'cholesky (potrf_diag + panel_trsm + syrk_update)', 'bound': 'mfma',
+                               'achieved': ach, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': ach / FP64_MFMA_PEAK_TFLOPS, 'traffic': None}
+        if world == 1 and not args.no_cpu_baseline:
+            nc = args.cpu_candidates or (8192 if N <= 4096 else 4096)
+            out['cpu_baseline'] = cpu_baseline(w, min(nc, M))
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

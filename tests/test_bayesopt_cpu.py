@@ -1,0 +1,94 @@
+"""The BO driver on CPU (BASELINE config[0], 'plumbing, no GPU'): pybo_amd.solve_bayesopt accepts any object
+with the model protocol, so here it is driven with the ORACLE model -- which is allowed in tests only -- to
+check the loop, the plugin wiring, checkpoint/resume and the reference's quirks without a GPU."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from oracle import gp_ref
+from pybo_amd import bayesopt, solve_bayesopt, policies, solvers
+from pybo_amd.bayesopt import Info
+
+
+def gramacy_lee(x):
+    """The objective of pybo/demos/animated.py:23-37 (maximised): xopt = 0.54856343."""
+    x = float(np.ravel(x)[0])
+    return -(np.sin(10 * np.pi * x) / (2 * x) + (x - 1) ** 4)
+
+
+def test_animated_demo_headless_finds_the_optimum():
+    bounds = [[0.5, 2.5]]
+    # the demo's model: make_gp(0.01, 1.9, 0.1, 0) (animated.py:47), EI with xi = 0.1 (animated.py:64)
+    model = gp_ref.make_gp(0.01, 1.9, 0.1, 0.0)
+    xbest, model, info = solve_bayesopt(gramacy_lee, bounds, model=model, niter=30, policy=('ei', {'xi': 0.1}),
+                                        recommender='incumbent', rng=0)
+    assert info.x.shape == (31, 1) and info.y.shape == (31,) and info.xbest.shape == (30, 1)
+    assert model.ndata == 31
+    assert abs(info.x[np.argmax(info.y)][0] - 0.54856343) < 2e-2
+    assert info.y.max() > 0.8
+
+
+@pytest.mark.parametrize('policy', ['ei', 'pi', 'ucb', 'thompson'])
+def test_every_policy_runs_and_is_seed_deterministic(policy):
+    bounds = [[0.0, 1.0], [0.0, 1.0]]
+    f = lambda x: float(-np.sum((np.asarray(x) - 0.3) ** 2))        # noqa: E731
+    runs = []
+    for _ in range(2):
+        m = gp_ref.make_gp(1e-4, 1.0, [0.3, 0.3], 0.0)
+        xb, mm, info = solve_bayesopt(f, bounds, model=m, niter=6, policy=policy,
+                                      solver=('lbfgs', {'ngrid': 400, 'nbest': 3}), rng=11)
+        runs.append(info)
+    np.testing.assert_array_equal(runs[0].x, runs[1].x)
+    np.testing.assert_array_equal(runs[0].xbest, runs[1].xbest)
+    assert runs[0].y.max() > -0.1
+
+
+def test_checkpoint_resume(tmp_path):
+    bounds = [[0.0, 1.0]]
+    f = lambda x: float(np.sin(6 * x[0]))                            # noqa: E731
+    log = str(tmp_path / 'bo.pkl')
+    m = gp_ref.make_gp(1e-4, 1.0, [0.2], 0.0)
+    _, _, full = solve_bayesopt(f, bounds, model=m.copy(), niter=6, rng=5,
+                                solver=('lbfgs', {'ngrid': 200}))
+    calls = []
+
+    def f_counted(x):
+        calls.append(1)
+        return f(x)
+    _, _, part = solve_bayesopt(f_counted, bounds, model=m.copy(), niter=3, rng=5, log=log,
+                                solver=('lbfgs', {'ngrid': 200}))
+    assert os.path.exists(log) and len(part.xbest) == 3 and len(calls) == 4
+    model_, info_ = pickle.load(open(log, 'rb'))
+    assert model_.ndata == 4 and len(info_.x) == 4
+    # resume: the loop restarts at len(info.xbest) (bayesopt.py:262) and the stored model is used
+    _, mm, resumed = solve_bayesopt(f_counted, bounds, model=None, niter=6, rng=5, log=log,
+                                    solver=('lbfgs', {'ngrid': 200}))
+    assert len(calls) == 7 and len(resumed.xbest) == 6 and mm.ndata == 7
+    np.testing.assert_array_equal(resumed.x[:4], part.x)
+
+
+def test_given_model_starts_from_the_middle_and_is_not_mutated():
+    bounds = [[0.0, 2.0], [1.0, 3.0]]
+    m = gp_ref.make_gp(1e-3, 1.0, [0.5, 0.5], 0.0)
+    _, mm, info = solve_bayesopt(lambda x: -float(np.sum(x)), bounds, model=m, niter=2, rng=0,
+                                 solver=('lbfgs', {'ngrid': 100}))
+    np.testing.assert_array_equal(info.x[0], [1.0, 2.0])
+    assert m.ndata == 0 and mm.ndata == 3
+
+
+def test_default_model_needs_the_device_and_fails_loudly(gpu_available):
+    if gpu_available:
+        pytest.skip('GPU present: covered by the gpu suite')
+    from pybo_amd._lib import GpxError
+    with pytest.raises(GpxError):
+        solve_bayesopt(lambda x: 0.0, [[0.0, 1.0]], niter=1, rng=0)     # init_model builds the HIP GP
+
+
+def test_info_is_a_namedtuple_of_arrays():
+    m = gp_ref.make_gp(1e-3, 1.0, [0.5], 0.0)
+    xb, mm, info = solve_bayesopt(lambda x: float(x[0]), [[0.0, 1.0]], model=m, niter=1, rng=0,
+                                  solver=('lbfgs', {'ngrid': 50}))
+    assert isinstance(info, Info) and info._fields == ('x', 'y', 'xbest')
+    assert all(isinstance(a, np.ndarray) for a in info)
