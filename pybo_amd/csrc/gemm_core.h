@@ -120,6 +120,81 @@ __device__ __forceinline__ void gemm_tile_128(d4 (&acc)[4][4], const double* __r
     }
 }
 
+
+// Variant B of the k-loop ("write-at-top", prefetch distance 2): the global loads of tile t+2 are issued
+// right after the registers holding tile t+1 have been written to LDS at the TOP of step t, so the
+// end-of-step barrier never waits on a fresh ds_write (its lgkmcnt is a whole MFMA phase old) and the
+// vmcnt wait at the top is for loads issued one full step earlier.  PRIO: raise the wave priority around
+// the MFMA phase so that, of the two workgroups sharing a CU, the one in its matrix phase owns the pipe
+// and the other one's staging/sync phase fills the gaps.
+template <bool PRIO>
+__device__ __forceinline__ void gemm_tile_128_b(d4 (&acc)[4][4], const double* __restrict__ A, int64_t lda,
+                                                const double* __restrict__ B, int64_t ldb, int k_lo,
+                                                int k_hi, double* smem) {
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    double* As = smem;
+    double* Bs = smem + 2 * BK * LDT;
+    const int lrow = w;
+    const int lcol = lane * 2;
+    d2 ra[4], rb[4];
+    const int nk = (k_hi - k_lo) / BK;
+    if (nk <= 0) return;
+    const double* Ap = A + (int64_t)(k_lo + lrow) * lda + lcol;
+    const double* Bp = B + (int64_t)(k_lo + lrow) * ldb + lcol;
+    auto gload = [&]() {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            ra[p] = *reinterpret_cast<const d2*>(Ap + (int64_t)(4 * p) * lda);
+            rb[p] = *reinterpret_cast<const d2*>(Bp + (int64_t)(4 * p) * ldb);
+        }
+        Ap += (int64_t)BK * lda;
+        Bp += (int64_t)BK * ldb;
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            *reinterpret_cast<d2*>(As + buf * BK * LDT + (lrow + 4 * p) * LDT + lcol) = ra[p];
+            *reinterpret_cast<d2*>(Bs + buf * BK * LDT + (lrow + 4 * p) * LDT + lcol) = rb[p];
+        }
+    };
+    gload();            // tile 0
+    swrite(0);
+    if (nk > 1) gload();  // tile 1 stays in registers until the top of step 0
+    __syncthreads();
+    const int fr = lane & 15, fk = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) {
+            swrite(buf ^ 1);                 // tile kt+1 (loaded during step kt-1)
+            if (kt + 2 < nk) gload();        // tile kt+2, consumed at the top of step kt+1
+        }
+        const double* as = As + buf * BK * LDT + wm * 64 + fr;
+        const double* bs = Bs + buf * BK * LDT + wn * 64 + fr;
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; ++kk) {
+            const int kr = kk * 4 + fk;
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = as[kr * LDT + i * 16];
+                b[i] = bs[kr * LDT + i * 16];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+    }
+}
+
+
 // element coordinates of accumulator register acc[i][j][r] inside the 128x128 tile
 __device__ __forceinline__ int acc_row(int i, int r) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;

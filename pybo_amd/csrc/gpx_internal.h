@@ -55,7 +55,7 @@ struct gpx_handle {
 
     // sweep workspace
     int64_t chunk = 65536;    // candidate columns per chunk (multiple of 128)
-    int tile_order = 0;
+    int tile_order = 10;      // bits 0-1 tile map (2 = XCD 8x8 super-tiles), bits 2-3 k-loop variant (2 = write-at-top + setprio)
     int64_t cap_ks = 0;       // elements of dKs
     double* dKs = nullptr;    // (Np, chunk) cross-Gram chunk
     double* dQp = nullptr;    // (Np/128, chunk) per-row-block partials of colsum(V^2)

@@ -125,75 +125,152 @@ void launch_gram_sym(hipStream_t s, const double* Xs, int64_t N, int64_t Np, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// R2a: diagonal-block factorisation + inversion, one workgroup, whole 128x128 block in LDS.
+// R2a: diagonal-block factorisation + inversion, one workgroup, the 128x128 block REGISTER-resident.
+// Thread (tr, tc) of a 16x16 grid owns the 8x8 elements M[tr+16a][tc+16b] (64 f64 = 128 VGPR), so the
+// rank-1 update of a pivot step is 64 register FMAs; the only shared traffic per step is the pivot row,
+// published through a double-buffered 128-entry LDS vector (one barrier per pivot).
 // Right-looking Cholesky on the upper triangle (rows of R); the same row operations applied to the
-// identity give T_pp = R_pp^-T in the strict lower triangle (Gauss-Jordan style), so one LDS array
-// holds both.  One barrier per pivot: row j is scaled one step late, while nobody reads it.
+// identity give T_pp = R_pp^-T in the strict lower triangle (Gauss-Jordan style), so one array holds both:
+//   step j:  d = sqrt(M[j][j]);  row j: R part (c > j) and T part (c < j) scaled by 1/d, T[j][j] = 1/d;
+//            rows r > j:  M[r][c] -= R[j][r] * rowj[c]   for c >= r (Cholesky) and c <= j (inverse).
 // ------------------------------------------------------------------------------------------------
-constexpr int PD_LD = NB + 1;
+// 1/sqrt(x) to fp64 round-off: hardware v_rsq_f64 seed + two Newton steps (no denormal/scale handling
+// needed: pivots of a PD matrix with unit-scale entries; a non-positive or NaN pivot yields NaN/inf,
+// which the uniform pivot check catches one step later)
+__device__ __forceinline__ double rsqrt_nr(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    return y;
+}
+
+// Sixteen pivot steps j = 16*JS .. 16*JS+15 with the slice index JS a compile-time constant, so that
+// every mask that depends on "which 16-row/16-column slice" folds away: slices a < JS are finished (no
+// code), columns b < JS are always left of the pivot (inverse part), b > JS always right of it (Cholesky
+// part), and the never-updated gap JS < b < a emits no FMA at all.  Only the pivot slice itself keeps
+// run-time compares.  Returns false (uniformly) on a non-positive pivot.
+template <int JS>
+__device__ __forceinline__ bool potrf_phase(double (&m)[8][8], double (&dinv)[8], double (*rowbuf)[NB + 8],
+                                            int tr, int tc, bool up_diag, bool on_diag, int64_t p0,
+                                            int* flag) {
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = JS * 16 + jj;
+        const double* rb = rowbuf[j & 1];
+        const double piv = rb[j];
+        if (!(piv > 0.0) || !(piv < 1.0e300)) {  // also catches NaN
+            if (threadIdx.x == 0) *flag = (int)(p0 + j) + 1;
+            return false;  // uniform: every thread read the same pivot
+        }
+        const double inv = rb[NB];
+        const int cj = tc + 16 * JS, rj = tr + 16 * JS;
+        double rowv[8];          // scaled pivot row
+#pragma unroll
+        for (int b = 0; b < 8; ++b) rowv[b] = rb[tc + 16 * b] * inv;
+        const double rR = (cj > j) ? rowv[JS] : 0.0;                          // Cholesky part of slice JS
+        const double rT = (cj < j) ? rowv[JS] : ((cj == j) ? inv : 0.0);      // inverse part of slice JS
+        double mult[8];
+#pragma unroll
+        for (int a = JS; a < 8; ++a) mult[a] = -(rb[tr + 16 * a] * inv);      // -R[j][r]
+        if (!(rj > j)) mult[JS] = 0.0;                                         // rows of slice JS above the pivot
+        dinv[JS] = (rj == j) ? inv : dinv[JS];
+        const int jn = j + 1;
+#pragma unroll
+        for (int a = JS; a < 8; ++a) {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                if (b < JS) {
+                    m[a][b] = fma(mult[a], rowv[b], m[a][b]);                  // inverse part, c < j
+                } else if (b == JS) {
+                    if (a == JS) m[a][b] = fma(mult[a], up_diag ? rR : rT, m[a][b]);
+                    else m[a][b] = fma(mult[a], rT, m[a][b]);                  // b < a: inverse part
+                } else {  // b > JS: right of the pivot
+                    if (b > a) m[a][b] = fma(mult[a], rowv[b], m[a][b]);       // Cholesky part
+                    else if (b == a) m[a][b] = fma(mult[a], up_diag ? rowv[b] : 0.0, m[a][b]);
+                    // JS < b < a: below the diagonal and right of the pivot -> never touched
+                }
+            }
+            if ((a == JS || a == JS + 1) && tr + 16 * a == jn) {   // publish the next pivot row + rsqrt
+                double* wb = rowbuf[jn & 1];
+#pragma unroll
+                for (int b = 0; b < 8; ++b) wb[tc + 16 * b] = m[a][b];
+                if (on_diag) wb[NB] = rsqrt_nr(m[a][a]);
+            }
+        }
+        __syncthreads();
+    }
+    return true;
+}
 
 __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, double* __restrict__ R,
                                                     double* __restrict__ T, double* __restrict__ U,
                                                     int64_t Np, int p, int* __restrict__ flag) {
-    __shared__ double M[NB * PD_LD];
+    __shared__ double rowbuf[2][NB + 8];   // [..][NB] = 1/sqrt(pivot), published by the pivot's owner
     if (*flag != 0) return;  // an earlier panel already failed
     const int t = threadIdx.x;
+    const int tr = t >> 4, tc = t & 15;
     const int64_t p0 = (int64_t)p * NB;
-    for (int e = t; e < NB * NB; e += 256) {
-        const int r = e >> 7, c = e & 127;
-        M[r * PD_LD + c] = (c >= r) ? S[(p0 + r) * Np + p0 + c] : 0.0;
+    double m[8][8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int r = tr + 16 * a, c = tc + 16 * b;
+            m[a][b] = (c >= r) ? S[(p0 + r) * Np + p0 + c] : 0.0;
+        }
+    // publish row 0 and its pivot's reciprocal square root
+    if (tr == 0) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) rowbuf[0][tc + 16 * b] = m[0][b];
+        if (tc == 0) rowbuf[0][NB] = rsqrt_nr(m[0][0]);
     }
     __syncthreads();
 
-    const int tr = t >> 4, tc = t & 15;
-    double d_prev = 1.0, inv_prev = 1.0;
-    for (int j = 0; j < NB; ++j) {
-        const double piv = M[j * PD_LD + j];
-        if (!(piv > 0.0) || !(piv < 1.0e300)) {  // also catches NaN
-            if (t == 0) *flag = (int)(p0 + j) + 1;
-            return;  // uniform: every thread read the same pivot
-        }
-        const double dj = sqrt(piv);
-        const double inv = 1.0 / dj;
-        // deferred scaling of row j-1 (nobody reads it any more)
-        if (j > 0 && t < NB) {
-            const int jr = j - 1;
-            const double v = M[jr * PD_LD + t];
-            M[jr * PD_LD + t] = (t == jr) ? d_prev : v * inv_prev;
-        }
-        // rank-1 update of rows r > j: Cholesky part (c >= r) and inverse part (c <= j)
-        for (int r = j + 1 + tr; r < NB; r += 16) {
-            const double mult = M[j * PD_LD + r] * inv;
+    // Element (r,c) = (tr+16a, tc+16b) is in the Cholesky part iff c >= r, i.e. b > a, or b == a and
+    // tc >= tr (a per-thread constant).
+    const bool up_diag = (tc >= tr);
+    const bool on_diag = (tc == tr);
+    double dinv[8];   // 1/d of each owned row, filled when the row is the pivot; applied at write-back
 #pragma unroll
-            for (int cc = 0; cc < NB / 16; ++cc) {
-                const int c = cc * 16 + tc;
-                if (c >= r || c <= j) {
-                    const double rj = (c == j) ? inv : M[j * PD_LD + c] * inv;
-                    M[r * PD_LD + c] = fma(-mult, rj, M[r * PD_LD + c]);
-                }
+    for (int a = 0; a < 8; ++a) dinv[a] = 1.0;
+
+    if (!potrf_phase<0>(m, dinv, rowbuf, tr, tc, up_diag, on_diag, p0, flag)) return;
+    if (!potrf_phase<1>(m, dinv, rowbuf, tr, tc, up_diag, on_diag, p0, flag)) return;
+    if (!potrf_phase<2>(m, dinv, rowbuf, tr, tc, up_diag, on_diag, p0, flag)) return;
+    if (!potrf_phase<3>(m, dinv, rowbuf, tr, tc, up_diag, on_diag, p0, flag)) return;
+    if (!potrf_phase<4>(m, dinv, rowbuf, tr, tc, up_diag, on_diag, p0, flag)) return;
+    if (!potrf_phase<5>(m, dinv, rowbuf, tr, tc, up_diag, on_diag, p0, flag)) return;
+    if (!potrf_phase<6>(m, dinv, rowbuf, tr, tc, up_diag, on_diag, p0, flag)) return;
+    if (!potrf_phase<7>(m, dinv, rowbuf, tr, tc, up_diag, on_diag, p0, flag)) return;
+    // rows were left unscaled: R[j][c>j] = m*inv_j, T[j][c<j] = m*inv_j, R[j][j] = piv*inv_j = d_j
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) m[a][b] *= dinv[a];
+    // write back: R (upper), T (lower) and U = T^T (upper), zeros elsewhere in the block
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int r = tr + 16 * a, c = tc + 16 * b;
+            const double v = m[a][b];
+            const int64_t g = (p0 + r) * Np + p0 + c;    // (r, c)
+            const int64_t gt = (p0 + c) * Np + p0 + r;   // (c, r)
+            if (c > r) {
+                R[g] = v;
+                T[g] = 0.0;
+                U[gt] = 0.0;
+            } else if (c < r) {
+                R[g] = 0.0;
+                T[g] = v;
+                U[gt] = v;
+            } else {
+                const double dinv = 1.0 / v;
+                R[g] = v;
+                T[g] = dinv;
+                U[g] = dinv;
             }
         }
-        d_prev = dj;
-        inv_prev = inv;
-        __syncthreads();
-    }
-    if (t < NB) {
-        const int jr = NB - 1;
-        const double v = M[jr * PD_LD + t];
-        M[jr * PD_LD + t] = (t == jr) ? d_prev : v * inv_prev;
-    }
-    __syncthreads();
-    // write back: R (upper), T (lower) and U = T^T (upper), zeros elsewhere in the block
-    for (int e = t; e < NB * NB; e += 256) {
-        const int r = e >> 7, c = e & 127;
-        const double m_rc = M[r * PD_LD + c];
-        const double m_cr = M[c * PD_LD + r];
-        const double dinv = 1.0 / M[r * PD_LD + r];
-        const int64_t g = (p0 + r) * Np + p0 + c;
-        R[g] = (c >= r) ? m_rc : 0.0;
-        T[g] = (c < r) ? m_rc : ((c == r) ? dinv : 0.0);
-        U[g] = (c > r) ? m_cr : ((c == r) ? dinv : 0.0);
-    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -108,6 +108,7 @@ void launch_cross_gram(hipStream_t s, const double* Xs, int64_t Np, int64_t N, i
 // Tile (mt, nt): 128 observed rows x 128 candidates, K-extent (mt+1)*128 (T is lower triangular),
 // N^2 * M flop in total.  Heavy tiles (large mt) are dispatched first.
 // ------------------------------------------------------------------------------------------------
+template <int VAR>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __restrict__ U, int64_t Np,
                                                                 const double* __restrict__ Ks,
                                                                 int64_t ldk, int NT,
@@ -130,6 +131,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __
             mt = nP - 1 - lm;
             nt = x * per + ln;
             if (nt >= NT || mt < 0) return;
+        } else if (order == 2) {
+            // XCD-aware 2-D super-tiles: the 64 workgroups resident on one XCD (32 CUs x 2) form an
+            // 8 (mt) x 8 (nt) patch, so every T row-panel and every Ks column-panel fetched into that
+            // XCD's L2 is used by 8 tiles -> ~4x less fabric/HBM traffic than one-panel-per-tile.
+            const int x = b & 7, q = b >> 3;
+            const int per = (NT + 7) / 8;             // candidate tiles per XCD (contiguous slice)
+            const int hper = (per + 7) / 8;           // 8-wide n-groups per XCD
+            const int s = q >> 6, r = q & 63;
+            const int G = s / hper, H = s - G * hper;
+            mt = nP - 1 - (G * 8 + (r >> 3));
+            const int ln = H * 8 + (r & 7);
+            nt = x * per + ln;
+            if (ln >= per || nt >= NT || mt < 0) return;
         } else {
             mt = nP - 1 - b / NT;
             nt = b - (b / NT) * NT;
@@ -138,7 +152,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __
     const int64_t m0 = (int64_t)mt * TB, n0 = (int64_t)nt * TB;
     d4 acc[4][4];
     acc_zero(acc);
-    gemm_tile_128(acc, U + m0, Np, Ks + n0, ldk, 0, (mt + 1) * TB, smem);
+    if (VAR == 0) gemm_tile_128(acc, U + m0, Np, Ks + n0, ldk, 0, (mt + 1) * TB, smem);
+    else if (VAR == 1) gemm_tile_128_b<false>(acc, U + m0, Np, Ks + n0, ldk, 0, (mt + 1) * TB, smem);
+    else gemm_tile_128_b<true>(acc, U + m0, Np, Ks + n0, ldk, 0, (mt + 1) * TB, smem);
 
     // epilogue: column sums of V^2 and V*a over this tile's 128 rows
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -190,14 +206,27 @@ void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double*
     const int NT = (int)(cols / TB);
     const int nP = (int)(Np / TB);
     unsigned nblk;
-    if (tile_order == 1) {
+    if ((tile_order & 3) == 1) {
         const int per = (NT + 7) / 8;
         nblk = (unsigned)(8 * per * nP);
+    } else if ((tile_order & 3) == 2) {
+        const int per = (NT + 7) / 8;
+        const int hper = (per + 7) / 8;
+        const int gm = (nP + 7) / 8;
+        nblk = (unsigned)(8 * 64 * hper * gm);
     } else {
         nblk = (unsigned)(NT * nP);
     }
-    hipLaunchKernelGGL(k_sweep_trmm, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
-                       ldp, tile_order);
+    const int order = tile_order & 3, var = tile_order >> 2;   // bits 0-1: tile map, bits 2..: k-loop variant
+    if (var == 0)
+        hipLaunchKernelGGL(k_sweep_trmm<0>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
+                           ldp, order);
+    else if (var == 1)
+        hipLaunchKernelGGL(k_sweep_trmm<1>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
+                           ldp, order);
+    else
+        hipLaunchKernelGGL(k_sweep_trmm<2>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
+                           ldp, order);
 }
 
 // ------------------------------------------------------------------------------------------------
