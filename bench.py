@@ -240,6 +240,7 @@ def main():
     tm = eng.timers(reset=True)
 
     if rank == 0:
+        Np_ = (N + 127) // 128 * 128
         sec = elapsed / args.steps
         out = {
             'metric': 'BO-step wall-clock (GP fit + 1e6-candidate acq sweep) at N obs; steps/sec',
@@ -258,10 +259,22 @@ def main():
         }
         if tm['sweep_trmm'] > 0:
             launches = tm['sweep_trmm_launches']
+            # HBM traffic per launch comes from the committed PMC passes (bench.py cannot collect
+            # counters itself); only reported when this run's launch geometry is the profiled one
+            traffic = None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+                cols = tm['sweep_trmm_flop'] / max(launches, 1) / (float(Np_) * (Np_ + 128))
+                if pmc['config']['Np'] == Np_ and abs(cols - pmc['config']['cols_per_launch']) < 1:
+                    traffic = pmc['k_sweep_trmm']['traffic_bytes_per_launch']
+            except Exception:
+                traffic = None
             ach = tm['sweep_trmm_flop'] / (tm['sweep_trmm'] * 1e-3) / 1e12
             out['roofline'] = {'kernel': 'k_sweep_trmm', 'bound': 'mfma', 'achieved': ach,
                                'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': ach / FP64_MFMA_PEAK_TFLOPS, 'traffic': None,
+                               'frac': ach / FP64_MFMA_PEAK_TFLOPS, 'traffic': traffic,
+                               'traffic_unit': 'bytes/launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, '
+                                               'profiles/r01_pmc_traffic.json)',
                                'launches': int(launches),
                                'avg_launch_ms': tm['sweep_trmm'] / max(launches, 1),
                                'flop_per_launch': tm['sweep_trmm_flop'] / max(launches, 1)}

@@ -64,7 +64,8 @@ int gpx_version(void);
 /* options: "chunk" = candidate columns per sweep chunk (multiple of 128);
  *          "tile_order" = sweep-kernel schedule: bits 0-1 blockIdx->tile map (0 linear heavy-first,
  *              1 per-XCD candidate slices, 2 per-XCD 8x8 super-tiles), bits 2-3 k-loop variant
- *              (0 write-at-end, 1 write-at-top, 2 write-at-top + s_setprio).  Default 10.
+ *              (0 write-at-end, 1 write-at-top, 2 write-at-top + s_setprio, 3 software-pipelined
+ *              fragments, 4 LDS-DMA staging).  Default 10 = super-tiles + variant 2.
  *              Every setting produces bit-identical results. */
 int gpx_set_option(gpx_handle *h, const char *name, int64_t value);
 

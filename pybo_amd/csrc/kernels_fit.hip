@@ -296,19 +296,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_panel_trsm(const double* __
 }
 
 // ------------------------------------------------------------------------------------------------
-// R2c: trailing update  S_IJ -= R_pI^T R_pJ  for p < I <= J  (the syrk/gemm on fp64 MFMA)
+// R2c: symmetric update  S_IJ -= sum_{k in [kb0,kb1)} R_kI^T R_kJ  for tiles I = ib0+by <= J = ib0+bx
+// (the syrk/gemm on fp64 MFMA).  Used two ways by the two-level blocked factorisation below:
+//   * in-panel "row update" (grid (nP-I, 1), ib0 = I): brings block row I up to date with the rows of the
+//     current outer panel that are already factored (left-looking inside the panel, K = up to (W-1)*128);
+//   * trailing update after an outer panel of W block rows (grid (t, t)): K = W*128 per pass, so every
+//     S tile is read-modified-written once per W panels instead of once per panel (the K = 128 version
+//     is HBM-bound: 8 flop/B against a machine balance of ~12).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(const double* __restrict__ R,
                                                                  double* __restrict__ S, int64_t Np,
-                                                                 int p) {
+                                                                 int kb0, int kb1, int ib0) {
     const int bi = blockIdx.y, bj = blockIdx.x;
     if (bi > bj) return;
     __shared__ __attribute__((aligned(16))) double smem[GEMM_LDS_F64];
-    const int64_t p0 = (int64_t)p * NB;
-    const int64_t i0 = (int64_t)(p + 1 + bi) * NB, j0 = (int64_t)(p + 1 + bj) * NB;
+    const int64_t i0 = (int64_t)(ib0 + bi) * NB, j0 = (int64_t)(ib0 + bj) * NB;
     d4 acc[4][4];
     acc_zero(acc);
-    gemm_tile_128(acc, R + p0 * Np + i0, Np, R + p0 * Np + j0, Np, 0, NB, smem);
+    gemm_tile_128_b<true>(acc, R + i0, Np, R + j0, Np, kb0 * NB, kb1 * NB, smem);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -320,21 +325,30 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(const double* _
             }
 }
 
+constexpr int CHOL_W = 4;   // outer panel width in 128-blocks
+
 void launch_cholesky(gpx_handle* h) {
     const int64_t Np = h->Np;
     const int nP = (int)(Np / NB);
     hipStream_t s = h->stream;
     hipMemsetAsync(h->dflag, 0, sizeof(int), s);
-    for (int p = 0; p < nP; ++p) {
-        hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, s, h->dS, h->dR, h->dT, h->dU, Np, p,
-                           h->dflag);
-        const int rem = nP - 1 - p;
-        if (rem > 0) {
-            hipLaunchKernelGGL(k_panel_trsm, dim3(rem), dim3(GEMM_THREADS), 0, s, h->dU, h->dS, h->dR,
-                               Np, p);
-            hipLaunchKernelGGL(k_syrk_update, dim3(rem, rem), dim3(GEMM_THREADS), 0, s, h->dR, h->dS,
-                               Np, p);
+    for (int P0 = 0; P0 < nP; P0 += CHOL_W) {
+        const int P1 = (P0 + CHOL_W < nP) ? P0 + CHOL_W : nP;
+        for (int I = P0; I < P1; ++I) {
+            if (I > P0)   // block row I <- contributions of rows P0..I-1 of this panel
+                hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)(nP - I), 1), dim3(GEMM_THREADS), 0, s, h->dR,
+                                   h->dS, Np, P0, I, I);
+            hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, s, h->dS, h->dR, h->dT, h->dU, Np, I,
+                               h->dflag);
+            const int rem = nP - 1 - I;
+            if (rem > 0)
+                hipLaunchKernelGGL(k_panel_trsm, dim3(rem), dim3(GEMM_THREADS), 0, s, h->dU, h->dS, h->dR, Np,
+                                   I);
         }
+        const int t = nP - P1;
+        if (t > 0)
+            hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)t, (unsigned)t), dim3(GEMM_THREADS), 0, s, h->dR,
+                               h->dS, Np, P0, P1, P1);
     }
 }
 
