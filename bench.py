@@ -138,6 +138,10 @@ def main():
     ap.add_argument('--draws', type=int, default=64, help='Thompson draws (workload d)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-candidates', type=int, default=0, help='candidates in the CPU sample (0 = auto)')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='process-group backend; gloo only for dry runs of the N>1 path')
+    ap.add_argument('--share-device', type=int, default=-1,
+                    help='dry run: every rank uses this one GPU (with --backend gloo)')
     args = ap.parse_args()
 
     import torch
@@ -147,12 +151,17 @@ def main():
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
                          % (args.gpus, world, args.gpus))
+    if args.share_device >= 0:
+        local = args.share_device
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)      # = RCCL over xGMI on MI355X
+        else:
+            dist.init_process_group('gloo')
 
     from pybo_amd._lib import Engine
     from pybo_amd import dist as pdist
@@ -206,10 +215,11 @@ def main():
         if world > 1:
             if w['acq'] == 'thompson':      # one (value, index) pair per draw: concatenate all ranks' draws
                 kk = len(tv)
-                tvals = torch.from_numpy(np.ascontiguousarray(tv)).to(dev)
-                tidx = torch.from_numpy(np.ascontiguousarray(ti)).to(dev)
-                allv = torch.empty(world * kk, dtype=torch.float64, device=dev)
-                alli = torch.empty(world * kk, dtype=torch.int64, device=dev)
+                cdev = dev if args.backend == 'nccl' else torch.device('cpu')
+                tvals = torch.from_numpy(np.ascontiguousarray(tv)).to(cdev)
+                tidx = torch.from_numpy(np.ascontiguousarray(ti)).to(cdev)
+                allv = torch.empty(world * kk, dtype=torch.float64, device=cdev)
+                alli = torch.empty(world * kk, dtype=torch.int64, device=cdev)
                 dist.all_gather_into_tensor(allv, tvals)
                 dist.all_gather_into_tensor(alli, tidx)
                 return allv.cpu().numpy(), alli.cpu().numpy()
@@ -234,7 +244,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     tm = eng.timers(reset=True)

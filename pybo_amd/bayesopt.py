@@ -1,24 +1,35 @@
 """
-The Bayesian-optimisation driver with pybo's public surface
-(/root/reference/pybo/bayesopt.py: `solve_bayesopt` :193-287, `init_model` :60-120,
-`get_component` :125-176, checkpoint helpers :36-55), re-expressed for Python 3 on top of the
-MI355X engine.  The loop body is the reference's: policy -> solver -> objective -> add_data ->
-recommender -> checkpoint (bayesopt.py:262-276); everything numerically heavy happens inside the model
-object, which here is `pybo_amd.models.GP` (HIP kernels behind a C-ABI) instead of `reggie`.
+Bayesian-optimisation driver with pybo's public surface, running on the MI355X engine.
 
-Differences from the reference, all deliberate:
-  * `init_model` builds a fixed-hyper-parameter GP with the reference's heuristic initial values
-    (bayesopt.py:98-102) instead of wrapping it in `reggie.MCMC(n=10, burn=100)` (bayesopt.py:115): the
-    hyper-posterior sampler is reggie-internal, unpinned, and excluded from the hot path (SURVEY F10,
-    R7).  The priors are recorded on the model's params (same `set_prior` calls) but not sampled.
-  * checkpoints are binary pickles (the reference opens the file in text mode, a Python-2-ism).
-  * `get_component` reports a bad component with a working format string (the reference's
-    '{:r}' at bayesopt.py:138 is itself a ValueError).
+Public names and semantics follow /root/reference/pybo/bayesopt.py:
+    solve_bayesopt(objective, bounds, model=None, niter=100, policy='ei', solver='lbfgs',
+                   recommender='latent', ninit=None, verbose=False, log=None, rng=None)      (:193-287)
+    init_model(f, bounds, ninit=None, design='latin', log=None, rng=None)                     (:60-120)
+    get_component(value, module, rng, lstrip='')                                               (:125-176)
+    Info, safe_dump, safe_load                                                                 (:36-55)
+One step of the loop is: policy -> solver -> objective -> model.add_data -> recommender -> checkpoint
+(:262-276); every numerically heavy call lands in the model object, here `pybo_amd.models.GP` (HIP kernels
+behind a C-ABI) instead of `reggie`.
+
+Behaviour kept on purpose (it decides which points get queried, so it is part of parity):
+  * a model handed in by the caller is copied and, if the trace is empty, first fed the centre of the box
+    (:249-259);
+  * with the default model, `init_model` evaluates a 3d-point latin design that lives in the model but NOT
+    in the returned trace, because the trace was read before the model was built (:243-246), and the box
+    centre is evaluated on top of it;
+  * the loop resumes at `len(trace.xbest)` after a checkpoint reload (:262).
+Deliberate differences:
+  * `init_model` returns the fixed-hyper-parameter GP with the reference's heuristic initial values (:98-102)
+    and records the same priors, but does not wrap it in `reggie.MCMC(n=10, burn=100)` (:115): the sampler
+    is reggie-internal, unpinned and outside the hot path;
+  * checkpoints are binary pickles written atomically (the reference opens the file in text mode);
+  * a malformed component tuple raises a ValueError with a working message (the reference's '{:r}' format at
+    :138 is itself an error).
 """
 import collections
 import functools
 import inspect
-import os.path
+import os
 import pickle
 
 import numpy as np
@@ -34,166 +45,180 @@ __all__ = ['solve_bayesopt', 'init_model']
 Info = collections.namedtuple('Info', ['x', 'y', 'xbest'])
 
 
-# -- checkpointing ---------------------------------------------------------------------------------
+# ----------------------------------------------------------------------------------------------------
+# checkpointing
+# ----------------------------------------------------------------------------------------------------
 def safe_dump(model, info, filename=None):
-    """Write (model, info) to `filename` if one was given (atomically: tmp file + rename)."""
+    """Persist (model, trace); a None filename disables checkpointing."""
     if filename is None:
         return
-    tmp = filename + '.tmp'
-    with open(tmp, 'wb') as fp:
-        pickle.dump((model, info), fp)
-    os.replace(tmp, filename)
+    scratch = '{}.part{}'.format(filename, os.getpid())
+    with open(scratch, 'wb') as fh:
+        pickle.dump((model, info), fh, protocol=pickle.HIGHEST_PROTOCOL)
+    os.replace(scratch, filename)
 
 
 def safe_load(filename=None):
-    """Read a checkpoint; (None, empty Info) if there is none."""
-    if filename is not None and os.path.exists(filename):
-        with open(filename, 'rb') as fp:
-            return pickle.load(fp)
-    return None, Info([], [], [])
+    """Return the stored (model, trace), or (None, empty trace) when there is nothing to resume."""
+    if filename is None or not os.path.exists(filename):
+        return None, Info([], [], [])
+    with open(filename, 'rb') as fh:
+        return pickle.load(fh)
 
 
-# -- model bootstrap -------------------------------------------------------------------------------
+# ----------------------------------------------------------------------------------------------------
+# model bootstrap
+# ----------------------------------------------------------------------------------------------------
+def _heuristic_hypers(y, bounds):
+    """Initial hyper-parameters from the design values (reference heuristics, bayesopt.py:98-102)."""
+    spread = (max(y) - min(y)) if len(y) > 1 else 1.0
+    return dict(sn2=1e-6,
+                rho=spread if spread >= 1e-1 else 1.0,
+                ell=0.25 * (bounds[:, 1] - bounds[:, 0]),
+                bias=float(np.mean(y)) if len(y) else 0.0)
+
+
 def init_model(f, bounds, ninit=None, design='latin', log=None, rng=None, kernel='se'):
-    """Evaluate an initial design (resumable) and return a GP with heuristic hyper-parameters."""
+    """Evaluate an initial design (resumable through `log`) and return a GP fitted to it."""
     from . import models
     rng = rstate(rng)
     bounds = np.array(bounds, dtype=float, ndmin=2)
-    ninit = 3 * len(bounds) if ninit is None else ninit
-    model, info = safe_load(log)
-    if model is not None:
-        return model
-    if len(info.x) == 0:
-        design = getattr(inits, 'init_' + design)
-        info.x.extend(design(bounds, ninit, rng))
-        info.y.extend(np.nan for _ in range(ninit))
+    stored_model, trace = safe_load(log)
+    if stored_model is not None:
+        return stored_model
 
-    for i, x in enumerate(info.x):
-        if np.isnan(info.y[i]):
-            info.y[i] = f(x)
-        safe_dump(None, info, filename=log)
+    if not trace.x:                      # fresh start: lay out the design, values still unknown
+        npts = 3 * len(bounds) if ninit is None else ninit
+        trace.x.extend(getattr(inits, 'init_' + design)(bounds, npts, rng))
+        trace.y.extend([np.nan] * npts)
+    for k, point in enumerate(trace.x):  # (re)evaluate whatever is still missing, saving as we go
+        if np.isnan(trace.y[k]):
+            trace.y[k] = f(point)
+        safe_dump(None, trace, filename=log)
 
-    # heuristic hyper-parameters, bayesopt.py:98-102
-    sn2 = 1e-6
-    rho = max(info.y) - min(info.y) if len(info.y) > 1 else 1.0
-    rho = 1.0 if rho < 1e-1 else rho
-    ell = 0.25 * (bounds[:, 1] - bounds[:, 0])
-    bias = np.mean(info.y) if len(info.y) > 0 else 0.0
-
-    model = models.make_gp(sn2, rho, ell, bias, kernel=kernel)
-    model.params['like.sn2'].set_prior('horseshoe', 0.1)
-    model.params['kern.rho'].set_prior('lognormal', np.log(rho), 1.0)
-    model.params['kern.ell'].set_prior('uniform', ell / 100, ell * 10)
-    model.params['mean.bias'].set_prior('normal', bias, rho)
-    model.add_data(info.x, info.y)
-
-    safe_dump(model, info, filename=log)
-    return model
+    hyp = _heuristic_hypers(trace.y, bounds)
+    gp = models.make_gp(hyp['sn2'], hyp['rho'], hyp['ell'], hyp['bias'], kernel=kernel)
+    gp.params['like.sn2'].set_prior('horseshoe', 0.1)
+    gp.params['kern.rho'].set_prior('lognormal', np.log(hyp['rho']), 1.0)
+    gp.params['kern.ell'].set_prior('uniform', hyp['ell'] / 100, hyp['ell'] * 10)
+    gp.params['mean.bias'].set_prior('normal', hyp['bias'], hyp['rho'])
+    gp.add_data(trace.x, trace.y)
+    safe_dump(gp, trace, filename=log)
+    return gp
 
 
-# -- plugin resolution -----------------------------------------------------------------------------
+# ----------------------------------------------------------------------------------------------------
+# plugin resolution
+# ----------------------------------------------------------------------------------------------------
+def _lookup(name, module, prefix):
+    """Find `name` among module.__all__, ignoring `prefix` and case of the exported names."""
+    for exported in module.__all__:
+        key = exported[len(prefix):] if exported.startswith(prefix) else exported
+        if key.lower() == name:
+            return getattr(module, exported)
+    raise ValueError('invalid component: {!s}'.format(name))
+
+
 def get_component(value, module, rng, lstrip=''):
     """
-    Resolve a component given as a name, a callable, or (name-or-callable, kwargs):
-      * names are matched case-insensitively against `module.__all__` after stripping `lstrip`;
-      * kwargs must be a subset of the callable's defaulted arguments, `rng` excluded;
-      * `rng` is injected iff the callable has an argument called `rng`.
-    Errors are ValueError, as in the reference (bayesopt.py:138,153,167).
+    Turn a component spec into a callable.  A spec is a name, a callable, or a pair (name-or-callable,
+    kwargs).  Rules (reference bayesopt.py:125-176): names match `module.__all__` case-insensitively after
+    stripping `lstrip`; kwargs must be a subset of the callable's defaulted arguments other than `rng`;
+    `rng` is bound iff the callable has an argument of that name.  Violations raise ValueError.
     """
-    kwargs = {}
+    extra = {}
     if isinstance(value, (list, tuple)):
+        if len(value) != 2:
+            raise ValueError('invalid component: {!r}'.format(value))
+        value, extra = value
         try:
-            value, kwargs = value
-            kwargs = dict(kwargs)
+            extra = dict(extra)
         except (ValueError, TypeError):
             raise ValueError('invalid component: {!r}'.format(value))
 
-    if callable(value):
-        func = value
-    else:
-        for fname in module.__all__:
-            func = getattr(module, fname)
-            short = fname[len(lstrip):] if fname.startswith(lstrip) else fname
-            if short.lower() == value:
-                break
-        else:
-            raise ValueError('invalid component: {!s}'.format(value))
+    target = value if callable(value) else _lookup(value, module, lstrip)
 
-    spec = inspect.getfullargspec(func)
-    valid = set(spec.args[-len(spec.defaults):]) if spec.defaults else set()
-    valid.discard('rng')
-    if not valid.issuperset(kwargs.keys()):
+    spec = inspect.getfullargspec(target)
+    ndef = len(spec.defaults or ())
+    tunable = set(spec.args[len(spec.args) - ndef:]) - {'rng'}
+    unknown = [k for k in extra if k not in tunable]
+    if unknown:
         raise ValueError('unknown arguments for {:s}: {:s}'.format(
-            getattr(func, '__name__', repr(func)), ', '.join(kwargs.keys())))
-
+            getattr(target, '__name__', repr(target)), ', '.join(extra)))
     if 'rng' in spec.args:
-        kwargs['rng'] = rng
-    return functools.partial(func, **kwargs) if kwargs else func
+        extra['rng'] = rng
+    return functools.partial(target, **extra) if extra else target
 
 
-# -- verbose formatting ----------------------------------------------------------------------------
+# ----------------------------------------------------------------------------------------------------
+# progress line
+# ----------------------------------------------------------------------------------------------------
 int2str = '{:03d}'.format
 float2str = '{: .3f}'.format
 
 
 def array2str(a):
-    return np.array2string(np.asarray(a), formatter=dict(float=float2str, int=int2str))
+    return np.array2string(np.asarray(a), formatter={'float': float2str, 'int': int2str})
 
 
-# -- the meta solver -------------------------------------------------------------------------------
+def _report(i, x, y, xbest):
+    print('i={:s}, x={:s}, y={:s}, xbest={:s}'.format(int2str(i), array2str(x), float2str(y),
+                                                     array2str(xbest)))
+
+
+# ----------------------------------------------------------------------------------------------------
+# the meta solver
+# ----------------------------------------------------------------------------------------------------
+def _bo_step(model, trace, objective, bounds, policy, solver, recommender):
+    """One iteration: choose, evaluate, absorb, recommend.  Mutates `model` and `trace`."""
+    index = policy(model, bounds, trace.x)          # acquisition closure over a model copy
+    x, _ = solver(index, bounds)                    # grid sweep + top-k + refinement
+    y = objective(x)
+    model.add_data(x, y)                            # refit
+    xbest = recommender(model, bounds, trace.x)     # NB: trace.x does not contain x yet (as in the reference)
+    trace.x.append(x)
+    trace.y.append(y)
+    trace.xbest.append(xbest)
+    return x, y, xbest
+
+
 def solve_bayesopt(objective, bounds, model=None, niter=100, policy='ei', solver='lbfgs',
                    recommender='latent', ninit=None, verbose=False, log=None, rng=None):
     """
     Maximise `objective` over the box `bounds` ((d,2) array-like) by Bayesian optimisation.
 
-    `policy`, `solver`, `recommender` are each a name, a callable, or a (name-or-callable, kwargs)
-    pair; `model` is any object with the model protocol (copy / add_data / predict / get_improvement /
-    get_tail / sample_f), by default a `pybo_amd.models.GP` built by `init_model`.
-
-    Returns (xbest, model, Info(x, y, xbest)) with the Info fields as arrays (bayesopt.py:285-287).
+    `policy`, `solver`, `recommender`: a name, a callable, or (name-or-callable, kwargs); see
+    `get_component`.  `model`: any object with the model protocol (copy / add_data / predict /
+    get_improvement / get_tail / sample_f); default: a `pybo_amd.models.GP` from `init_model`.
+    Returns (xbest, model, Info(x, y, xbest)) with the Info fields as arrays.
     """
     rng = rstate(rng)
     bounds = np.array(bounds, dtype=float, ndmin=2)
-
     policy = get_component(policy, policies, rng)
     solver = get_component(solver, solvers, rng, lstrip='solve_')
     recommender = get_component(recommender, recommenders, rng, lstrip='best_')
 
-    model_, info = safe_load(log)
-    if model is None and model_ is None:
-        # NOTE (kept from the reference, bayesopt.py:243-259): `info` was loaded BEFORE init_model ran,
-        # so the initial design lives in the model but not in the returned trace, and the "single point
-        # in the middle" below is evaluated as well.  Policies therefore see info.x without the design.
-        model = init_model(objective, bounds, ninit, log=log, rng=rng)
+    resumed, trace = safe_load(log)
+    if resumed is not None:
+        model = resumed
+    elif model is None:
+        model = init_model(objective, bounds, ninit, log=log, rng=rng)   # trace stays as loaded above
     else:
-        model = model_ if model_ is not None else model.copy()
+        model = model.copy()             # never mutate the caller's model
 
-    # a user-supplied empty model is started from the centre of the box (bayesopt.py:253-259)
-    if len(info.x) == 0:
-        x = inits.init_middle(bounds)[0]
-        y = objective(x)
-        info.x.append(x)
-        info.y.append(y)
-        model.add_data(x, y)
-        safe_dump(model, info, filename=log)
+    if not trace.x:                      # seed the trace with the centre of the box
+        x0 = inits.init_middle(bounds)[0]
+        y0 = objective(x0)
+        trace.x.append(x0)
+        trace.y.append(y0)
+        model.add_data(x0, y0)
+        safe_dump(model, trace, filename=log)
 
-    xbest = info.xbest[-1] if len(info.xbest) else None
-    for i in range(len(info.xbest), niter):
-        index = policy(model, bounds, info.x)
-        x, _ = solver(index, bounds)
-
-        y = objective(x)
-        model.add_data(x, y)
-        xbest = recommender(model, bounds, info.x)
-
-        info.x.append(x)
-        info.y.append(y)
-        info.xbest.append(xbest)
-        safe_dump(model, info, filename=log)
-
+    xbest = trace.xbest[-1] if trace.xbest else None
+    for i in range(len(trace.xbest), niter):
+        x, y, xbest = _bo_step(model, trace, objective, bounds, policy, solver, recommender)
+        safe_dump(model, trace, filename=log)
         if verbose:
-            print('i={:s}, x={:s}, y={:s}, xbest={:s}'.format(
-                int2str(i), array2str(x), float2str(y), array2str(xbest)))
+            _report(i, x, y, xbest)
 
-    info = Info(*[np.array(_) for _ in info])
-    return xbest, model, info
+    return xbest, model, Info(*(np.array(col) for col in trace))

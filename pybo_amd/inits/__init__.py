@@ -1,5 +1,4 @@
-"""Initial designs (same public names as pybo.inits)."""
-from .methods import *          # noqa: F401,F403
-from . import methods
+"""Initial designs; the exported names match pybo.inits (`init_middle|uniform|latin|sobol`)."""
+from .methods import init_middle, init_uniform, init_latin, init_sobol
 
-__all__ = list(methods.__all__)
+__all__ = ['init_middle', 'init_uniform', 'init_latin', 'init_sobol']

@@ -1,5 +1,4 @@
-"""Acquisition policies (same public names as pybo.policies)."""
-from .simple import *           # noqa: F401,F403
-from . import simple
+"""Acquisition policies; the exported names match pybo.policies (`EI`, `PI`, `UCB`, `Thompson`)."""
+from .simple import EI, PI, UCB, Thompson
 
-__all__ = list(simple.__all__)
+__all__ = ['EI', 'PI', 'UCB', 'Thompson']

@@ -27,10 +27,15 @@ def _attach_topk(index, model, kind, param):
     return index
 
 
+def _incumbent_target(model, X, xi):
+    """Copy the model (the caller's must stay untouched) and compute best-posterior-mean-at-the-data + xi."""
+    snapshot = model.copy()
+    return snapshot, snapshot.predict(X)[0].max() + xi
+
+
 def EI(model, _, X, xi=0.0):
     """Expected improvement over (best posterior mean at the data) + xi."""
-    model = model.copy()
-    target = model.predict(X)[0].max() + xi
+    model, target = _incumbent_target(model, X, xi)
 
     def index(X, grad=False):
         return model.get_improvement(target, X, grad)
@@ -40,8 +45,7 @@ def EI(model, _, X, xi=0.0):
 
 def PI(model, _, X, xi=0.05):
     """Probability of improvement over (best posterior mean at the data) + xi."""
-    model = model.copy()
-    target = model.predict(X)[0].max() + xi
+    model, target = _incumbent_target(model, X, xi)
 
     def index(X, grad=False):
         return model.get_tail(target, X, grad)
@@ -50,24 +54,23 @@ def PI(model, _, X, xi=0.05):
 
 
 def Thompson(model, _, __, n=100, rng=None):
-    """Thompson sampling: the index is one posterior function sample (n random features)."""
+    """Thompson sampling: the index is one posterior function sample built from n random features."""
     return model.sample_f(n, rng).get
 
 
 def UCB(model, _, X, delta=0.1, xi=0.2):
-    """GP-UCB; `delta` = failure probability of the bound, `xi` scales the exploration term."""
+    """GP-UCB.  `delta`: failure probability of the bound; `xi`: scale of the exploration term.
+    NB the reference's `d` is len(X), the number of observations (simple.py:58)."""
     model = model.copy()
     nobs = len(X)
-    a = xi * 2 * np.log(np.pi ** 2 / 3 / delta)
-    b = xi * (4 + nobs)
-    beta = a + b * np.log(nobs + 1)
+    beta = xi * 2 * np.log(np.pi ** 2 / 3 / delta) + xi * (4 + nobs) * np.log(nobs + 1)
 
     def index(X, grad=False):
-        post = model.predict(X, grad=grad)
-        mu, s2 = post[:2]
         if not grad:
+            mu, s2 = model.predict(X)
             return mu + np.sqrt(beta * s2)
-        dmu, ds2 = post[2:]
-        return mu + np.sqrt(beta * s2), dmu + 0.5 * np.sqrt(beta / s2[:, None]) * ds2
+        mu, s2, dmu, ds2 = model.predict(X, grad=True)
+        width = np.sqrt(beta * s2)
+        return mu + width, dmu + 0.5 * np.sqrt(beta / s2[:, None]) * ds2
 
     return _attach_topk(index, model, 'ucb', beta)

@@ -1,5 +1,4 @@
-"""Inner-loop solvers (same public names as pybo.solvers; DIRECT needs nlopt and is out of scope)."""
-from .lbfgs import *            # noqa: F401,F403
-from . import lbfgs
+"""Inner-loop solvers; `solve_lbfgs` as in pybo.solvers (DIRECT needs nlopt and is out of scope)."""
+from .lbfgs import solve_lbfgs
 
-__all__ = list(lbfgs.__all__)
+__all__ = ['solve_lbfgs']
