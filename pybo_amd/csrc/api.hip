@@ -113,6 +113,17 @@ extern "C" int gpx_create(int device, void* stream, gpx_handle** out) {
         }
         h->own_stream = true;
     }
+    int prio_lo = 0, prio_hi = 0;   // numerically lowest value = highest priority
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    // the side stream carries only off-critical-path work (far trailing updates): lowest priority, so the
+    // serial chain on the caller's stream wins the dispatcher whenever both have workgroups pending
+    if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_far, hipEventDisableTiming) != hipSuccess) {
+        g_create_err = "gpx_create: side stream / event creation failed";
+        delete h;
+        return GPX_EHIP;
+    }
     if (hipMalloc((void**)&h->dflag, 64) != hipSuccess || hipMalloc((void**)&h->dscal, 16 * 8) != hipSuccess ||
         hipMalloc((void**)&h->dinvell, DMAX * 8) != hipSuccess) {
         g_create_err = "gpx_create: device allocation failed";
@@ -134,6 +145,9 @@ extern "C" int gpx_destroy(gpx_handle* h) {
                     h->dtopv, h->drff, h->dgrad};  // dPp, dtopi alias dQp, dtopv
     for (void* p : ptrs)
         if (p) hipFree(p);
+    if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+    if (h->ev_chain) hipEventDestroy(h->ev_chain);
+    if (h->ev_far) hipEventDestroy(h->ev_far);
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
     return GPX_OK;

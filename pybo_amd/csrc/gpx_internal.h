@@ -27,6 +27,8 @@ struct gpx_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t stream2 = nullptr;   // library-owned side stream (Cholesky lookahead)
+    hipEvent_t ev_chain = nullptr, ev_far = nullptr;
     std::string err;
 
     // model state

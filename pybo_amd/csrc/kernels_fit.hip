@@ -276,23 +276,28 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, doub
 // ------------------------------------------------------------------------------------------------
 // R2b: panel solve  R_pJ = T_pp S_pJ  (J > p) as a GEMM:  A(m,k) = T_pp(m,k) = U[p0+k][p0+m]
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_panel_trsm(const double* __restrict__ U,
-                                                                const double* __restrict__ S,
-                                                                double* __restrict__ R, int64_t Np,
-                                                                int p) {
-    __shared__ __attribute__((aligned(16))) double smem[GEMM_LDS_F64];
+__global__ __launch_bounds__(GEMM_THREADS) void k_panel_trsm(const double* __restrict__ U,
+                                                             const double* __restrict__ S,
+                                                             double* __restrict__ R, int64_t Np, int p) {
+    // 64x64 tiles: blockIdx.y = 64-row half of the block row, blockIdx.x = 64-column tile right of the
+    // diagonal block.  T_pp is lower triangular (U_pp[k][m] = 0 for k > m): the upper half needs k < 64 only.
+    __shared__ __attribute__((aligned(16))) double smem[GEMM64_LDS_F64];
     const int64_t p0 = (int64_t)p * NB;
-    const int64_t j0 = (int64_t)(p + 1 + blockIdx.x) * NB;
-    d4 acc[4][4];
-    acc_zero(acc);
-    gemm_tile_128(acc, U + p0 * Np + p0, Np, S + p0 * Np + j0, Np, 0, NB, smem);
+    const int mh = blockIdx.y;
+    const int64_t j0 = (int64_t)(p + 1) * NB + (int64_t)blockIdx.x * T64;
+    d4 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+    gemm_tile_64(acc, U + p0 * Np + p0 + mh * T64, Np, S + p0 * Np + j0, Np, 0, (mh + 1) * T64, smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                R[(p0 + acc_row(i, r)) * Np + j0 + acc_col(j)] = acc[i][j][r];
+                R[(p0 + mh * T64 + acc_row64(i, r)) * Np + j0 + acc_col64(j)] = acc[i][j][r];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -306,11 +311,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_panel_trsm(const double* __
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(const double* __restrict__ R,
                                                                  double* __restrict__ S, int64_t Np,
-                                                                 int kb0, int kb1, int ib0) {
-    const int bi = blockIdx.y, bj = blockIdx.x;
-    if (bi > bj) return;
+                                                                 int kb0, int kb1, int ib0, int jb0) {
+    const int I = ib0 + blockIdx.y, J = jb0 + blockIdx.x;
+    if (I > J) return;
     __shared__ __attribute__((aligned(16))) double smem[GEMM_LDS_F64];
-    const int64_t i0 = (int64_t)(ib0 + bi) * NB, j0 = (int64_t)(ib0 + bj) * NB;
+    const int64_t i0 = (int64_t)I * NB, j0 = (int64_t)J * NB;
     d4 acc[4][4];
     acc_zero(acc);
     gemm_tile_128_b<true>(acc, R + i0, Np, R + j0, Np, kb0 * NB, kb1 * NB, smem);
@@ -325,31 +330,78 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(const double* _
             }
 }
 
+// In-panel row update on 64x64 tiles: block row I (two 64-row halves) <- rows kb0..kb1-1 of R.
+// grid (2*(nP-I), 2): blockIdx.y = row half, blockIdx.x = 64-column tile counted from the diagonal block.
+__global__ __launch_bounds__(GEMM_THREADS) void k_row_update64(const double* __restrict__ R,
+                                                               double* __restrict__ S, int64_t Np, int kb0,
+                                                               int kb1, int I) {
+    if (blockIdx.x < blockIdx.y) return;   // strictly below the diagonal inside the diagonal block
+    __shared__ __attribute__((aligned(16))) double smem[GEMM64_LDS_F64];
+    const int64_t i0 = (int64_t)I * NB + (int64_t)blockIdx.y * T64;
+    const int64_t j0 = (int64_t)I * NB + (int64_t)blockIdx.x * T64;
+    d4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+    gemm_tile_64(acc, R + i0, Np, R + j0, Np, kb0 * NB, kb1 * NB, smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double* q = S + (i0 + acc_row64(i, r)) * Np + j0 + acc_col64(j);
+                *q -= acc[i][j][r];
+            }
+}
+
 constexpr int CHOL_W = 4;   // outer panel width in 128-blocks
 
+// Two-level blocked right-looking factorisation with one panel of lookahead.
+//   chain(P)   rows P0..P1-1 one by one: row update (left-looking inside the panel) -> k_potrf_diag ->
+//              k_panel_trsm.  Serial and latency-bound (~120 us per 128-block), uses a handful of CUs.
+//   near(P)    trailing update of the NEXT panel's block rows (P1 .. P1+W-1, all J >= I), K = W*128.
+//              On the main stream: chain(P+1) needs it.
+//   far(P)     trailing update of everything below (rows >= P1+W).  On the second (low-priority) stream,
+//              started after near(P) and concurrent with chain(P+1); near(P+1) waits for it (same tiles).
 void launch_cholesky(gpx_handle* h) {
     const int64_t Np = h->Np;
     const int nP = (int)(Np / NB);
-    hipStream_t s = h->stream;
+    hipStream_t s = h->stream, s2 = h->stream2;
     hipMemsetAsync(h->dflag, 0, sizeof(int), s);
+    bool far_pending = false;
     for (int P0 = 0; P0 < nP; P0 += CHOL_W) {
         const int P1 = (P0 + CHOL_W < nP) ? P0 + CHOL_W : nP;
         for (int I = P0; I < P1; ++I) {
             if (I > P0)   // block row I <- contributions of rows P0..I-1 of this panel
-                hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)(nP - I), 1), dim3(GEMM_THREADS), 0, s, h->dR,
-                                   h->dS, Np, P0, I, I);
+                hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - I)), 2), dim3(GEMM_THREADS), 0, s,
+                                   h->dR, h->dS, Np, P0, I, I);
             hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, s, h->dS, h->dR, h->dT, h->dU, Np, I,
                                h->dflag);
             const int rem = nP - 1 - I;
             if (rem > 0)
-                hipLaunchKernelGGL(k_panel_trsm, dim3(rem), dim3(GEMM_THREADS), 0, s, h->dU, h->dS, h->dR, Np,
-                                   I);
+                hipLaunchKernelGGL(k_panel_trsm, dim3((unsigned)(2 * rem), 2), dim3(GEMM_THREADS), 0, s, h->dU,
+                                   h->dS, h->dR, Np, I);
         }
-        const int t = nP - P1;
-        if (t > 0)
-            hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)t, (unsigned)t), dim3(GEMM_THREADS), 0, s, h->dR,
-                               h->dS, Np, P0, P1, P1);
+        if (P1 >= nP) break;
+        const int nnear = (P1 + CHOL_W < nP) ? CHOL_W : nP - P1;   // block rows of the next panel
+        const int tfar = nP - P1 - nnear;                           // block rows below it
+        if (far_pending) hipStreamWaitEvent(s, h->ev_far, 0);       // far(P-1) wrote the tiles near(P) touches
+        hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)(nP - P1), (unsigned)nnear), dim3(GEMM_THREADS), 0, s,
+                           h->dR, h->dS, Np, P0, P1, P1, P1);
+        hipEventRecord(h->ev_chain, s);   // after near(P): it runs alone, far(P) then overlaps chain(P+1) only
+        if (tfar > 0) {
+            hipStreamWaitEvent(s2, h->ev_chain, 0);                 // needs R rows P0..P1-1
+            hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)tfar, (unsigned)tfar), dim3(GEMM_THREADS), 0, s2,
+                               h->dR, h->dS, Np, P0, P1, P1 + nnear, P1 + nnear);
+            hipEventRecord(h->ev_far, s2);
+            far_pending = true;
+        } else {
+            far_pending = false;
+        }
     }
+    if (far_pending) hipStreamWaitEvent(s, h->ev_far, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
