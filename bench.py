@@ -189,19 +189,21 @@ def main():
         eng.fit_dev(dX.data_ptr(), N, d, dy.data_ptr(), w['kernel'], w['ell'], w['rho'], w['sn2'], w['bias'])
         if w['acq'] == 'thompson':
             # each rank owns S/world posterior draws and sweeps ALL candidates for them
-            Ws, bs, ths = [], [], []
+            Ws, bs, zs = [], [], []
             for s in mine:
                 rng = np.random.RandomState(100 + s)
-                W = rng.randn(100, d) / w['ell']
-                b = rng.rand(100) * 2 * np.pi
-                z = rng.randn(100)
-                A, v = eng.rff_gram(W, b)
-                sc = np.sqrt(2.0 * w['rho'] / 100)
+                Ws.append(rng.randn(100, d) / w['ell'])
+                bs.append(rng.rand(100) * 2 * np.pi)
+                zs.append(rng.randn(100))
+            Ws, bs = np.array(Ws), np.array(bs)
+            As, vs = eng.rff_gram_batch(Ws, bs)          # feature Grams of all local draws, one device call
+            sc = np.sqrt(2.0 * w['rho'] / 100)
+            ths = []
+            for A, v, z in zip(As, vs, zs):              # 100 x 100 weight posteriors on the host
                 L = np.linalg.cholesky(sc * sc * A + w['sn2'] * np.eye(100))
-                th = sc * (np.linalg.solve(L.T, np.linalg.solve(L, sc * v)) +
-                           np.sqrt(w['sn2']) * np.linalg.solve(L.T, z))
-                Ws.append(W); bs.append(b); ths.append(th)
-            tv, ti = eng.rff_sweep_dev(np.array(Ws), np.array(bs), np.array(ths), w['bias'],
+                ths.append(sc * (np.linalg.solve(L.T, np.linalg.solve(L, sc * v)) +
+                                 np.sqrt(w['sn2']) * np.linalg.solve(L.T, z)))
+            tv, ti = eng.rff_sweep_dev(Ws, bs, np.array(ths), w['bias'],
                                        dXc_full.data_ptr(), M, 1)
             tv, ti = tv[:, 0], ti[:, 0]
         else:

@@ -130,6 +130,9 @@ int gpx_rff_grad(gpx_handle *h, const double *W, const double *b, const double *
 /* feature Gram for the weight posterior: Phi = cos(X_obs W^T + b) (N,n) on the device's X_obs;
  * returns A = Phi^T Phi (n,n) and v = Phi^T (y - bias) (n,) in host buffers. */
 int gpx_rff_gram(gpx_handle *h, const double *W, const double *b, int64_t n, double *A, double *v);
+/* the same for S draws in one call: W (S,n,d), b (S,n) -> A (S,n,n), v (S,n) */
+int gpx_rff_gram_batch(gpx_handle *h, const double *W, const double *b, int64_t S, int64_t n, double *A,
+                       double *v);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 /* Stage timers in milliseconds accumulated since the last reset (HIP events on the handle's

@@ -37,6 +37,7 @@ SYMBOLS = {
     'gpx_rff_sweep_dev': (C.c_int, [_P, _P, _P, _P, _i64, _i64, _i64, _dbl, _P, _i64, _i64, _P, _P, _P]),
     'gpx_rff_grad': (C.c_int, [_P, _P, _P, _P, _i64, _i64, _dbl, _P, _i64, _P, _P]),
     'gpx_rff_gram': (C.c_int, [_P, _P, _P, _i64, _P, _P]),
+    'gpx_rff_gram_batch': (C.c_int, [_P, _P, _P, _i64, _i64, _P, _P]),
     'gpx_timers': (C.c_int, [_P, _P, C.c_int, C.c_int]),
     'gpx_sync': (C.c_int, [_P]),
 }
@@ -216,6 +217,15 @@ class Engine(object):
         A = np.empty((n, n))
         v = np.empty(n)
         self._check(self._lib.gpx_rff_gram(self._h, _ptr(W), _ptr(b), n, _ptr(A), _ptr(v)))
+        return A, v
+
+    def rff_gram_batch(self, W, b):
+        W = _f64(W)
+        S, n, d = W.shape
+        b = _f64(b).reshape(S, n)
+        A = np.empty((S, n, n))
+        v = np.empty((S, n))
+        self._check(self._lib.gpx_rff_gram_batch(self._h, _ptr(W), _ptr(b), S, n, _ptr(A), _ptr(v)))
         return A, v
 
     def rff_sweep(self, W, b, theta, bias, Xc, k=0, want_all=True):

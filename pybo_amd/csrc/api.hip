@@ -142,7 +142,7 @@ extern "C" int gpx_destroy(gpx_handle* h) {
     for (auto e : h->pool) hipEventDestroy(e);
     void* ptrs[] = {h->dXs, h->dXraw, h->dy, h->dS, h->dR, h->dT, h->dU, h->da, h->dalpha, h->dinvell,
                     h->dflag, h->dscal, h->dKs, h->dQp, h->dXc, h->dout, h->dblkv, h->dblki,
-                    h->dtopv, h->drff, h->dgrad};  // dPp, dtopi alias dQp, dtopv
+                    h->dtopv, h->drff, h->drffs, h->dgrad};  // dPp, dtopi alias dQp, dtopv
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
@@ -514,21 +514,37 @@ static int rff_core(gpx_handle* h, const double* W, const double* b, const doubl
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
     int rc;
-    const int64_t npar = S * n * d + 2 * S * n;
-    if ((rc = ensure(h, h->drff, h->cap_rff, npar))) return rc;
-    double* dW = h->drff;
-    double* db = dW + S * n * d;
-    double* dth = db + S * n;
-    HIPCHK(h, hipMemcpyAsync(dW, W, (size_t)S * n * d * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(db, b, (size_t)S * n * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(dth, theta, (size_t)S * n * 8, hipMemcpyHostToDevice, s));
+    // re-tile the draw parameters for the MFMA kernel: features padded to 128 per tile, k-major tiles
+    const int64_t dp = (d + 3) / 4 * 4;
+    const int64_t nfb = (n + TBH - 1) / TBH;
+    const int64_t nW = S * nfb * dp * TBH, nV = S * nfb * TBH;
+    std::vector<double> stage((size_t)(nW + 2 * nV), 0.0);
+    {
+        double* Wt = stage.data();
+        double* bt = Wt + nW;
+        double* tt = bt + nV;
+        for (int64_t q = 0; q < S; ++q)
+            for (int64_t j = 0; j < n; ++j) {
+                const int64_t fb = j / TBH, c = j % TBH;
+                for (int64_t kk = 0; kk < d; ++kk)
+                    Wt[((q * nfb + fb) * dp + kk) * TBH + c] = W[(q * n + j) * d + kk];
+                bt[(q * nfb + fb) * TBH + c] = b[q * n + j];
+                tt[(q * nfb + fb) * TBH + c] = theta[q * n + j];
+            }
+    }
+    if ((rc = ensure(h, h->drff, h->cap_rff, nW + 2 * nV))) return rc;
+    double* dWt = h->drff;
+    double* dbt = dWt + nW;
+    double* dtt = dbt + nV;
+    HIPCHK(h, hipMemcpyAsync(dWt, stage.data(), stage.size() * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipStreamSynchronize(s));   // `stage` is a local buffer
     if (!d_vals) {
         if ((rc = ensure(h, h->dout, h->cap_out, S * M))) return rc;
         d_vals = h->dout;
     }
     {
         Span sp(h, T_RFF);
-        launch_rff_eval(s, dW, db, dth, (int)S, (int)n, (int)d, bias, dXc, M, d_vals);
+        launch_rff_mfma(s, dWt, dbt, dtt, (int)S, (int)nfb, (int)d, (int)dp, bias, dXc, M, d_vals);
     }
     if (k > 0) {
         const int64_t nblk = topk_blocks(M);
@@ -587,31 +603,70 @@ extern "C" int gpx_rff_grad(gpx_handle* h, const double* W, const double* b, con
     return gpx::rff_grad_host(h, W, b, theta, n, d, bias, Xc, M, f, g);
 }
 
-extern "C" int gpx_rff_gram(gpx_handle* h, const double* W, const double* b, int64_t n, double* A, double* v) {
+extern "C" int gpx_rff_gram_batch(gpx_handle* h, const double* W, const double* b, int64_t S, int64_t n,
+                                  double* A, double* v) {
     if (!h) return GPX_EARG;
     if (h->stage < 1) return fail(h, GPX_ESTATE, "rff_gram: no data on the device (fit first)");
-    if (!W || !b || !A || !v || n < 1) return fail(h, GPX_EARG, "rff_gram: bad arguments");
+    if (!W || !b || !A || !v || n < 1 || S < 1) return fail(h, GPX_EARG, "rff_gram: bad arguments");
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
-    const int64_t d = h->d, Np = h->Np;
+    const int64_t d = h->d, Np = h->Np, N = h->N;
     int rc;
-    // layout: [W n*d][b n][A n*n][v n][Ft n*Np]
-    const int64_t need = n * d + n + n * n + n + n * Np;
+    if (n >= TBH) {
+        // wide feature maps: one draw at a time on the generic path
+        // layout: [W n*d][b n][A n*n][v n][Ft n*Np]
+        const int64_t need = n * d + n + n * n + n + n * Np;
+        if ((rc = ensure(h, h->drff, h->cap_rff, need))) return rc;
+        double* dW = h->drff;
+        double* db = dW + n * d;
+        double* dA = db + n;
+        double* dv = dA + n * n;
+        double* dFt = dv + n;
+        for (int64_t q = 0; q < S; ++q) {
+            HIPCHK(h, hipMemcpyAsync(dW, W + q * n * d, (size_t)n * d * 8, hipMemcpyHostToDevice, s));
+            HIPCHK(h, hipMemcpyAsync(db, b + q * n, (size_t)n * 8, hipMemcpyHostToDevice, s));
+            {
+                Span sp(h, T_RFF);
+                launch_rff_gram(s, h->dXraw, dFt, N, (int)d, dW, db, (int)n, h->dy, h->bias, dA, dv);
+            }
+            HIPCHK(h, hipMemcpyAsync(A + q * n * n, dA, (size_t)n * n * 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipMemcpyAsync(v + q * n, dv, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipStreamSynchronize(s));
+        }
+        HIPCHK(h, hipGetLastError());
+        return GPX_OK;
+    }
+    // batched MFMA path: feature tiles [S][dp][128] k-major, phases [S][128]
+    const int64_t dp = (d + 3) / 4 * 4;
+    const int64_t nW = S * dp * TBH, nV = S * TBH;
+    std::vector<double> stage((size_t)(nW + nV), 0.0);
+    for (int64_t q = 0; q < S; ++q)
+        for (int64_t j = 0; j < n; ++j) {
+            for (int64_t kk = 0; kk < d; ++kk) stage[(size_t)((q * dp + kk) * TBH + j)] = W[(q * n + j) * d + kk];
+            stage[(size_t)(nW + q * TBH + j)] = b[q * n + j];
+        }
+    // device: [Wt nW][bt nV][A S*n*n][v S*n]
+    const int64_t need = nW + nV + S * n * n + S * n;
     if ((rc = ensure(h, h->drff, h->cap_rff, need))) return rc;
-    double* dW = h->drff;
-    double* db = dW + n * d;
-    double* dA = db + n;
-    double* dv = dA + n * n;
-    double* dFt = dv + n;
-    HIPCHK(h, hipMemcpyAsync(dW, W, (size_t)n * d * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(db, b, (size_t)n * 8, hipMemcpyHostToDevice, s));
+    if ((rc = ensure(h, h->drffs, h->cap_rffs, rff_gram_batch_scratch(S, Np)))) return rc;
+    double* dWt = h->drff;
+    double* dbt = dWt + nW;
+    double* dA = dbt + nV;
+    double* dv = dA + S * n * n;
+    HIPCHK(h, hipMemcpyAsync(dWt, stage.data(), stage.size() * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipStreamSynchronize(s));   // `stage` is a local buffer
     {
         Span sp(h, T_RFF);
-        launch_rff_gram(s, h->dXraw, dFt, h->N, (int)d, dW, db, (int)n, h->dy, h->bias, dA, dv);
+        launch_rff_gram_batch(s, h->dXraw, N, Np, (int)d, (int)dp, dWt, dbt, (int)S, (int)n, h->dy, h->bias,
+                              h->drffs, dA, dv);
     }
-    HIPCHK(h, hipMemcpyAsync(A, dA, (size_t)n * n * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipMemcpyAsync(v, dv, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(A, dA, (size_t)S * n * n * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(v, dv, (size_t)S * n * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     HIPCHK(h, hipGetLastError());
     return GPX_OK;
+}
+
+extern "C" int gpx_rff_gram(gpx_handle* h, const double* W, const double* b, int64_t n, double* A, double* v) {
+    return gpx_rff_gram_batch(h, W, b, 1, n, A, v);
 }

@@ -76,6 +76,8 @@ struct gpx_handle {
     int64_t cap_top = 0;
     double* drff = nullptr;   // RFF parameter staging
     int64_t cap_rff = 0;
+    double* drffs = nullptr;  // RFF feature-Gram scratch (Phi slabs + split-K partials)
+    int64_t cap_rffs = 0;
     double* dgrad = nullptr;  // predict-with-gradient scratch
     int64_t cap_grad = 0;
 
@@ -123,6 +125,12 @@ int rff_grad_host(gpx_handle* h, const double* W, const double* b, const double*
 // launchers (kernels_rff.hip)
 void launch_rff_eval(hipStream_t s, const double* W, const double* b, const double* theta, int S, int n,
                      int d, double bias, const double* Xc, int64_t M, double* vals /* (S,M) */);
+void launch_rff_mfma(hipStream_t s, const double* Wt, const double* bt, const double* tt, int S, int nfb, int d,
+                     int dp, double bias, const double* Xc, int64_t M, double* vals);
+int64_t rff_gram_batch_scratch(int64_t S, int64_t Np);
+void launch_rff_gram_batch(hipStream_t s, const double* Xraw, int64_t N, int64_t Np, int d, int dp,
+                           const double* Wt, const double* bt, int S, int n, const double* y, double bias,
+                           double* scratch, double* A, double* v);
 void launch_rff_gram(hipStream_t s, const double* Xraw, const double* Ft_scratch, int64_t N, int d,
                      const double* W, const double* b, int n, const double* y, double bias, double* A,
                      double* v);

@@ -5,6 +5,7 @@
 // spectral draws W, b and the weight-posterior noise are made on the host from the caller's seeded
 // RandomState so a draw is reproducible; the device does the O(N n^2) feature Gram for the weight
 // posterior and the O(M S n d) evaluation sweep.
+#include "gemm_core.h"
 #include "gpx_internal.h"
 
 namespace gpx {
@@ -65,7 +66,278 @@ void launch_rff_eval(hipStream_t s, const double* W, const double* b, const doub
     hipLaunchKernelGGL(k_rff_eval, grid, dim3(RF_T), lds, s, W, b, theta, n, d, bias, Xc, M, vals);
 }
 
-// Ft[j][i] = cos(w_j . x_i + b_j) for observed points i < N (0 beyond); one thread per (j, i)
+// ------------------------------------------------------------------------------------------------
+// MFMA form of the Thompson sweep.  The projection Z = Xc W^T is a GEMM (M x d) x (d x S*n): on the VALU it
+// is operand-delivery bound (one LDS/scalar read per FMA); the 16x16x4 outer-product structure of
+// v_mfma_f64 needs 0.03 operand reads per FMA instead.  (fp64 MFMA and fp64 VALU share the DP lanes on
+// gfx950, so this buys operand bandwidth, not extra flop/s -- see DESIGN.md.)
+//   grid (ceil(M/128), S); workgroup = 4 waves (2x2), tile = 128 candidates x 128 features of ONE draw
+//   (features zero-padded to a multiple of 128 with theta = 0), K = d padded to a multiple of 4.
+//   The candidate tile stays in LDS (k-major) for the workgroup's life; feature tiles stream through.
+//   Epilogue per accumulator element: theta_f * cos(z + b_f), summed over the tile's 128 columns into a
+//   per-row register, reduced across lanes / the two column-waves once at the end.
+// cos: 3-term Cody-Waite reduction by pi/2 + the fdlibm minimax kernels on [-pi/4, pi/4] (both evaluated,
+// selected by quadrant: branch-free, ~25 DP ops).  |z| = |w.x + b| stays far below the 2^20*pi/2 validity
+// range of the reduction.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double cos_cw(double z) {
+    const double n = rint(z * 6.36619772367581382433e-01);
+    double r = fma(-n, 1.57079632673412561417e+00, z);
+    r = fma(-n, 6.07710050630396597660e-11, r);
+    r = fma(-n, 2.02226624879595063154e-21, r);
+    const double r2 = r * r;
+    double ps = fma(r2, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(r2, ps, 2.75573137070700676789e-06);
+    ps = fma(r2, ps, -1.98412698298579493134e-04);
+    ps = fma(r2, ps, 8.33333333332248946124e-03);
+    ps = fma(r2, ps, -1.66666666666666324348e-01);
+    const double sn = fma(r * r2, ps, r);
+    double pc = fma(r2, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(r2, pc, -2.75573143513906633035e-07);
+    pc = fma(r2, pc, 2.48015872894767294178e-05);
+    pc = fma(r2, pc, -1.38888888888741095749e-03);
+    pc = fma(r2, pc, 4.16666666666666019037e-02);
+    const double cs = fma(r2 * r2, pc, fma(-0.5, r2, 1.0));
+    const int q = ((int)n) & 3;
+    const double v = (q & 1) ? sn : cs;
+    return (q == 1 || q == 2) ? -v : v;
+}
+
+// Wt:  [S][nfb][dp][128]   feature tiles, k-major (zero padded);  bt, tt: [S][nfb][128]
+// grid (ceil(M/128)): one workgroup per 128-candidate tile, looping over all S draws.
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_rff_mfma(const double* __restrict__ Wt,
+                                                              const double* __restrict__ bt,
+                                                              const double* __restrict__ tt, int S, int nfb,
+                                                              int d, int dp, double bias,
+                                                              const double* __restrict__ Xc, int64_t M,
+                                                              double* __restrict__ vals) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // At[dp][LDT] | Bt[dp][LDT] | red[2][128]
+    // (single-buffered feature tile: 2*dp*144*8 B = 74 KB at d = 32, so TWO workgroups share a CU and hide
+    //  each other's tile loads and cosine chains; a double-buffered tile would leave one workgroup per CU)
+    double* At = lds;
+    double* Bt = lds + dp * LDT;
+    double* red = Bt + dp * LDT;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int64_t m0 = (int64_t)blockIdx.x * TB;
+    // candidate tile, transposed into k-major once (lane <-> candidate: conflict-free LDS stores)
+    for (int e = t; e < TB * dp; e += GEMM_THREADS) {
+        const int k = e >> 7, m = e & 127;
+        const int64_t gm = m0 + m;
+        At[k * LDT + m] = (k < d && gm < M) ? Xc[gm * d + k] : 0.0;
+    }
+    const int fr = lane & 15, fk = lane >> 4;
+    const int ntile = S * nfb;
+    auto load_b = [&](int tile) {   // 16-byte pieces, coalesced rows of 1 KiB
+        const double* Wtile = Wt + (int64_t)tile * dp * TB;
+        double* dst = Bt;
+        for (int e = t; e < (TB / 2) * dp; e += GEMM_THREADS) {
+            const int k = e >> 6, c = (e & 63) * 2;
+            *reinterpret_cast<d2*>(dst + k * LDT + c) = *reinterpret_cast<const d2*>(Wtile + (int64_t)k * TB + c);
+        }
+    };
+    double rowsum[4][4];
+    for (int tile = 0; tile < ntile; ++tile) {
+        const int fb = tile % nfb, s = tile / nfb;
+        load_b(tile);
+        __syncthreads();   // feature tile (and, first time, the candidate tile) complete
+        if (fb == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rowsum[i][r] = 0.0;
+        }
+        d4 acc[4][4];
+        acc_zero(acc);
+        const double* as = At + wm * 64 + fr;
+        const double* bs = Bt + wn * 64 + fr;
+        for (int kk = 0; kk < dp / 4; ++kk) {
+            const int kr = kk * 4 + fk;
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = as[kr * LDT + i * 16];
+                b[i] = bs[kr * LDT + i * 16];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        const double* bb = bt + (int64_t)tile * TB + wn * 64 + fr;
+        const double* th = tt + (int64_t)tile * TB + wn * 64 + fr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double bj = bb[j * 16], tj = th[j * 16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rowsum[i][r] = fma(tj, cos_cw(acc[i][j][r] + bj), rowsum[i][r]);
+        }
+        if (fb == nfb - 1) {
+            // draw s complete: reduce over the 16 lanes sharing a row, then over the two column-waves
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double v = rowsum[i][r];
+                    v += __shfl_xor(v, 1);
+                    v += __shfl_xor(v, 2);
+                    v += __shfl_xor(v, 4);
+                    v += __shfl_xor(v, 8);
+                    if (fr == 0) red[wn * TB + wm * 64 + i * 16 + fk + 4 * r] = v;
+                }
+            __syncthreads();
+            if (t < TB) {
+                const int64_t gm = m0 + t;
+                if (gm < M) vals[(int64_t)s * M + gm] = bias + red[t] + red[TB + t];
+            }
+        }
+        __syncthreads();   // everyone is done with this feature tile (and red): it may be overwritten
+    }
+}
+
+// device staging layout for the MFMA path: [Wt S*nfb*dp*128][bt S*nfb*128][tt S*nfb*128]
+void launch_rff_mfma(hipStream_t s, const double* Wt, const double* bt, const double* tt, int S, int nfb, int d,
+                     int dp, double bias, const double* Xc, int64_t M, double* vals) {
+    dim3 grid((unsigned)((M + TB - 1) / TB));
+    const size_t ldsb = (size_t)(2 * dp * LDT + 2 * TB) * sizeof(double);
+    if (ldsb > 64 * 1024)
+        hipFuncSetAttribute((const void*)k_rff_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    hipLaunchKernelGGL(k_rff_mfma, grid, dim3(GEMM_THREADS), ldsb, s, Wt, bt, tt, S, nfb, d, dp, bias, Xc, M,
+                       vals);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight-posterior statistics for S draws at once:  A_s = C_s^T C_s (n x n),  v_s = C_s^T (y - bias),
+// C_s = cos(X_obs W_s^T + b_s).  Three launches, all on the MFMA tile engine:
+//   k_rff_phi     Phi[s][i][f] = cos(w_sf . x_i + b_sf) for f < n;  Phi[s][i][n] = y_i - bias (the residual
+//                 rides along as one extra "feature" in the zero padding);  0 beyond; rows i >= N are 0.
+//   k_rff_gram_sk split-K Gram of the (Np x 128) slab of each draw: partial[s][sp] = Phi_s[rows sp]^T Phi_s[..]
+//                 (both operands are the same k-major matrix: A(m,k) = B(k,m) = Phi_s[k][m])
+//   k_rff_gram_rd fixed-order reduction of the partials (deterministic) -> A (S,n,n), v (S,n)
+// Requires n < 128 (the Thompson default is 100); larger n takes the per-draw path.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_rff_phi(const double* __restrict__ Wt,
+                                                             const double* __restrict__ bt, int S, int n, int d,
+                                                             int dp, const double* __restrict__ X, int64_t N,
+                                                             int64_t Np, const double* __restrict__ y,
+                                                             double bias, double* __restrict__ Phi) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // At[dp][LDT] | Bt[dp][LDT]
+    double* At = lds;
+    double* Bt = lds + dp * LDT;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int64_t m0 = (int64_t)blockIdx.x * TB;
+    for (int e = t; e < TB * dp; e += GEMM_THREADS) {
+        const int k = e >> 7, m = e & 127;
+        const int64_t gm = m0 + m;
+        At[k * LDT + m] = (k < d && gm < N) ? X[gm * d + k] : 0.0;
+    }
+    const int fr = lane & 15, fk = lane >> 4;
+    for (int s = 0; s < S; ++s) {
+        const double* Wtile = Wt + (int64_t)s * dp * TB;
+        for (int e = t; e < (TB / 2) * dp; e += GEMM_THREADS) {
+            const int k = e >> 6, c = (e & 63) * 2;
+            *reinterpret_cast<d2*>(Bt + k * LDT + c) = *reinterpret_cast<const d2*>(Wtile + (int64_t)k * TB + c);
+        }
+        __syncthreads();
+        d4 acc[4][4];
+        acc_zero(acc);
+        const double* as = At + wm * 64 + fr;
+        const double* bs = Bt + wn * 64 + fr;
+        for (int kk = 0; kk < dp / 4; ++kk) {
+            const int kr = kk * 4 + fk;
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = as[kr * LDT + i * 16];
+                b[i] = bs[kr * LDT + i * 16];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        double* out = Phi + (int64_t)s * Np * TB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int f = wn * 64 + j * 16 + fr;
+            const double bj = bt[(int64_t)s * TB + f];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t gi = m0 + wm * 64 + i * 16 + fk + 4 * r;
+                    double v = 0.0;
+                    if (gi < N) v = (f < n) ? cos_cw(acc[i][j][r] + bj) : ((f == n) ? y[gi] - bias : 0.0);
+                    out[gi * TB + f] = v;
+                }
+        }
+        __syncthreads();
+    }
+}
+
+constexpr int RFF_SPLIT = 16;
+
+// grid (RFF_SPLIT, S): partial Gram over rows [sp*rows, (sp+1)*rows) of draw s
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_rff_gram_sk(const double* __restrict__ Phi, int64_t Np,
+                                                                 double* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) double smem[GEMM_LDS_F64];
+    const int sp = blockIdx.x, s = blockIdx.y;
+    const int64_t rows = (Np / TB + RFF_SPLIT - 1) / RFF_SPLIT * TB;   // multiple of 128 (hence of BK)
+    const int64_t k_lo = (int64_t)sp * rows;
+    const int64_t k_hi = (k_lo + rows < Np) ? k_lo + rows : Np;
+    const double* P = Phi + (int64_t)s * Np * TB;
+    d4 acc[4][4];
+    acc_zero(acc);
+    if (k_lo < k_hi) gemm_tile_128(acc, P, TB, P, TB, (int)k_lo, (int)k_hi, smem);
+    double* out = part + ((int64_t)s * RFF_SPLIT + sp) * TB * TB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[acc_row(i, r) * TB + acc_col(j)] = acc[i][j][r];
+}
+
+// one thread per (s, j1, j2 <= n): A[s][j1][j2] for j2 < n, v[s][j1] for j2 == n
+__global__ __launch_bounds__(256) void k_rff_gram_rd(const double* __restrict__ part, int S, int n,
+                                                     double* __restrict__ A, double* __restrict__ v) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t per = (int64_t)n * (n + 1);
+    if (idx >= per * S) return;
+    const int s = (int)(idx / per);
+    const int64_t r = idx - (int64_t)s * per;
+    const int j1 = (int)(r / (n + 1)), j2 = (int)(r - (int64_t)j1 * (n + 1));
+    double acc = 0.0;
+    for (int sp = 0; sp < RFF_SPLIT; ++sp)
+        acc += part[(((int64_t)s * RFF_SPLIT + sp) * TB + j1) * TB + j2];
+    if (j2 < n) A[((int64_t)s * n + j1) * n + j2] = acc;
+    else v[(int64_t)s * n + j1] = acc;
+}
+
+// scratch: Phi (S*Np*128) | part (S*RFF_SPLIT*128*128)
+int64_t rff_gram_batch_scratch(int64_t S, int64_t Np) { return S * Np * TB + S * RFF_SPLIT * TB * TB; }
+
+void launch_rff_gram_batch(hipStream_t s, const double* Xraw, int64_t N, int64_t Np, int d, int dp,
+                           const double* Wt, const double* bt, int S, int n, const double* y, double bias,
+                           double* scratch, double* A, double* v) {
+    double* Phi = scratch;
+    double* part = scratch + (int64_t)S * Np * TB;
+    const size_t ldsb = (size_t)(2 * dp * LDT) * sizeof(double);
+    if (ldsb > 64 * 1024)
+        hipFuncSetAttribute((const void*)k_rff_phi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    hipLaunchKernelGGL(k_rff_phi, dim3((unsigned)(Np / TB)), dim3(GEMM_THREADS), ldsb, s, Wt, bt, S, n, d, dp,
+                       Xraw, N, Np, y, bias, Phi);
+    hipLaunchKernelGGL(k_rff_gram_sk, dim3(RFF_SPLIT, (unsigned)S), dim3(GEMM_THREADS), 0, s, Phi, Np, part);
+    const int64_t outs = (int64_t)S * n * (n + 1);
+    hipLaunchKernelGGL(k_rff_gram_rd, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, s, part, S, n, A, v);
+}
+
+// ---- per-draw path (any n): Ft[j][i] = cos(w_j . x_i + b_j) for observed points i < N (0 beyond)
 __global__ __launch_bounds__(256) void k_rff_features(const double* __restrict__ X, int64_t N, int64_t Np,
                                                       int d, const double* __restrict__ W,
                                                       const double* __restrict__ b, int n,

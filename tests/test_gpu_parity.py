@@ -224,6 +224,17 @@ def test_rff_paths_match_oracle(kernel):
     A, v = e.rff_gram(Ws[0], bs[0])
     np.testing.assert_allclose(A, C.T @ C, rtol=1e-11, atol=1e-10)
     np.testing.assert_allclose(v, C.T @ (y - bias), rtol=1e-11, atol=1e-10)
+    Ab, vb = e.rff_gram_batch(np.array(Ws), np.array(bs))
+    for q in range(S):
+        Cq = np.cos(X @ Ws[q].T + bs[q])
+        np.testing.assert_allclose(Ab[q], Cq.T @ Cq, rtol=1e-11, atol=1e-10)
+        np.testing.assert_allclose(vb[q], Cq.T @ (y - bias), rtol=1e-11, atol=1e-10)
+    # wide feature maps (n >= 128) take the per-draw path
+    wide = ref.sample_f(130, rng=5)
+    Cw = np.cos(X @ wide.W.T + wide.b)
+    Aw, vw = e.rff_gram(wide.W, wide.b)
+    np.testing.assert_allclose(Aw, Cw.T @ Cw, rtol=1e-11, atol=1e-10)
+    np.testing.assert_allclose(vw, Cw.T @ (y - bias), rtol=1e-11, atol=1e-10)
     # evaluation sweep, S draws at once, with per-draw top-k
     Z = np.random.RandomState(8).rand(3000, 3)
     r = e.rff_sweep(np.array(Ws), np.array(bs), np.array(ths), bias, Z, k=5)
