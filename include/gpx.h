@@ -76,6 +76,11 @@ int gpx_fit(gpx_handle *h, const double *X, int64_t N, int64_t d, const double *
             const double *ell, double rho, double sn2, double bias);
 int gpx_fit_dev(gpx_handle *h, const double *dX, int64_t N, int64_t d, const double *dy,
                 int kernel_id, const double *ell, double rho, double sn2, double bias);
+/* Incremental fit: absorb ONE more observation x (d,), y into the current factorisation in O(N^2)
+ * (two memory-bound passes over T and U) instead of refitting -- the per-iteration
+ * `model.add_data(x, y)` of the BO loop [pybo/bayesopt.py:269].  GPX_ESTATE when the current 128-block
+ * has no padding left (N == ceil(N/128)*128): refit with gpx_fit.  GPX_ENOTPD like gpx_fit. */
+int gpx_append(gpx_handle *h, const double *x, double y);
 /* 0-based index of the failing pivot of the last GPX_ENOTPD fit, else -1. */
 int64_t gpx_fail_pivot(const gpx_handle *h);
 

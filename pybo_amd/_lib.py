@@ -25,6 +25,7 @@ SYMBOLS = {
     'gpx_set_option': (C.c_int, [_P, C.c_char_p, _i64]),
     'gpx_fit': (C.c_int, [_P, _P, _i64, _i64, _P, C.c_int, _P, _dbl, _dbl, _dbl]),
     'gpx_fit_dev': (C.c_int, [_P, _P, _i64, _i64, _P, C.c_int, _P, _dbl, _dbl, _dbl]),
+    'gpx_append': (C.c_int, [_P, _P, _dbl]),
     'gpx_fail_pivot': (_i64, [_P]),
     'gpx_get_matrix': (C.c_int, [_P, C.c_int, _P]),
     'gpx_get_vectors': (C.c_int, [_P, _P, _P]),
@@ -146,6 +147,18 @@ class Engine(object):
         self._check(self._lib.gpx_fit_dev(self._h, _P(dX_ptr), N, d, _P(dy_ptr), kid, _ptr(ell), rho, sn2,
                                           bias))
         self.N, self.d = N, d
+
+    def append(self, x, y):
+        """Rank-1 extension by one observation; returns False when a refit is needed (block boundary)."""
+        x = _f64(x).reshape(-1)
+        if len(x) != self.d:
+            raise ValueError('x must have %d coordinates' % self.d)
+        rc = self._lib.gpx_append(self._h, _ptr(x), float(y))
+        if rc == GPX_ESTATE:
+            return False
+        self._check(rc)
+        self.N += 1
+        return True
 
     def fail_pivot(self):
         return int(self._lib.gpx_fail_pivot(self._h))

@@ -173,7 +173,8 @@ def _bo_step(model, trace, objective, bounds, policy, solver, recommender):
     """One iteration: choose, evaluate, absorb, recommend.  Mutates `model` and `trace`."""
     index = policy(model, bounds, trace.x)          # acquisition closure over a model copy
     x, _ = solver(index, bounds)                    # grid sweep + top-k + refinement
-    y = objective(x)
+    del index                                       # drop the policy's model copy: add_data below may then
+    y = objective(x)                                # extend the factorisation in place instead of refitting
     model.add_data(x, y)                            # refit
     xbest = recommender(model, bounds, trace.x)     # NB: trace.x does not contain x yet (as in the reference)
     trace.x.append(x)

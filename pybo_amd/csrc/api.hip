@@ -322,6 +322,11 @@ extern "C" int gpx_fit_stage(gpx_handle* h, const double* X, int64_t N, int64_t 
     return fit_host(h, X, N, d, y, kernel_id, ell, rho, sn2, bias, stage);
 }
 
+extern "C" int gpx_append(gpx_handle* h, const double* x, double y) {
+    if (!h) return GPX_EARG;
+    return gpx::append_host(h, x, y);
+}
+
 extern "C" int64_t gpx_fail_pivot(const gpx_handle* h) { return h ? h->fail_pivot : -1; }
 
 extern "C" int gpx_get_matrix(gpx_handle* h, int which, double* out) {

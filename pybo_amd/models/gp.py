@@ -88,6 +88,8 @@ class RFFSampleDevice(object):
 
 
 class GP(object):
+    APPEND_MAX = 16     # add_data with at most this many new rows extends the factorisation in place
+
     def __init__(self, sn2, rho, ell, bias=0.0, kernel='se', device=0):
         if kernel not in _KERNELS:
             raise ValueError('unknown kernel {!r}; choose from {}'.format(kernel, _KERNELS))
@@ -169,8 +171,25 @@ class GP(object):
         Y = np.array(Y, dtype=float).reshape(-1)
         if len(X) != len(Y):
             raise ValueError('X and Y must have the same number of rows')
+        can_append = (self._fitted and self._state is not None and self._state.nrefs == 1
+                      and 0 < len(X) <= self.APPEND_MAX)
         self._X = np.vstack([self._X, X])
         self._Y = np.hstack([self._Y, Y])
+        if can_append:
+            # sole owner of a fitted device state: rank-1 extension per new row (O(N^2)) instead of the
+            # O(N^3) refit; falls through to a refit when a 128-block boundary is crossed
+            eng = self._state.engine
+            done = 0
+            try:
+                for xr, yr in zip(X, Y):
+                    if not eng.append(xr, yr):
+                        break
+                    done += 1
+            except Exception:
+                self._fitted = False        # device and host data now disagree: force a refit next time
+                raise
+            if done == len(X):
+                return
         self._fitted = False
         self._engine()              # refit now: a non-PD Gram matrix must surface here (LinAlgError)
 
