@@ -76,6 +76,9 @@ int gpx_fit(gpx_handle *h, const double *X, int64_t N, int64_t d, const double *
             const double *ell, double rho, double sn2, double bias);
 int gpx_fit_dev(gpx_handle *h, const double *dX, int64_t N, int64_t d, const double *dy,
                 int kernel_id, const double *ell, double rho, double sn2, double bias);
+/* log marginal likelihood of the fitted model, -1/2 a.a - sum log R_ii - N/2 log 2pi: what a
+ * hyper-parameter sampler (reggie.MCMC, pybo/bayesopt.py:115) evaluates once per proposal. */
+int gpx_loglik(gpx_handle *h, double *out);
 /* Incremental fit: absorb ONE more observation x (d,), y into the current factorisation in O(N^2)
  * (two memory-bound passes over T and U) instead of refitting -- the per-iteration
  * `model.add_data(x, y)` of the BO loop [pybo/bayesopt.py:269].  GPX_ESTATE when the current 128-block

@@ -140,6 +140,14 @@ def rff_posterior_theta(A, v, n, rho, sn2, z):
     return s * (mean + noise)
 
 
+class _ParamRef(object):
+    def __init__(self):
+        self.prior = None
+
+    def set_prior(self, kind, *args):
+        self.prior = (kind,) + tuple(np.array(a, dtype=float) for a in args)
+
+
 class GPRef(object):
     """Exact GP regression with a constant mean and gaussian noise; fp64, numpy/scipy."""
 
@@ -153,10 +161,31 @@ class GPRef(object):
         self.Y = None
         self.L = None
         self.a = None
+        self.params = {k: _ParamRef() for k in ('like.sn2', 'kern.rho', 'kern.ell', 'mean.bias')}
+
+    # -- hyper-parameters / evidence (what a hyper-parameter sampler needs) ----------------------------
+    def hyper_vector(self):
+        return np.concatenate([[np.log(self.sn2), np.log(self.rho)], np.log(self.ell), [self.bias]])
+
+    def set_hyper_vector(self, theta):
+        theta = np.asarray(theta, dtype=float)
+        d = len(self.ell)
+        self.sn2, self.rho = float(np.exp(theta[0])), float(np.exp(theta[1]))
+        self.ell = np.exp(theta[2:2 + d])
+        self.bias = float(theta[2 + d])
+        if self.X is not None:
+            self._fit()
+
+    def loglikelihood(self):
+        """R&W eq. 2.30:  -1/2 a.a - sum log L_ii - N/2 log 2 pi."""
+        n = len(self.X)
+        return float(-0.5 * self.a @ self.a - np.sum(np.log(np.diag(self.L))) - 0.5 * n * np.log(2 * np.pi))
 
     # -- protocol ------------------------------------------------------------------------------
     def copy(self):
         new = GPRef(self.sn2, self.rho, self.ell.copy(), self.bias, self.kid)
+        for k, p in self.params.items():
+            new.params[k].prior = p.prior
         if self.X is not None:
             new.X, new.Y = self.X.copy(), self.Y.copy()
             new.L, new.a = self.L, self.a

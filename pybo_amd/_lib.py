@@ -25,6 +25,7 @@ SYMBOLS = {
     'gpx_set_option': (C.c_int, [_P, C.c_char_p, _i64]),
     'gpx_fit': (C.c_int, [_P, _P, _i64, _i64, _P, C.c_int, _P, _dbl, _dbl, _dbl]),
     'gpx_fit_dev': (C.c_int, [_P, _P, _i64, _i64, _P, C.c_int, _P, _dbl, _dbl, _dbl]),
+    'gpx_loglik': (C.c_int, [_P, _P]),
     'gpx_append': (C.c_int, [_P, _P, _dbl]),
     'gpx_fail_pivot': (_i64, [_P]),
     'gpx_get_matrix': (C.c_int, [_P, C.c_int, _P]),
@@ -147,6 +148,11 @@ class Engine(object):
         self._check(self._lib.gpx_fit_dev(self._h, _P(dX_ptr), N, d, _P(dy_ptr), kid, _ptr(ell), rho, sn2,
                                           bias))
         self.N, self.d = N, d
+
+    def loglik(self):
+        out = C.c_double()
+        self._check(self._lib.gpx_loglik(self._h, C.byref(out)))
+        return out.value
 
     def append(self, x, y):
         """Rank-1 extension by one observation; returns False when a refit is needed (block boundary)."""

@@ -19,9 +19,9 @@ Behaviour kept on purpose (it decides which points get queried, so it is part of
     centre is evaluated on top of it;
   * the loop resumes at `len(trace.xbest)` after a checkpoint reload (:262).
 Deliberate differences:
-  * `init_model` returns the fixed-hyper-parameter GP with the reference's heuristic initial values (:98-102)
-    and records the same priors, but does not wrap it in `reggie.MCMC(n=10, burn=100)` (:115): the sampler
-    is reggie-internal, unpinned and outside the hot path (SURVEY.md F10 / R7);
+  * `init_model` builds the GP with the reference's heuristic initial values and priors (:98-111) and wraps
+    it in `pybo_amd.models.MCMC(n=10, burn=100)` like the reference (:115) -- but the sampler is this
+    build's own (random-direction slice sampling, models/mcmc.py): reggie's is absent and unpinned;
   * checkpoints are binary pickles written atomically (the reference opens the file in text mode);
   * a malformed component tuple raises a ValueError with a working message (the reference's '{:r}' format at
     :138 is itself an error).
@@ -103,8 +103,9 @@ def init_model(f, bounds, ninit=None, design='latin', log=None, rng=None, kernel
     gp.params['kern.ell'].set_prior('uniform', hyp['ell'] / 100, hyp['ell'] * 10)
     gp.params['mean.bias'].set_prior('normal', hyp['bias'], hyp['rho'])
     gp.add_data(trace.x, trace.y)
-    safe_dump(gp, trace, filename=log)
-    return gp
+    model = models.MCMC(gp, n=10, burn=100, rng=rng)     # hyper-parameter marginalisation, as the reference
+    safe_dump(model, trace, filename=log)
+    return model
 
 
 # ----------------------------------------------------------------------------------------------------

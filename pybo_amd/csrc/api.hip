@@ -322,6 +322,11 @@ extern "C" int gpx_fit_stage(gpx_handle* h, const double* X, int64_t N, int64_t 
     return fit_host(h, X, N, d, y, kernel_id, ell, rho, sn2, bias, stage);
 }
 
+extern "C" int gpx_loglik(gpx_handle* h, double* out) {
+    if (!h) return GPX_EARG;
+    return gpx::loglik_host(h, out);
+}
+
 extern "C" int gpx_append(gpx_handle* h, const double* x, double y) {
     if (!h) return GPX_EARG;
     return gpx::append_host(h, x, y);

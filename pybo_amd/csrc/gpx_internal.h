@@ -119,6 +119,7 @@ int64_t topk_blocks(int64_t M);
 int predict_grad_host(gpx_handle* h, const double* Xc, int64_t M, double* mu, double* s2, double* dmu,
                       double* ds2);
 
+int loglik_host(gpx_handle* h, double* out);
 int append_host(gpx_handle* h, const double* x, double ynew);
 int rff_grad_host(gpx_handle* h, const double* W, const double* b, const double* theta, int64_t n, int64_t d,
                   double bias, const double* Xc, int64_t M, double* f, double* g);

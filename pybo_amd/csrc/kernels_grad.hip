@@ -341,6 +341,37 @@ int append_host(gpx_handle* h, const double* x, double ynew) {
     return GPX_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// log marginal likelihood of the current fit:  -1/2 a.a - sum_i log R_ii - N/2 log(2 pi)
+// (R&W eq. 2.30 with K + sn2 I = R^T R, a = R^-T (y - bias)).  One workgroup; the quantities exist already.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_loglik(const double* __restrict__ R, int64_t Np, int64_t N,
+                                                const double* __restrict__ a, double* __restrict__ out) {
+    __shared__ double sh[4];
+    double q = 0.0, ld = 0.0;
+    for (int64_t i = threadIdx.x; i < N; i += 256) {
+        const double v = a[i];
+        q = fma(v, v, q);
+        ld += log(R[i * Np + i]);
+    }
+    q = block_sum(q, sh);
+    ld = block_sum(ld, sh);
+    if (threadIdx.x == 0) out[0] = -0.5 * q - ld - 0.5 * (double)N * 1.83787706640934548356;
+}
+
+int loglik_host(gpx_handle* h, double* out) {
+    if (!h->fitted) { h->err = "loglik: model is not fitted"; return GPX_ESTATE; }
+    if (!out) { h->err = "loglik: NULL output"; return GPX_EARG; }
+    if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return GPX_EHIP; }
+    hipLaunchKernelGGL(k_loglik, dim3(1), dim3(256), 0, h->stream, h->dR, h->Np, h->N, h->da, h->dscal + 8);
+    if (hipMemcpyAsync(out, h->dscal + 8, 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+        h->err = "loglik: kernel or D2H copy failed";
+        return GPX_EHIP;
+    }
+    return GPX_OK;
+}
+
 // ---- RFF sample value + gradient at M points: grid (M), threads over features -------------------
 // out per point: [f, df/dx_0 .. df/dx_{d-1}]
 __global__ __launch_bounds__(256) void k_rff_grad(const double* __restrict__ W, const double* __restrict__ b,

@@ -43,7 +43,7 @@ class _DeviceState(object):
     def release(self):
         self.nrefs -= 1
         if self.nrefs == 0 and self.engine is not None:
-            if self.engine._h and len(_ENGINE_POOL) < 4:
+            if self.engine._h and len(_ENGINE_POOL) < 16:
                 _ENGINE_POOL.append(self.engine)
             self.engine = None
 
@@ -207,6 +207,27 @@ class GP(object):
             s2 = eng.sweep('mean', None, X, k=0, want_all=False, want_moments=True)['s2']
             return mu, s2
         return eng.predict(X, grad=grad)
+
+    # -- hyper-parameter access (used by the MCMC meta-model) ---------------------------------------------
+    def hyper_vector(self):
+        """[log sn2, log rho, log ell_1..d, bias]"""
+        return np.concatenate([[np.log(self.sn2), np.log(self.rho)], np.log(self.ell), [self.bias]])
+
+    def set_hyper_vector(self, theta):
+        theta = np.asarray(theta, dtype=float)
+        d = len(self.ell)
+        self.sn2, self.rho = float(np.exp(theta[0])), float(np.exp(theta[1]))
+        self.ell = np.exp(theta[2:2 + d])
+        self.bias = float(theta[2 + d])
+        self._fitted = False                     # same data, new hyper-parameters: refit on next use
+
+    def loglikelihood(self):
+        """log p(y | X, hyper-parameters) of the current fit, computed on the device."""
+        return self._engine().loglik()
+
+    def acq_values(self, kind, param, xgrid):
+        """Acquisition values over a whole grid (device sweep, values copied back)."""
+        return self._engine().sweep(kind, param, np.array(xgrid, ndmin=2, dtype=float), k=0)['acq']
 
     def posterior_mean_at_data(self):
         return self._engine().mean_at_obs()[0]

@@ -1,0 +1,216 @@
+"""
+Hyper-parameter marginalisation by MCMC: the meta-model pybo wraps its default GP in,
+`reggie.MCMC(model, n=10, burn=100, rng=rng)` (/root/reference/pybo/bayesopt.py:115), refreshed on every
+`add_data`.  It exposes the same model protocol as a single GP (copy / add_data / predict /
+get_improvement / get_tail / sample_f), with every quantity averaged over `n` posterior samples of the
+hyper-parameters.
+
+reggie's sampler is not available (absent, unpinned), so the algorithm here is this build's own and is
+stated in full:
+  * state  theta = [log sn2, log rho, log ell_1..d, bias];  target  log p(y | theta) + log prior(theta)
+    (+ the log-Jacobian of the log transform), priors as recorded on `model.params` (priors.py);
+  * one sample = one slice-sampling update (Neal 2003) along a random direction  sigma * scale * N(0, I)
+    (scale = 1 for the log-parameters, sqrt(rho) for the bias): bracket by stepping out (<= 8 doublings of
+    unit steps each side), then shrinkage;
+  * `burn` updates are discarded at construction, then `n` are kept; `add_data` continues the chain from
+    its last state and keeps the next `n` samples (no new burn-in).
+Each log-likelihood evaluation is one fit of the member model -- on the device for `pybo_amd.models.GP`
+(`gpx_fit` + `gpx_loglik`).  This file is host logic only and works with ANY member model that offers
+`hyper_vector() / set_hyper_vector(theta) / loglikelihood() / params / copy() / add_data()`, which is how
+the CPU tests drive it with the oracle model.
+"""
+import numpy as np
+
+from ..utils import rstate
+from .priors import log_prior
+
+__all__ = ['MCMC']
+
+
+def _log_target(model, theta):
+    """log posterior density of the transformed hyper-parameters (-inf outside the support)."""
+    d = len(theta) - 3
+    if not np.all(np.isfinite(theta)) or np.any(np.abs(theta[:2 + d]) > 60.0):
+        return -np.inf
+    sn2, rho, ell, bias = np.exp(theta[0]), np.exp(theta[1]), np.exp(theta[2:2 + d]), theta[2 + d]
+    pr = model.params
+    lp = (log_prior(pr['like.sn2'].prior, sn2) + log_prior(pr['kern.rho'].prior, rho) +
+          log_prior(pr['kern.ell'].prior, ell) + log_prior(pr['mean.bias'].prior, bias))
+    if not np.isfinite(lp):
+        return -np.inf
+    lp += float(np.sum(theta[:2 + d]))            # Jacobian of x = exp(theta)
+    try:
+        model.set_hyper_vector(theta)
+        return lp + model.loglikelihood()
+    except np.linalg.LinAlgError:
+        return -np.inf
+
+
+def _slice_update(model, theta, lp, rng, sigma=1.0, max_out=8):
+    """One slice-sampling update along a random direction; returns (theta', lp')."""
+    d = len(theta) - 3
+    scale = np.ones(len(theta))
+    scale[-1] = np.sqrt(np.exp(theta[1]))        # the bias moves on the scale of the signal std
+    direction = sigma * scale * rng.randn(len(theta))
+    level = lp + np.log(rng.rand())
+    r = rng.rand()
+    lo, hi = -r, 1.0 - r
+    for _ in range(max_out):
+        if _log_target(model, theta + lo * direction) <= level:
+            break
+        lo -= 1.0
+    for _ in range(max_out):
+        if _log_target(model, theta + hi * direction) <= level:
+            break
+        hi += 1.0
+    while True:
+        t = lo + (hi - lo) * rng.rand()
+        cand = theta + t * direction
+        lpc = _log_target(model, cand)
+        if lpc > level:
+            return cand, lpc
+        if t < 0:
+            lo = t
+        else:
+            hi = t
+        if hi - lo < 1e-12:                      # numerically collapsed bracket: stay put
+            return theta, lp
+
+
+class MCMC(object):
+    def __init__(self, model, n=10, burn=100, rng=None):
+        self._proto = model.copy()               # work-horse whose hyper-parameters the chain moves
+        self._n = int(n)
+        self._rng = rstate(rng)
+        self._theta = np.array(self._proto.hyper_vector(), dtype=float)
+        self._lp = None
+        self._members = []
+        self._bind_hooks()
+        if self._proto.ndata > 0:
+            self._advance(int(burn), keep=False)
+            self._advance(self._n, keep=True)
+
+    def _bind_hooks(self):
+        # the whole-grid top-k hook only exists for device-backed members (policies probe it with getattr)
+        if hasattr(self._proto, 'acq_values'):
+            self.acq_topk = self._acq_topk
+
+    # -- sampling ----------------------------------------------------------------------------------
+    def _advance(self, nsteps, keep):
+        if self._lp is None:
+            self._lp = _log_target(self._proto, self._theta)
+            if not np.isfinite(self._lp):
+                raise ValueError('MCMC: the initial hyper-parameters have zero posterior density')
+        kept = []
+        for _ in range(nsteps):
+            self._theta, self._lp = _slice_update(self._proto, self._theta, self._lp, self._rng)
+            kept.append(self._theta.copy())
+        if keep:
+            members = []
+            for th in kept:
+                m = self._proto.copy()
+                m.set_hyper_vector(th)
+                m.loglikelihood()                # forces the (re)fit of this member
+                members.append(m)
+            self._members = members
+        self._proto.set_hyper_vector(self._theta)
+
+    @property
+    def samples(self):
+        """(n, 3 + d) array of the kept hyper-parameter states [log sn2, log rho, log ell.., bias]."""
+        return np.array([m.hyper_vector() for m in self._members])
+
+    # -- model protocol ----------------------------------------------------------------------------
+    @property
+    def ndata(self):
+        return self._proto.ndata
+
+    @property
+    def data(self):
+        return self._proto.data
+
+    @property
+    def params(self):
+        return self._proto.params
+
+    def copy(self):
+        new = MCMC.__new__(MCMC)
+        new._proto = self._proto.copy()
+        new._n = self._n
+        new._rng = self._rng                     # shared stream, as a chain continued from a copy would
+        new._theta = self._theta.copy()
+        new._lp = self._lp
+        new._members = [m.copy() for m in self._members]
+        new._bind_hooks()
+        return new
+
+    def add_data(self, X, Y):
+        self._proto.add_data(X, Y)
+        self._lp = None                          # the target changed with the data
+        self._advance(self._n, keep=True)
+
+    def _need(self):
+        if not self._members:
+            raise RuntimeError('the model has no data yet')
+        return self._members
+
+    def predict(self, X, grad=False):
+        posts = [m.predict(X, grad) for m in self._need()]
+        mus = np.array([p[0] for p in posts])
+        s2s = np.array([p[1] for p in posts])
+        mu = mus.mean(axis=0)
+        s2 = (s2s + mus ** 2).mean(axis=0) - mu ** 2
+        if not grad:
+            return mu, s2
+        dmus = np.array([p[2] for p in posts])
+        ds2s = np.array([p[3] for p in posts])
+        dmu = dmus.mean(axis=0)
+        ds2 = (ds2s + 2.0 * mus[:, :, None] * dmus).mean(axis=0) - 2.0 * mu[:, None] * dmu
+        return mu, s2, dmu, ds2
+
+    def _mean_of(self, name, target, X, grad):
+        outs = [getattr(m, name)(target, X, grad) for m in self._need()]
+        if not grad:
+            return np.mean(outs, axis=0)
+        return np.mean([o[0] for o in outs], axis=0), np.mean([o[1] for o in outs], axis=0)
+
+    def get_improvement(self, target, X, grad=False):
+        return self._mean_of('get_improvement', target, X, grad)
+
+    def get_tail(self, target, X, grad=False):
+        return self._mean_of('get_tail', target, X, grad)
+
+    def sample_f(self, n, rng=None):
+        rng = rstate(rng)
+        members = self._need()
+        return members[rng.randint(len(members))].sample_f(n, rng)
+
+    def _acq_topk(self, kind, param, xgrid, k):
+        """Ensemble acquisition over a grid + top-k.  Each member sweeps the grid on the device; the n value
+        arrays are combined on the host (mean for EI/PI/mean, mixture moments for UCB)."""
+        members = self._need()
+        xgrid = np.array(xgrid, ndmin=2, dtype=float)
+        if kind == 'ucb':
+            mu, s2 = self.predict(xgrid)
+            vals = mu + np.sqrt(param * s2)
+        else:
+            vals = np.mean([m.acq_values(kind, param, xgrid) for m in members], axis=0)
+        v = np.where(np.isnan(vals), -np.inf, vals)
+        order = np.lexsort((np.arange(len(v)), -v))[:int(k)]
+        return vals[order], order
+
+    # -- pickling: hyper-parameter states + data, members are rebuilt on load -------------------------
+    def __getstate__(self):
+        # (the bound acq_topk hook is re-created on load)
+        return dict(proto=self._proto, n=self._n, rng=self._rng, theta=self._theta,
+                    samples=[np.array(m.hyper_vector()) for m in self._members])
+
+    def __setstate__(self, st):
+        self._proto, self._n, self._rng, self._theta = st['proto'], st['n'], st['rng'], st['theta']
+        self._lp = None
+        self._members = []
+        for th in st['samples']:
+            m = self._proto.copy()
+            m.set_hyper_vector(th)
+            self._members.append(m)
+        self._bind_hooks()

@@ -1,0 +1,70 @@
+"""MCMC ensemble with device-backed members (log-likelihood by gpx_loglik, one device fit per proposal) against
+the same host sampler driving the oracle model with the same seed; and the default model path of
+solve_bayesopt (init_model -> MCMC) end to end."""
+import numpy as np
+import pytest
+
+from oracle import gp_ref
+from helpers import synth_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def _priors(m, d):
+    m.params['like.sn2'].set_prior('horseshoe', 0.1)
+    m.params['kern.rho'].set_prior('lognormal', 0.0, 1.0)
+    m.params['kern.ell'].set_prior('uniform', [0.02] * d, [3.0] * d)
+    m.params['mean.bias'].set_prior('normal', 0.0, 4.0)
+
+
+@pytest.mark.parametrize('N,d,kernel', [(60, 2, 'se'), (300, 3, 'matern5')])
+def test_loglik_matches_oracle(N, d, kernel):
+    from pybo_amd import models
+    X, y, ell = synth_problem(N, d, seed=N)
+    gp = models.make_gp(1e-3, 1.4, ell, 0.2, kernel=kernel)
+    ref = gp_ref.make_gp(1e-3, 1.4, ell, 0.2, kernel)
+    gp.add_data(X, y); ref.add_data(X, y)
+    assert abs(gp.loglikelihood() - ref.loglikelihood()) < 1e-9 * abs(ref.loglikelihood())
+    th = ref.hyper_vector() + 0.3
+    gp.set_hyper_vector(th); ref.set_hyper_vector(th)
+    np.testing.assert_allclose(gp.hyper_vector(), th, rtol=1e-15)
+    assert abs(gp.loglikelihood() - ref.loglikelihood()) < 1e-9 * abs(ref.loglikelihood())
+
+
+def test_device_ensemble_follows_the_same_chain_as_the_cpu_ensemble():
+    from pybo_amd import models
+    X, y, ell = synth_problem(50, 2, seed=9)
+    dev = models.make_gp(1e-3, 1.0, [0.4, 0.4], 0.0)
+    ref = gp_ref.make_gp(1e-3, 1.0, [0.4, 0.4], 0.0)
+    for m in (dev, ref):
+        _priors(m, 2)
+        m.add_data(X, y)
+    a = models.MCMC(dev, n=6, burn=40, rng=7)
+    b = models.MCMC(ref, n=6, burn=40, rng=7)
+    np.testing.assert_allclose(a.samples, b.samples, rtol=1e-6, atol=1e-8)
+    Z = np.random.RandomState(1).rand(400, 2)
+    for got, want in zip(a.predict(Z[:10], True), b.predict(Z[:10], True)):
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(a.get_improvement(0.5, Z), b.get_improvement(0.5, Z), rtol=1e-5, atol=1e-10)
+    # whole-grid hook: ensemble EI on the device members, ranked
+    vals, idx = a.acq_topk('ei', 0.5, Z, 5)
+    want = b.get_improvement(0.5, Z)
+    assert idx[0] == int(np.argmax(want))
+    np.testing.assert_allclose(vals, want[idx], rtol=1e-5)
+    vals, idx = a.acq_topk('ucb', 2.0, Z, 3)
+    mu, s2 = b.predict(Z)
+    assert idx[0] == int(np.argmax(mu + np.sqrt(2.0 * s2)))
+    a.add_data(Z[0], 0.1); b.add_data(Z[0], 0.1)
+    np.testing.assert_allclose(a.samples, b.samples, rtol=1e-6, atol=1e-8)
+
+
+def test_default_model_path_end_to_end():
+    """solve_bayesopt(f, bounds) with no model: latin design -> GP with heuristic hypers and priors -> MCMC
+    ensemble -> EI / lbfgs / latent recommender, all on the device."""
+    from pybo_amd import solve_bayesopt, models
+    f = lambda x: float(-(x[0] - 0.3) ** 2 - (x[1] + 0.2) ** 2)      # noqa: E731
+    bounds = [[-1.0, 1.0], [-1.0, 1.0]]
+    xbest, model, info = solve_bayesopt(f, bounds, niter=8, rng=0, solver=('lbfgs', {'ngrid': 2000}))
+    assert isinstance(model, models.MCMC) and model.ndata == 6 + 1 + 8
+    assert info.x.shape == (9, 2) and info.y.max() > -0.05
+    assert np.linalg.norm(np.asarray(xbest) - [0.3, -0.2]) < 0.25
