@@ -12,7 +12,7 @@ Inputs (observations, candidates) are resident in HBM before the timed region st
 refits redundantly (bitwise-identical factor, zero communication) and sweeps its contiguous candidate
 slice, so the job is STRONG scaling: total work fixed at M candidates.
 
-Launch:  python bench.py [--gpus 1 --steps K --warmup W --workload ns|b|c|d]
+Launch:  python bench.py [--gpus 1 --steps K --warmup W --workload ns|b|c|d|e]
          python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 Prints ONE JSON line on rank 0.
 """
@@ -76,6 +76,13 @@ def make_workload(name, M):
         X = lo + (hi - lo) * rng.rand(N, d)
         y = -(X ** 2).sum(1) + 1e-3 * rng.randn(N)
         desc = 'config D: d=32 quadratic, N=16384 observed, SE-ARD, Thompson (64 RFF draws x 100 features)'
+    elif name == 'e':     # BASELINE configs[4]: batch-BO q=8, one Thompson recommendation per GPU
+        N, d, seed, kernel, acq = 8192, 6, 1, 'matern5', 'thompson'
+        lo, hi = np.zeros(d), np.ones(d)
+        rng = np.random.RandomState(seed)
+        X = lo + (hi - lo) * rng.rand(N, d)
+        y = -hartmann6(X) + 1e-3 * rng.randn(N)
+        desc = 'config E: batch-BO q=8 on Hartmann-6, N=8192, Matern-5/2, 8 Thompson draws (100 RFF), one per GPU'
     else:
         raise SystemExit('unknown workload %r' % name)
     ell = 0.25 * (hi - lo)
@@ -130,12 +137,12 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--workload', default='ns', choices=['ns', 'b', 'c', 'd'])
+    ap.add_argument('--workload', default='ns', choices=['ns', 'b', 'c', 'd', 'e'])
     ap.add_argument('--candidates', type=int, default=1 << 20)
     ap.add_argument('--topk', type=int, default=10)
     ap.add_argument('--chunk', type=int, default=0)
     ap.add_argument('--tile-order', type=int, default=-1)
-    ap.add_argument('--draws', type=int, default=64, help='Thompson draws (workload d)')
+    ap.add_argument('--draws', type=int, default=0, help='Thompson draws (default: 64 for workload d, 8 for e)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-candidates', type=int, default=0, help='candidates in the CPU sample (0 = auto)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
@@ -182,8 +189,9 @@ def main():
 
     thompson = None
     if w['acq'] == 'thompson':
-        S = args.draws
+        S = args.draws or (8 if w['name'] == 'e' else 64)
         mine = [s for s in range(S) if s % world == rank]      # draws are the sharded unit here
+        nu = {'matern5': 2.5, 'matern3': 1.5, 'matern1': 0.5}.get(w['kernel'])
 
     def step():
         eng.fit_dev(dX.data_ptr(), N, d, dy.data_ptr(), w['kernel'], w['ell'], w['rho'], w['sn2'], w['bias'])
@@ -191,8 +199,11 @@ def main():
             # each rank owns S/world posterior draws and sweeps ALL candidates for them
             Ws, bs, zs = [], [], []
             for s in mine:
-                rng = np.random.RandomState(100 + s)
-                Ws.append(rng.randn(100, d) / w['ell'])
+                rng = np.random.RandomState(100 + s)     # same draw order as GP.sample_f / the oracle
+                Wd = rng.randn(100, d)
+                if nu is not None:                        # Matern spectral density = scale mixture of normals
+                    Wd = Wd * np.sqrt(2.0 * nu / rng.chisquare(2.0 * nu, size=100))[:, None]
+                Ws.append(Wd / w['ell'])
                 bs.append(rng.rand(100) * 2 * np.pi)
                 zs.append(rng.randn(100))
             Ws, bs = np.array(Ws), np.array(bs)
@@ -224,7 +235,7 @@ def main():
                 alli = torch.empty(world * kk, dtype=torch.int64, device=cdev)
                 dist.all_gather_into_tensor(allv, tvals)
                 dist.all_gather_into_tensor(alli, tidx)
-                return allv.cpu().numpy(), alli.cpu().numpy()
+                return allv.cpu().numpy(), alli.cpu().numpy()   # the q recommendations: w['Xc'][alli]
             return pdist.gather_topk(tv, ti, k)      # RCCL all-gather + deterministic merge
         return tv, ti
 
