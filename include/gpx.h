@@ -66,7 +66,8 @@ int gpx_version(void);
  *              1 per-XCD candidate slices, 2 per-XCD 8x8 super-tiles), bits 2-3 k-loop variant
  *              (0 write-at-end, 1 write-at-top, 2 write-at-top + s_setprio, 3 software-pipelined
  *              fragments, 4 LDS-DMA staging).  Default 10 = super-tiles + variant 2.
- *              Every setting produces bit-identical results. */
+ *              Every setting produces bit-identical results.
+ *          "super_m" = rows of the XCD super-tile of 64 workgroups (8 -> 8x8 default, 4 -> 4x16, ...). */
 int gpx_set_option(gpx_handle *h, const char *name, int64_t value);
 
 /* ---- GP fit = model.add_data(X, Y)            [pybo/bayesopt.py:114,258,269] ------------- */

@@ -31,6 +31,25 @@ static int fail(gpx_handle* h, int code, const char* msg) {
     return code;
 }
 
+// Every extern "C" body runs inside this guard: nothing the C++ runtime throws (bad_alloc from the
+// std::vector / std::string used for staging and messages) may cross the C boundary.
+template <typename F>
+static int guarded(gpx_handle* h, F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        if (h) {
+            try { h->err = "out of host memory"; } catch (...) {}
+        }
+        return GPX_EOOM;
+    } catch (...) {
+        if (h) {
+            try { h->err = "unexpected C++ exception inside libgpx"; } catch (...) {}
+        }
+        return GPX_EHIP;
+    }
+}
+
 template <typename T>
 static int ensure(gpx_handle* h, T*& p, int64_t& cap, int64_t need) {
     if (need <= cap && p) return GPX_OK;
@@ -85,7 +104,18 @@ extern "C" const char* gpx_last_error(const gpx_handle* h) {
     return h ? h->err.c_str() : g_create_err.c_str();
 }
 
+static int create_impl(int device, void* stream, gpx_handle** out);
+
 extern "C" int gpx_create(int device, void* stream, gpx_handle** out) {
+    try {
+        return create_impl(device, stream, out);
+    } catch (...) {
+        if (out) *out = nullptr;
+        return GPX_EOOM;
+    }
+}
+
+static int create_impl(int device, void* stream, gpx_handle** out) {
     if (!out) { g_create_err = "gpx_create: out is NULL"; return GPX_EARG; }
     *out = nullptr;
     int ndev = 0;
@@ -154,34 +184,46 @@ extern "C" int gpx_destroy(gpx_handle* h) {
 }
 
 extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
-    if (!h || !name) return GPX_EARG;
-    if (!strcmp(name, "chunk")) {
-        if (value < 128 || value % 128) return fail(h, GPX_EARG, "chunk must be a positive multiple of 128");
-        h->chunk = value;
-        return GPX_OK;
-    }
-    if (!strcmp(name, "tile_order")) {
-        if (value < 0 || value > 19 || (value & 3) == 3) return fail(h, GPX_EARG, "tile_order: bits 0-1 in {0,1,2} (tile map), bits 2-3 in {0,1,2} (k-loop variant)");
-        h->tile_order = (int)value;
-        return GPX_OK;
-    }
-    return fail(h, GPX_EARG, "unknown option");
+    return guarded(h, [&]() -> int {
+        if (!h || !name) return GPX_EARG;
+        if (!strcmp(name, "chunk")) {
+            if (value < 128 || value % 128) return fail(h, GPX_EARG, "chunk must be a positive multiple of 128");
+            h->chunk = value;
+            return GPX_OK;
+        }
+        if (!strcmp(name, "super_m")) {
+            if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16)
+                return fail(h, GPX_EARG, "super_m must be 1, 2, 4, 8 or 16");
+            h->super_m = (int)value;
+            return GPX_OK;
+        }
+        if (!strcmp(name, "tile_order")) {
+            if (value < 0 || value > 19 || (value & 3) == 3) return fail(h, GPX_EARG, "tile_order: bits 0-1 in {0,1,2} (tile map), bits 2-3 in {0,1,2} (k-loop variant)");
+            h->tile_order = (int)value;
+            return GPX_OK;
+        }
+        return fail(h, GPX_EARG, "unknown option");
+    });
 }
 
 extern "C" int gpx_sync(gpx_handle* h) {
-    if (!h) return GPX_EARG;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return GPX_OK;
+    return guarded(h, [&]() -> int {
+        if (!h) return GPX_EARG;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return GPX_OK;
+    });
 }
 
 extern "C" int gpx_timers(gpx_handle* h, double* out, int n, int reset) {
-    if (!h) return GPX_EARG;
-    harvest(h);
-    const int m = std::min(n, (int)T_COUNT);
-    for (int i = 0; i < m; ++i) out[i] = h->tacc[i];
-    if (reset)
-        for (int i = 0; i < T_COUNT; ++i) h->tacc[i] = 0;
-    return m;
+    return guarded(h, [&]() -> int {
+        if (!h) return GPX_EARG;
+        harvest(h);
+        const int m = std::min(n, (int)T_COUNT);
+        for (int i = 0; i < m; ++i) out[i] = h->tacc[i];
+        if (reset)
+            for (int i = 0; i < T_COUNT; ++i) h->tacc[i] = 0;
+        return m;
+    });
 }
 
 // ---- fit --------------------------------------------------------------------------------------
@@ -290,9 +332,11 @@ static int fit_core(gpx_handle* h, const double* dX, int64_t N, int64_t d, const
 
 extern "C" int gpx_fit_dev(gpx_handle* h, const double* dX, int64_t N, int64_t d, const double* dy,
                            int kernel_id, const double* ell, double rho, double sn2, double bias) {
-    int rc = check_fit_args(h, dX, N, d, dy, kernel_id, ell, rho, sn2);
-    if (rc) return rc;
-    return fit_core(h, dX, N, d, dy, kernel_id, ell, rho, sn2, bias, 3);
+    return guarded(h, [&]() -> int {
+        int rc = check_fit_args(h, dX, N, d, dy, kernel_id, ell, rho, sn2);
+        if (rc) return rc;
+        return fit_core(h, dX, N, d, dy, kernel_id, ell, rho, sn2, bias, 3);
+    });
 }
 
 static int fit_host(gpx_handle* h, const double* X, int64_t N, int64_t d, const double* y, int kid,
@@ -312,85 +356,99 @@ static int fit_host(gpx_handle* h, const double* X, int64_t N, int64_t d, const 
 
 extern "C" int gpx_fit(gpx_handle* h, const double* X, int64_t N, int64_t d, const double* y, int kernel_id,
                        const double* ell, double rho, double sn2, double bias) {
-    return fit_host(h, X, N, d, y, kernel_id, ell, rho, sn2, bias, 3);
+    return guarded(h, [&]() -> int {
+        return fit_host(h, X, N, d, y, kernel_id, ell, rho, sn2, bias, 3);
+    });
 }
 
 extern "C" int gpx_fit_stage(gpx_handle* h, const double* X, int64_t N, int64_t d, const double* y,
                              int kernel_id, const double* ell, double rho, double sn2, double bias,
                              int stage) {
-    if (stage < 1 || stage > 3) return h ? fail(h, GPX_EARG, "fit_stage: stage must be 1..3") : GPX_EARG;
-    return fit_host(h, X, N, d, y, kernel_id, ell, rho, sn2, bias, stage);
+    return guarded(h, [&]() -> int {
+        if (stage < 1 || stage > 3) return h ? fail(h, GPX_EARG, "fit_stage: stage must be 1..3") : GPX_EARG;
+        return fit_host(h, X, N, d, y, kernel_id, ell, rho, sn2, bias, stage);
+    });
 }
 
 extern "C" int gpx_loglik(gpx_handle* h, double* out) {
-    if (!h) return GPX_EARG;
-    return gpx::loglik_host(h, out);
+    return guarded(h, [&]() -> int {
+        if (!h) return GPX_EARG;
+        return gpx::loglik_host(h, out);
+    });
 }
 
 extern "C" int gpx_append(gpx_handle* h, const double* x, double y) {
-    if (!h) return GPX_EARG;
-    return gpx::append_host(h, x, y);
+    return guarded(h, [&]() -> int {
+        if (!h) return GPX_EARG;
+        return gpx::append_host(h, x, y);
+    });
 }
 
 extern "C" int64_t gpx_fail_pivot(const gpx_handle* h) { return h ? h->fail_pivot : -1; }
 
 extern "C" int gpx_get_matrix(gpx_handle* h, int which, double* out) {
-    if (!h || !out) return GPX_EARG;
-    if (which < 0 || which > 2) return fail(h, GPX_EARG, "get_matrix: which must be 0..2");
-    if ((which == 2 && h->stage != 1) || (which == 0 && h->stage < 2) || (which == 1 && h->stage < 3))
-        return fail(h, GPX_ESTATE, "get_matrix: the requested matrix is not available at this stage");
-    HIPCHK(h, hipSetDevice(h->device));
-    const int64_t N = h->N, Np = h->Np;
-    int rc = ensure(h, h->dout, h->cap_out, N * N);
-    if (rc) return rc;
-    if (which == 0) {
-        launch_transpose_lower(h->stream, h->dR, Np, h->dout, N);  // L = R^T
-        HIPCHK(h, hipMemcpyAsync(out, h->dout, (size_t)N * N * 8, hipMemcpyDeviceToHost, h->stream));
-    } else {
-        const double* src = (which == 1) ? h->dT : h->dS;
-        HIPCHK(h, hipMemcpy2DAsync(out, (size_t)N * 8, src, (size_t)Np * 8, (size_t)N * 8, (size_t)N,
-                                   hipMemcpyDeviceToHost, h->stream));
-    }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (which == 2) {  // only the upper 128-block triangle was built: blank the rest
-        for (int64_t i = 0; i < N; ++i)
-            for (int64_t j = 0; j < i; ++j) out[i * N + j] = 0.0;
-    }
-    if (which == 1) {  // T is lower triangular; blocks above the diagonal are never written
-        for (int64_t i = 0; i < N; ++i)
-            for (int64_t j = i + 1; j < N; ++j) out[i * N + j] = 0.0;
-    }
-    return GPX_OK;
+    return guarded(h, [&]() -> int {
+        if (!h || !out) return GPX_EARG;
+        if (which < 0 || which > 2) return fail(h, GPX_EARG, "get_matrix: which must be 0..2");
+        if ((which == 2 && h->stage != 1) || (which == 0 && h->stage < 2) || (which == 1 && h->stage < 3))
+            return fail(h, GPX_ESTATE, "get_matrix: the requested matrix is not available at this stage");
+        HIPCHK(h, hipSetDevice(h->device));
+        const int64_t N = h->N, Np = h->Np;
+        int rc = ensure(h, h->dout, h->cap_out, N * N);
+        if (rc) return rc;
+        if (which == 0) {
+            launch_transpose_lower(h->stream, h->dR, Np, h->dout, N);  // L = R^T
+            HIPCHK(h, hipMemcpyAsync(out, h->dout, (size_t)N * N * 8, hipMemcpyDeviceToHost, h->stream));
+        } else {
+            const double* src = (which == 1) ? h->dT : h->dS;
+            HIPCHK(h, hipMemcpy2DAsync(out, (size_t)N * 8, src, (size_t)Np * 8, (size_t)N * 8, (size_t)N,
+                                       hipMemcpyDeviceToHost, h->stream));
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (which == 2) {  // only the upper 128-block triangle was built: blank the rest
+            for (int64_t i = 0; i < N; ++i)
+                for (int64_t j = 0; j < i; ++j) out[i * N + j] = 0.0;
+        }
+        if (which == 1) {  // T is lower triangular; blocks above the diagonal are never written
+            for (int64_t i = 0; i < N; ++i)
+                for (int64_t j = i + 1; j < N; ++j) out[i * N + j] = 0.0;
+        }
+        return GPX_OK;
+    });
 }
 
 extern "C" int gpx_get_vectors(gpx_handle* h, double* a, double* alpha) {
-    if (!h) return GPX_EARG;
-    if (!h->fitted) return fail(h, GPX_ESTATE, "get_vectors: model is not fitted");
-    HIPCHK(h, hipSetDevice(h->device));
-    if (a) HIPCHK(h, hipMemcpyAsync(a, h->da, (size_t)h->N * 8, hipMemcpyDeviceToHost, h->stream));
-    if (alpha) HIPCHK(h, hipMemcpyAsync(alpha, h->dalpha, (size_t)h->N * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return GPX_OK;
+    return guarded(h, [&]() -> int {
+        if (!h) return GPX_EARG;
+        if (!h->fitted) return fail(h, GPX_ESTATE, "get_vectors: model is not fitted");
+        HIPCHK(h, hipSetDevice(h->device));
+        if (a) HIPCHK(h, hipMemcpyAsync(a, h->da, (size_t)h->N * 8, hipMemcpyDeviceToHost, h->stream));
+        if (alpha) HIPCHK(h, hipMemcpyAsync(alpha, h->dalpha, (size_t)h->N * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return GPX_OK;
+    });
 }
 
 extern "C" int gpx_mean_at_obs(gpx_handle* h, double* mu_host, double* mu_max) {
-    if (!h) return GPX_EARG;
-    if (!h->fitted) return fail(h, GPX_ESTATE, "mean_at_obs: model is not fitted");
-    HIPCHK(h, hipSetDevice(h->device));
-    const int64_t N = h->N;
-    std::vector<double> al((size_t)N), yy((size_t)N);
-    HIPCHK(h, hipMemcpyAsync(al.data(), h->dalpha, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipMemcpyAsync(yy.data(), h->dy, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    // latent posterior mean at the observed inputs: K alpha + bias = y - sn2 * alpha
-    double mx = -HUGE_VAL;
-    for (int64_t i = 0; i < N; ++i) {
-        const double m = yy[i] - h->sn2 * al[i];
-        if (mu_host) mu_host[i] = m;
-        if (m > mx) mx = m;
-    }
-    if (mu_max) *mu_max = mx;
-    return GPX_OK;
+    return guarded(h, [&]() -> int {
+        if (!h) return GPX_EARG;
+        if (!h->fitted) return fail(h, GPX_ESTATE, "mean_at_obs: model is not fitted");
+        HIPCHK(h, hipSetDevice(h->device));
+        const int64_t N = h->N;
+        std::vector<double> al((size_t)N), yy((size_t)N);
+        HIPCHK(h, hipMemcpyAsync(al.data(), h->dalpha, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipMemcpyAsync(yy.data(), h->dy, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        // latent posterior mean at the observed inputs: K alpha + bias = y - sn2 * alpha
+        double mx = -HUGE_VAL;
+        for (int64_t i = 0; i < N; ++i) {
+            const double m = yy[i] - h->sn2 * al[i];
+            if (mu_host) mu_host[i] = m;
+            if (m > mx) mx = m;
+        }
+        if (mu_max) *mu_max = mx;
+        return GPX_OK;
+    });
 }
 
 // ---- sweep ------------------------------------------------------------------------------------
@@ -429,7 +487,7 @@ static int sweep_core(gpx_handle* h, int acq_id, const double* params, int npara
         {
             Span sp(h, T_TRMM);
             launch_sweep_trmm(s, h->dU, Np, h->dKs, chunk, cols, h->da, h->dQp, h->dPp, chunk,
-                              h->tile_order);
+                              h->tile_order, h->super_m);
         }
         h->tacc[T_NLAUNCH] += 1.0;
         // algorithmic work of this launch: sum over row blocks mt of 2*128*128*(mt+1)*128 per
@@ -467,51 +525,57 @@ static int sweep_core(gpx_handle* h, int acq_id, const double* params, int npara
 extern "C" int gpx_sweep_dev(gpx_handle* h, int acq_id, const double* params, int nparams, const double* dXc,
                              int64_t M, int64_t k, double* top_val, int64_t* top_idx, double* d_acq_all,
                              double* d_mu, double* d_s2) {
-    if (!h) return GPX_EARG;
-    return sweep_core(h, acq_id, params, nparams, dXc, M, k, top_val, top_idx, d_acq_all, d_mu, d_s2);
+    return guarded(h, [&]() -> int {
+        if (!h) return GPX_EARG;
+        return sweep_core(h, acq_id, params, nparams, dXc, M, k, top_val, top_idx, d_acq_all, d_mu, d_s2);
+    });
 }
 
 extern "C" int gpx_sweep(gpx_handle* h, int acq_id, const double* params, int nparams, const double* Xc,
                          int64_t M, int64_t k, double* top_val, int64_t* top_idx, double* acq_all, double* mu,
                          double* s2) {
-    if (!h) return GPX_EARG;
-    if (!h->fitted) return fail(h, GPX_ESTATE, "sweep: model is not fitted");
-    if (!Xc || M < 1) return fail(h, GPX_EARG, "sweep: need M >= 1 candidates");
-    HIPCHK(h, hipSetDevice(h->device));
-    int rc;
-    const int64_t d = h->d;
-    // staging: [Xc (M*d)] [acq M] [mu M] [s2 M]
-    if ((rc = ensure(h, h->dXc, h->cap_xc, M * d + 3 * M))) return rc;
-    double* dX = h->dXc;
-    double* dacq = dX + M * d;
-    double* dmu = dacq + M;
-    double* ds2 = dmu + M;
-    {
-        Span sp(h, T_COPY);
-        HIPCHK(h, hipMemcpyAsync(dX, Xc, (size_t)M * d * 8, hipMemcpyHostToDevice, h->stream));
-    }
-    rc = sweep_core(h, acq_id, params, nparams, dX, M, k, top_val, top_idx, dacq, mu ? dmu : nullptr,
-                    s2 ? ds2 : nullptr);
-    if (rc) return rc;
-    {
-        Span sp(h, T_COPY);
-        if (acq_all) HIPCHK(h, hipMemcpyAsync(acq_all, dacq, (size_t)M * 8, hipMemcpyDeviceToHost, h->stream));
-        if (mu) HIPCHK(h, hipMemcpyAsync(mu, dmu, (size_t)M * 8, hipMemcpyDeviceToHost, h->stream));
-        if (s2) HIPCHK(h, hipMemcpyAsync(s2, ds2, (size_t)M * 8, hipMemcpyDeviceToHost, h->stream));
-    }
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    return GPX_OK;
+    return guarded(h, [&]() -> int {
+        if (!h) return GPX_EARG;
+        if (!h->fitted) return fail(h, GPX_ESTATE, "sweep: model is not fitted");
+        if (!Xc || M < 1) return fail(h, GPX_EARG, "sweep: need M >= 1 candidates");
+        HIPCHK(h, hipSetDevice(h->device));
+        int rc;
+        const int64_t d = h->d;
+        // staging: [Xc (M*d)] [acq M] [mu M] [s2 M]
+        if ((rc = ensure(h, h->dXc, h->cap_xc, M * d + 3 * M))) return rc;
+        double* dX = h->dXc;
+        double* dacq = dX + M * d;
+        double* dmu = dacq + M;
+        double* ds2 = dmu + M;
+        {
+            Span sp(h, T_COPY);
+            HIPCHK(h, hipMemcpyAsync(dX, Xc, (size_t)M * d * 8, hipMemcpyHostToDevice, h->stream));
+        }
+        rc = sweep_core(h, acq_id, params, nparams, dX, M, k, top_val, top_idx, dacq, mu ? dmu : nullptr,
+                        s2 ? ds2 : nullptr);
+        if (rc) return rc;
+        {
+            Span sp(h, T_COPY);
+            if (acq_all) HIPCHK(h, hipMemcpyAsync(acq_all, dacq, (size_t)M * 8, hipMemcpyDeviceToHost, h->stream));
+            if (mu) HIPCHK(h, hipMemcpyAsync(mu, dmu, (size_t)M * 8, hipMemcpyDeviceToHost, h->stream));
+            if (s2) HIPCHK(h, hipMemcpyAsync(s2, ds2, (size_t)M * 8, hipMemcpyDeviceToHost, h->stream));
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return GPX_OK;
+    });
 }
 
 extern "C" int gpx_predict(gpx_handle* h, const double* Xc, int64_t M, double* mu, double* s2, double* dmu,
                            double* ds2) {
-    if (!h) return GPX_EARG;
-    if (!mu || !s2) return fail(h, GPX_EARG, "predict: mu and s2 outputs are required");
-    if (dmu || ds2) {
-        if (!dmu || !ds2) return fail(h, GPX_EARG, "predict: pass both gradient outputs or neither");
-        return gpx::predict_grad_host(h, Xc, M, mu, s2, dmu, ds2);
-    }
-    return gpx_sweep(h, GPX_ACQ_MEAN, nullptr, 0, Xc, M, 0, nullptr, nullptr, nullptr, mu, s2);
+    return guarded(h, [&]() -> int {
+        if (!h) return GPX_EARG;
+        if (!mu || !s2) return fail(h, GPX_EARG, "predict: mu and s2 outputs are required");
+        if (dmu || ds2) {
+            if (!dmu || !ds2) return fail(h, GPX_EARG, "predict: pass both gradient outputs or neither");
+            return gpx::predict_grad_host(h, Xc, M, mu, s2, dmu, ds2);
+        }
+        return gpx_sweep(h, GPX_ACQ_MEAN, nullptr, 0, Xc, M, 0, nullptr, nullptr, nullptr, mu, s2);
+    });
 }
 
 // ---- Thompson / RFF ---------------------------------------------------------------------------
@@ -584,99 +648,109 @@ static int rff_core(gpx_handle* h, const double* W, const double* b, const doubl
 extern "C" int gpx_rff_sweep_dev(gpx_handle* h, const double* W, const double* b, const double* theta,
                                  int64_t S, int64_t n, int64_t d, double bias, const double* dXc, int64_t M,
                                  int64_t k, double* top_val, int64_t* top_idx, double* d_vals_all) {
-    if (!h) return GPX_EARG;
-    return rff_core(h, W, b, theta, S, n, d, bias, dXc, M, k, top_val, top_idx, d_vals_all);
+    return guarded(h, [&]() -> int {
+        if (!h) return GPX_EARG;
+        return rff_core(h, W, b, theta, S, n, d, bias, dXc, M, k, top_val, top_idx, d_vals_all);
+    });
 }
 
 extern "C" int gpx_rff_sweep(gpx_handle* h, const double* W, const double* b, const double* theta, int64_t S,
                              int64_t n, int64_t d, double bias, const double* Xc, int64_t M, int64_t k,
                              double* top_val, int64_t* top_idx, double* vals_all) {
-    if (!h) return GPX_EARG;
-    if (!Xc || M < 1 || d < 1) return fail(h, GPX_EARG, "rff_sweep: bad candidates");
-    HIPCHK(h, hipSetDevice(h->device));
-    int rc;
-    if ((rc = ensure(h, h->dXc, h->cap_xc, M * d))) return rc;
-    HIPCHK(h, hipMemcpyAsync(h->dXc, Xc, (size_t)M * d * 8, hipMemcpyHostToDevice, h->stream));
-    if ((rc = ensure(h, h->dout, h->cap_out, S * M))) return rc;
-    rc = rff_core(h, W, b, theta, S, n, d, bias, h->dXc, M, k, top_val, top_idx, h->dout);
-    if (rc) return rc;
-    if (vals_all) {
-        HIPCHK(h, hipMemcpyAsync(vals_all, h->dout, (size_t)S * M * 8, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-    }
-    return GPX_OK;
+    return guarded(h, [&]() -> int {
+        if (!h) return GPX_EARG;
+        if (!Xc || M < 1 || d < 1) return fail(h, GPX_EARG, "rff_sweep: bad candidates");
+        HIPCHK(h, hipSetDevice(h->device));
+        int rc;
+        if ((rc = ensure(h, h->dXc, h->cap_xc, M * d))) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->dXc, Xc, (size_t)M * d * 8, hipMemcpyHostToDevice, h->stream));
+        if ((rc = ensure(h, h->dout, h->cap_out, S * M))) return rc;
+        rc = rff_core(h, W, b, theta, S, n, d, bias, h->dXc, M, k, top_val, top_idx, h->dout);
+        if (rc) return rc;
+        if (vals_all) {
+            HIPCHK(h, hipMemcpyAsync(vals_all, h->dout, (size_t)S * M * 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+        }
+        return GPX_OK;
+    });
 }
 
 extern "C" int gpx_rff_grad(gpx_handle* h, const double* W, const double* b, const double* theta, int64_t n,
                             int64_t d, double bias, const double* Xc, int64_t M, double* f, double* g) {
-    if (!h) return GPX_EARG;
-    return gpx::rff_grad_host(h, W, b, theta, n, d, bias, Xc, M, f, g);
+    return guarded(h, [&]() -> int {
+        if (!h) return GPX_EARG;
+        return gpx::rff_grad_host(h, W, b, theta, n, d, bias, Xc, M, f, g);
+    });
 }
 
 extern "C" int gpx_rff_gram_batch(gpx_handle* h, const double* W, const double* b, int64_t S, int64_t n,
                                   double* A, double* v) {
-    if (!h) return GPX_EARG;
-    if (h->stage < 1) return fail(h, GPX_ESTATE, "rff_gram: no data on the device (fit first)");
-    if (!W || !b || !A || !v || n < 1 || S < 1) return fail(h, GPX_EARG, "rff_gram: bad arguments");
-    HIPCHK(h, hipSetDevice(h->device));
-    hipStream_t s = h->stream;
-    const int64_t d = h->d, Np = h->Np, N = h->N;
-    int rc;
-    if (n >= TBH) {
-        // wide feature maps: one draw at a time on the generic path
-        // layout: [W n*d][b n][A n*n][v n][Ft n*Np]
-        const int64_t need = n * d + n + n * n + n + n * Np;
-        if ((rc = ensure(h, h->drff, h->cap_rff, need))) return rc;
-        double* dW = h->drff;
-        double* db = dW + n * d;
-        double* dA = db + n;
-        double* dv = dA + n * n;
-        double* dFt = dv + n;
-        for (int64_t q = 0; q < S; ++q) {
-            HIPCHK(h, hipMemcpyAsync(dW, W + q * n * d, (size_t)n * d * 8, hipMemcpyHostToDevice, s));
-            HIPCHK(h, hipMemcpyAsync(db, b + q * n, (size_t)n * 8, hipMemcpyHostToDevice, s));
-            {
-                Span sp(h, T_RFF);
-                launch_rff_gram(s, h->dXraw, dFt, N, (int)d, dW, db, (int)n, h->dy, h->bias, dA, dv);
+    return guarded(h, [&]() -> int {
+        if (!h) return GPX_EARG;
+        if (h->stage < 1) return fail(h, GPX_ESTATE, "rff_gram: no data on the device (fit first)");
+        if (!W || !b || !A || !v || n < 1 || S < 1) return fail(h, GPX_EARG, "rff_gram: bad arguments");
+        HIPCHK(h, hipSetDevice(h->device));
+        hipStream_t s = h->stream;
+        const int64_t d = h->d, Np = h->Np, N = h->N;
+        int rc;
+        if (n >= TBH) {
+            // wide feature maps: one draw at a time on the generic path
+            // layout: [W n*d][b n][A n*n][v n][Ft n*Np]
+            const int64_t need = n * d + n + n * n + n + n * Np;
+            if ((rc = ensure(h, h->drff, h->cap_rff, need))) return rc;
+            double* dW = h->drff;
+            double* db = dW + n * d;
+            double* dA = db + n;
+            double* dv = dA + n * n;
+            double* dFt = dv + n;
+            for (int64_t q = 0; q < S; ++q) {
+                HIPCHK(h, hipMemcpyAsync(dW, W + q * n * d, (size_t)n * d * 8, hipMemcpyHostToDevice, s));
+                HIPCHK(h, hipMemcpyAsync(db, b + q * n, (size_t)n * 8, hipMemcpyHostToDevice, s));
+                {
+                    Span sp(h, T_RFF);
+                    launch_rff_gram(s, h->dXraw, dFt, N, (int)d, dW, db, (int)n, h->dy, h->bias, dA, dv);
+                }
+                HIPCHK(h, hipMemcpyAsync(A + q * n * n, dA, (size_t)n * n * 8, hipMemcpyDeviceToHost, s));
+                HIPCHK(h, hipMemcpyAsync(v + q * n, dv, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+                HIPCHK(h, hipStreamSynchronize(s));
             }
-            HIPCHK(h, hipMemcpyAsync(A + q * n * n, dA, (size_t)n * n * 8, hipMemcpyDeviceToHost, s));
-            HIPCHK(h, hipMemcpyAsync(v + q * n, dv, (size_t)n * 8, hipMemcpyDeviceToHost, s));
-            HIPCHK(h, hipStreamSynchronize(s));
+            HIPCHK(h, hipGetLastError());
+            return GPX_OK;
         }
+        // batched MFMA path: feature tiles [S][dp][128] k-major, phases [S][128]
+        const int64_t dp = (d + 3) / 4 * 4;
+        const int64_t nW = S * dp * TBH, nV = S * TBH;
+        std::vector<double> stage((size_t)(nW + nV), 0.0);
+        for (int64_t q = 0; q < S; ++q)
+            for (int64_t j = 0; j < n; ++j) {
+                for (int64_t kk = 0; kk < d; ++kk) stage[(size_t)((q * dp + kk) * TBH + j)] = W[(q * n + j) * d + kk];
+                stage[(size_t)(nW + q * TBH + j)] = b[q * n + j];
+            }
+        // device: [Wt nW][bt nV][A S*n*n][v S*n]
+        const int64_t need = nW + nV + S * n * n + S * n;
+        if ((rc = ensure(h, h->drff, h->cap_rff, need))) return rc;
+        if ((rc = ensure(h, h->drffs, h->cap_rffs, rff_gram_batch_scratch(S, Np)))) return rc;
+        double* dWt = h->drff;
+        double* dbt = dWt + nW;
+        double* dA = dbt + nV;
+        double* dv = dA + S * n * n;
+        HIPCHK(h, hipMemcpyAsync(dWt, stage.data(), stage.size() * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipStreamSynchronize(s));   // `stage` is a local buffer
+        {
+            Span sp(h, T_RFF);
+            launch_rff_gram_batch(s, h->dXraw, N, Np, (int)d, (int)dp, dWt, dbt, (int)S, (int)n, h->dy, h->bias,
+                                  h->drffs, dA, dv);
+        }
+        HIPCHK(h, hipMemcpyAsync(A, dA, (size_t)S * n * n * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(v, dv, (size_t)S * n * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
         HIPCHK(h, hipGetLastError());
         return GPX_OK;
-    }
-    // batched MFMA path: feature tiles [S][dp][128] k-major, phases [S][128]
-    const int64_t dp = (d + 3) / 4 * 4;
-    const int64_t nW = S * dp * TBH, nV = S * TBH;
-    std::vector<double> stage((size_t)(nW + nV), 0.0);
-    for (int64_t q = 0; q < S; ++q)
-        for (int64_t j = 0; j < n; ++j) {
-            for (int64_t kk = 0; kk < d; ++kk) stage[(size_t)((q * dp + kk) * TBH + j)] = W[(q * n + j) * d + kk];
-            stage[(size_t)(nW + q * TBH + j)] = b[q * n + j];
-        }
-    // device: [Wt nW][bt nV][A S*n*n][v S*n]
-    const int64_t need = nW + nV + S * n * n + S * n;
-    if ((rc = ensure(h, h->drff, h->cap_rff, need))) return rc;
-    if ((rc = ensure(h, h->drffs, h->cap_rffs, rff_gram_batch_scratch(S, Np)))) return rc;
-    double* dWt = h->drff;
-    double* dbt = dWt + nW;
-    double* dA = dbt + nV;
-    double* dv = dA + S * n * n;
-    HIPCHK(h, hipMemcpyAsync(dWt, stage.data(), stage.size() * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipStreamSynchronize(s));   // `stage` is a local buffer
-    {
-        Span sp(h, T_RFF);
-        launch_rff_gram_batch(s, h->dXraw, N, Np, (int)d, (int)dp, dWt, dbt, (int)S, (int)n, h->dy, h->bias,
-                              h->drffs, dA, dv);
-    }
-    HIPCHK(h, hipMemcpyAsync(A, dA, (size_t)S * n * n * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipMemcpyAsync(v, dv, (size_t)S * n * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipStreamSynchronize(s));
-    HIPCHK(h, hipGetLastError());
-    return GPX_OK;
+    });
 }
 
 extern "C" int gpx_rff_gram(gpx_handle* h, const double* W, const double* b, int64_t n, double* A, double* v) {
-    return gpx_rff_gram_batch(h, W, b, 1, n, A, v);
+    return guarded(h, [&]() -> int {
+        return gpx_rff_gram_batch(h, W, b, 1, n, A, v);
+    });
 }

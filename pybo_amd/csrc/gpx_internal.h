@@ -57,6 +57,7 @@ struct gpx_handle {
 
     // sweep workspace
     int64_t chunk = 65536;    // candidate columns per chunk (multiple of 128)
+    int super_m = 8;          // rows (mt) of an XCD super-tile of 64 workgroups: 8 -> 8x8, 4 -> 4x16, 2 -> 2x32
     int tile_order = 10;      // bits 0-1 tile map (2 = XCD 8x8 super-tiles), bits 2-3 k-loop variant (2 = write-at-top + setprio)
     int64_t cap_ks = 0;       // elements of dKs
     double* dKs = nullptr;    // (Np, chunk) cross-Gram chunk
@@ -105,7 +106,7 @@ void launch_cross_gram(hipStream_t s, const double* Xs, int64_t Np, int64_t N, i
                        double rho, double* Ks, int64_t ldk);
 void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double* Ks, int64_t ldk,
                        int64_t cols, const double* a, double* Qp, double* Pp, int64_t ldp,
-                       int tile_order);
+                       int tile_order, int super_m);
 // reduce partials, form mu/s2/acq for columns [0,cols) of this chunk -> global candidate m0+..
 void launch_acq(hipStream_t s, const double* Qp, const double* Pp, int64_t ldp, int nrb, int64_t m0,
                 int64_t cols_valid, double rho, double bias, int acq_id, double p0, double* acq_out,

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __
                                                                 const double* __restrict__ avec,
                                                                 double* __restrict__ Qp,
                                                                 double* __restrict__ Pp, int64_t ldp,
-                                                                int order) {
+                                                                int order, int sm) {
     __shared__ __attribute__((aligned(16))) double smem[GEMM_LDS_F64];
     const int nP = (int)(Np / TB);
     int mt, nt;
@@ -136,12 +136,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __
             // 8 (mt) x 8 (nt) patch, so every T row-panel and every Ks column-panel fetched into that
             // XCD's L2 is used by 8 tiles -> ~4x less fabric/HBM traffic than one-panel-per-tile.
             const int x = b & 7, q = b >> 3;
+            const int SN = 64 / sm;                   // super-tile = sm (mt) x SN (nt) = 64 workgroups
             const int per = (NT + 7) / 8;             // candidate tiles per XCD (contiguous slice)
-            const int hper = (per + 7) / 8;           // 8-wide n-groups per XCD
+            const int hper = (per + SN - 1) / SN;     // n-groups per XCD
             const int s = q >> 6, r = q & 63;
             const int G = s / hper, H = s - G * hper;
-            mt = nP - 1 - (G * 8 + (r >> 3));
-            const int ln = H * 8 + (r & 7);
+            mt = nP - 1 - (G * sm + r / SN);
+            const int ln = H * SN + (r - (r / SN) * SN);
             nt = x * per + ln;
             if (ln >= per || nt >= NT || mt < 0) return;
         } else {
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __
 
 void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double* Ks, int64_t ldk,
                        int64_t cols, const double* a, double* Qp, double* Pp, int64_t ldp,
-                       int tile_order) {
+                       int tile_order, int super_m) {
     const int NT = (int)(cols / TB);
     const int nP = (int)(Np / TB);
     unsigned nblk;
@@ -212,9 +213,10 @@ void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double*
         const int per = (NT + 7) / 8;
         nblk = (unsigned)(8 * per * nP);
     } else if ((tile_order & 3) == 2) {
+        const int SN = 64 / super_m;
         const int per = (NT + 7) / 8;
-        const int hper = (per + 7) / 8;
-        const int gm = (nP + 7) / 8;
+        const int hper = (per + SN - 1) / SN;
+        const int gm = (nP + super_m - 1) / super_m;
         nblk = (unsigned)(8 * 64 * hper * gm);
     } else {
         nblk = (unsigned)(NT * nP);
@@ -222,19 +224,19 @@ void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double*
     const int order = tile_order & 3, var = tile_order >> 2;   // bits 0-1: tile map, bits 2..: k-loop variant
     if (var == 0)
         hipLaunchKernelGGL(k_sweep_trmm<0>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
-                           ldp, order);
+                           ldp, order, super_m);
     else if (var == 1)
         hipLaunchKernelGGL(k_sweep_trmm<1>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
-                           ldp, order);
+                           ldp, order, super_m);
     else if (var == 2)
         hipLaunchKernelGGL(k_sweep_trmm<2>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
-                           ldp, order);
+                           ldp, order, super_m);
     else if (var == 3)
         hipLaunchKernelGGL(k_sweep_trmm<3>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
-                           ldp, order);
+                           ldp, order, super_m);
     else
         hipLaunchKernelGGL(k_sweep_trmm<4>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
-                           ldp, order);
+                           ldp, order, super_m);
 }
 
 // ------------------------------------------------------------------------------------------------

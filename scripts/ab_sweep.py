@@ -19,7 +19,8 @@ ref = None
 res = {v: [] for v in variants}
 for r in range(rounds + 1):
     for v in variants:
-        e.set_option('tile_order', v)
+        e.set_option('tile_order', v % 100)
+        e.set_option('super_m', (v // 100) or 8)
         e.timers(reset=True)
         out = e.sweep('ei', 0.0, Xc, k=4, want_all=True)
         tm = e.timers(reset=True)
