@@ -145,56 +145,97 @@ __device__ __forceinline__ double rsqrt_nr(double x) {
     return y;
 }
 
-// Sixteen pivot steps j = 16*JS .. 16*JS+15 with the slice index JS a compile-time constant, so that
-// every mask that depends on "which 16-row/16-column slice" folds away: slices a < JS are finished (no
-// code), columns b < JS are always left of the pivot (inverse part), b > JS always right of it (Cholesky
-// part), and the never-updated gap JS < b < a emits no FMA at all.  Only the pivot slice itself keeps
-// run-time compares.  Returns false (uniformly) on a non-positive pivot.
+// Sixteen pivots j = 16*JS .. 16*JS+15, taken TWO AT A TIME, with the slice index JS a compile-time
+// constant so that every mask that depends on "which 16-row/16-column slice" folds away: slices a < JS are
+// finished (no code), columns b < JS are always left of the pivots (inverse part), b > JS always right of
+// them (Cholesky part), and the never-updated gap JS < b < a emits no FMA at all.
+//
+// Pair step (j, j+1): the two pivot rows p1 = M[j][:], p2 = M[j+1][:] are published UNSCALED in LDS (p2 not yet
+// touched by pivot j).  Every thread forms the 2x2 pivot block in closed form
+//     inv1 = 1/sqrt(p1[j]),  l = p1[j+1]*inv1 (= R[j][j+1]),  inv2 = 1/sqrt(p2[j+1] - l^2)
+// the two scaled pivot rows  row1 = p1*inv1,  row2 = (p2 - l*row1)*inv2  (with the identity columns of the
+// inverse part: T[j][j] = inv1, T[j+1][j] = -l*inv1*inv2, T[j+1][j+1] = inv2), and applies the rank-2 update
+//     M[r][c] -= R1[r]*row1[c] + R2[r]*row2[c]          (R2 = 0 for r = j+1: that row only sees pivot j)
+// i.e. one barrier and one LDS round trip per TWO pivots for the same FMA count.  Rows are left unscaled
+// in registers; their 1/d is remembered in dinv[] and applied at write-back.
+// Returns false (uniformly) on a non-positive pivot.
 template <int JS>
-__device__ __forceinline__ bool potrf_phase(double (&m)[8][8], double (&dinv)[8], double (*rowbuf)[NB + 8],
-                                            int tr, int tc, bool up_diag, bool on_diag, int64_t p0,
-                                            int* flag) {
-    for (int jj = 0; jj < 16; ++jj) {
+__device__ __forceinline__ bool potrf_phase(double (&m)[8][8], double (&dinv)[8],
+                                            double (*rowbuf)[2][NB + 8], int tr, int tc, bool up_diag,
+                                            int64_t p0, int* flag) {
+    for (int jj = 0; jj < 16; jj += 2) {
         const int j = JS * 16 + jj;
-        const double* rb = rowbuf[j & 1];
-        const double piv = rb[j];
-        if (!(piv > 0.0) || !(piv < 1.0e300)) {  // also catches NaN
+        const int par = (j >> 1) & 1;
+        const double* p1 = rowbuf[par][0];
+        const double* p2 = rowbuf[par][1];
+        const double piv1 = p1[j];
+        if (!(piv1 > 0.0) || !(piv1 < 1.0e300)) {  // also catches NaN; uniform
             if (threadIdx.x == 0) *flag = (int)(p0 + j) + 1;
-            return false;  // uniform: every thread read the same pivot
+            return false;
         }
-        const double inv = rb[NB];
+        const double inv1 = rsqrt_nr(piv1);
+        const double l = p1[j + 1] * inv1;
+        const double piv2 = fma(-l, l, p2[j + 1]);
+        if (!(piv2 > 0.0) || !(piv2 < 1.0e300)) {
+            if (threadIdx.x == 0) *flag = (int)(p0 + j + 1) + 1;
+            return false;
+        }
+        const double inv2 = rsqrt_nr(piv2);
         const int cj = tc + 16 * JS, rj = tr + 16 * JS;
-        double rowv[8];          // scaled pivot row
+        // scaled pivot rows per owned column; for slice JS split into Cholesky (R*) and inverse (T*) parts
+        double row1[8], row2[8];
 #pragma unroll
-        for (int b = 0; b < 8; ++b) rowv[b] = rb[tc + 16 * b] * inv;
-        const double rR = (cj > j) ? rowv[JS] : 0.0;                          // Cholesky part of slice JS
-        const double rT = (cj < j) ? rowv[JS] : ((cj == j) ? inv : 0.0);      // inverse part of slice JS
-        double mult[8];
+        for (int b = 0; b < 8; ++b) {
+            if (b == JS) continue;
+            row1[b] = p1[tc + 16 * b] * inv1;
+            row2[b] = fma(-l, row1[b], p2[tc + 16 * b]) * inv2;
+        }
+        double R1, R2, T1, T2;
+        {
+            const double q1 = p1[cj] * inv1;
+            const double q2 = fma(-l, q1, p2[cj]) * inv2;
+            R1 = (cj > j) ? q1 : 0.0;                       // includes c = j+1: R[j][j+1] = l
+            R2 = (cj > j + 1) ? q2 : 0.0;
+            T1 = (cj < j) ? q1 : ((cj == j) ? inv1 : 0.0);
+            T2 = (cj < j) ? q2 : ((cj == j) ? (-l * inv1) * inv2 : ((cj == j + 1) ? inv2 : 0.0));
+        }
+        double mu1[8], mu2[8];
 #pragma unroll
-        for (int a = JS; a < 8; ++a) mult[a] = -(rb[tr + 16 * a] * inv);      // -R[j][r]
-        if (!(rj > j)) mult[JS] = 0.0;                                         // rows of slice JS above the pivot
-        dinv[JS] = (rj == j) ? inv : dinv[JS];
-        const int jn = j + 1;
+        for (int a = JS; a < 8; ++a) {
+            const int r = tr + 16 * a;
+            const double q1 = p1[r] * inv1;                 // R[j][r]
+            mu1[a] = -q1;
+            mu2[a] = -(fma(-l, q1, p2[r]) * inv2);          // R[j+1][r]
+        }
+        if (!(rj > j)) mu1[JS] = 0.0;                       // rows of slice JS at or above pivot j
+        if (!(rj > j + 1)) mu2[JS] = 0.0;                   // row j+1 is only eliminated by pivot j
+        dinv[JS] = (rj == j) ? inv1 : ((rj == j + 1) ? inv2 : dinv[JS]);
+        const int jn = j + 2;
 #pragma unroll
         for (int a = JS; a < 8; ++a) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) {
-                if (b < JS) {
-                    m[a][b] = fma(mult[a], rowv[b], m[a][b]);                  // inverse part, c < j
+                double v1, v2;
+                bool live = true;
+                if (b < JS) {                      // inverse part, c < j
+                    v1 = row1[b]; v2 = row2[b];
                 } else if (b == JS) {
-                    if (a == JS) m[a][b] = fma(mult[a], up_diag ? rR : rT, m[a][b]);
-                    else m[a][b] = fma(mult[a], rT, m[a][b]);                  // b < a: inverse part
-                } else {  // b > JS: right of the pivot
-                    if (b > a) m[a][b] = fma(mult[a], rowv[b], m[a][b]);       // Cholesky part
-                    else if (b == a) m[a][b] = fma(mult[a], up_diag ? rowv[b] : 0.0, m[a][b]);
-                    // JS < b < a: below the diagonal and right of the pivot -> never touched
+                    if (a == JS) { v1 = up_diag ? R1 : T1; v2 = up_diag ? R2 : T2; }
+                    else { v1 = T1; v2 = T2; }     // b < a: inverse part
+                } else {                           // b > JS: right of the pivots
+                    if (b > a) { v1 = row1[b]; v2 = row2[b]; }
+                    else if (b == a) { v1 = up_diag ? row1[b] : 0.0; v2 = up_diag ? row2[b] : 0.0; }
+                    else { live = false; v1 = 0.0; v2 = 0.0; }   // JS < b < a: never touched
                 }
+                if (live) m[a][b] = fma(mu2[a], v2, fma(mu1[a], v1, m[a][b]));
             }
-            if ((a == JS || a == JS + 1) && tr + 16 * a == jn) {   // publish the next pivot row + rsqrt
-                double* wb = rowbuf[jn & 1];
+            if (a == JS || a == JS + 1) {          // publish the next pivot pair, rows jn and jn+1 (unscaled)
+                const int r = tr + 16 * a;
+                if (r == jn || r == jn + 1) {
+                    double* wb = rowbuf[par ^ 1][r - jn];
 #pragma unroll
-                for (int b = 0; b < 8; ++b) wb[tc + 16 * b] = m[a][b];
-                if (on_diag) wb[NB] = rsqrt_nr(m[a][a]);
+                    for (int b = 0; b < 8; ++b) wb[tc + 16 * b] = m[a][b];
+                }
             }
         }
         __syncthreads();
@@ -205,7 +246,7 @@ __device__ __forceinline__ bool potrf_phase(double (&m)[8][8], double (&dinv)[8]
 __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, double* __restrict__ R,
                                                     double* __restrict__ T, double* __restrict__ U,
                                                     int64_t Np, int p, int* __restrict__ flag) {
-    __shared__ double rowbuf[2][NB + 8];   // [..][NB] = 1/sqrt(pivot), published by the pivot's owner
+    __shared__ double rowbuf[2][2][NB + 8];   // [parity][first|second pivot row of the pair][column]
     if (*flag != 0) return;  // an earlier panel already failed
     const int t = threadIdx.x;
     const int tr = t >> 4, tc = t & 15;
@@ -218,31 +259,30 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, doub
             const int r = tr + 16 * a, c = tc + 16 * b;
             m[a][b] = (c >= r) ? S[(p0 + r) * Np + p0 + c] : 0.0;
         }
-    // publish row 0 and its pivot's reciprocal square root
-    if (tr == 0) {
+    // publish rows 0 and 1
+    if (tr < 2) {
 #pragma unroll
-        for (int b = 0; b < 8; ++b) rowbuf[0][tc + 16 * b] = m[0][b];
-        if (tc == 0) rowbuf[0][NB] = rsqrt_nr(m[0][0]);
+        for (int b = 0; b < 8; ++b) rowbuf[0][tr][tc + 16 * b] = m[0][b];
     }
     __syncthreads();
 
     // Element (r,c) = (tr+16a, tc+16b) is in the Cholesky part iff c >= r, i.e. b > a, or b == a and
     // tc >= tr (a per-thread constant).
     const bool up_diag = (tc >= tr);
-    const bool on_diag = (tc == tr);
-    double dinv[8];   // 1/d of each owned row, filled when the row is the pivot; applied at write-back
+    double dinv[8];   // 1/d of each owned row, filled when the row is a pivot; applied at write-back
 #pragma unroll
     for (int a = 0; a < 8; ++a) dinv[a] = 1.0;
 
-    if (!potrf_phase<0>(m, dinv, rowbuf, tr, tc, up_diag, on_diag, p0, flag)) return;
-    if (!potrf_phase<1>(m, dinv, rowbuf, tr, tc, up_diag, on_diag, p0, flag)) return;
-    if (!potrf_phase<2>(m, dinv, rowbuf, tr, tc, up_diag, on_diag, p0, flag)) return;
-    if (!potrf_phase<3>(m, dinv, rowbuf, tr, tc, up_diag, on_diag, p0, flag)) return;
-    if (!potrf_phase<4>(m, dinv, rowbuf, tr, tc, up_diag, on_diag, p0, flag)) return;
-    if (!potrf_phase<5>(m, dinv, rowbuf, tr, tc, up_diag, on_diag, p0, flag)) return;
-    if (!potrf_phase<6>(m, dinv, rowbuf, tr, tc, up_diag, on_diag, p0, flag)) return;
-    if (!potrf_phase<7>(m, dinv, rowbuf, tr, tc, up_diag, on_diag, p0, flag)) return;
+    if (!potrf_phase<0>(m, dinv, rowbuf, tr, tc, up_diag, p0, flag)) return;
+    if (!potrf_phase<1>(m, dinv, rowbuf, tr, tc, up_diag, p0, flag)) return;
+    if (!potrf_phase<2>(m, dinv, rowbuf, tr, tc, up_diag, p0, flag)) return;
+    if (!potrf_phase<3>(m, dinv, rowbuf, tr, tc, up_diag, p0, flag)) return;
+    if (!potrf_phase<4>(m, dinv, rowbuf, tr, tc, up_diag, p0, flag)) return;
+    if (!potrf_phase<5>(m, dinv, rowbuf, tr, tc, up_diag, p0, flag)) return;
+    if (!potrf_phase<6>(m, dinv, rowbuf, tr, tc, up_diag, p0, flag)) return;
+    if (!potrf_phase<7>(m, dinv, rowbuf, tr, tc, up_diag, p0, flag)) return;
     // rows were left unscaled: R[j][c>j] = m*inv_j, T[j][c<j] = m*inv_j, R[j][j] = piv*inv_j = d_j
+    // (for the second row of a pair the register already holds row - l*row1, its own pivot included)
 #pragma unroll
     for (int a = 0; a < 8; ++a)
 #pragma unroll
