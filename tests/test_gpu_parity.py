@@ -251,6 +251,33 @@ def test_topk_edge_cases():
     e.close()
 
 
+def test_nan_candidates_rank_last_and_max_dimension():
+    # d = 64 is the largest supported input dimension; 65 is refused
+    from pybo_amd._lib import GpxError, GPX_EARG
+    X, y, ell = synth_problem(130, 64, seed=8)
+    ref = gp_ref.make_gp(1e-3, 1.0, ell * 4, 0.0)
+    ref.add_data(X, y)
+    e = _engine()
+    e.fit(X, y, 'se', ell * 4, 1.0, 1e-3, 0.0)
+    Z = np.random.RandomState(2).rand(300, 64)
+    mu, s2 = e.predict(Z)
+    mr, sr = ref.predict(Z)
+    assert np.all(np.abs(mu - mr) <= mu_tol(mr, 1.0)) and np.all(np.abs(s2 - sr) <= s2_tol(sr, 1.0))
+    with pytest.raises(GpxError) as ei:
+        e.fit(np.random.rand(10, 65), np.random.rand(10), 'se', np.ones(65), 1.0, 1e-3, 0.0)
+    assert ei.value.code == GPX_EARG
+    # a NaN coordinate poisons that candidate only; it ranks below every finite value
+    e.fit(X, y, 'se', ell * 4, 1.0, 1e-3, 0.0)
+    Zn = Z.copy()
+    Zn[7, 3] = np.nan
+    r = e.sweep('ucb', 2.0, Zn, k=64)
+    assert np.isnan(r['acq'][7]) and np.sum(np.isnan(r['acq'])) == 1
+    assert 7 not in r['top_idx'].tolist()
+    clean = e.sweep('ucb', 2.0, np.delete(Z, 7, axis=0), k=5)
+    np.testing.assert_array_equal(r['top_val'][:5], clean['top_val'])
+    e.close()
+
+
 @pytest.mark.parametrize('kernel', ['se', 'matern5', 'matern3'])
 def test_predict_with_gradients(kernel):
     e, ref, (X, y, ell, rho, sn2, bias) = _pair(300, 5, kernel, seed=21)
