@@ -26,7 +26,7 @@ for r in range(rounds + 1):
         tm = e.timers(reset=True)
         if ref is None: ref = out['acq']
         same = np.array_equal(ref, out['acq'])
-        if r > 0: res[v].append(tm['sweep_trmm_flop'] / (tm['sweep_trmm'] + tm['cross_gram']) / 1e9)
+        if r > 0: res[v].append(tm['sweep_trmm_flop'] / tm['sweep_trmm'] / 1e9)
         if not same: print("variant", v, "DIFFERS from variant", variants[0], np.max(np.abs(ref-out['acq'])))
 for v in variants:
-    a = np.array(res[v]); print(f"N={N} M={M} variant {v}: (incl. cross-gram time) TF/s median {np.median(a):.2f} min {a.min():.2f} max {a.max():.2f}")
+    a = np.array(res[v]); print(f"N={N} M={M} variant {v}: TF/s median {np.median(a):.2f} min {a.min():.2f} max {a.max():.2f}")
