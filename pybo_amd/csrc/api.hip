@@ -198,7 +198,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             return GPX_OK;
         }
         if (!strcmp(name, "tile_order")) {
-            if (value < 0 || value > 19 || (value & 3) == 3) return fail(h, GPX_EARG, "tile_order: bits 0-1 in {0,1,2} (tile map), bits 2-3 in {0,1,2} (k-loop variant)");
+            if (value < 0 || value > 23 || (value & 3) == 3) return fail(h, GPX_EARG, "tile_order: bits 0-1 in {0,1,2} (tile map), bits 2-3 in {0,1,2} (k-loop variant)");
             h->tile_order = (int)value;
             return GPX_OK;
         }

@@ -344,6 +344,79 @@ __device__ __forceinline__ void gemm_tile_128_e(d4 (&acc)[4][4], const double* _
     }
 }
 
+// Variant G: k-step of 32 through a SINGLE LDS buffer (same 73,728 B, so still two workgroups per CU):
+// 128 MFMAs per wave between staging phases instead of 64, i.e. half as many step boundaries per flop.  The
+// staging phase (barrier - LDS write - barrier) is exposed inside a workgroup and relies on the co-resident
+// workgroup to keep the matrix pipe busy meanwhile.
+constexpr int BK32 = 32;
+
+template <bool PRIO>
+__device__ __forceinline__ void gemm_tile_128_g(d4 (&acc)[4][4], const double* __restrict__ A, int64_t lda,
+                                                const double* __restrict__ B, int64_t ldb, int k_lo,
+                                                int k_hi, double* smem) {
+    // k_hi - k_lo must be a multiple of 32 (every caller's extent is a multiple of 128)
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    double* As = smem;                 // [BK32][LDT]
+    double* Bs = smem + BK32 * LDT;    // [BK32][LDT]
+    const int lrow = w;
+    const int lcol = lane * 2;
+    d2 ra[8], rb[8];
+    const int nk = (k_hi - k_lo) / BK32;
+    if (nk <= 0) return;
+    const double* Ap = A + (int64_t)(k_lo + lrow) * lda + lcol;
+    const double* Bp = B + (int64_t)(k_lo + lrow) * ldb + lcol;
+    auto gload = [&]() {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            ra[p] = *reinterpret_cast<const d2*>(Ap + (int64_t)(4 * p) * lda);
+            rb[p] = *reinterpret_cast<const d2*>(Bp + (int64_t)(4 * p) * ldb);
+        }
+        Ap += (int64_t)BK32 * lda;
+        Bp += (int64_t)BK32 * ldb;
+    };
+    auto swrite = [&]() {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            *reinterpret_cast<d2*>(As + (lrow + 4 * p) * LDT + lcol) = ra[p];
+            *reinterpret_cast<d2*>(Bs + (lrow + 4 * p) * LDT + lcol) = rb[p];
+        }
+    };
+    const int fr = lane & 15, fk = lane >> 4;
+    gload();
+    swrite();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload();
+        const double* as = As + wm * 64 + fr;
+        const double* bs = Bs + wn * 64 + fr;
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < BK32 / 4; ++kk) {
+            const int kr = kk * 4 + fk;
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = as[kr * LDT + i * 16];
+                b[i] = bs[kr * LDT + i * 16];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        __syncthreads();               // everyone has finished reading the buffer
+        if (kt + 1 < nk) {
+            swrite();
+            __syncthreads();
+        }
+    }
+}
+
 // element coordinates of accumulator register acc[i][j][r] inside the 128x128 tile
 __device__ __forceinline__ int acc_row(int i, int r) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(const double* _
     const int64_t i0 = (int64_t)I * NB, j0 = (int64_t)J * NB;
     d4 acc[4][4];
     acc_zero(acc);
-    gemm_tile_128_b<true>(acc, R + i0, Np, R + j0, Np, kb0 * NB, kb1 * NB, smem);
+    gemm_tile_128_g<true>(acc, R + i0, Np, R + j0, Np, kb0 * NB, kb1 * NB, smem);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trtri_gemm1(const double* _
     const int64_t m0 = r2e + (int64_t)bm * NB, n0 = r1e + (int64_t)bn * NB;
     d4 acc[4][4];
     acc_zero(acc);
-    gemm_tile_128_b<true>(acc, R + r1e * Np + m0, Np, T + r1e * Np + n0, Np, bn * NB, hb * NB, smem);
+    gemm_tile_128_g<true>(acc, R + r1e * Np + m0, Np, T + r1e * Np + n0, Np, bn * NB, hb * NB, smem);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trtri_gemm2(const double* _
     d4 acc[4][4];
     acc_zero(acc);
     // A(m,k) = T_22(m,k) = U[r2e+k][m0+m], k <= m  ->  k-blocks [0, bm]
-    gemm_tile_128_b<true>(acc, U + r2e * Np + m0, Np, W + r2e * Np + n0, Np, 0, (bm + 1) * NB, smem);
+    gemm_tile_128_g<true>(acc, U + r2e * Np + m0, Np, W + r2e * Np + n0, Np, 0, (bm + 1) * NB, smem);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __
     else if (VAR == 1) gemm_tile_128_b<false>(acc, U + m0, Np, Ks + n0, ldk, 0, (mt + 1) * TB, smem);
     else if (VAR == 2) gemm_tile_128_b<true>(acc, U + m0, Np, Ks + n0, ldk, 0, (mt + 1) * TB, smem);
     else if (VAR == 3) gemm_tile_128_d<true>(acc, U + m0, Np, Ks + n0, ldk, 0, (mt + 1) * TB, smem);
-    else gemm_tile_128_e<true>(acc, U + m0, Np, Ks + n0, ldk, 0, (mt + 1) * TB, smem);
+    else if (VAR == 4) gemm_tile_128_e<true>(acc, U + m0, Np, Ks + n0, ldk, 0, (mt + 1) * TB, smem);
+    else gemm_tile_128_g<true>(acc, U + m0, Np, Ks + n0, ldk, 0, (mt + 1) * TB, smem);
 
     // epilogue: column sums of V^2 and V*a over this tile's 128 rows
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -234,8 +235,11 @@ void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double*
     else if (var == 3)
         hipLaunchKernelGGL(k_sweep_trmm<3>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
                            ldp, order, super_m);
-    else
+    else if (var == 4)
         hipLaunchKernelGGL(k_sweep_trmm<4>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
+                           ldp, order, super_m);
+    else
+        hipLaunchKernelGGL(k_sweep_trmm<5>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
                            ldp, order, super_m);
 }
 

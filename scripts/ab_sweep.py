@@ -6,7 +6,7 @@ from pybo_amd._lib import Engine
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 d = 8
 M = int(sys.argv[2]) if len(sys.argv) > 2 else (1 << 17)
-variants = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 4, 8]
+variants = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [10, 22]
 rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 rng = np.random.RandomState(1)
 X = rng.rand(N, d); y = -((X - 0.5) ** 2).sum(1) + 1e-3 * rng.randn(N)
