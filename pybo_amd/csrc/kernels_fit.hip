@@ -455,7 +455,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trtri_gemm1(const double* _
                                                                  const double* __restrict__ T,
                                                                  double* __restrict__ W, int64_t Np,
                                                                  int nP, int hb) {
-    const int g = blockIdx.z, bm = blockIdx.y, bn = blockIdx.x;
+    // K-extent of a tile is (hb - bn) blocks: bn is the SLOW grid index so tiles are dispatched heaviest
+    // first (LPT) -- with bn fastest, some CU slots drew two K = hb*128 tiles and set the makespan
+    const int g = blockIdx.z, bm = blockIdx.x, bn = blockIdx.y;
     const int r1 = g * 2 * hb, r2 = r1 + hb;
     if (r2 >= nP) return;
     const int size2 = min(hb, nP - r2);
@@ -478,7 +480,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trtri_gemm2(const double* _
                                                                  double* __restrict__ T,
                                                                  double* __restrict__ U, int64_t Np,
                                                                  int nP, int hb) {
-    const int g = blockIdx.z, bm = blockIdx.y, bn = blockIdx.x;
+    // K-extent is (bm + 1) blocks: heaviest (largest bm) first
+    const int g = blockIdx.z, bm = hb - 1 - (int)blockIdx.y, bn = blockIdx.x;
     const int r1 = g * 2 * hb, r2 = r1 + hb;
     if (r2 >= nP) return;
     const int size2 = min(hb, nP - r2);
