@@ -398,19 +398,21 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_row_update64(const double* __r
 
 constexpr int CHOL_W = 4;   // outer panel width in 128-blocks
 
-// Two-level blocked right-looking factorisation with one panel of lookahead.
+// Two-level blocked right-looking factorisation with lookahead.  U(Q, P) = update of panel Q's block rows
+// with the factored rows of panel P (K = W*128); chain(Q) needs every U(Q, P < Q).
 //   chain(P)   rows P0..P1-1 one by one: row update (left-looking inside the panel) -> k_potrf_diag ->
-//              k_panel_trsm.  Serial and latency-bound (~120 us per 128-block), uses a handful of CUs.
-//   near(P)    trailing update of the NEXT panel's block rows (P1 .. P1+W-1, all J >= I), K = W*128.
-//              On the main stream: chain(P+1) needs it.
-//   far(P)     trailing update of everything below (rows >= P1+W).  On the second (low-priority) stream,
-//              started after near(P) and concurrent with chain(P+1); near(P+1) waits for it (same tiles).
+//              k_panel_trsm.  Serial and latency-bound (~100 us per 128-block), uses a handful of CUs.
+//   near(P)    U(P+1, P): on the main stream, chain(P+1) needs it.
+//   mid(P)     U(P+2, P): first thing on the side stream; near(P+1) touches the same rows and waits for it.
+//   rest(P)    U(Q >= P+3, P): the bulk, streams back-to-back on the (low-priority) side stream and only
+//              has to be finished before mid(P+1) -- which follows it in stream order anyway.
+// So the critical path never waits for a whole trailing update, only for the W block rows it is about to use.
 void launch_cholesky(gpx_handle* h) {
     const int64_t Np = h->Np;
     const int nP = (int)(Np / NB);
     hipStream_t s = h->stream, s2 = h->stream2;
     hipMemsetAsync(h->dflag, 0, sizeof(int), s);
-    bool far_pending = false;
+    bool mid_pending = false, side_used = false;
     for (int P0 = 0; P0 < nP; P0 += CHOL_W) {
         const int P1 = (P0 + CHOL_W < nP) ? P0 + CHOL_W : nP;
         for (int I = P0; I < P1; ++I) {
@@ -425,23 +427,32 @@ void launch_cholesky(gpx_handle* h) {
                                    h->dS, h->dR, Np, I);
         }
         if (P1 >= nP) break;
-        const int nnear = (P1 + CHOL_W < nP) ? CHOL_W : nP - P1;   // block rows of the next panel
-        const int tfar = nP - P1 - nnear;                           // block rows below it
-        if (far_pending) hipStreamWaitEvent(s, h->ev_far, 0);       // far(P-1) wrote the tiles near(P) touches
+        const int nnear = (P1 + CHOL_W < nP) ? CHOL_W : nP - P1;
+        const int m0 = P1 + nnear;                                    // first block row of mid(P)
+        const int nmid = (m0 + CHOL_W < nP) ? CHOL_W : nP - m0;       // may be 0
+        const int r0 = m0 + nmid;                                     // first block row of rest(P)
+        const int nrest = nP - r0;
+        if (mid_pending) hipStreamWaitEvent(s, h->ev_far, 0);        // mid(P-1) (and rest(P-2)) wrote these rows
         hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)(nP - P1), (unsigned)nnear), dim3(GEMM_THREADS), 0, s,
                            h->dR, h->dS, Np, P0, P1, P1, P1);
-        hipEventRecord(h->ev_chain, s);   // after near(P): it runs alone, far(P) then overlaps chain(P+1) only
-        if (tfar > 0) {
-            hipStreamWaitEvent(s2, h->ev_chain, 0);                 // needs R rows P0..P1-1
-            hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)tfar, (unsigned)tfar), dim3(GEMM_THREADS), 0, s2,
-                               h->dR, h->dS, Np, P0, P1, P1 + nnear, P1 + nnear);
+        mid_pending = false;
+        if (nmid > 0) {
+            hipEventRecord(h->ev_chain, s);                           // R rows P0..P1-1 are final
+            hipStreamWaitEvent(s2, h->ev_chain, 0);
+            hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)(nP - m0), (unsigned)nmid), dim3(GEMM_THREADS), 0, s2,
+                               h->dR, h->dS, Np, P0, P1, m0, m0);
             hipEventRecord(h->ev_far, s2);
-            far_pending = true;
-        } else {
-            far_pending = false;
+            mid_pending = true;
+            side_used = true;
+            if (nrest > 0)
+                hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)nrest, (unsigned)nrest), dim3(GEMM_THREADS), 0, s2,
+                                   h->dR, h->dS, Np, P0, P1, r0, r0);
         }
     }
-    if (far_pending) hipStreamWaitEvent(s, h->ev_far, 0);
+    if (side_used) {   // join: everything queued on the side stream is done before the caller's stream goes on
+        hipEventRecord(h->ev_far, s2);
+        hipStreamWaitEvent(s, h->ev_far, 0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
