@@ -41,7 +41,7 @@ struct gpx_handle {
     int64_t fail_pivot = -1;
 
     // device buffers (capacity tracked in elements)
-    int64_t cap_np = 0, cap_d = 0;
+    int64_t cap_np = 0;
     double* dXs = nullptr;    // (Np, d) observed points scaled by 1/ell, padded rows = 0
     double* dXraw = nullptr;  // (N, d) observed points as given
     double* dy = nullptr;     // (Np,) y (padded 0)
@@ -126,8 +126,6 @@ int rff_grad_host(gpx_handle* h, const double* W, const double* b, const double*
                   double bias, const double* Xc, int64_t M, double* f, double* g);
 
 // launchers (kernels_rff.hip)
-void launch_rff_eval(hipStream_t s, const double* W, const double* b, const double* theta, int S, int n,
-                     int d, double bias, const double* Xc, int64_t M, double* vals /* (S,M) */);
 void launch_rff_mfma(hipStream_t s, const double* Wt, const double* bt, const double* tt, int S, int nfb, int d,
                      int dp, double bias, const double* Xc, int64_t M, double* vals);
 int64_t rff_gram_batch_scratch(int64_t S, int64_t Np);

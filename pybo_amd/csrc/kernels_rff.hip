@@ -10,62 +10,6 @@
 
 namespace gpx {
 
-constexpr int RF_T = 256;   // candidates per block
-constexpr int RF_DC = 32;   // coordinates staged per pass
-
-// vals[s][m] = bias + sum_j theta[s][j] * cos(W[s][j][:] . Xc[m][:] + b[s][j])
-// grid (ceil(M/256), S).  x tile lives in LDS coordinate-major (conflict-free per-lane reads);
-// W/b/theta are wave-uniform -> scalar loads.
-__global__ __launch_bounds__(RF_T) void k_rff_eval(const double* __restrict__ W,
-                                                   const double* __restrict__ b,
-                                                   const double* __restrict__ theta, int n, int d,
-                                                   double bias, const double* __restrict__ Xc, int64_t M,
-                                                   double* __restrict__ vals) {
-    extern __shared__ __attribute__((aligned(16))) double xs[];  // [d][RF_T]
-    const int s = blockIdx.y;
-    const int t = threadIdx.x;
-    const int64_t m0 = (int64_t)blockIdx.x * RF_T;
-    for (int e = t; e < RF_T * d; e += RF_T) {
-        const int row = e / d, k = e - row * d;
-        const int64_t gm = m0 + row;
-        xs[k * RF_T + row] = (gm < M) ? Xc[gm * d + k] : 0.0;
-    }
-    __syncthreads();
-    const double* Ws = W + (int64_t)s * n * d;
-    const double* bs = b + (int64_t)s * n;
-    const double* ts = theta + (int64_t)s * n;
-    double f = 0.0;
-    int j = 0;
-    for (; j + 4 <= n; j += 4) {
-        double a0 = bs[j], a1 = bs[j + 1], a2 = bs[j + 2], a3 = bs[j + 3];
-        for (int k = 0; k < d; ++k) {
-            const double xk = xs[k * RF_T + t];
-            a0 = fma(Ws[(j + 0) * d + k], xk, a0);
-            a1 = fma(Ws[(j + 1) * d + k], xk, a1);
-            a2 = fma(Ws[(j + 2) * d + k], xk, a2);
-            a3 = fma(Ws[(j + 3) * d + k], xk, a3);
-        }
-        f = fma(ts[j], cos(a0), f);
-        f = fma(ts[j + 1], cos(a1), f);
-        f = fma(ts[j + 2], cos(a2), f);
-        f = fma(ts[j + 3], cos(a3), f);
-    }
-    for (; j < n; ++j) {
-        double a0 = bs[j];
-        for (int k = 0; k < d; ++k) a0 = fma(Ws[j * d + k], xs[k * RF_T + t], a0);
-        f = fma(ts[j], cos(a0), f);
-    }
-    const int64_t gm = m0 + t;
-    if (gm < M) vals[(int64_t)s * M + gm] = bias + f;
-}
-
-void launch_rff_eval(hipStream_t s, const double* W, const double* b, const double* theta, int S, int n,
-                     int d, double bias, const double* Xc, int64_t M, double* vals) {
-    dim3 grid((unsigned)((M + RF_T - 1) / RF_T), (unsigned)S);
-    const size_t lds = (size_t)d * RF_T * sizeof(double);
-    hipLaunchKernelGGL(k_rff_eval, grid, dim3(RF_T), lds, s, W, b, theta, n, d, bias, Xc, M, vals);
-}
-
 // ------------------------------------------------------------------------------------------------
 // MFMA form of the Thompson sweep.  The projection Z = Xc W^T is a GEMM (M x d) x (d x S*n): on the VALU it
 // is operand-delivery bound (one LDS/scalar read per FMA); the 16x16x4 outer-product structure of
