@@ -87,6 +87,37 @@ def test_against_long_double():
     np.testing.assert_allclose(s2, s2_l, rtol=1e-7, atol=1e-12)
 
 
+def test_against_mpmath_50_digits():
+    """Bounds the fp64 error of the cancellation-prone latent variance s2 = rho - |L^-1 k*|^2 near the data."""
+    mp = pytest.importorskip('mpmath')
+    mp.mp.dps = 50
+    rng = np.random.RandomState(11)
+    N, d = 24, 2
+    X = rng.rand(N, d)
+    y = np.sin(4 * X.sum(1))
+    ell, rho, sn2, bias = np.array([0.35, 0.5]), 1.3, 1e-5, 0.1
+    Z = np.vstack([X[:3] + 1e-3, rng.rand(3, d)])          # three points almost on top of observations
+    gp = gp_ref.make_gp(sn2, rho, ell, bias)
+    gp.add_data(X, y)
+    mu, s2 = gp.predict(Z)
+
+    def k(a, b):
+        r2 = sum(((mp.mpf(float(a[j])) - mp.mpf(float(b[j]))) / mp.mpf(float(ell[j]))) ** 2 for j in range(d))
+        return mp.mpf(rho) * mp.exp(-r2 / 2)
+    K = mp.matrix(N, N)
+    for i in range(N):
+        for j in range(N):
+            K[i, j] = k(X[i], X[j]) + (mp.mpf(sn2) if i == j else 0)
+    Kinv = K ** -1
+    r = mp.matrix([mp.mpf(float(v)) - mp.mpf(bias) for v in y])
+    for m in range(len(Z)):
+        ks = mp.matrix([k(X[i], Z[m]) for i in range(N)])
+        mu_m = mp.mpf(bias) + (ks.T * Kinv * r)[0]
+        s2_m = mp.mpf(rho) - (ks.T * Kinv * ks)[0]
+        assert abs(mu[m] - float(mu_m)) <= 1e-9 * max(1.0, abs(float(mu_m)))
+        assert abs(s2[m] - float(s2_m)) <= 1e-6 * float(s2_m) + 1e-10 * rho
+
+
 def test_ei_pi_known_answers():
     gp = gp_ref.make_gp(1e-2, 1.0, [0.4, 0.4], 0.0)
     X, y, _ = synth_problem(30, 2, seed=4)
