@@ -51,13 +51,13 @@ def gather_topk(vals, idx, k, group=None):
         return merge_topk(vals, idx, k)
     import torch
     world = dist.get_world_size(group)
+    if len(vals) > k:                      # only the k best of a rank can make the global top-k
+        vals, idx = merge_topk(vals, idx, k)
     n = len(vals)
     dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' \
         else torch.device('cpu')
-    # ranks may hold different counts (k > shard size): pad to a common length with index -1
-    nmax = torch.tensor([n], dtype=torch.int64, device=dev)
-    dist.all_reduce(nmax, op=dist.ReduceOp.MAX, group=group)
-    nmax = int(nmax.item())
+    # ranks may hold fewer than k pairs (k > shard size): pad to k with index -1 (no extra collective needed)
+    nmax = int(k)
     pv = np.full(nmax, -np.inf)
     pi = np.full(nmax, -1, dtype=np.int64)
     pv[:n], pi[:n] = vals, idx
