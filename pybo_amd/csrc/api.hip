@@ -72,10 +72,28 @@ static hipEvent_t ev_get(gpx_handle* h) {
     hipEventCreate(&e);
     return e;
 }
+// Recycle finished spans without blocking (callers that never read the timers must not leak events).
+static void harvest_finished(gpx_handle* h) {
+    size_t keep = 0;
+    for (size_t i = 0; i < h->pending.size(); ++i) {
+        EventPair p = h->pending[i];
+        if (hipEventQuery(p.b) == hipSuccess) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) h->tacc[p.slot] += ms;
+            h->pool.push_back(p.a);
+            h->pool.push_back(p.b);
+        } else {
+            h->pending[keep++] = p;
+        }
+    }
+    h->pending.resize(keep);
+}
+
 struct Span {
     gpx_handle* h;
     EventPair p;
     Span(gpx_handle* h_, int slot) : h(h_) {
+        if (h->pending.size() >= 256) harvest_finished(h);
         p.a = ev_get(h);
         p.b = ev_get(h);
         p.slot = slot;

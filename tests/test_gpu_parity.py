@@ -416,3 +416,14 @@ def test_bo_loop_selects_the_same_points_as_the_cpu_path(policy):
     np.testing.assert_allclose(out['dev'].x, out['ref'].x, rtol=0, atol=2e-4)
     np.testing.assert_allclose(out['dev'].y, out['ref'].y, rtol=0, atol=2e-4)
     np.testing.assert_allclose(out['dev'].xbest, out['ref'].xbest, rtol=0, atol=2e-4)
+
+
+def test_timer_events_do_not_accumulate_without_a_reader():
+    """A long loop that never reads gpx_timers must not pile up HIP events (non-blocking recycling)."""
+    e, ref, _ = _pair(64, 2, seed=1)
+    Z = np.random.RandomState(0).rand(50, 2)
+    for _ in range(400):                     # 3 spans per sweep -> 1200 spans
+        e.sweep('mean', None, Z, k=1, want_all=False)
+    tm = e.timers(reset=True)
+    assert tm['sweep_trmm_launches'] == 400 and tm['sweep_trmm'] > 0
+    e.close()
