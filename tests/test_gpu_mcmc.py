@@ -68,3 +68,10 @@ def test_default_model_path_end_to_end():
     assert isinstance(model, models.MCMC) and model.ndata == 6 + 1 + 8
     assert info.x.shape == (9, 2) and info.y.max() > -0.05
     assert np.linalg.norm(np.asarray(xbest) - [0.3, -0.2]) < 0.25
+
+
+def test_animated_demo_headless_on_the_device():
+    from pybo_amd.demos import animated
+    X, Y, xb = animated.run(niter=20, rng=0, verbose=False)
+    assert X.shape == (23, 1) and np.all(X >= 0.5) and np.all(X <= 2.5)
+    assert abs(X[np.argmax(Y)][0] - animated.XOPT) < 3e-2 and Y.max() > 0.8
