@@ -287,7 +287,7 @@ def main():
             traffic = None
             try:
                 pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
-                cols = tm['sweep_trmm_flop'] / max(launches, 1) / (float(Np_) * (Np_ + 128))
+                cols = tm['sweep_trmm_flop'] / max(launches, 1) / (float(N) * N)
                 if pmc['config']['Np'] == Np_ and abs(cols - pmc['config']['cols_per_launch']) < 1:
                     traffic = pmc['k_sweep_trmm']['traffic_bytes_per_launch']
             except Exception:

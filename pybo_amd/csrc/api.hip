@@ -508,9 +508,10 @@ static int sweep_core(gpx_handle* h, int acq_id, const double* params, int npara
                               h->tile_order, h->super_m);
         }
         h->tacc[T_NLAUNCH] += 1.0;
-        // algorithmic work of this launch: sum over row blocks mt of 2*128*128*(mt+1)*128 per
-        // candidate tile = Np*(Np+128) flop per candidate column
-        h->tacc[T_FLOP] += (double)Np * (double)(Np + TBH) * (double)cols;
+        // ALGORITHMIC work of this launch: N^2 flop per candidate (N^2/2 multiply-adds of the
+        // triangular product).  The kernel executes Np*(Np+128) per padded column (identity padding and full
+        // diagonal blocks): 1.6 % more at N = 8192 -- not counted.
+        h->tacc[T_FLOP] += (double)h->N * (double)h->N * (double)valid;
         {
             Span sp(h, T_ACQ);
             launch_acq(s, h->dQp, h->dPp, chunk, nP, m0, valid, h->rho, h->bias, acq_id, p0, d_acq, d_mu,
