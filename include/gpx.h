@@ -144,6 +144,38 @@ int gpx_rff_gram(gpx_handle *h, const double *W, const double *b, int64_t n, dou
 int gpx_rff_gram_batch(gpx_handle *h, const double *W, const double *b, int64_t S, int64_t n, double *A,
                        double *v);
 
+/* ---- hyper-parameter ensemble = pybo's DEFAULT model, reggie.MCMC(gp, n=10)
+ *      [pybo/bayesopt.py:115]: every index is the average over the n member GPs.  `members` are fitted
+ *      handles on ONE device with the same input dimension (members[0] owns the scratch and the error text).
+ *      EI / PI: value = mean_m acq_m(x).  UCB / MEAN: mixture moments mu = mean_m mu_m,
+ *      s2 = mean_m(s2_m + mu_m^2) - mu^2, value = mu + sqrt(params[0] * s2) (UCB) or mu (MEAN); only these
+ *      two can return mu / s2.  The member sweeps never leave the device; sums run in member order and are
+ *      divided once by n.  Outputs as in gpx_sweep / gpx_sweep_dev. */
+int gpx_ensemble_sweep(gpx_handle *const *members, int n_members, int acq_id, const double *params,
+                       int nparams, const double *Xc, int64_t M, int64_t k, double *top_val,
+                       int64_t *top_idx, double *acq_all, double *mu, double *s2);
+int gpx_ensemble_sweep_dev(gpx_handle *const *members, int n_members, int acq_id, const double *params,
+                           int nparams, const double *dXc, int64_t M, int64_t k, double *top_val,
+                           int64_t *top_idx, double *d_acq_all, double *d_mu, double *d_s2);
+
+/* ---- candidate grid generated and kept in HBM = the solver's grid
+ *      xgrid = init_uniform(bounds, ngrid, rng)   [pybo/solvers/lbfgs.py:45; pybo/inits/methods.py:24-38]
+ *      or a Sobol' grid                            [pybo/inits/methods.py:62-77]
+ *      without the host array and its PCIe upload; pass gpx_grid_data() to the *_dev sweeps.
+ * GPX_GRID_UNIFORM: counter-based Philox4x32-10, key = seed, counter = element-pair index; element 2c, 2c+1
+ *      of the row-major (M,d) array = the two 53-bit uniforms of output c; x = lo + u*(hi-lo).
+ * GPX_GRID_SOBOL: unscrambled Sobol' points first .. first+M-1 in Gray-code order (the order of
+ *      scipy.stats.qmc.Sobol), from caller-supplied direction numbers sv (d, bits) uint32, 1 <= bits <= 32.
+ * bounds (d,2) row-major [lo, hi].  Errors of the grid calls are read with gpx_last_error(NULL). */
+typedef struct gpx_grid gpx_grid;
+enum { GPX_GRID_UNIFORM = 0, GPX_GRID_SOBOL = 1 };
+int gpx_grid_create(int device, int kind, const double *bounds, int64_t M, int64_t d, uint64_t seed,
+                    int64_t first, const uint32_t *sv, int bits, gpx_grid **out);
+const double *gpx_grid_data(const gpx_grid *g);     /* device pointer, (M,d) row-major */
+/* rows idx[0..k) -> out (k,d) host; idx == NULL: the whole grid (M,d) */
+int gpx_grid_rows(gpx_grid *g, const int64_t *idx, int64_t k, double *out);
+int gpx_grid_destroy(gpx_grid *g);
+
 /* ---- measurement ------------------------------------------------------------------------ */
 /* Stage timers in milliseconds accumulated since the last reset (HIP events on the handle's
  * stream): [0] gram [1] cholesky [2] trtri [3] alpha [4] cross_gram [5] sweep_trmm [6] acq_topk

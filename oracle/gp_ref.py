@@ -320,3 +320,46 @@ def topk_desc(vals, k):
     v = np.where(np.isnan(vals), -np.inf, vals)
     order = np.lexsort((np.arange(len(v)), -v))
     return order[:k]
+
+
+# ---------------------------------------------------------------------------------------------------
+# candidate grids (checker for gpx_grid_create; include/gpx.h)
+# ---------------------------------------------------------------------------------------------------
+def philox4x32_10(counter, key):
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11),
+    vectorised over `counter` (n, 4) uint32 with one `key` (2,) uint32.  Known-answer vectors of the paper's
+    reference implementation are checked in tests/test_oracle.py."""
+    c = np.array(counter, dtype=np.uint64, ndmin=2).copy()
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = M0 * c[:, 0]
+        p1 = M1 * c[:, 2]
+        n0 = ((p1 >> np.uint64(32)) ^ c[:, 1] ^ k0) & mask
+        n1 = p1 & mask
+        n2 = ((p0 >> np.uint64(32)) ^ c[:, 3] ^ k1) & mask
+        n3 = p0 & mask
+        c = np.stack([n0, n1, n2, n3], axis=1)
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    return c.astype(np.uint32)
+
+
+def grid_uniform(seed, bounds, M):
+    """Host restatement of GPX_GRID_UNIFORM: counter = element-pair index, key = seed; each output gives the
+    two 53-bit uniforms of elements 2c, 2c+1 of the row-major (M, d) array; x = lo + u * (hi - lo)."""
+    b = np.array(bounds, dtype=float, ndmin=2)
+    d = len(b)
+    total = M * d
+    pairs = (total + 1) // 2
+    ctr = np.zeros((pairs, 4), dtype=np.uint64)
+    idx = np.arange(pairs, dtype=np.uint64)
+    ctr[:, 0] = idx & np.uint64(0xFFFFFFFF)
+    ctr[:, 1] = idx >> np.uint64(32)
+    out = philox4x32_10(ctr, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)).astype(np.uint64)
+    u = np.empty(2 * pairs)
+    u[0::2] = ((out[:, 0] << np.uint64(32) | out[:, 1]) >> np.uint64(11)).astype(np.float64) / 9007199254740992.0
+    u[1::2] = ((out[:, 2] << np.uint64(32) | out[:, 3]) >> np.uint64(11)).astype(np.float64) / 9007199254740992.0
+    u = u[:total].reshape(M, d)
+    return b[:, 0] + u * (b[:, 1] - b[:, 0])

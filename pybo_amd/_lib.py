@@ -40,6 +40,12 @@ SYMBOLS = {
     'gpx_rff_grad': (C.c_int, [_P, _P, _P, _P, _i64, _i64, _dbl, _P, _i64, _P, _P]),
     'gpx_rff_gram': (C.c_int, [_P, _P, _P, _i64, _P, _P]),
     'gpx_rff_gram_batch': (C.c_int, [_P, _P, _P, _i64, _i64, _P, _P]),
+    'gpx_ensemble_sweep': (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _P, _i64, _i64, _P, _P, _P, _P, _P]),
+    'gpx_ensemble_sweep_dev': (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _P, _i64, _i64, _P, _P, _P, _P, _P]),
+    'gpx_grid_create': (C.c_int, [C.c_int, C.c_int, _P, _i64, _i64, C.c_uint64, _i64, _P, C.c_int, C.POINTER(_P)]),
+    'gpx_grid_data': (_P, [_P]),
+    'gpx_grid_rows': (C.c_int, [_P, _P, _i64, _P]),
+    'gpx_grid_destroy': (C.c_int, [_P]),
     'gpx_timers': (C.c_int, [_P, _P, C.c_int, C.c_int]),
     'gpx_sync': (C.c_int, [_P]),
 }
@@ -85,6 +91,102 @@ def _f64(a, shape=None):
     if shape is not None:
         a = a.reshape(shape)
     return a
+
+
+def sobol_direction_numbers(d, nbits):
+    """Direction numbers (d, bits) uint32 of scipy's unscrambled Sobol' generator (Joe-Kuo), LSB-first in the
+    Gray-code recurrence: point i = XOR_b [bit b of i^(i>>1)] * sv[:, b], x = point * 2^-bits.  Read from the
+    generator object when it exposes them, otherwise derived through the public API (the point with Gray
+    code 2^b is number 2^(b+1) - 1); checked against the generator's first points either way."""
+    from scipy.stats import qmc
+    eng = qmc.Sobol(d, scramble=False)
+    bits = int(getattr(eng, 'bits', 30) or 30)
+    sv = getattr(eng, '_sv', None)
+    if sv is not None and np.shape(sv) == (d, bits):
+        sv = np.ascontiguousarray(sv, dtype=np.uint32)
+    else:
+        sv = np.zeros((d, bits), dtype=np.uint32)
+        pos = 0
+        for b in range(min(bits, max(int(nbits), 4))):
+            target = 2 ** (b + 1) - 1
+            if target > pos:
+                eng.fast_forward(target - pos)
+            sv[:, b] = np.round(eng.random(1)[0] * 2.0 ** bits).astype(np.uint32)
+            pos = target + 1
+    ref = qmc.Sobol(d, scramble=False).random(16)
+    acc = np.zeros(d, dtype=np.uint32)
+    for i in range(16):
+        g = i ^ (i >> 1)
+        acc[:] = 0
+        for b in range(5):
+            if (g >> b) & 1:
+                acc ^= sv[:, b]
+        if not np.array_equal(acc * 2.0 ** -bits, ref[i]):
+            raise RuntimeError('scipy Sobol generator does not follow the expected Gray-code recurrence')
+    return sv, bits
+
+
+class DeviceGrid(object):
+    """A candidate grid generated and kept in HBM (gpx_grid_*): `kind` 'sobol' (points first..first+n-1 of
+    scipy's unscrambled sequence, scaled to the box) or 'uniform' (Philox4x32-10 keyed by `seed`).  Behaves
+    like a read-only (n, d) array for the solver: len(), .shape, grid[idx] (rows copied to the host),
+    np.asarray(grid) (the whole grid -- avoid on the hot path)."""
+
+    def __init__(self, kind, bounds, n, seed=0, first=0, device=0):
+        self._lib = load()
+        bounds = _f64(np.array(bounds, dtype=float, ndmin=2))
+        n = int(n)
+        d = len(bounds)
+        g = _P()
+        if kind == 'sobol':
+            sv, bits = sobol_direction_numbers(d, int(first + n).bit_length())
+            rc = self._lib.gpx_grid_create(int(device), 1, _ptr(bounds), n, d, 0, int(first),
+                                           sv.ctypes.data_as(_P), bits, C.byref(g))
+        elif kind == 'uniform':
+            rc = self._lib.gpx_grid_create(int(device), 0, _ptr(bounds), n, d, int(seed), 0, None, 0, C.byref(g))
+        else:
+            raise ValueError("grid kind must be 'sobol' or 'uniform'")
+        if rc != GPX_OK:
+            raise GpxError(rc, (self._lib.gpx_last_error(None) or b'').decode())
+        self._g = g
+        self.kind, self.bounds, self.device = kind, bounds, int(device)
+        self.shape = (n, d)
+        self.ptr = self._lib.gpx_grid_data(g)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def rows(self, idx):
+        idx = np.ascontiguousarray(np.atleast_1d(idx), dtype=np.int64)
+        out = np.empty((len(idx), self.shape[1]))
+        rc = self._lib.gpx_grid_rows(self._g, _ptr(idx), len(idx), _ptr(out))
+        if rc != GPX_OK:
+            raise GpxError(rc, (self._lib.gpx_last_error(None) or b'').decode())
+        return out
+
+    def __getitem__(self, idx):
+        if np.isscalar(idx):
+            return self.rows([idx])[0]
+        return self.rows(idx)
+
+    def __array__(self, dtype=None, copy=None):
+        out = np.empty(self.shape)
+        rc = self._lib.gpx_grid_rows(self._g, None, 0, _ptr(out))
+        if rc != GPX_OK:
+            raise GpxError(rc, (self._lib.gpx_last_error(None) or b'').decode())
+        return out if dtype is None else out.astype(dtype)
+
+    def close(self):
+        if getattr(self, '_g', None):
+            self._lib.gpx_grid_destroy(self._g)
+            self._g = None
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Engine(object):
@@ -227,6 +329,32 @@ class Engine(object):
                                             _P(d_acq) if d_acq else None, _P(d_mu) if d_mu else None,
                                             _P(d_s2) if d_s2 else None))
         return tv, ti
+
+    @staticmethod
+    def ensemble_sweep(engines, acq, param, Xc, k=0, want_all=True, want_moments=False):
+        """Hyper-parameter ensemble sweep (gpx_ensemble_sweep[_dev]): the member sweeps and their average stay
+        on the device.  `Xc`: host array (M, d) or a DeviceGrid.  Returns dict(top_val, top_idx, acq, mu, s2)."""
+        lead = engines[0]
+        handles = (_P * len(engines))(*[e._h for e in engines])
+        aid = ACQ[acq] if isinstance(acq, str) else int(acq)
+        params = _f64([0.0 if param is None else param])
+        tv = np.empty(k)
+        ti = np.empty(k, dtype=np.int64)
+        if isinstance(Xc, DeviceGrid):
+            M = len(Xc)
+            lead._check(lead._lib.gpx_ensemble_sweep_dev(handles, len(engines), aid, _ptr(params), 1, Xc.ptr, M,
+                                                         k, _ptr(tv) if k else None, _ptr(ti) if k else None,
+                                                         None, None, None))
+            return dict(top_val=tv, top_idx=ti, acq=None, mu=None, s2=None)
+        Xc = _f64(Xc).reshape(-1, lead.d)
+        M = len(Xc)
+        out = np.empty(M) if want_all else None
+        mu = np.empty(M) if want_moments else None
+        s2 = np.empty(M) if want_moments else None
+        lead._check(lead._lib.gpx_ensemble_sweep(handles, len(engines), aid, _ptr(params), 1, _ptr(Xc), M, k,
+                                                 _ptr(tv) if k else None, _ptr(ti) if k else None, _ptr(out),
+                                                 _ptr(mu), _ptr(s2)))
+        return dict(top_val=tv, top_idx=ti, acq=out, mu=mu, s2=s2)
 
     # -- Thompson --------------------------------------------------------------------------------
     def rff_gram(self, W, b):

@@ -190,7 +190,7 @@ extern "C" int gpx_destroy(gpx_handle* h) {
     for (auto e : h->pool) hipEventDestroy(e);
     void* ptrs[] = {h->dXs, h->dXraw, h->dy, h->dS, h->dR, h->dT, h->dU, h->da, h->dalpha, h->dinvell,
                     h->dflag, h->dscal, h->dKs, h->dQp, h->dXc, h->dout, h->dblkv, h->dblki,
-                    h->dtopv, h->drff, h->drffs, h->dgrad};  // dPp, dtopi alias dQp, dtopv
+                    h->dtopv, h->drff, h->drffs, h->dgrad, h->dens};  // dPp, dtopi alias dQp, dtopv
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
@@ -470,6 +470,26 @@ extern "C" int gpx_mean_at_obs(gpx_handle* h, double* mu_host, double* mu_max) {
 }
 
 // ---- sweep ------------------------------------------------------------------------------------
+// top-k of a device vector (value descending, index ascending, NaN last) -> host buffers; synchronises.
+static int topk_core(gpx_handle* h, const double* d_vals, int64_t M, int64_t k, double* top_val,
+                     int64_t* top_idx) {
+    int rc;
+    hipStream_t s = h->stream;
+    const int64_t nblk = topk_blocks(M);
+    if ((rc = ensure(h, h->dblkv, h->cap_blk, nblk * k))) return rc;
+    if ((rc = ensure(h, h->dblki, h->cap_blki, nblk * k))) return rc;
+    if ((rc = ensure(h, h->dtopv, h->cap_top, (int64_t)TOPK_MAX * 2))) return rc;
+    h->dtopi = reinterpret_cast<int64_t*>(h->dtopv + TOPK_MAX);
+    {
+        Span sp(h, T_ACQ);
+        launch_topk(s, d_vals, M, (int)k, h->dblkv, h->dblki, nblk, h->dtopv, h->dtopi);
+    }
+    HIPCHK(h, hipMemcpyAsync(top_val, h->dtopv, (size_t)k * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(top_idx, h->dtopi, (size_t)k * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    return GPX_OK;
+}
+
 static int sweep_core(gpx_handle* h, int acq_id, const double* params, int nparams, const double* dXc,
                       int64_t M, int64_t k, double* top_val, int64_t* top_idx, double* d_acq,
                       double* d_mu, double* d_s2) {
@@ -518,25 +538,7 @@ static int sweep_core(gpx_handle* h, int acq_id, const double* params, int npara
                        d_s2);
         }
     }
-    if (k > 0) {
-        const int64_t nblk = topk_blocks(M);
-        if ((rc = ensure(h, h->dblkv, h->cap_blk, nblk * k))) return rc;
-        if (!h->dblki || h->cap_blki < nblk * k) {
-            if (h->dblki) HIPCHK(h, hipFree(h->dblki));
-            h->dblki = nullptr;
-            HIPCHK(h, hipMalloc((void**)&h->dblki, (size_t)nblk * k * 8));
-            h->cap_blki = nblk * k;
-        }
-        if ((rc = ensure(h, h->dtopv, h->cap_top, (int64_t)TOPK_MAX * 2))) return rc;
-        h->dtopi = reinterpret_cast<int64_t*>(h->dtopv + TOPK_MAX);
-        {
-            Span sp(h, T_ACQ);
-            launch_topk(s, d_acq, M, (int)k, h->dblkv, h->dblki, nblk, h->dtopv, h->dtopi);
-        }
-        HIPCHK(h, hipMemcpyAsync(top_val, h->dtopv, (size_t)k * 8, hipMemcpyDeviceToHost, s));
-        HIPCHK(h, hipMemcpyAsync(top_idx, h->dtopi, (size_t)k * 8, hipMemcpyDeviceToHost, s));
-        HIPCHK(h, hipStreamSynchronize(s));
-    }
+    if (k > 0 && (rc = topk_core(h, d_acq, M, k, top_val, top_idx))) return rc;
     HIPCHK(h, hipGetLastError());
     return GPX_OK;
 }
@@ -772,4 +774,209 @@ extern "C" int gpx_rff_gram(gpx_handle* h, const double* W, const double* b, int
     return guarded(h, [&]() -> int {
         return gpx_rff_gram_batch(h, W, b, 1, n, A, v);
     });
+}
+
+// ---- ensemble sweep (hyper-parameter marginalisation; pybo/bayesopt.py:115) ------------------------------
+static int ensemble_core(gpx_handle* const* mem, int n, int acq_id, const double* params, int nparams,
+                         const double* dXc, int64_t M, int64_t k, double* top_val, int64_t* top_idx,
+                         double* d_out, double* d_mu, double* d_s2) {
+    gpx_handle* L = mem[0];
+    if (acq_id < GPX_ACQ_EI || acq_id > GPX_ACQ_MEAN) return fail(L, GPX_EARG, "ensemble_sweep: unknown acquisition id");
+    if (acq_id != GPX_ACQ_MEAN && (nparams < 1 || !params)) return fail(L, GPX_EARG, "ensemble_sweep: missing acquisition parameter");
+    if (!dXc || M < 1) return fail(L, GPX_EARG, "ensemble_sweep: need M >= 1 candidates");
+    if (k < 0 || k > TOPK_MAX) return fail(L, GPX_EARG, "ensemble_sweep: k must be in [0, 64]");
+    if (k > 0 && (!top_val || !top_idx)) return fail(L, GPX_EARG, "ensemble_sweep: NULL top-k output");
+    for (int m = 0; m < n; ++m) {
+        if (!mem[m]->fitted) return fail(L, GPX_ESTATE, "ensemble_sweep: a member model is not fitted");
+        if (mem[m]->device != L->device || mem[m]->d != L->d)
+            return fail(L, GPX_EARG, "ensemble_sweep: members must share the device and the input dimension");
+    }
+    HIPCHK(L, hipSetDevice(L->device));
+    // mixture moments for UCB / mean (mu = mean mu_m, s2 = mean(s2_m + mu_m^2) - mu^2), plain mean for EI / PI
+    const int mode = (acq_id == GPX_ACQ_UCB || acq_id == GPX_ACQ_MEAN) ? 1 : 0;
+    int rc;
+    if ((rc = ensure(L, L->dens, L->cap_ens, 5 * M))) return rc;
+    double* acc0 = L->dens;
+    double* acc1 = acc0 + M;
+    double* t0 = acc1 + M;
+    double* t1 = t0 + M;
+    double* out = d_out ? d_out : t1 + M;
+    for (int m = 0; m < n; ++m) {
+        gpx_handle* h = mem[m];
+        rc = (mode == 0) ? sweep_core(h, acq_id, params, nparams, dXc, M, 0, nullptr, nullptr, t0, nullptr, nullptr)
+                         : sweep_core(h, GPX_ACQ_MEAN, nullptr, 0, dXc, M, 0, nullptr, nullptr, nullptr, t0, t1);
+        if (rc) {
+            if (h != L) L->err = "ensemble member " + std::to_string(m) + ": " + h->err;
+            return rc;
+        }
+        HIPCHK(L, hipStreamSynchronize(h->stream));
+        launch_ens_accum(L->stream, acc0, acc1, t0, t1, M, mode, m == 0);
+        HIPCHK(L, hipStreamSynchronize(L->stream));    // t0/t1 are reused by the next member
+    }
+    const double beta = (acq_id == GPX_ACQ_UCB) ? params[0] : 0.0;
+    if (acq_id == GPX_ACQ_MEAN)     // value = mixture mean
+        launch_ens_finish(L->stream, acc0, acc1, M, 1, (double)n, 0.0, out, d_mu, d_s2);
+    else
+        launch_ens_finish(L->stream, acc0, acc1, M, mode, (double)n, beta, out, d_mu, d_s2);
+    if (k > 0) {
+        if ((rc = topk_core(L, out, M, k, top_val, top_idx))) return rc;
+    } else {
+        HIPCHK(L, hipStreamSynchronize(L->stream));
+    }
+    HIPCHK(L, hipGetLastError());
+    return GPX_OK;
+}
+
+static int ensemble_check(gpx_handle* const* members, int n) {
+    if (!members || n < 1 || !members[0]) return GPX_EARG;
+    for (int m = 1; m < n; ++m)
+        if (!members[m]) {
+            members[0]->err = "ensemble_sweep: NULL member handle";
+            return GPX_EARG;
+        }
+    return GPX_OK;
+}
+
+extern "C" int gpx_ensemble_sweep_dev(gpx_handle* const* members, int n_members, int acq_id, const double* params,
+                                      int nparams, const double* dXc, int64_t M, int64_t k, double* top_val,
+                                      int64_t* top_idx, double* d_acq_all, double* d_mu, double* d_s2) {
+    if (ensemble_check(members, n_members)) return GPX_EARG;
+    return guarded(members[0], [&]() -> int {
+        return ensemble_core(members, n_members, acq_id, params, nparams, dXc, M, k, top_val, top_idx, d_acq_all,
+                             d_mu, d_s2);
+    });
+}
+
+extern "C" int gpx_ensemble_sweep(gpx_handle* const* members, int n_members, int acq_id, const double* params,
+                                  int nparams, const double* Xc, int64_t M, int64_t k, double* top_val,
+                                  int64_t* top_idx, double* acq_all, double* mu, double* s2) {
+    if (ensemble_check(members, n_members)) return GPX_EARG;
+    gpx_handle* h = members[0];
+    return guarded(h, [&]() -> int {
+        if (!Xc || M < 1) return fail(h, GPX_EARG, "ensemble_sweep: need M >= 1 candidates");
+        if ((mu || s2) && acq_id != GPX_ACQ_UCB && acq_id != GPX_ACQ_MEAN)
+            return fail(h, GPX_EARG, "ensemble_sweep: mixture moments are only formed for UCB / mean");
+        HIPCHK(h, hipSetDevice(h->device));
+        int rc;
+        const int64_t d = h->d;
+        if ((rc = ensure(h, h->dXc, h->cap_xc, M * d + 3 * M))) return rc;
+        double* dX = h->dXc;
+        double* dacq = dX + M * d;
+        double* dmu = dacq + M;
+        double* ds2 = dmu + M;
+        {
+            Span sp(h, T_COPY);
+            HIPCHK(h, hipMemcpyAsync(dX, Xc, (size_t)M * d * 8, hipMemcpyHostToDevice, h->stream));
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));     // the members read dX from their own streams
+        rc = ensemble_core(members, n_members, acq_id, params, nparams, dX, M, k, top_val, top_idx, dacq,
+                           mu ? dmu : nullptr, s2 ? ds2 : nullptr);
+        if (rc) return rc;
+        {
+            Span sp(h, T_COPY);
+            if (acq_all) HIPCHK(h, hipMemcpyAsync(acq_all, dacq, (size_t)M * 8, hipMemcpyDeviceToHost, h->stream));
+            if (mu) HIPCHK(h, hipMemcpyAsync(mu, dmu, (size_t)M * 8, hipMemcpyDeviceToHost, h->stream));
+            if (s2) HIPCHK(h, hipMemcpyAsync(s2, ds2, (size_t)M * 8, hipMemcpyDeviceToHost, h->stream));
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return GPX_OK;
+    });
+}
+
+// ---- candidate grids resident in HBM (pybo/solvers/lbfgs.py:45; pybo/inits/methods.py) -------------------
+struct gpx_grid {
+    int device = 0;
+    int64_t M = 0, d = 0;
+    double* dX = nullptr;
+};
+
+#define GRIDCHK(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            g_create_err = std::string(#call) + " failed: " + hipGetErrorString(e_);               \
+            return (e_ == hipErrorOutOfMemory) ? GPX_EOOM : GPX_EHIP;                              \
+        }                                                                                          \
+    } while (0)
+
+static int grid_create_impl(int device, int kind, const double* bounds, int64_t M, int64_t d, uint64_t seed,
+                            int64_t first, const uint32_t* sv, int bits, gpx_grid** out) {
+    if (!out) return GPX_EARG;
+    *out = nullptr;
+    if (!bounds || M < 1 || d < 1 || d > DMAX) { g_create_err = "grid_create: bad sizes or NULL bounds"; return GPX_EARG; }
+    if (kind != GPX_GRID_UNIFORM && kind != GPX_GRID_SOBOL) { g_create_err = "grid_create: unknown grid kind"; return GPX_EARG; }
+    if (kind == GPX_GRID_SOBOL && (!sv || bits < 1 || bits > 32 || first < 0 ||
+                                   (bits < 63 && (uint64_t)(first + M) > (1ull << bits)))) {
+        g_create_err = "grid_create: Sobol needs direction numbers (d, bits), 1 <= bits <= 32, first + M <= 2^bits";
+        return GPX_EARG;
+    }
+    GRIDCHK(hipSetDevice(device));
+    gpx_grid* g = new gpx_grid();
+    g->device = device; g->M = M; g->d = d;
+    double* dB = nullptr;
+    uint32_t* dsv = nullptr;
+    auto cleanup = [&]() { if (dB) hipFree(dB); if (dsv) hipFree(dsv); };
+    auto bail = [&](int rc) { cleanup(); if (g->dX) hipFree(g->dX); delete g; return rc; };
+#define GRIDTRY(call)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            g_create_err = std::string(#call) + " failed: " + hipGetErrorString(e_);               \
+            return bail((e_ == hipErrorOutOfMemory) ? GPX_EOOM : GPX_EHIP);                        \
+        }                                                                                          \
+    } while (0)
+    GRIDTRY(hipMalloc((void**)&g->dX, (size_t)M * d * 8));
+    GRIDTRY(hipMalloc((void**)&dB, (size_t)d * 2 * 8));
+    GRIDTRY(hipMemcpy(dB, bounds, (size_t)d * 2 * 8, hipMemcpyHostToDevice));
+    if (kind == GPX_GRID_SOBOL) {
+        GRIDTRY(hipMalloc((void**)&dsv, (size_t)d * bits * 4));
+        GRIDTRY(hipMemcpy(dsv, sv, (size_t)d * bits * 4, hipMemcpyHostToDevice));
+        launch_grid_sobol(nullptr, dsv, bits, first, M, (int)d, dB, g->dX);
+    } else {
+        launch_grid_uniform(nullptr, seed, M, (int)d, dB, g->dX);
+    }
+    GRIDTRY(hipGetLastError());
+    GRIDTRY(hipDeviceSynchronize());
+    cleanup();
+    *out = g;
+    return GPX_OK;
+}
+
+extern "C" int gpx_grid_create(int device, int kind, const double* bounds, int64_t M, int64_t d, uint64_t seed,
+                               int64_t first, const uint32_t* sv, int bits, gpx_grid** out) {
+    try {
+        return grid_create_impl(device, kind, bounds, M, d, seed, first, sv, bits, out);
+    } catch (...) {
+        if (out) *out = nullptr;
+        return GPX_EOOM;
+    }
+}
+
+extern "C" const double* gpx_grid_data(const gpx_grid* g) { return g ? g->dX : nullptr; }
+
+extern "C" int gpx_grid_rows(gpx_grid* g, const int64_t* idx, int64_t k, double* out) {
+    try {
+        if (!g || !out) { g_create_err = "grid_rows: NULL pointer"; return GPX_EARG; }
+        GRIDCHK(hipSetDevice(g->device));
+        if (!idx) {                                   // the whole grid
+            GRIDCHK(hipMemcpy(out, g->dX, (size_t)g->M * g->d * 8, hipMemcpyDeviceToHost));
+            return GPX_OK;
+        }
+        if (k < 1) return GPX_OK;
+        for (int64_t i = 0; i < k; ++i)
+            if (idx[i] < 0 || idx[i] >= g->M) { g_create_err = "grid_rows: index out of range"; return GPX_EARG; }
+        for (int64_t i = 0; i < k; ++i)
+            GRIDCHK(hipMemcpy(out + i * g->d, g->dX + idx[i] * g->d, (size_t)g->d * 8, hipMemcpyDeviceToHost));
+        return GPX_OK;
+    } catch (...) {
+        return GPX_EOOM;
+    }
+}
+
+extern "C" int gpx_grid_destroy(gpx_grid* g) {
+    if (!g) return GPX_OK;
+    hipSetDevice(g->device);
+    if (g->dX) hipFree(g->dX);
+    delete g;
+    return GPX_OK;
 }

@@ -81,6 +81,8 @@ struct gpx_handle {
     int64_t cap_rffs = 0;
     double* dgrad = nullptr;  // predict-with-gradient scratch
     int64_t cap_grad = 0;
+    double* dens = nullptr;   // ensemble sweep: accumulators + member outputs (5 M)
+    int64_t cap_ens = 0;
 
     // timers
     std::vector<gpx::EventPair> pending;
@@ -135,5 +137,14 @@ void launch_rff_gram_batch(hipStream_t s, const double* Xraw, int64_t N, int64_t
 void launch_rff_gram(hipStream_t s, const double* Xraw, const double* Ft_scratch, int64_t N, int d,
                      const double* W, const double* b, int n, const double* y, double bias, double* A,
                      double* v);
+
+// launchers (kernels_ens.hip)
+void launch_ens_accum(hipStream_t s, double* acc0, double* acc1, const double* t0, const double* t1, int64_t M,
+                      int mode, int first);
+void launch_ens_finish(hipStream_t s, const double* acc0, const double* acc1, int64_t M, int mode, double n,
+                       double beta, double* out, double* mu_out, double* s2_out);
+void launch_grid_sobol(hipStream_t s, const uint32_t* sv, int bits, int64_t first, int64_t M, int d,
+                       const double* bounds, double* X);
+void launch_grid_uniform(hipStream_t s, uint64_t seed, int64_t M, int d, const double* bounds, double* X);
 
 }  // namespace gpx

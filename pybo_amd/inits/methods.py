@@ -12,7 +12,8 @@ import numpy as np
 
 from ..utils import rstate
 
-__all__ = ['init_middle', 'init_uniform', 'init_latin', 'init_sobol']
+__all__ = ['init_middle', 'init_uniform', 'init_latin', 'init_sobol', 'init_sobol_device',
+           'init_uniform_device']
 
 
 def _box(bounds):
@@ -55,3 +56,26 @@ def init_sobol(bounds, n=None, rng=None):
     if skip:
         eng.fast_forward(skip)
     return lo + width * eng.random(n)
+
+
+# ---- grids generated and kept in HBM -------------------------------------------------
+def init_sobol_device(bounds, n=None, rng=None, device=0):
+    """The points of `init_sobol(bounds, n, rng)` -- same `skip` draw, bit-identical coordinates -- generated
+    on the GPU and left there: returns a `DeviceGrid` for `solve_lbfgs(..., xgrid=...)`."""
+    from .._lib import DeviceGrid
+    rng = rstate(rng)
+    d = len(np.array(bounds, dtype=float, ndmin=2))
+    n = 3 * d if n is None else n
+    skip = rng.randint(100, 200)
+    return DeviceGrid('sobol', bounds, n, first=skip, device=device)
+
+
+def init_uniform_device(bounds, n=None, rng=None, device=0):
+    """n i.i.d. uniform points generated on the GPU (Philox4x32-10 keyed by one 62-bit draw from `rng`) -- the
+    device counterpart of `init_uniform`; a different stream of numbers than numpy's MT19937."""
+    from .._lib import DeviceGrid
+    rng = rstate(rng)
+    d = len(np.array(bounds, dtype=float, ndmin=2))
+    n = 3 * d if n is None else n
+    seed = (int(rng.randint(0, 2 ** 31 - 1)) << 31) | int(rng.randint(0, 2 ** 31 - 1))
+    return DeviceGrid('uniform', bounds, n, seed=seed, device=device)

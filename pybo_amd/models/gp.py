@@ -19,6 +19,7 @@ import numpy as np
 from scipy.special import erfc
 
 from .. import _lib
+from .._lib import DeviceGrid
 from ..utils import rstate
 
 __all__ = ['GP', 'make_gp']
@@ -80,8 +81,13 @@ class RFFSampleDevice(object):
         return out['vals'][0]
 
     def topk(self, xgrid, k):
-        out = self._model._engine().rff_sweep(self.W[None], self.b[None], self.theta[None],
-                                              self._model.bias, xgrid, k=int(k), want_all=False)
+        eng = self._model._engine()
+        if isinstance(xgrid, DeviceGrid):            # grid already resident in HBM
+            tv, ti = eng.rff_sweep_dev(self.W[None], self.b[None], self.theta[None], self._model.bias,
+                                       xgrid.ptr, len(xgrid), int(k))
+            return tv[0], ti[0]
+        out = eng.rff_sweep(self.W[None], self.b[None], self.theta[None], self._model.bias, xgrid, k=int(k),
+                            want_all=False)
         return out['top_val'][0], out['top_idx'][0]
 
     __call__ = get
@@ -256,7 +262,10 @@ class GP(object):
         return self._acq('pi', target, X, grad)
 
     def acq_topk(self, kind, param, xgrid, k):
-        """Whole-grid acquisition + top-k on the device: (values (k,), grid indices (k,))."""
+        """Whole-grid acquisition + top-k on the device: (values (k,), grid indices (k,)).  `xgrid` is a
+        host array (uploaded) or a `DeviceGrid` (already in HBM)."""
+        if isinstance(xgrid, DeviceGrid):
+            return self._engine().sweep_dev(kind, param, xgrid.ptr, len(xgrid), int(k))
         xgrid = np.array(xgrid, ndmin=2, dtype=float)
         out = self._engine().sweep(kind, param, xgrid, k=int(k), want_all=False)
         return out['top_val'], out['top_idx']

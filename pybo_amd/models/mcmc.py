@@ -155,11 +155,17 @@ class MCMC(object):
         return self._members
 
     def predict(self, X, grad=False):
+        engines = None if grad else self._engines()
+        if engines is not None:                      # mixture moments formed on the device
+            from .._lib import Engine
+            out = Engine.ensemble_sweep(engines, 'mean', None, np.array(X, ndmin=2, dtype=float), k=0,
+                                        want_all=False, want_moments=True)
+            return out['mu'], out['s2']
         posts = [m.predict(X, grad) for m in self._need()]
         mus = np.array([p[0] for p in posts])
         s2s = np.array([p[1] for p in posts])
         mu = mus.mean(axis=0)
-        s2 = (s2s + mus ** 2).mean(axis=0) - mu ** 2
+        s2 = np.maximum((s2s + mus ** 2).mean(axis=0) - mu ** 2, 0.0)
         if not grad:
             return mu, s2
         dmus = np.array([p[2] for p in posts])
@@ -169,6 +175,11 @@ class MCMC(object):
         return mu, s2, dmu, ds2
 
     def _mean_of(self, name, target, X, grad):
+        engines = None if grad else self._engines()
+        if engines is not None:
+            from .._lib import Engine
+            kind = {'get_improvement': 'ei', 'get_tail': 'pi'}[name]
+            return Engine.ensemble_sweep(engines, kind, target, np.array(X, ndmin=2, dtype=float), k=0)['acq']
         outs = [getattr(m, name)(target, X, grad) for m in self._need()]
         if not grad:
             return np.mean(outs, axis=0)
@@ -185,19 +196,22 @@ class MCMC(object):
         members = self._need()
         return members[rng.randint(len(members))].sample_f(n, rng)
 
-    def _acq_topk(self, kind, param, xgrid, k):
-        """Ensemble acquisition over a grid + top-k.  Each member sweeps the grid on the device; the n value
-        arrays are combined on the host (mean for EI/PI/mean, mixture moments for UCB)."""
+    def _engines(self):
+        """The members' device engines when every member is a device GP (pybo_amd.models.GP), else None."""
         members = self._need()
-        xgrid = np.array(xgrid, ndmin=2, dtype=float)
-        if kind == 'ucb':
-            mu, s2 = self.predict(xgrid)
-            vals = mu + np.sqrt(param * s2)
-        else:
-            vals = np.mean([m.acq_values(kind, param, xgrid) for m in members], axis=0)
-        v = np.where(np.isnan(vals), -np.inf, vals)
-        order = np.lexsort((np.arange(len(v)), -v))[:int(k)]
-        return vals[order], order
+        if not all(hasattr(m, '_engine') for m in members):
+            return None
+        return [m._engine() for m in members]
+
+    def _acq_topk(self, kind, param, xgrid, k):
+        """Ensemble acquisition over a grid + top-k in one device call (gpx_ensemble_sweep): every member
+        sweeps the grid, the n value vectors are averaged in HBM (mean for EI/PI/mean, mixture moments for
+        UCB) and only the k winners come back.  `xgrid`: host array or `DeviceGrid`."""
+        from .._lib import Engine, DeviceGrid
+        if not isinstance(xgrid, DeviceGrid):
+            xgrid = np.array(xgrid, ndmin=2, dtype=float)
+        out = Engine.ensemble_sweep(self._engines(), kind, param, xgrid, k=int(k), want_all=False)
+        return out['top_val'], out['top_idx']
 
     # -- pickling: hyper-parameter states + data, members are rebuilt on load -------------------------
     def __getstate__(self):

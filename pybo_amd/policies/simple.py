@@ -55,7 +55,16 @@ def PI(model, _, X, xi=0.05):
 
 def Thompson(model, _, __, n=100, rng=None):
     """Thompson sampling: the index is one posterior function sample built from n random features."""
-    return model.sample_f(n, rng).get
+    sample = model.sample_f(n, rng)
+    fast = getattr(sample, 'topk', None)
+    if fast is None:
+        return sample.get
+
+    def index(X, grad=False):
+        return sample.get(X, grad)
+
+    index.topk = fast                     # device sample: grid evaluation + top-k stay on the GPU
+    return index
 
 
 def UCB(model, _, X, delta=0.1, xi=0.2):

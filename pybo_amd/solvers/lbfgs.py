@@ -12,7 +12,9 @@ Kept from the reference:
     not compute them; `select='best'` refines all `nbest` seeds and returns the best refined value.
 Changed:
   * if the index carries `.topk(xgrid, k)` (device-backed models) the grid evaluation and the top-k run
-    on the GPU and only k (value, index) pairs come back; otherwise `f(xgrid)` is ranked on the host
+    on the GPU and only k (value, index) pairs come back; `xgrid` may then also be a
+    `pybo_amd.inits.DeviceGrid` (generated and kept in HBM: `init_sobol_device`, `init_uniform_device`), of
+    which only the k seed rows are ever copied to the host; otherwise `f(xgrid)` is ranked on the host
     with a deterministic order (value descending, then index ascending -- the reference's
     `argsort(finit)[::-1]` leaves ties unspecified, SURVEY F14).
 """
@@ -20,6 +22,7 @@ import numpy as np
 import scipy.optimize
 
 from ..inits import init_uniform
+from .._lib import DeviceGrid
 
 __all__ = ['solve_lbfgs']
 
@@ -33,12 +36,15 @@ def _rank_host(finit, k):
 def solve_lbfgs(f, bounds, nbest=10, ngrid=10000, xgrid=None, rng=None, select='first'):
     """Maximise f over the box; returns (xmax, fmax)."""
     bounds = np.array(bounds, dtype=float, ndmin=2)
+    topk = getattr(f, 'topk', None)
     if xgrid is None:
         xgrid = init_uniform(bounds, ngrid, rng)
+    elif isinstance(xgrid, DeviceGrid):
+        if topk is None:                      # host-side index: it needs the coordinates
+            xgrid = np.asarray(xgrid)
     else:
         xgrid = np.array(xgrid, ndmin=2, dtype=float)
 
-    topk = getattr(f, 'topk', None)
     k = min(int(nbest), len(xgrid))
     if topk is not None:
         _, best = topk(xgrid, k)

@@ -1,0 +1,184 @@
+"""the hyper-parameter ENSEMBLE sweep (pybo's default model is an MCMC ensemble of GPs,
+reference bayesopt.py:115) and candidate grids generated in HBM, through the C-ABI, against the oracle."""
+import numpy as np
+import pytest
+
+from oracle import gp_ref
+from helpers import synth_problem
+
+pytestmark = pytest.mark.gpu
+
+HYPERS = [(1e-3, 1.0, 0.30, 0.0), (5e-3, 1.6, 0.45, 0.2), (2e-4, 0.7, 0.22, -0.1), (1e-2, 1.2, 0.60, 0.05)]
+
+
+def _members(N, d, kernel, seed):
+    from pybo_amd import models
+    X, y, _ = synth_problem(N, d, seed=seed)
+    dev, ref = [], []
+    for sn2, rho, ell, bias in HYPERS:
+        g = models.make_gp(sn2, rho, [ell] * d, bias, kernel=kernel)
+        r = gp_ref.make_gp(sn2, rho, [ell] * d, bias, kernel)
+        g.add_data(X, y); r.add_data(X, y)
+        dev.append(g); ref.append(r)
+    return dev, ref
+
+
+def _ref_ensemble(ref, kind, param, Xc):
+    mus = np.array([r.predict(Xc)[0] for r in ref])
+    s2s = np.array([r.predict(Xc)[1] for r in ref])
+    mu = mus.mean(0)
+    s2 = np.maximum((s2s + mus ** 2).mean(0) - mu ** 2, 0.0)
+    if kind == 'ei':
+        return np.mean([r.get_improvement(param, Xc) for r in ref], axis=0), mu, s2
+    if kind == 'pi':
+        return np.mean([r.get_tail(param, Xc) for r in ref], axis=0), mu, s2
+    if kind == 'ucb':
+        return mu + np.sqrt(param * s2), mu, s2
+    return mu, mu, s2
+
+
+@pytest.mark.parametrize('kind,param', [('ei', 0.4), ('pi', 0.3), ('ucb', 3.0), ('mean', None)])
+@pytest.mark.parametrize('N,d,kernel', [(150, 2, 'se'), (700, 3, 'matern5')])
+def test_ensemble_sweep_matches_oracle_members(kind, param, N, d, kernel):
+    from pybo_amd._lib import Engine
+    dev, ref = _members(N, d, kernel, seed=N + d)
+    Xc = np.random.RandomState(5).rand(3000, d)
+    engines = [g._engine() for g in dev]
+    moments = kind in ('ucb', 'mean')
+    out = Engine.ensemble_sweep(engines, kind, param, Xc, k=8, want_all=True, want_moments=moments)
+    want, mu, s2 = _ref_ensemble(ref, kind, param, Xc)
+    scale = np.max(np.abs(want))
+    np.testing.assert_allclose(out['acq'], want, rtol=1e-6, atol=1e-9 * scale)
+    if moments:
+        np.testing.assert_allclose(out['mu'], mu, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(out['s2'], s2, rtol=1e-6, atol=1e-10)
+    # the top-k is the exact ranking of the device's own averaged values (value desc, index asc)
+    idx = gp_ref.topk_desc(out['acq'], 8)
+    np.testing.assert_array_equal(out['top_idx'], idx)
+    np.testing.assert_array_equal(out['top_val'], out['acq'][idx])
+    # and the average is the member-order sum of the members' own sweeps divided once by n
+    if kind in ('ei', 'pi'):
+        own = np.mean([e.sweep(kind, param, Xc, k=0)['acq'] for e in engines], axis=0)
+        np.testing.assert_allclose(out['acq'], own, rtol=1e-14, atol=0)
+
+
+def test_ensemble_errors():
+    from pybo_amd._lib import Engine, GpxError
+    dev, _ = _members(40, 2, 'se', seed=3)
+    other = Engine(0)                                   # never fitted
+    with pytest.raises(GpxError):
+        Engine.ensemble_sweep([dev[0]._engine(), other], 'ei', 0.1, np.zeros((4, 2)), k=1)
+    with pytest.raises(GpxError):                       # moments only exist for ucb / mean
+        Engine.ensemble_sweep([dev[0]._engine()], 'ei', 0.1, np.zeros((4, 2)), k=0, want_moments=True)
+    with pytest.raises(GpxError):
+        Engine.ensemble_sweep([dev[0]._engine()], 'ei', 0.1, np.zeros((4, 2)), k=65)
+
+
+def test_mcmc_model_uses_the_device_ensemble():
+    """MCMC over device GPs: predict / get_improvement / acq_topk run as ONE ensemble call and agree with
+    the member-by-member host combination."""
+    from pybo_amd import models
+    X, y, _ = synth_problem(40, 2, seed=11)
+    gp = models.make_gp(1e-3, 1.0, [0.4, 0.4], 0.0)
+    gp.params['like.sn2'].set_prior('horseshoe', 0.1)
+    gp.params['kern.rho'].set_prior('lognormal', 0.0, 1.0)
+    gp.params['kern.ell'].set_prior('uniform', [0.02] * 2, [3.0] * 2)
+    gp.params['mean.bias'].set_prior('normal', 0.0, 4.0)
+    gp.add_data(X, y)
+    ens = models.MCMC(gp, n=5, burn=10, rng=0)
+    Xc = np.random.RandomState(1).rand(500, 2)
+    mu, s2 = ens.predict(Xc)
+    posts = [m.predict(Xc) for m in ens._members]
+    mus = np.array([p[0] for p in posts]); s2s = np.array([p[1] for p in posts])
+    np.testing.assert_allclose(mu, mus.mean(0), rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(s2, (s2s + mus ** 2).mean(0) - mus.mean(0) ** 2, rtol=1e-9, atol=1e-14)
+    ei = ens.get_improvement(0.2, Xc)
+    np.testing.assert_allclose(ei, np.mean([m.get_improvement(0.2, Xc) for m in ens._members], axis=0),
+                               rtol=1e-13, atol=0)
+    tv, ti = ens.acq_topk('ei', 0.2, Xc, 5)
+    np.testing.assert_array_equal(ti, gp_ref.topk_desc(ei, 5))
+    np.testing.assert_array_equal(tv, ei[ti])
+    tv, ti = ens.acq_topk('ucb', 2.0, Xc, 5)
+    ucb = mu + np.sqrt(2.0 * s2)
+    np.testing.assert_array_equal(ti, gp_ref.topk_desc(ucb, 5))
+
+
+# ---- grids in HBM ------------------------------------------------------------------------------------
+@pytest.mark.parametrize('d,n', [(1, 7), (2, 1000), (8, 4097), (21, 333)])
+def test_device_sobol_equals_host_sobol_bit_for_bit(d, n):
+    from pybo_amd import inits
+    bounds = np.stack([-1.0 - np.arange(d), 2.0 + 0.5 * np.arange(d)], axis=1)
+    host = inits.init_sobol(bounds, n, rng=4)
+    grid = inits.init_sobol_device(bounds, n, rng=4)
+    assert grid.shape == (n, d) and len(grid) == n
+    np.testing.assert_array_equal(np.asarray(grid), host)
+    pick = np.array([n - 1, 0, n // 2])
+    np.testing.assert_array_equal(grid[pick], host[pick])
+    np.testing.assert_array_equal(grid[n - 1], host[n - 1])
+
+
+@pytest.mark.parametrize('d,n', [(1, 5), (3, 1001), (8, 5000)])
+def test_device_uniform_equals_philox_restatement(d, n):
+    from pybo_amd._lib import DeviceGrid
+    bounds = np.stack([-2.0 + np.arange(d), 1.0 + 2.0 * np.arange(d)], axis=1)
+    seed = 0x1234567890ABCDE
+    grid = DeviceGrid('uniform', bounds, n, seed=seed)
+    got = np.asarray(grid)
+    np.testing.assert_array_equal(got, gp_ref.grid_uniform(seed, bounds, n))
+    assert np.all(got >= bounds[:, 0]) and np.all(got <= bounds[:, 1])
+    # crude uniformity: every coordinate's mean within 5 sigma of the centre for the larger grids
+    if n >= 1000:
+        u = (got - bounds[:, 0]) / (bounds[:, 1] - bounds[:, 0])
+        assert np.all(np.abs(u.mean(0) - 0.5) < 5.0 / np.sqrt(12.0 * n))
+
+
+def test_grid_errors():
+    from pybo_amd._lib import DeviceGrid, GpxError
+    with pytest.raises(ValueError):
+        DeviceGrid('halton', [[0, 1]], 4)
+    g = DeviceGrid('uniform', [[0, 1], [0, 1]], 16, seed=1)
+    with pytest.raises(GpxError):
+        g.rows([16])
+    with pytest.raises(GpxError):
+        DeviceGrid('uniform', np.zeros((65, 2)), 4)         # d > 64
+
+
+def test_sweeps_over_a_device_grid_equal_sweeps_over_the_host_copy():
+    from pybo_amd import models, inits, policies
+    X, y, ell = synth_problem(300, 3, seed=2)
+    gp = models.make_gp(1e-3, 1.2, ell, 0.1)
+    gp.add_data(X, y)
+    bounds = np.array([[0.0, 1.0]] * 3)
+    grid = inits.init_sobol_device(bounds, 20000, rng=0)
+    host = np.asarray(grid)
+    for kind, param in (('ei', 0.3), ('ucb', 2.5)):
+        tv_d, ti_d = gp.acq_topk(kind, param, grid, 10)
+        tv_h, ti_h = gp.acq_topk(kind, param, host, 10)
+        np.testing.assert_array_equal(ti_d, ti_h)
+        np.testing.assert_array_equal(tv_d, tv_h)
+    sample = gp.sample_f(40, rng=3)
+    tv_d, ti_d = sample.topk(grid, 6)
+    tv_h, ti_h = sample.topk(host, 6)
+    np.testing.assert_array_equal(ti_d, ti_h)
+    np.testing.assert_array_equal(tv_d, tv_h)
+    index = policies.Thompson(gp, bounds, None, n=30, rng=1)
+    assert hasattr(index, 'topk')
+
+
+def test_solver_with_a_device_grid_gives_the_host_grid_answer():
+    from pybo_amd import models, inits, policies, solvers
+    X, y, ell = synth_problem(120, 2, seed=6)
+    gp = models.make_gp(1e-3, 1.0, ell, 0.0)
+    gp.add_data(X, y)
+    bounds = np.array([[0.0, 1.0]] * 2)
+    grid = inits.init_sobol_device(bounds, 4096, rng=2)
+    index = policies.EI(gp, bounds, X)
+    xd, fd = solvers.solve_lbfgs(index, bounds, xgrid=grid)
+    xh, fh = solvers.solve_lbfgs(index, bounds, xgrid=np.asarray(grid))
+    np.testing.assert_array_equal(xd, xh)
+    assert fd == fh
+    # a host-side index (no .topk) still works: the grid is materialised
+    f = lambda Z, grad=False: ((-np.sum((Z - 0.3) ** 2, axis=1), -2 * (Z - 0.3)) if grad
+                               else -np.sum((Z - 0.3) ** 2, axis=1))
+    xs, _ = solvers.solve_lbfgs(f, bounds, xgrid=grid)
+    np.testing.assert_allclose(xs, [0.3, 0.3], atol=1e-6)

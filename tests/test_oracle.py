@@ -202,3 +202,31 @@ def test_copy_is_independent_and_not_pd_raises():
     bad = gp_ref.make_gp(0.0, 1.0, ell, 0.0)
     with pytest.raises(np.linalg.LinAlgError):
         bad.add_data(np.vstack([X, X]), np.hstack([y, y]))    # duplicated rows, no noise -> singular
+
+
+def test_philox_known_answers():
+    """Philox4x32-10 known-answer vectors of the Random123 distribution (kat_vectors: zeros, all-ones, and the
+    pi-digits case) pin the generator the device uniform grid is checked against."""
+    cases = [((0, 0, 0, 0), (0, 0), '6627e8d5 e169c58d bc57ac4c 9b00dbd8'),
+             ((0xffffffff,) * 4, (0xffffffff,) * 2, '408f276d 41c83b0e a20bc7c6 6d5451fd'),
+             ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+              'd16cfe09 94fdcceb 5001e420 24126ea1')]
+    for ctr, key, want in cases:
+        got = ' '.join('%08x' % v for v in gp_ref.philox4x32_10([ctr], key)[0])
+        assert got == want
+    g = gp_ref.grid_uniform(7, [[0, 1], [2, 4], [-1, 1]], 5)
+    assert g.shape == (5, 3) and np.all(g[:, 1] >= 2) and np.all(g[:, 1] < 4)
+
+
+def test_sobol_direction_numbers_reproduce_the_host_generator():
+    from scipy.stats import qmc
+    from pybo_amd._lib import sobol_direction_numbers
+    d = 5
+    sv, bits = sobol_direction_numbers(d, 12)
+    ref = qmc.Sobol(d, scramble=False).random(2048)
+    i = np.arange(2048)
+    g = i ^ (i >> 1)
+    acc = np.zeros((2048, d), dtype=np.uint32)
+    for b in range(11):
+        acc ^= np.where(((g >> b) & 1)[:, None] == 1, sv[:, b][None, :], 0).astype(np.uint32)
+    np.testing.assert_array_equal(acc * 2.0 ** -bits, ref)
