@@ -92,3 +92,43 @@ def test_info_is_a_namedtuple_of_arrays():
                                   solver=('lbfgs', {'ngrid': 50}))
     assert isinstance(info, Info) and info._fields == ('x', 'y', 'xbest')
     assert all(isinstance(a, np.ndarray) for a in info)
+
+
+def test_lockstep_refinement_equals_sequential_and_batches_the_calls():
+    """select='best': the nbest L-BFGS-B runs in lock-step give exactly the sequential answer, with one
+    batched index call per round instead of one call per instance and iteration."""
+    from pybo_amd import solvers
+    from helpers import analytic_index
+    f, bounds = analytic_index('bimodal2')
+    calls = {'n': 0, 'rows': 0}
+
+    def counted(X, grad=False):
+        if grad:
+            calls['n'] += 1
+            calls['rows'] += len(np.atleast_2d(X))
+        return f(X, grad)
+
+    grid = np.random.RandomState(3).rand(400, 2)
+    xa, fa = solvers.solve_lbfgs(counted, bounds, nbest=6, xgrid=grid, select='best', batched=False)
+    seq_calls = calls['n']
+    calls.update(n=0, rows=0)
+    xb, fb = solvers.solve_lbfgs(counted, bounds, nbest=6, xgrid=grid, select='best', batched=True)
+    np.testing.assert_array_equal(xa, xb)
+    assert fa == fb
+    assert calls['rows'] == seq_calls            # same evaluations ...
+    assert calls['n'] < seq_calls / 2            # ... in far fewer calls
+    assert np.max(np.abs(f(xb[None], grad=True)[1])) < 1e-4      # a stationary point of the index
+
+
+def test_lockstep_refinement_surfaces_index_errors():
+    from pybo_amd import solvers
+
+    def broken(X, grad=False):
+        X = np.atleast_2d(X)
+        if grad:
+            raise ValueError('index failed')
+        return -np.sum((X - 0.5) ** 2, axis=1)
+
+    with pytest.raises(ValueError, match='index failed'):
+        solvers.solve_lbfgs(broken, [[0, 1], [0, 1]], nbest=3, xgrid=np.random.RandomState(0).rand(20, 2),
+                            select='best')

@@ -182,3 +182,26 @@ def test_solver_with_a_device_grid_gives_the_host_grid_answer():
                                else -np.sum((Z - 0.3) ** 2, axis=1))
     xs, _ = solvers.solve_lbfgs(f, bounds, xgrid=grid)
     np.testing.assert_allclose(xs, [0.3, 0.3], atol=1e-6)
+
+
+# ---- batched multi-start refinement ------------------------------------------------------
+def test_lockstep_refinement_on_the_device_equals_sequential():
+    """Rows of a batched predict-with-gradient call are independent of the batch they travel in, so the
+    lock-step refinement of all seeds reproduces the one-after-the-other refinement exactly."""
+    from pybo_amd import models, policies, solvers
+    X, y, ell = synth_problem(200, 3, seed=8)
+    gp = models.make_gp(1e-3, 1.0, ell, 0.0, kernel='matern5')
+    gp.add_data(X, y)
+    bounds = np.array([[0.0, 1.0]] * 3)
+    index = policies.EI(gp, bounds, X)
+    P = np.random.RandomState(0).rand(11, 3)
+    fb, gb = index(P, grad=True)
+    for i in range(len(P)):
+        fi, gi = index(P[i:i + 1], grad=True)
+        assert fi[0] == fb[i]
+        np.testing.assert_array_equal(gi[0], gb[i])
+    grid = np.random.RandomState(1).rand(3000, 3)
+    xa, fa = solvers.solve_lbfgs(index, bounds, nbest=5, xgrid=grid, select='best', batched=False)
+    xb, fb_ = solvers.solve_lbfgs(index, bounds, nbest=5, xgrid=grid, select='best', batched=True)
+    np.testing.assert_array_equal(xa, xb)
+    assert fa == fb_
