@@ -163,6 +163,7 @@ template <int JS>
 __device__ __forceinline__ bool potrf_phase(double (&m)[8][8], double (&dinv)[8],
                                             double (*rowbuf)[2][NB + 8], int tr, int tc, bool up_diag,
                                             int64_t p0, int* flag) {
+#pragma unroll 1
     for (int jj = 0; jj < 16; jj += 2) {
         const int j = JS * 16 + jj;
         const int par = (j >> 1) & 1;
