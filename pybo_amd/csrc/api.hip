@@ -235,6 +235,7 @@ extern "C" int gpx_sync(gpx_handle* h) {
 extern "C" int gpx_timers(gpx_handle* h, double* out, int n, int reset) {
     return guarded(h, [&]() -> int {
         if (!h) return GPX_EARG;
+        if (!out || n < 0) return fail(h, GPX_EARG, "timers: NULL output");
         harvest(h);
         const int m = std::min(n, (int)T_COUNT);
         for (int i = 0; i < m; ++i) out[i] = h->tacc[i];
@@ -252,9 +253,11 @@ static int check_fit_args(gpx_handle* h, const void* X, int64_t N, int64_t d, co
     if (N < 1) return fail(h, GPX_EARG, "fit: N must be >= 1");
     if (d < 1 || d > DMAX) return fail(h, GPX_EARG, "fit: d must be in [1, 64]");
     if (kid < GPX_KERN_SE_ARD || kid > GPX_KERN_MATERN12) return fail(h, GPX_EARG, "fit: unknown kernel id");
-    if (!(rho > 0) || !(sn2 >= 0)) return fail(h, GPX_EARG, "fit: need rho > 0 and sn2 >= 0");
+    if (!(rho > 0) || !(sn2 >= 0) || !std::isfinite(rho) || !std::isfinite(sn2))
+        return fail(h, GPX_EARG, "fit: need finite rho > 0 and sn2 >= 0");
     for (int64_t k = 0; k < d; ++k)
-        if (!(ell[k] > 0)) return fail(h, GPX_EARG, "fit: length-scales must be positive");
+        if (!(ell[k] > 0) || !std::isfinite(ell[k]))
+            return fail(h, GPX_EARG, "fit: length-scales must be positive and finite");
     return GPX_OK;
 }
 

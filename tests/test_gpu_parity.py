@@ -104,7 +104,8 @@ def test_argument_errors():
     with pytest.raises(GpxError) as ei:
         e.sweep('ei', 0.0, X, k=1)
     assert ei.value.code == GPX_ESTATE
-    for bad in [dict(rho=-1.0), dict(sn2=-1e-3), dict(ell=[0.1, -0.2])]:
+    for bad in [dict(rho=-1.0), dict(sn2=-1e-3), dict(ell=[0.1, -0.2]), dict(rho=np.inf), dict(rho=np.nan),
+                dict(sn2=np.inf), dict(ell=[0.1, np.inf]), dict(ell=[np.nan, 0.2])]:
         kw = dict(rho=1.0, sn2=1e-3, ell=ell)
         kw.update(bad)
         with pytest.raises(GpxError) as ei:
