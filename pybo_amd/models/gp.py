@@ -33,6 +33,7 @@ class _DeviceState(object):
 
     def __init__(self, device):
         self.engine = None
+        self.key = None            # hyper-parameters of the fit the engine holds
         while _ENGINE_POOL and self.engine is None:
             cand = _ENGINE_POOL.pop()
             if cand._h and cand.device == device:      # never hand out a closed handle
@@ -160,12 +161,23 @@ class GP(object):
             self._state = _DeviceState(self.device)
         return self._state
 
+    def _hyper_key(self):
+        return (self.sn2, self.rho, self.bias, self.kernel, tuple(np.ravel(self.ell).tolist()))
+
+    def _stale(self):
+        """True when the device state was fitted with other hyper-parameters than the model now carries
+        (the attributes sn2 / rho / ell / bias may be assigned directly)."""
+        return self._fitted and self._state is not None and self._state.key != self._hyper_key()
+
     def _engine(self):
         if self.ndata == 0:
             raise RuntimeError('the model has no data yet')
+        if self._stale():
+            self._fitted = False
         if not self._fitted:
             st = self._own_state()
             st.engine.fit(self._X, self._Y, self.kernel, self.ell, self.rho, self.sn2, self.bias)
+            st.key = self._hyper_key()
             self._fitted = True
         return self._state.engine
 
@@ -177,7 +189,7 @@ class GP(object):
         Y = np.array(Y, dtype=float).reshape(-1)
         if len(X) != len(Y):
             raise ValueError('X and Y must have the same number of rows')
-        can_append = (self._fitted and self._state is not None and self._state.nrefs == 1
+        can_append = (self._fitted and not self._stale() and self._state is not None and self._state.nrefs == 1
                       and 0 < len(X) <= self.APPEND_MAX)
         self._X = np.vstack([self._X, X])
         self._Y = np.hstack([self._Y, Y])

@@ -428,3 +428,26 @@ def test_timer_events_do_not_accumulate_without_a_reader():
     tm = e.timers(reset=True)
     assert tm['sweep_trmm_launches'] == 400 and tm['sweep_trmm'] > 0
     e.close()
+
+
+def test_direct_hyperparameter_assignment_triggers_a_refit():
+    """sn2 / rho / ell / bias are plain attributes: assigning them must not leave a stale device fit behind,
+    neither for predictions nor for the in-place append."""
+    from pybo_amd import models
+    X, y, ell = synth_problem(90, 2, seed=12)
+    gp = models.make_gp(1e-3, 1.0, ell, 0.0)
+    gp.add_data(X[:80], y[:80])
+    Z = np.random.RandomState(0).rand(50, 2)
+    gp.predict(Z)
+    gp.rho = 1.7
+    gp.ell = np.array([0.21, 0.33])
+    ref = gp_ref.make_gp(1e-3, 1.7, [0.21, 0.33], 0.0)
+    ref.add_data(X[:80], y[:80])
+    mu, s2 = gp.predict(Z); mr, sr = ref.predict(Z)
+    assert np.all(np.abs(mu - mr) <= mu_tol(mr, 1.7)) and np.all(np.abs(s2 - sr) <= s2_tol(sr, 1.7))
+    gp.bias = 0.4                       # changed between fit and add_data: the append path must not be taken
+    gp.add_data(X[80:], y[80:])
+    ref = gp_ref.make_gp(1e-3, 1.7, [0.21, 0.33], 0.4)
+    ref.add_data(X, y)
+    mu, s2 = gp.predict(Z); mr, sr = ref.predict(Z)
+    assert np.all(np.abs(mu - mr) <= mu_tol(mr, 1.7)) and np.all(np.abs(s2 - sr) <= s2_tol(sr, 1.7))
