@@ -1,7 +1,7 @@
 """
 Multi-GPU layout of the acquisition sweep: one process per GPU, candidates split into contiguous index
 ranges, every rank fits the GP redundantly (deterministic -> bitwise-identical factor, no communication),
-and the only exchange is an all-gather of each rank's k best (value, GLOBAL index) pairs -- 16*k bytes per
+and the only exchange is ONE all-gather of each rank's k best (value, GLOBAL index) pairs -- 16*k bytes per
 rank -- after which every rank computes the same merged top-k with the deterministic rule
 (value descending, then global index ascending).  RCCL has no MAXLOC, hence gather + local merge
 (SURVEY.md F13).  The reference has no distributed code at all; this is new.
@@ -61,13 +61,12 @@ def gather_topk(vals, idx, k, group=None):
     pv = np.full(nmax, -np.inf)
     pi = np.full(nmax, -1, dtype=np.int64)
     pv[:n], pi[:n] = vals, idx
-    tv = torch.from_numpy(pv).to(dev)
-    ti = torch.from_numpy(pi).to(dev)
-    allv = torch.empty(world * nmax, dtype=torch.float64, device=dev)
-    alli = torch.empty(world * nmax, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(allv, tv, group=group)
-    dist.all_gather_into_tensor(alli, ti, group=group)
-    return merge_topk(allv.cpu().numpy(), alli.cpu().numpy(), k)
+    # ONE collective per step: values and indices travel in the same float64 buffer (indices < 2^53 are exact)
+    mine = torch.from_numpy(np.concatenate([pv, pi.astype(np.float64)])).to(dev)
+    everyone = torch.empty(world * 2 * nmax, dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(everyone, mine, group=group)
+    table = everyone.cpu().numpy().reshape(world, 2, nmax)
+    return merge_topk(table[:, 0, :], table[:, 1, :].astype(np.int64), k)
 
 
 def sharded_topk(index, xgrid, k, group=None):
