@@ -63,10 +63,11 @@ const char *gpx_last_error(const gpx_handle *h);
 int gpx_version(void);
 /* options: "chunk" = candidate columns per sweep chunk (multiple of 128);
  *          "tile_order" = sweep-kernel schedule: bits 0-1 blockIdx->tile map (0 linear heavy-first,
- *              1 per-XCD candidate slices, 2 per-XCD 8x8 super-tiles), bits 2-3 k-loop variant
+ *              1 per-XCD candidate slices, 2 per-XCD 8x8 super-tiles, 3 the same with every workgroup
+ *              computing the PAIR of tiles (nP-1-i, nt), (i, nt): equal work per workgroup), bits 2-4 k-loop variant
  *              (0 write-at-end, 1 write-at-top, 2 write-at-top + s_setprio, 3 software-pipelined
  *              fragments, 4 LDS-DMA staging, 5 k-step 32 through a single LDS buffer).
- *              Default 22 = super-tiles + variant 5.
+ *              Default 23 = paired super-tiles + variant 5.
  *              Every setting produces bit-identical results.
  *          "super_m" = rows of the XCD super-tile of 64 workgroups (8 -> 8x8 default, 4 -> 4x16, ...). */
 int gpx_set_option(gpx_handle *h, const char *name, int64_t value);

@@ -216,7 +216,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             return GPX_OK;
         }
         if (!strcmp(name, "tile_order")) {
-            if (value < 0 || value > 23 || (value & 3) == 3) return fail(h, GPX_EARG, "tile_order: bits 0-1 in {0,1,2} (tile map), bits 2-3 in {0,1,2} (k-loop variant)");
+            if (value < 0 || value > 23) return fail(h, GPX_EARG, "tile_order: bits 0-1 tile map (0..3), bits 2-4 k-loop variant (0..5)");
             h->tile_order = (int)value;
             return GPX_OK;
         }

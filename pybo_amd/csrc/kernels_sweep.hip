@@ -118,7 +118,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __
                                                                 int order, int sm) {
     __shared__ __attribute__((aligned(16))) double smem[GEMM_LDS_F64];
     const int nP = (int)(Np / TB);
-    int mt, nt;
+    int mt, nt, mt2 = -1;      // mt2 >= 0: this workgroup also computes tile (mt2, nt) afterwards
     {
         const int b = blockIdx.x;
         if (order == 1) {
@@ -145,10 +145,34 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __
             const int ln = H * SN + (r - (r / SN) * SN);
             nt = x * per + ln;
             if (ln >= per || nt >= NT || mt < 0) return;
+        } else if (order == 3) {
+            // PAIRED tiles on the super-tile map: the workgroup computes (nP-1-i, nt) and then (i, nt), so every
+            // workgroup of the launch does the same (nP+1)*128 of K.  Equal durations keep the 64 workgroups
+            // of a super-tile in step for the whole launch: tiles that share a Ks column panel (same nt,
+            // different mt) walk k together instead of drifting apart by their K-extent difference.
+            const int x = b & 7, q = b >> 3;
+            const int SN = 64 / sm;
+            const int per = (NT + 7) / 8;
+            const int hper = (per + SN - 1) / SN;
+            const int s = q >> 6, r = q & 63;
+            const int G = s / hper, H = s - G * hper;
+            const int i = G * sm + r / SN;              // pair row
+            const int ln = H * SN + (r - (r / SN) * SN);
+            nt = x * per + ln;
+            mt = nP - 1 - i;
+            if (ln >= per || nt >= NT || i > mt) return;
+            if (i < mt) mt2 = i;
         } else {
             mt = nP - 1 - b / NT;
             nt = b - (b / NT) * NT;
         }
+    }
+#pragma unroll 1
+  for (int ph = 0; ph < 2; ++ph) {
+    if (ph == 1) {
+        if (mt2 < 0) break;
+        mt = mt2;
+        __syncthreads();               // the epilogue's LDS reads are done before the next tile stages
     }
     const int64_t m0 = (int64_t)mt * TB, n0 = (int64_t)nt * TB;
     d4 acc[4][4];
@@ -202,6 +226,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __
         Qp[(int64_t)mt * ldp + n0 + c] = red[c * 2] + red[(TB + c) * 2];
         Pp[(int64_t)mt * ldp + n0 + c] = red[c * 2 + 1] + red[(TB + c) * 2 + 1];
     }
+  }
 }
 
 void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double* Ks, int64_t ldk,
@@ -218,6 +243,12 @@ void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double*
         const int per = (NT + 7) / 8;
         const int hper = (per + SN - 1) / SN;
         const int gm = (nP + super_m - 1) / super_m;
+        nblk = (unsigned)(8 * 64 * hper * gm);
+    } else if ((tile_order & 3) == 3) {
+        const int SN = 64 / super_m;
+        const int per = (NT + 7) / 8;
+        const int hper = (per + SN - 1) / SN;
+        const int gm = ((nP + 1) / 2 + super_m - 1) / super_m;
         nblk = (unsigned)(8 * 64 * hper * gm);
     } else {
         nblk = (unsigned)(NT * nP);

@@ -191,7 +191,9 @@ def test_posterior_moments_match_oracle(kernel, N, d, M):
 @pytest.mark.parametrize('opts', [dict(chunk=128), dict(chunk=256, tile_order=1), dict(chunk=65536, tile_order=0),
                                   dict(chunk=512, tile_order=6), dict(chunk=1024, tile_order=9),
                                   dict(chunk=256, tile_order=14), dict(chunk=384, tile_order=18),
-                                  dict(chunk=512, super_m=4), dict(chunk=256, super_m=2), dict(chunk=640, tile_order=10)])
+                                  dict(chunk=512, super_m=4), dict(chunk=256, super_m=2), dict(chunk=640, tile_order=10),
+                                  dict(chunk=384, tile_order=22), dict(chunk=256, tile_order=3),
+                                  dict(chunk=640, tile_order=23, super_m=4)])
 def test_chunking_and_tile_order_do_not_change_results(opts):
     e0, ref, (X, y, ell, rho, sn2, bias) = _pair(300, 3, 'matern5', seed=5)
     e1 = _engine(**opts)
