@@ -523,7 +523,7 @@ static int sweep_core(gpx_handle* h, int acq_id, const double* params, int npara
         {
             Span sp(h, T_XGRAM);
             launch_cross_gram(s, h->dXs, Np, h->N, (int)h->d, dXc, m0, M, cols, h->dinvell, h->kernel_id,
-                              h->rho, h->dKs, chunk);
+                              h->rho, h->dKs, Np);
         }
         {
             Span sp(h, T_TRMM);

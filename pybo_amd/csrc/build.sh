@@ -6,7 +6,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-const-variable"
 pids=()
 for f in kernels_fit kernels_sweep kernels_rff kernels_grad kernels_ens api; do
-  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ gemm_core.h -nt $f.o ] || [ gpx_internal.h -nt $f.o ] || [ ../../include/gpx.h -nt $f.o ]; then
+  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ gemm_core.h -nt $f.o ] || [ gpx_internal.h -nt $f.o ] || [ gpx_math.h -nt $f.o ] || [ ../../include/gpx.h -nt $f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o $f.o &
     pids+=($!)
   fi

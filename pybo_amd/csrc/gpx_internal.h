@@ -60,7 +60,7 @@ struct gpx_handle {
     int super_m = 8;          // rows (mt) of an XCD super-tile of 64 workgroups: 8 -> 8x8, 4 -> 4x16, 2 -> 2x32
     int tile_order = 23;      // bits 0-1 tile map (3 = XCD 8x8 super-tiles of PAIRED tiles), bits 2-4 k-loop variant (5 = BK 32, single LDS buffer, setprio)
     int64_t cap_ks = 0;       // elements of dKs
-    double* dKs = nullptr;    // (Np, chunk) cross-Gram chunk
+    double* dKs = nullptr;    // cross-Gram chunk, tile-blocked [chunk/128][Np][128]
     double* dQp = nullptr;    // (Np/128, chunk) per-row-block partials of colsum(V^2)
     double* dPp = nullptr;    // (Np/128, chunk) per-row-block partials of V^T a
     int64_t cap_part = 0;

@@ -11,29 +11,11 @@
 // (see gemm_core.h), which is what keeps the loads coalesced without any transpose.
 #include "gemm_core.h"
 #include "gpx_internal.h"
+#include "gpx_math.h"
 
 namespace gpx {
 
-// ------------------------------------------------------------------------------------------------
-// covariance functions of the squared scaled distance r2
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double kern_eval(int kid, double r2, double rho) {
-    switch (kid) {
-        case GPX_KERN_SE_ARD:
-            return rho * exp(-0.5 * r2);
-        case GPX_KERN_MATERN52: {
-            const double s = 2.23606797749978969641 * sqrt(r2);
-            return rho * (1.0 + s + (5.0 / 3.0) * r2) * exp(-s);
-        }
-        case GPX_KERN_MATERN32: {
-            const double s = 1.73205080756887729353 * sqrt(r2);
-            return rho * (1.0 + s) * exp(-s);
-        }
-        default:
-            return rho * exp(-sqrt(r2));
-    }
-}
-
+// (covariance functions: gpx_math.h)
 // Xs[i][k] = X[i][k] / ell[k] for i < n, 0 for n <= i < np
 __global__ void k_scale_x(const double* __restrict__ X, int64_t n, int64_t np, int d,
                           const double* __restrict__ invell, double* __restrict__ Xs) {

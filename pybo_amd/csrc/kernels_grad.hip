@@ -13,6 +13,7 @@
 #include <algorithm>
 
 #include "gpx_internal.h"
+#include "gpx_math.h"
 
 namespace gpx {
 

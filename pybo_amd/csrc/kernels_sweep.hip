@@ -6,7 +6,8 @@
 // `np.argsort(finit)[::-1]` [pybo/solvers/lbfgs.py:51] of which only the first nbest are used.
 //
 // Per chunk of candidate columns:
-//   1. k_cross_gram   Ks[k][n] = k(x_k, c_n)                      (HBM-write bound, exp on VALU)
+//   1. k_cross_gram   Ks[nt][k][c] = k(x_k, cand_{128 nt + c})    (HBM-write bound; tile-blocked so that every
+//                     128-candidate column panel is one contiguous Np x 128 block)
 //   2. k_sweep_trmm   V = T Ks on fp64 MFMA, tile (mt, nt); V never leaves registers: the epilogue
 //                     reduces colsum(V^2) and V^T a per 128-row block into Qp/Pp[mt][n]
 //   3. k_acq          q = sum_mt Qp, p = sum_mt Pp (fixed order -> deterministic),
@@ -14,25 +15,9 @@
 // then one block-local + one merge top-k pass over all M values.
 #include "gemm_core.h"
 #include "gpx_internal.h"
+#include "gpx_math.h"
 
 namespace gpx {
-
-__device__ __forceinline__ double kern_eval_s(int kid, double r2, double rho) {
-    switch (kid) {
-        case GPX_KERN_SE_ARD:
-            return rho * exp(-0.5 * r2);
-        case GPX_KERN_MATERN52: {
-            const double s = 2.23606797749978969641 * sqrt(r2);
-            return rho * (1.0 + s + (5.0 / 3.0) * r2) * exp(-s);
-        }
-        case GPX_KERN_MATERN32: {
-            const double s = 1.73205080756887729353 * sqrt(r2);
-            return rho * (1.0 + s) * exp(-s);
-        }
-        default:
-            return rho * exp(-sqrt(r2));
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // cross-Gram: tile 64 observed rows x 128 candidate columns, 8x4 outputs per thread
@@ -89,9 +74,10 @@ __global__ __launch_bounds__(256) void k_cross_gram(const double* __restrict__ X
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
             const int64_t gm = m0 + n0 + tx * 4 + b;
-            o[b] = (gk < N && gm < M) ? kern_eval_s(kid, r2[a][b], rho) : 0.0;
+            o[b] = (gk < N && gm < M) ? kern_eval(kid, r2[a][b], rho) : 0.0;
         }
-        *reinterpret_cast<d4*>(Ks + gk * ldk + n0 + tx * 4) = o;
+        // tile-blocked layout [nt][k][128]: the 64 x 128 outputs of this block are ONE contiguous 64 KB run
+        *reinterpret_cast<d4*>(Ks + ((int64_t)blockIdx.x * ldk + gk) * XN + tx * 4) = o;
     }
 }
 
@@ -177,12 +163,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __
     const int64_t m0 = (int64_t)mt * TB, n0 = (int64_t)nt * TB;
     d4 acc[4][4];
     acc_zero(acc);
-    if (VAR == 0) gemm_tile_128(acc, U + m0, Np, Ks + n0, ldk, 0, (mt + 1) * TB, smem);
-    else if (VAR == 1) gemm_tile_128_b<false>(acc, U + m0, Np, Ks + n0, ldk, 0, (mt + 1) * TB, smem);
-    else if (VAR == 2) gemm_tile_128_b<true>(acc, U + m0, Np, Ks + n0, ldk, 0, (mt + 1) * TB, smem);
-    else if (VAR == 3) gemm_tile_128_d<true>(acc, U + m0, Np, Ks + n0, ldk, 0, (mt + 1) * TB, smem);
-    else if (VAR == 4) gemm_tile_128_e<true>(acc, U + m0, Np, Ks + n0, ldk, 0, (mt + 1) * TB, smem);
-    else gemm_tile_128_g<true>(acc, U + m0, Np, Ks + n0, ldk, 0, (mt + 1) * TB, smem);
+    if (VAR == 0) gemm_tile_128(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
+    else if (VAR == 1) gemm_tile_128_b<false>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
+    else if (VAR == 2) gemm_tile_128_b<true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
+    else if (VAR == 3) gemm_tile_128_d<true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
+    else if (VAR == 4) gemm_tile_128_e<true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
+    else gemm_tile_128_g<true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
 
     // epilogue: column sums of V^2 and V*a over this tile's 128 rows
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
