@@ -22,27 +22,27 @@ constexpr int GB = 8;  // candidates per batch
 __device__ __forceinline__ void kern_and_grad(int kid, double r2, double rho, double& k, double& g) {
     switch (kid) {
         case GPX_KERN_SE_ARD: {
-            k = rho * exp(-0.5 * r2);
+            k = rho * exp_nonpos(-0.5 * r2);
             g = -0.5 * k;
             break;
         }
         case GPX_KERN_MATERN52: {
             const double s = 2.23606797749978969641 * sqrt(r2);
-            const double e = rho * exp(-s);
+            const double e = rho * exp_nonpos(-s);
             k = (1.0 + s + (5.0 / 3.0) * r2) * e;
             g = -(5.0 / 6.0) * (1.0 + s) * e;
             break;
         }
         case GPX_KERN_MATERN32: {
             const double s = 1.73205080756887729353 * sqrt(r2);
-            const double e = rho * exp(-s);
+            const double e = rho * exp_nonpos(-s);
             k = (1.0 + s) * e;
             g = -1.5 * e;
             break;
         }
         default: {
             const double r = sqrt(r2);
-            k = rho * exp(-r);
+            k = rho * exp_nonpos(-r);
             g = -0.5 * k / r;
         }
     }
