@@ -53,3 +53,28 @@ def test_product_never_imports_the_oracle():
             if f.endswith('.py'):
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle', txt, flags=re.M), f
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The boundary is a C ABI: include/gpx.h compiles as strict C99 and a C program linked against
+    libgpx.so can call it (here only gpx_version / gpx_last_error: no device work on a CPU-only host)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no C compiler on this host')
+    libdir = os.path.join(ROOT, 'pybo_amd', 'csrc')
+    src = tmp_path / 'abi_probe.c'
+    src.write_text('#include <stdio.h>\n#include "gpx.h"\n'
+                   'int main(void) {\n'
+                   '    gpx_handle *h = 0; gpx_grid *g = 0;\n'
+                   '    const char *msg = gpx_last_error(0);\n'
+                   '    printf("%d %d\\n", gpx_version(), (int)(msg != 0));\n'
+                   '    return (h == 0 && g == 0 && GPX_OK == 0 && GPX_GRID_SOBOL == 1) ? 0 : 1;\n'
+                   '}\n')
+    exe = tmp_path / 'abi_probe'
+    subprocess.check_call([gcc, '-std=c99', '-Wall', '-Wextra', '-Werror', '-pedantic',
+                           '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe),
+                           '-L', libdir, '-lgpx', '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib'])
+    out = subprocess.check_output([str(exe)]).decode().split()
+    assert int(out[0]) >= 100 and out[1] == '1'
