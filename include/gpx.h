@@ -34,7 +34,8 @@ enum gpx_status {
     GPX_ENOTPD = -2,  /* K + sn2*I not positive definite; see gpx_fail_pivot */
     GPX_EHIP = -3,    /* HIP runtime error */
     GPX_EOOM = -4,    /* device allocation failed */
-    GPX_ESTATE = -5   /* call order error (e.g. sweep before fit) */
+    GPX_ESTATE = -5,  /* call order error (e.g. sweep before fit) */
+    GPX_ERCCL = -6    /* RCCL could not be loaded, or a collective failed; see gpx_comm_last_error */
 };
 
 /* covariance functions; parametrisation (sn2, rho, ell[d], bias) = the arguments of
@@ -64,17 +65,18 @@ int gpx_version(void);
 /* options: "chunk" = candidate columns per sweep chunk (multiple of 128);
  *          "tile_order" = sweep-kernel schedule: bits 0-1 blockIdx->tile map (0 linear heavy-first,
  *              1 per-XCD candidate slices, 2 per-XCD 8x8 super-tiles, 3 the same with every workgroup
- *              computing the PAIR of tiles (nP-1-i, nt), (i, nt): equal work per workgroup), bits 2-4 k-loop variant
- *              (0 write-at-end, 1 write-at-top, 2 write-at-top + s_setprio, 3 software-pipelined
- *              fragments, 4 LDS-DMA staging, 5 k-step 32 through a single LDS buffer).
- *              Default 23 = paired super-tiles + variant 5.
+ *              computing the PAIR of tiles (nP-1-i, nt), (i, nt): equal work per workgroup), bits 2-4 k-loop schedule
+ *              (5 = k-step 32 through a single LDS buffer, the default; 2 = k-step 16 through a 2-deep LDS
+ *              ring, kept as an independently scheduled witness).  Default 23 = paired super-tiles + schedule 5.
  *              Every setting produces bit-identical results.
- *          "super_m" = rows of the XCD super-tile of 64 workgroups (8 -> 8x8 default, 4 -> 4x16, ...). */
+ *          "super_m" = rows of the XCD super-tile of 64 workgroups (8 -> 8x8 default, 4 -> 4x16, ...).
+ *          "eager_inverse" = 1: form the triangular inverse inside gpx_fit instead of on first use. */
 int gpx_set_option(gpx_handle *h, const char *name, int64_t value);
 
 /* ---- GP fit = model.add_data(X, Y)            [pybo/bayesopt.py:114,258,269] ------------- */
-/* Gram build K = k(X,X) + sn2 I, Cholesky K = R^T R, triangular inverse T = R^-T,
- * a = T (y - bias).  X is (N,d), y is (N,), ell is (d,) on the HOST in both variants. */
+/* Gram build K = k(X,X) + sn2 I and Cholesky K = R^T R.  The triangular inverse T = R^-T, a = T (y - bias)
+ * and alpha follow on FIRST USE (sweep, predict, mean_at_obs, loglik, append, introspection): the Thompson
+ * entry points never read them.  X is (N,d), y is (N,), ell is (d,) on the HOST in both variants. */
 int gpx_fit(gpx_handle *h, const double *X, int64_t N, int64_t d, const double *y, int kernel_id,
             const double *ell, double rho, double sn2, double bias);
 int gpx_fit_dev(gpx_handle *h, const double *dX, int64_t N, int64_t d, const double *dy,
@@ -176,6 +178,32 @@ const double *gpx_grid_data(const gpx_grid *g);     /* device pointer, (M,d) row
 /* rows idx[0..k) -> out (k,d) host; idx == NULL: the whole grid (M,d) */
 int gpx_grid_rows(gpx_grid *g, const int64_t *idx, int64_t k, double *out);
 int gpx_grid_destroy(gpx_grid *g);
+
+/* ---- multi-GPU exchange: the one collective of the sharded sweep -----------------------------------------
+ *      The reference is single-process (its only hint at parallelism is the comment pybo/solvers/lbfgs.py:60);
+ *      layout per SURVEY.md 8(e): one process per GPU, candidates sharded contiguously, every rank fits
+ *      redundantly (bitwise-identical factor), and each rank's best (value, GLOBAL index) pairs are
+ *      all-gathered over RCCL/xGMI and merged with the rule "value descending, then index ascending".
+ *      RCCL is bound at run time (dlopen of librccl, override with $GPX_RCCL_LIB): single-GPU use never loads it.
+ *      Errors of these calls are read with gpx_comm_last_error() (thread-local). */
+typedef struct gpx_comm gpx_comm;
+#define GPX_COMM_ID_BYTES 128
+/* rank 0 generates the id (ncclGetUniqueId) and hands its 128 bytes to every rank over any side channel */
+int gpx_comm_unique_id(unsigned char *id);
+/* collective over all ranks: binds the communicator to the handle's device and stream */
+int gpx_comm_init(gpx_handle *h, int rank, int nranks, const unsigned char *id, gpx_comm **out);
+int gpx_comm_destroy(gpx_comm *c);
+int gpx_comm_size(const gpx_comm *c, int *rank, int *nranks);
+const char *gpx_comm_last_error(void);
+/* All-gather of the n (value, index) pairs the handle's LAST sweep left in HBM (n = its k for gpx_sweep* /
+ * gpx_ensemble_sweep*, S*k for gpx_rff_sweep*), taken straight from the device, `index_offset` (this rank's
+ * shard origin) added to every valid index.
+ *   k > 0: every rank receives the same merged k best in out_val[k], out_idx[k]
+ *          = the global argsort(finit)[::-1][:k] of pybo/solvers/lbfgs.py:51 over the sharded grid.
+ *   k = 0: no merge; out_val / out_idx receive all nranks*n pairs in rank order (batch-BO: one recommendation
+ *          per Thompson draw, draws sharded over ranks). */
+int gpx_topk_allgather(gpx_comm *c, int64_t n, int64_t index_offset, int64_t k, double *out_val,
+                       int64_t *out_idx);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 /* Stage timers in milliseconds accumulated since the last reset (HIP events on the handle's

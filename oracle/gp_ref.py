@@ -63,7 +63,7 @@ def kern_from_r2(kid, r2, rho):
 
 
 def dkern_dr2(kid, r2, rho):
-    """d k / d r2 (finite at r2 = 0 for every kernel except Matern-1/2)."""
+    """d k / d r2 (Matern-1/2 is not differentiable at r2 = 0: see below)."""
     if kid == SE_ARD:
         return -0.5 * rho * np.exp(-0.5 * r2)
     if kid == MATERN52:
@@ -73,9 +73,11 @@ def dkern_dr2(kid, r2, rho):
         s = _SQRT3 * np.sqrt(r2)
         return -1.5 * rho * np.exp(-s)
     if kid == MATERN12:
+        # kink at r = 0 (a candidate on top of an observation): the one-sided slopes are +-1, the symmetric
+        # value 0 is used there so that gradients at training inputs stay finite
         r = np.sqrt(r2)
         with np.errstate(divide='ignore', invalid='ignore'):
-            return -0.5 * rho * np.exp(-r) / r
+            return np.where(r > 0.0, -0.5 * rho * np.exp(-r) / r, 0.0)
     raise ValueError('unknown kernel id')
 
 

@@ -46,11 +46,18 @@ SYMBOLS = {
     'gpx_grid_data': (_P, [_P]),
     'gpx_grid_rows': (C.c_int, [_P, _P, _i64, _P]),
     'gpx_grid_destroy': (C.c_int, [_P]),
+    'gpx_comm_unique_id': (C.c_int, [_P]),
+    'gpx_comm_init': (C.c_int, [_P, C.c_int, C.c_int, _P, C.POINTER(_P)]),
+    'gpx_comm_destroy': (C.c_int, [_P]),
+    'gpx_comm_size': (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'gpx_comm_last_error': (C.c_char_p, []),
+    'gpx_topk_allgather': (C.c_int, [_P, _i64, _i64, _i64, _P, _P]),
     'gpx_timers': (C.c_int, [_P, _P, C.c_int, C.c_int]),
     'gpx_sync': (C.c_int, [_P]),
 }
 
-GPX_OK, GPX_EARG, GPX_ENOTPD, GPX_EHIP, GPX_EOOM, GPX_ESTATE = 0, -1, -2, -3, -4, -5
+GPX_OK, GPX_EARG, GPX_ENOTPD, GPX_EHIP, GPX_EOOM, GPX_ESTATE, GPX_ERCCL = 0, -1, -2, -3, -4, -5, -6
+COMM_ID_BYTES = 128
 KERNELS = {'se': 0, 'matern5': 1, 'matern3': 2, 'matern1': 3}
 ACQ = {'ei': 0, 'pi': 1, 'ucb': 2, 'mean': 3}
 TIMER_NAMES = ['gram', 'cholesky', 'trtri', 'alpha', 'cross_gram', 'sweep_trmm', 'acq_topk', 'rff',
@@ -181,6 +188,55 @@ class DeviceGrid(object):
             self._lib.gpx_grid_destroy(self._g)
             self._g = None
             self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm(object):
+    """RCCL communicator bound to an Engine's device and stream (gpx_comm_*): the exchange step of the sharded
+    sweep without torch.distributed.  Rank 0 creates the id with `Comm.unique_id()` and hands the 128 bytes to
+    the other ranks over any side channel; every rank then constructs `Comm(engine, rank, nranks, id)`."""
+
+    @staticmethod
+    def unique_id():
+        lib = load()
+        buf = (C.c_ubyte * COMM_ID_BYTES)()
+        rc = lib.gpx_comm_unique_id(C.cast(buf, _P))
+        if rc != GPX_OK:
+            raise GpxError(rc, (lib.gpx_comm_last_error() or b'').decode())
+        return bytes(buf)
+
+    def __init__(self, engine, rank, nranks, uid):
+        self._lib = load()
+        if len(uid) != COMM_ID_BYTES:
+            raise ValueError('the communicator id has %d bytes' % COMM_ID_BYTES)
+        buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(bytes(uid))
+        c = _P()
+        rc = self._lib.gpx_comm_init(engine._h, int(rank), int(nranks), C.cast(buf, _P), C.byref(c))
+        if rc != GPX_OK:
+            raise GpxError(rc, (self._lib.gpx_comm_last_error() or b'').decode())
+        self._c, self._engine = c, engine            # the engine must outlive the communicator
+        self.rank, self.nranks = int(rank), int(nranks)
+
+    def topk_allgather(self, n, index_offset, k):
+        """Gather the engine's last n device (value, index) pairs from every rank; k > 0: merged k best
+        (identical on every rank), k = 0: all nranks*n pairs in rank order."""
+        m = int(k) if k > 0 else int(n) * self.nranks
+        tv = np.empty(m)
+        ti = np.empty(m, dtype=np.int64)
+        rc = self._lib.gpx_topk_allgather(self._c, int(n), int(index_offset), int(k), _ptr(tv), _ptr(ti))
+        if rc != GPX_OK:
+            raise GpxError(rc, (self._lib.gpx_comm_last_error() or b'').decode())
+        return tv, ti
+
+    def close(self):
+        if getattr(self, '_c', None):
+            self._lib.gpx_comm_destroy(self._c)
+            self._c = None
 
     def __del__(self):
         try:

@@ -216,8 +216,14 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             return GPX_OK;
         }
         if (!strcmp(name, "tile_order")) {
-            if (value < 0 || value > 23) return fail(h, GPX_EARG, "tile_order: bits 0-1 tile map (0..3), bits 2-4 k-loop variant (0..5)");
+            if (value < 0 || value > 23 || ((value >> 2) != 2 && (value >> 2) != 5))
+                return fail(h, GPX_EARG, "tile_order: bits 0-1 tile map (0..3), bits 2-4 k-loop schedule (2 or 5)");
             h->tile_order = (int)value;
+            return GPX_OK;
+        }
+        if (!strcmp(name, "eager_inverse")) {
+            if (value != 0 && value != 1) return fail(h, GPX_EARG, "eager_inverse must be 0 or 1");
+            h->eager_inverse = (value != 0);
             return GPX_OK;
         }
         return fail(h, GPX_EARG, "unknown option");
@@ -291,7 +297,28 @@ static int alloc_model(gpx_handle* h, int64_t Np, int64_t d) {
     return GPX_OK;
 }
 
-// core: dX (N,d), dy (N,) device pointers; stage 1 = stop after Gram, 2 = after Cholesky, 3 = full
+// The triangular inverse T = R^-T (and U, a, alpha) is formed on FIRST USE, not by the fit: the Thompson path
+// (gpx_rff_gram / gpx_rff_sweep, pybo/policies/simple.py:44-48) never reads it, and it is a quarter of a fit
+// at N = 16384.  Every entry point that reads T, U, a or alpha calls this first.
+int gpx::ensure_inverse(gpx_handle* h) {
+    if (h->stage >= 3) return GPX_OK;
+    if (h->stage < 2) return fail(h, GPX_ESTATE, "model is not fitted");
+    HIPCHK(h, hipSetDevice(h->device));
+    {
+        Span sp(h, T_TRTRI);
+        launch_trtri(h);
+    }
+    {
+        Span sp(h, T_ALPHA);
+        launch_alpha(h);
+    }
+    HIPCHK(h, hipGetLastError());
+    h->stage = 3;
+    return GPX_OK;
+}
+
+// core: dX (N,d), dy (N,) device pointers; stage 1 = stop after Gram, 2 = after Cholesky (what gpx_fit does: the
+// model counts as fitted, the inverse follows lazily), 3 = Cholesky + inverse eagerly
 static int fit_core(gpx_handle* h, const double* dX, int64_t N, int64_t d, const double* dy, int kid,
                     const double* ell, double rho, double sn2, double bias, int stage) {
     HIPCHK(h, hipSetDevice(h->device));
@@ -299,6 +326,7 @@ static int fit_core(gpx_handle* h, const double* dX, int64_t N, int64_t d, const
     h->fitted = false;
     h->stage = 0;
     h->fail_pivot = -1;
+    h->last_topn = 0;
     int rc = alloc_model(h, Np, d);
     if (rc) return rc;
     h->N = N; h->Np = Np; h->d = d; h->kernel_id = kid;
@@ -334,20 +362,10 @@ static int fit_core(gpx_handle* h, const double* dX, int64_t N, int64_t d, const
             return fail(h, GPX_ENOTPD, buf);
         }
         h->stage = 2;
-    }
-    if (stage >= 3) {
-        {
-            Span sp(h, T_TRTRI);
-            launch_trtri(h);
-        }
-        {
-            Span sp(h, T_ALPHA);
-            launch_alpha(h);
-        }
-        h->stage = 3;
         h->fitted = true;
     }
     HIPCHK(h, hipGetLastError());
+    if (stage >= 3 || h->eager_inverse) return (h->stage >= 2) ? ensure_inverse(h) : GPX_OK;
     return GPX_OK;
 }
 
@@ -356,7 +374,7 @@ extern "C" int gpx_fit_dev(gpx_handle* h, const double* dX, int64_t N, int64_t d
     return guarded(h, [&]() -> int {
         int rc = check_fit_args(h, dX, N, d, dy, kernel_id, ell, rho, sn2);
         if (rc) return rc;
-        return fit_core(h, dX, N, d, dy, kernel_id, ell, rho, sn2, bias, 3);
+        return fit_core(h, dX, N, d, dy, kernel_id, ell, rho, sn2, bias, 2);
     });
 }
 
@@ -378,7 +396,7 @@ static int fit_host(gpx_handle* h, const double* X, int64_t N, int64_t d, const 
 extern "C" int gpx_fit(gpx_handle* h, const double* X, int64_t N, int64_t d, const double* y, int kernel_id,
                        const double* ell, double rho, double sn2, double bias) {
     return guarded(h, [&]() -> int {
-        return fit_host(h, X, N, d, y, kernel_id, ell, rho, sn2, bias, 3);
+        return fit_host(h, X, N, d, y, kernel_id, ell, rho, sn2, bias, 2);
     });
 }
 
@@ -411,9 +429,13 @@ extern "C" int gpx_get_matrix(gpx_handle* h, int which, double* out) {
     return guarded(h, [&]() -> int {
         if (!h || !out) return GPX_EARG;
         if (which < 0 || which > 2) return fail(h, GPX_EARG, "get_matrix: which must be 0..2");
-        if ((which == 2 && h->stage != 1) || (which == 0 && h->stage < 2) || (which == 1 && h->stage < 3))
+        if ((which == 2 && h->stage != 1) || (which != 2 && h->stage < 2))
             return fail(h, GPX_ESTATE, "get_matrix: the requested matrix is not available at this stage");
         HIPCHK(h, hipSetDevice(h->device));
+        if (which == 1) {
+            int rc0 = ensure_inverse(h);
+            if (rc0) return rc0;
+        }
         const int64_t N = h->N, Np = h->Np;
         int rc = ensure(h, h->dout, h->cap_out, N * N);
         if (rc) return rc;
@@ -443,6 +465,10 @@ extern "C" int gpx_get_vectors(gpx_handle* h, double* a, double* alpha) {
         if (!h) return GPX_EARG;
         if (!h->fitted) return fail(h, GPX_ESTATE, "get_vectors: model is not fitted");
         HIPCHK(h, hipSetDevice(h->device));
+        {
+            int rc0 = ensure_inverse(h);
+            if (rc0) return rc0;
+        }
         if (a) HIPCHK(h, hipMemcpyAsync(a, h->da, (size_t)h->N * 8, hipMemcpyDeviceToHost, h->stream));
         if (alpha) HIPCHK(h, hipMemcpyAsync(alpha, h->dalpha, (size_t)h->N * 8, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -455,6 +481,10 @@ extern "C" int gpx_mean_at_obs(gpx_handle* h, double* mu_host, double* mu_max) {
         if (!h) return GPX_EARG;
         if (!h->fitted) return fail(h, GPX_ESTATE, "mean_at_obs: model is not fitted");
         HIPCHK(h, hipSetDevice(h->device));
+        {
+            int rc0 = ensure_inverse(h);
+            if (rc0) return rc0;
+        }
         const int64_t N = h->N;
         std::vector<double> al((size_t)N), yy((size_t)N);
         HIPCHK(h, hipMemcpyAsync(al.data(), h->dalpha, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
@@ -487,6 +517,7 @@ static int topk_core(gpx_handle* h, const double* d_vals, int64_t M, int64_t k, 
         Span sp(h, T_ACQ);
         launch_topk(s, d_vals, M, (int)k, h->dblkv, h->dblki, nblk, h->dtopv, h->dtopi);
     }
+    h->last_topv = h->dtopv; h->last_topi = h->dtopi; h->last_topn = k;
     HIPCHK(h, hipMemcpyAsync(top_val, h->dtopv, (size_t)k * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipMemcpyAsync(top_idx, h->dtopi, (size_t)k * 8, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
@@ -503,11 +534,12 @@ static int sweep_core(gpx_handle* h, int acq_id, const double* params, int npara
     if (k < 0 || k > TOPK_MAX) return fail(h, GPX_EARG, "sweep: k must be in [0, 64]");
     if (k > 0 && (!top_val || !top_idx)) return fail(h, GPX_EARG, "sweep: NULL top-k output");
     HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure_inverse(h))) return rc;
     hipStream_t s = h->stream;
     const int64_t Np = h->Np;
     const int nP = (int)(Np / NB);
     const int64_t chunk = std::min<int64_t>(h->chunk, (M + TBH - 1) / TBH * TBH);
-    int rc;
     if ((rc = ensure(h, h->dKs, h->cap_ks, Np * chunk))) return rc;
     if ((rc = ensure(h, h->dQp, h->cap_part, (int64_t)nP * chunk * 2))) return rc;
     h->dPp = h->dQp + (int64_t)nP * chunk;
@@ -661,6 +693,7 @@ static int rff_core(gpx_handle* h, const double* W, const double* b, const doubl
             for (int64_t q = 0; q < S; ++q)
                 launch_topk(s, d_vals + q * M, M, (int)k, h->dblkv, h->dblki, nblk, tv + q * k, ti + q * k);
         }
+        h->last_topv = tv; h->last_topi = ti; h->last_topn = S * k;
         HIPCHK(h, hipMemcpyAsync(top_val, tv, (size_t)S * k * 8, hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipMemcpyAsync(top_idx, ti, (size_t)S * k * 8, hipMemcpyDeviceToHost, s));
     }

@@ -14,10 +14,10 @@
 // the two 32-lane groups of a ds_read_b64 hit disjoint bank halves -> conflict-free.
 // Result layout (f64 MFMA, NOT the f32 map): D[row = (lane>>4) + 4*r][col = lane&15], r = 0..3.
 //
-// K is stepped 16 at a time through a 2-deep LDS ring (register-staged: the global loads of step
-// t+1 are issued before the 64 MFMAs of step t and written to the other LDS buffer after them;
-// one barrier per step).  fp64 MFMA is 64 cycles/instruction/SIMD, so one k-step is ~4096 matrix
-// cycles per wave against 8 x 16-B global loads and 8 ds_write_b128 per thread.
+// Two k-loop schedules (same arithmetic order, bit-identical results): gemm_tile_128_g steps K 32 at a time
+// through a single LDS buffer (default everywhere), gemm_tile_128_b 16 at a time through a 2-deep ring.
+// fp64 MFMA is 64 cycles/instruction/SIMD: a 32-row k-step is ~8192 matrix cycles per wave against
+// 16 x 16-B global loads and 16 ds_write_b128 per thread.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -41,93 +41,19 @@ __device__ __forceinline__ void acc_zero(d4 (&acc)[4][4]) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
 }
 
-// A, B already point at (k = 0, m = tile origin) / (k = 0, n = tile origin).
-// k_lo, k_hi are multiples of BK; all 256 threads of the workgroup must call this.
-__device__ __forceinline__ void gemm_tile_128(d4 (&acc)[4][4], const double* __restrict__ A,
-                                              int64_t lda, const double* __restrict__ B,
-                                              int64_t ldb, int k_lo, int k_hi, double* smem) {
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int w = t >> 6;
-    const int wm = w >> 1, wn = w & 1;
-    double* As = smem;                  // [2][BK][LDT]
-    double* Bs = smem + 2 * BK * LDT;   // [2][BK][LDT]
-
-    // global->LDS staging map: wave w loads row (w + 4p) of the k-slab, lane -> 16-B chunk
-    const int lrow = w;
-    const int lcol = lane * 2;
-    d2 ra[4], rb[4];
-
-    const int nk = (k_hi - k_lo) / BK;
-    if (nk <= 0) return;
-
-    const double* Ap = A + (int64_t)(k_lo + lrow) * lda + lcol;
-    const double* Bp = B + (int64_t)(k_lo + lrow) * ldb + lcol;
-
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        ra[p] = *reinterpret_cast<const d2*>(Ap + (int64_t)(4 * p) * lda);
-        rb[p] = *reinterpret_cast<const d2*>(Bp + (int64_t)(4 * p) * ldb);
-    }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        *reinterpret_cast<d2*>(As + (lrow + 4 * p) * LDT + lcol) = ra[p];
-        *reinterpret_cast<d2*>(Bs + (lrow + 4 * p) * LDT + lcol) = rb[p];
-    }
-    __syncthreads();
-
-    const int fr = lane & 15;   // fragment row/col within a 16x16 MFMA tile
-    const int fk = lane >> 4;   // fragment k within the 4-deep MFMA
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        const bool more = (kt + 1 < nk);
-        if (more) {
-            Ap += (int64_t)BK * lda;
-            Bp += (int64_t)BK * ldb;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                ra[p] = *reinterpret_cast<const d2*>(Ap + (int64_t)(4 * p) * lda);
-                rb[p] = *reinterpret_cast<const d2*>(Bp + (int64_t)(4 * p) * ldb);
-            }
-        }
-        const double* as = As + buf * BK * LDT + wm * 64 + fr;
-        const double* bs = Bs + buf * BK * LDT + wn * 64 + fr;
-#pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            const int kr = kk * 4 + fk;
-            double a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = as[kr * LDT + i * 16];
-                b[i] = bs[kr * LDT + i * 16];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        if (more) {
-            const int nb = buf ^ 1;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                *reinterpret_cast<d2*>(As + nb * BK * LDT + (lrow + 4 * p) * LDT + lcol) = ra[p];
-                *reinterpret_cast<d2*>(Bs + nb * BK * LDT + (lrow + 4 * p) * LDT + lcol) = rb[p];
-            }
-        }
-        __syncthreads();
-    }
-}
-
-
-// Variant B of the k-loop ("write-at-top", prefetch distance 2): the global loads of tile t+2 are issued
-// right after the registers holding tile t+1 have been written to LDS at the TOP of step t, so the
+// A, B already point at (k = 0, m = tile origin) / (k = 0, n = tile origin); k_lo, k_hi are multiples of BK;
+// all 256 threads of the workgroup must call this.
+//
+// k-loop on the 2 x 16-row LDS ring ("write-at-top", prefetch distance 2): the global loads of tile t+2 are
+// issued right after the registers holding tile t+1 have been written to LDS at the TOP of step t, so the
 // end-of-step barrier never waits on a fresh ds_write (its lgkmcnt is a whole MFMA phase old) and the
 // vmcnt wait at the top is for loads issued one full step earlier.  PRIO: raise the wave priority around
 // the MFMA phase so that, of the two workgroups sharing a CU, the one in its matrix phase owns the pipe
 // and the other one's staging/sync phase fills the gaps.
-template <bool PRIO, int ABLATE = 0>   // ABLATE (timing experiments only): 1 = no global loads / LDS writes after tile 0, 2 = no barrier
+// (Round 1 also carried a write-at-end ring, a register-double-buffered fragment pipeline and an LDS-DMA
+// staging variant; all tied or lost against the two schedules kept here -- DESIGN.md section 4 -- and were
+// removed.  This one stays as the second, independently scheduled witness of the bit-identity test.)
+template <bool PRIO>
 __device__ __forceinline__ void gemm_tile_128_b(d4 (&acc)[4][4], const double* __restrict__ A, int64_t lda,
                                                 const double* __restrict__ B, int64_t ldb, int k_lo,
                                                 int k_hi, double* smem) {
@@ -167,7 +93,7 @@ __device__ __forceinline__ void gemm_tile_128_b(d4 (&acc)[4][4], const double* _
     const int fr = lane & 15, fk = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (ABLATE != 1 && kt + 1 < nk) {
+        if (kt + 1 < nk) {
             swrite(buf ^ 1);                 // tile kt+1 (loaded during step kt-1)
             if (kt + 2 < nk) gload();        // tile kt+2, consumed at the top of step kt+1
         }
@@ -190,161 +116,12 @@ __device__ __forceinline__ void gemm_tile_128_b(d4 (&acc)[4][4], const double* _
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (PRIO) __builtin_amdgcn_s_setprio(0);
-        if (ABLATE != 2) __syncthreads();
-    }
-}
-
-
-// Variant D: software-pipelined k-loop.
-//   * operand fragments are double-buffered in registers (F0/F1), each MFMA group of 16 runs while the
-//     next group's fragments are being read from LDS;
-//   * the per-step barrier sits BEFORE the last MFMA group: once every wave has read its last fragments
-//     of this step (and the next tile's LDS image is complete) the first fragments of the NEXT step are
-//     requested, and the 16 pending MFMAs cover that LDS latency;
-//   * the LDS writes of tile t+1 and the global loads of tile t+2 are issued right after the first MFMA
-//     group of step t, i.e. in the shadow of 64-cycle matrix instructions instead of in front of them.
-template <bool PRIO>
-__device__ __forceinline__ void gemm_tile_128_d(d4 (&acc)[4][4], const double* __restrict__ A, int64_t lda,
-                                                const double* __restrict__ B, int64_t ldb, int k_lo,
-                                                int k_hi, double* smem) {
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int w = t >> 6;
-    const int wm = w >> 1, wn = w & 1;
-    double* As = smem;
-    double* Bs = smem + 2 * BK * LDT;
-    const int lrow = w;
-    const int lcol = lane * 2;
-    d2 ra[4], rb[4];
-    const int nk = (k_hi - k_lo) / BK;
-    if (nk <= 0) return;
-    const double* Ap = A + (int64_t)(k_lo + lrow) * lda + lcol;
-    const double* Bp = B + (int64_t)(k_lo + lrow) * ldb + lcol;
-    auto gload = [&]() {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            ra[p] = *reinterpret_cast<const d2*>(Ap + (int64_t)(4 * p) * lda);
-            rb[p] = *reinterpret_cast<const d2*>(Bp + (int64_t)(4 * p) * ldb);
-        }
-        Ap += (int64_t)BK * lda;
-        Bp += (int64_t)BK * ldb;
-    };
-    auto swrite = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            *reinterpret_cast<d2*>(As + buf * BK * LDT + (lrow + 4 * p) * LDT + lcol) = ra[p];
-            *reinterpret_cast<d2*>(Bs + buf * BK * LDT + (lrow + 4 * p) * LDT + lcol) = rb[p];
-        }
-    };
-    const int fr = lane & 15, fk = lane >> 4;
-    const double* as0 = As + wm * 64 + fr + fk * LDT;
-    const double* bs0 = Bs + wn * 64 + fr + fk * LDT;
-    double a0[4], b0[4], a1[4], b1[4];
-#define GPX_FRAG(FA, FB, BUF, KK)                                        \
-    {                                                                    \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                  \
-            FA[i] = as0[(BUF) * BK * LDT + (KK) * 4 * LDT + i * 16];     \
-            FB[i] = bs0[(BUF) * BK * LDT + (KK) * 4 * LDT + i * 16];     \
-        }                                                                \
-    }
-#define GPX_MFMA16(FA, FB)                                                                            \
-    {                                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)   \
-            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(FA[i], FB[j], acc[i][j], 0, 0, 0);       \
-    }
-    gload();              // tile 0
-    swrite(0);
-    if (nk > 1) gload();  // tile 1 stays in registers until step 0
-    __syncthreads();
-    GPX_FRAG(a0, b0, 0, 0);
-    if (PRIO) __builtin_amdgcn_s_setprio(1);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        GPX_FRAG(a1, b1, buf, 1);
-        GPX_MFMA16(a0, b0);
-        if (kt + 1 < nk) {
-            swrite(buf ^ 1);             // tile kt+1 (loaded during step kt-1)
-            if (kt + 2 < nk) gload();    // tile kt+2
-        }
-        GPX_FRAG(a0, b0, buf, 2);
-        GPX_MFMA16(a1, b1);
-        GPX_FRAG(a1, b1, buf, 3);
-        GPX_MFMA16(a0, b0);
-        __syncthreads();                 // everyone has read buffer `buf`; buffer `buf^1` is complete
-        if (kt + 1 < nk) GPX_FRAG(a0, b0, buf ^ 1, 0);
-        __builtin_amdgcn_sched_barrier(0);   // keep the 16 MFMAs below AFTER the reads above
-        GPX_MFMA16(a1, b1);
-    }
-    if (PRIO) __builtin_amdgcn_s_setprio(0);
-    __syncthreads();   // callers reuse the LDS right after
-#undef GPX_FRAG
-#undef GPX_MFMA16
-}
-
-// Variant E: LDS-DMA staging.  Each wave moves whole 1 KiB k-rows global -> LDS with
-// global_load_lds_dwordx4 (LDS destination = wave-uniform row base + lane*16, exactly the padded k-major
-// image the fragment reads expect), so there are no staging VGPRs and no ds_write pass.  The DMA for
-// tile t+1 is issued at the top of step t into the other buffer and drained (vmcnt(0)) just before the
-// end-of-step barrier, a full MFMA phase later.
-template <bool PRIO>
-__device__ __forceinline__ void gemm_tile_128_e(d4 (&acc)[4][4], const double* __restrict__ A, int64_t lda,
-                                                const double* __restrict__ B, int64_t ldb, int k_lo,
-                                                int k_hi, double* smem) {
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int w = t >> 6;
-    const int wm = w >> 1, wn = w & 1;
-    double* As = smem;
-    double* Bs = smem + 2 * BK * LDT;
-    const int nk = (k_hi - k_lo) / BK;
-    if (nk <= 0) return;
-    const double* Ap = A + (int64_t)(k_lo + w) * lda + lane * 2;
-    const double* Bp = B + (int64_t)(k_lo + w) * ldb + lane * 2;
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-    auto dma = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(Ap + (int64_t)(4 * p) * lda),
-                                             (lds_ptr_t)(As + buf * BK * LDT + (w + 4 * p) * LDT), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(Bp + (int64_t)(4 * p) * ldb),
-                                             (lds_ptr_t)(Bs + buf * BK * LDT + (w + 4 * p) * LDT), 16, 0, 0);
-        }
-        Ap += (int64_t)BK * lda;
-        Bp += (int64_t)BK * ldb;
-    };
-    dma(0);
-    __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0) lgkmcnt(0) expcnt(0)
-    __syncthreads();
-    const int fr = lane & 15, fk = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) dma(buf ^ 1);
-        const double* as = As + buf * BK * LDT + wm * 64 + fr;
-        const double* bs = Bs + buf * BK * LDT + wn * 64 + fr;
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            const int kr = kk * 4 + fk;
-            double a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = as[kr * LDT + i * 16];
-                b[i] = bs[kr * LDT + i * 16];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_s_waitcnt(0);   // this wave's DMA rows have landed
         __syncthreads();
     }
 }
 
-// Variant G: k-step of 32 through a SINGLE LDS buffer (same 73,728 B, so still two workgroups per CU):
+
+// DEFAULT k-loop: k-step of 32 through a SINGLE LDS buffer (same 73,728 B, so still two workgroups per CU):
 // 128 MFMAs per wave between staging phases instead of 64, i.e. half as many step boundaries per flop.  The
 // staging phase (barrier - LDS write - barrier) is exposed inside a workgroup and relies on the co-resident
 // workgroup to keep the matrix pipe busy meanwhile.

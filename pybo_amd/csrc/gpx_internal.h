@@ -33,7 +33,8 @@ struct gpx_handle {
 
     // model state
     bool fitted = false;
-    int stage = 0;               // 0 none, 1 gram, 2 chol, 3 full
+    int stage = 0;               // 0 none, 1 gram, 2 chol (fitted; T/U/a/alpha not formed yet), 3 + inverse
+    bool eager_inverse = false;  // option: form the inverse inside the fit (timing experiments)
     int64_t N = 0, Np = 0, d = 0;
     int kernel_id = 0;
     double rho = 1, sn2 = 0, bias = 0;
@@ -75,6 +76,9 @@ struct gpx_handle {
     double* dtopv = nullptr;  // final top-k (S*k)
     int64_t* dtopi = nullptr;
     int64_t cap_top = 0;
+    const double* last_topv = nullptr;   // device (value, index) pairs of the last sweep's top-k, read by
+    const int64_t* last_topi = nullptr;  // gpx_topk_allgather
+    int64_t last_topn = 0;
     double* drff = nullptr;   // RFF parameter staging
     int64_t cap_rff = 0;
     double* drffs = nullptr;  // RFF feature-Gram scratch (Phi slabs + split-K partials)
@@ -116,11 +120,16 @@ void launch_acq(hipStream_t s, const double* Qp, const double* Pp, int64_t ldp, 
 // block-local top-k over vals[0..M) then merge -> topv/topi (k entries)
 void launch_topk(hipStream_t s, const double* vals, int64_t M, int k, double* blkv, int64_t* blki,
                  int64_t nblk, double* topv, int64_t* topi);
+// merge n candidate (value, index) pairs (index == INT64_MAX: no entry; consumed in place) into the k best
+void launch_topk_merge(hipStream_t s, double* vals, int64_t* idx, int64_t n, int k, double* topv, int64_t* topi);
 int64_t topk_blocks(int64_t M);
 
 // predict with gradients (small M path)
 int predict_grad_host(gpx_handle* h, const double* Xc, int64_t M, double* mu, double* s2, double* dmu,
                       double* ds2);
+
+// form T, U, a, alpha if the current fit has not done so yet (api.hip)
+int ensure_inverse(gpx_handle* h);
 
 int loglik_host(gpx_handle* h, double* out);
 int append_host(gpx_handle* h, const double* x, double ynew);

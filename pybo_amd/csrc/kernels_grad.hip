@@ -43,7 +43,9 @@ __device__ __forceinline__ void kern_and_grad(int kid, double r2, double rho, do
         default: {
             const double r = sqrt(r2);
             k = rho * exp_nonpos(-r);
-            g = -0.5 * k / r;
+            // exp(-r) has a kink at r = 0 (a candidate on top of an observation: the L-BFGS seeds of the
+            // recommender ARE observations): dk/dx is +-1 from either side, take the symmetric value 0
+            g = (r > 0.0) ? -0.5 * k / r : 0.0;
         }
     }
 }
@@ -158,6 +160,7 @@ int predict_grad_host(gpx_handle* h, const double* Xc, int64_t M, double* mu, do
     if (!h->fitted) { h->err = "predict: model is not fitted"; return GPX_ESTATE; }
     if (!Xc || M < 1) { h->err = "predict: need M >= 1 points"; return GPX_EARG; }
     if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return GPX_EHIP; }
+    if (int rc0 = ensure_inverse(h)) return rc0;
     hipStream_t s = h->stream;
     const int64_t Np = h->Np, N = h->N;
     const int d = (int)h->d;
@@ -292,6 +295,7 @@ int append_host(gpx_handle* h, const double* x, double ynew) {
     if (!x) { h->err = "append: NULL point"; return GPX_EARG; }
     if (h->N >= h->Np) { h->err = "append: no padding left in the current 128-block (refit)"; return GPX_ESTATE; }
     if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return GPX_EHIP; }
+    if (int rc0 = ensure_inverse(h)) return rc0;     // the rank-1 extension updates T, U, a, alpha in place
     hipStream_t s = h->stream;
     const int64_t Np = h->Np, N = h->N;
     const int d = (int)h->d;
@@ -364,6 +368,7 @@ int loglik_host(gpx_handle* h, double* out) {
     if (!h->fitted) { h->err = "loglik: model is not fitted"; return GPX_ESTATE; }
     if (!out) { h->err = "loglik: NULL output"; return GPX_EARG; }
     if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return GPX_EHIP; }
+    if (int rc0 = ensure_inverse(h)) return rc0;     // a = T (y - bias)
     hipLaunchKernelGGL(k_loglik, dim3(1), dim3(256), 0, h->stream, h->dR, h->Np, h->N, h->da, h->dscal + 8);
     if (hipMemcpyAsync(out, h->dscal + 8, 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
         hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) {

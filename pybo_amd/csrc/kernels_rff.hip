@@ -237,7 +237,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_rff_gram_sk(const double* _
     const double* P = Phi + (int64_t)s * Np * TB;
     d4 acc[4][4];
     acc_zero(acc);
-    if (k_lo < k_hi) gemm_tile_128(acc, P, TB, P, TB, (int)k_lo, (int)k_hi, smem);
+    if (k_lo < k_hi) gemm_tile_128_b<false>(acc, P, TB, P, TB, (int)k_lo, (int)k_hi, smem);
     double* out = part + ((int64_t)s * RFF_SPLIT + sp) * TB * TB;
 #pragma unroll
     for (int i = 0; i < 4; ++i)

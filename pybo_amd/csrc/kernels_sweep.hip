@@ -163,11 +163,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __
     const int64_t m0 = (int64_t)mt * TB, n0 = (int64_t)nt * TB;
     d4 acc[4][4];
     acc_zero(acc);
-    if (VAR == 0) gemm_tile_128(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
-    else if (VAR == 1) gemm_tile_128_b<false>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
-    else if (VAR == 2) gemm_tile_128_b<true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
-    else if (VAR == 3) gemm_tile_128_d<true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
-    else if (VAR == 4) gemm_tile_128_e<true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
+    if (VAR == 2) gemm_tile_128_b<true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
     else gemm_tile_128_g<true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
 
     // epilogue: column sums of V^2 and V*a over this tile's 128 rows
@@ -197,7 +193,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __
         qs[j] = q;
         ps[j] = p;
     }
-    double* red = smem;  // [2][128][2]; gemm_tile_128 ended on a barrier, LDS is free
+    double* red = smem;  // [2][128][2]; the k-loop ended on a barrier, LDS is free
     if (lane < 16) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -239,21 +235,9 @@ void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double*
     } else {
         nblk = (unsigned)(NT * nP);
     }
-    const int order = tile_order & 3, var = tile_order >> 2;   // bits 0-1: tile map, bits 2..: k-loop variant
-    if (var == 0)
-        hipLaunchKernelGGL(k_sweep_trmm<0>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
-                           ldp, order, super_m);
-    else if (var == 1)
-        hipLaunchKernelGGL(k_sweep_trmm<1>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
-                           ldp, order, super_m);
-    else if (var == 2)
+    const int order = tile_order & 3, var = tile_order >> 2;   // bits 0-1: tile map, bits 2-4: k-loop (2 or 5)
+    if (var == 2)
         hipLaunchKernelGGL(k_sweep_trmm<2>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
-                           ldp, order, super_m);
-    else if (var == 3)
-        hipLaunchKernelGGL(k_sweep_trmm<3>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
-                           ldp, order, super_m);
-    else if (var == 4)
-        hipLaunchKernelGGL(k_sweep_trmm<4>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
                            ldp, order, super_m);
     else
         hipLaunchKernelGGL(k_sweep_trmm<5>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
@@ -399,6 +383,10 @@ __global__ __launch_bounds__(256) void k_topk_merge(double* __restrict__ blkv, i
         if (threadIdx.x == 0) { topv[it] = bv; topi[it] = (bi == GPX_IDX_NONE) ? -1 : bi; }
         __syncthreads();
     }
+}
+
+void launch_topk_merge(hipStream_t s, double* vals, int64_t* idx, int64_t n, int k, double* topv, int64_t* topi) {
+    hipLaunchKernelGGL(k_topk_merge, dim3(1), dim3(256), 0, s, vals, idx, n, k, topv, topi);
 }
 
 int64_t topk_blocks(int64_t M) { return (M + TK_PER_BLOCK - 1) / TK_PER_BLOCK; }

@@ -71,23 +71,30 @@ class RFFSampleDevice(object):
     """One RFF posterior function sample; `.get(X, grad=False)` evaluates on the device."""
 
     def __init__(self, model, W, b, theta):
-        self._model, self.W, self.b, self.theta = model, W, b, theta
+        # the sample is a fixed function: the mean offset is captured now, later hyper-parameter changes of
+        # the model do not alter it
+        self._model, self.W, self.b, self.theta, self.bias = model, W, b, theta, float(model.bias)
+
+    def _eng(self):
+        # evaluating the feature expansion needs a device handle but no fit (a prior sample of a model
+        # without data is a valid Thompson index)
+        return self._model._any_engine()
 
     def get(self, X, grad=False):
         X = np.array(X, ndmin=2, dtype=float)
-        eng = self._model._engine()
+        eng = self._eng()
         if grad:
-            return eng.rff_eval_grad(self.W, self.b, self.theta, self._model.bias, X)
-        out = eng.rff_sweep(self.W[None], self.b[None], self.theta[None], self._model.bias, X, k=0)
+            return eng.rff_eval_grad(self.W, self.b, self.theta, self.bias, X)
+        out = eng.rff_sweep(self.W[None], self.b[None], self.theta[None], self.bias, X, k=0)
         return out['vals'][0]
 
     def topk(self, xgrid, k):
-        eng = self._model._engine()
+        eng = self._eng()
         if isinstance(xgrid, DeviceGrid):            # grid already resident in HBM
-            tv, ti = eng.rff_sweep_dev(self.W[None], self.b[None], self.theta[None], self._model.bias,
+            tv, ti = eng.rff_sweep_dev(self.W[None], self.b[None], self.theta[None], self.bias,
                                        xgrid.ptr, len(xgrid), int(k))
             return tv[0], ti[0]
-        out = eng.rff_sweep(self.W[None], self.b[None], self.theta[None], self._model.bias, xgrid, k=int(k),
+        out = eng.rff_sweep(self.W[None], self.b[None], self.theta[None], self.bias, xgrid, k=int(k),
                             want_all=False)
         return out['top_val'][0], out['top_idx'][0]
 
@@ -179,6 +186,15 @@ class GP(object):
             st.engine.fit(self._X, self._Y, self.kernel, self.ell, self.rho, self.sn2, self.bias)
             st.key = self._hyper_key()
             self._fitted = True
+        return self._state.engine
+
+    def _any_engine(self):
+        """A device handle for work that needs no fit (RFF feature evaluation): the fitted engine when there is
+        data, otherwise this model's (possibly still empty) device state."""
+        if self.ndata > 0:
+            return self._engine()
+        if self._state is None:
+            self._state = _DeviceState(self.device)
         return self._state.engine
 
     # -- protocol ------------------------------------------------------------------------------

@@ -9,9 +9,11 @@ reggie's sampler is not available (absent, unpinned), so the algorithm here is t
 stated in full:
   * state  theta = [log sn2, log rho, log ell_1..d, bias];  target  log p(y | theta) + log prior(theta)
     (+ the log-Jacobian of the log transform), priors as recorded on `model.params` (priors.py);
-  * one sample = one slice-sampling update (Neal 2003) along a random direction  sigma * scale * N(0, I)
-    (scale = 1 for the log-parameters, sqrt(rho) for the bias): bracket by stepping out (<= 8 doublings of
-    unit steps each side), then shrinkage;
+  * one sample = one slice-sampling update (Neal 2003) along a random direction  scale * N(0, I) with a
+    STATE-INDEPENDENT scale (1 for the log-parameters; for the bias the signal std sqrt(rho) of the model the
+    ensemble was built from, frozen at construction -- a scale that moved with the chain's own rho would make
+    the update irreversible): bracket by stepping out in unit steps (at most 16 expansions, split at random
+    between the sides as in Neal's fig. 3), then shrinkage;
   * `burn` updates are discarded at construction, then `n` are kept; `add_data` continues the chain from
     its last state and keeps the next `n` samples (no new burn-in).
 Each log-likelihood evaluation is one fit of the member model -- on the device for `pybo_amd.models.GP`
@@ -46,27 +48,29 @@ def _log_target(model, theta):
         return -np.inf
 
 
-def _slice_update(model, theta, lp, rng, sigma=1.0, max_out=8):
-    """One slice-sampling update along a random direction; returns (theta', lp')."""
-    d = len(theta) - 3
-    scale = np.ones(len(theta))
-    scale[-1] = np.sqrt(np.exp(theta[1]))        # the bias moves on the scale of the signal std
-    direction = sigma * scale * rng.randn(len(theta))
+def _slice_update(logp, theta, lp, rng, scale, max_out=16):
+    """One slice-sampling update (Neal 2003, fig. 3 + fig. 5) of `theta` along a random direction
+    scale * N(0, I); returns (theta', lp').  `logp` is the log target density (callable), `lp` its value at
+    `theta`.  `scale` is a vector that must NOT depend on the current state: the direction has to be drawn
+    from the same distribution at theta and at theta' for the update to leave the target invariant.
+    The bracket grows by stepping out in unit steps with the total number of expansions capped at `max_out`
+    and split at random between the two sides (Neal's J/K rule), then shrinks towards the current point."""
+    direction = scale * rng.randn(len(theta))
     level = lp + np.log(rng.rand())
     r = rng.rand()
     lo, hi = -r, 1.0 - r
-    for _ in range(max_out):
-        if _log_target(model, theta + lo * direction) <= level:
-            break
+    nlo = int(np.floor(max_out * rng.rand()))
+    nhi = (max_out - 1) - nlo
+    while nlo > 0 and logp(theta + lo * direction) > level:
         lo -= 1.0
-    for _ in range(max_out):
-        if _log_target(model, theta + hi * direction) <= level:
-            break
+        nlo -= 1
+    while nhi > 0 and logp(theta + hi * direction) > level:
         hi += 1.0
+        nhi -= 1
     while True:
         t = lo + (hi - lo) * rng.rand()
         cand = theta + t * direction
-        lpc = _log_target(model, cand)
+        lpc = logp(cand)
         if lpc > level:
             return cand, lpc
         if t < 0:
@@ -83,6 +87,8 @@ class MCMC(object):
         self._n = int(n)
         self._rng = rstate(rng)
         self._theta = np.array(self._proto.hyper_vector(), dtype=float)
+        self._scale = np.ones(len(self._theta))
+        self._scale[-1] = np.sqrt(np.exp(self._theta[1]))   # bias moves on the INITIAL signal std (frozen)
         self._lp = None
         self._members = []
         self._bind_hooks()
@@ -102,8 +108,9 @@ class MCMC(object):
             if not np.isfinite(self._lp):
                 raise ValueError('MCMC: the initial hyper-parameters have zero posterior density')
         kept = []
+        logp = lambda th: _log_target(self._proto, th)      # noqa: E731
         for _ in range(nsteps):
-            self._theta, self._lp = _slice_update(self._proto, self._theta, self._lp, self._rng)
+            self._theta, self._lp = _slice_update(logp, self._theta, self._lp, self._rng, self._scale)
             kept.append(self._theta.copy())
         if keep:
             members = []
@@ -139,6 +146,7 @@ class MCMC(object):
         new._n = self._n
         new._rng = self._rng                     # shared stream, as a chain continued from a copy would
         new._theta = self._theta.copy()
+        new._scale = self._scale.copy()
         new._lp = self._lp
         new._members = [m.copy() for m in self._members]
         new._bind_hooks()
@@ -216,11 +224,12 @@ class MCMC(object):
     # -- pickling: hyper-parameter states + data, members are rebuilt on load -------------------------
     def __getstate__(self):
         # (the bound acq_topk hook is re-created on load)
-        return dict(proto=self._proto, n=self._n, rng=self._rng, theta=self._theta,
+        return dict(proto=self._proto, n=self._n, rng=self._rng, theta=self._theta, scale=self._scale,
                     samples=[np.array(m.hyper_vector()) for m in self._members])
 
     def __setstate__(self, st):
         self._proto, self._n, self._rng, self._theta = st['proto'], st['n'], st['rng'], st['theta']
+        self._scale = st['scale']
         self._lp = None
         self._members = []
         for th in st['samples']:

@@ -26,7 +26,7 @@ import numpy as np
 import scipy.optimize
 
 from ..inits import init_uniform
-from .._lib import DeviceGrid
+from .._lib import DeviceGrid, TOPK_MAX
 
 __all__ = ['solve_lbfgs']
 
@@ -113,6 +113,12 @@ def solve_lbfgs(f, bounds, nbest=10, ngrid=10000, xgrid=None, rng=None, select='
         xgrid = np.array(xgrid, ndmin=2, dtype=float)
 
     k = min(int(nbest), len(xgrid))
+    if topk is not None and k > TOPK_MAX:
+        # the device top-k keeps at most TOPK_MAX entries; the reference accepts any nbest
+        # (pybo/solvers/lbfgs.py:51 is a full argsort), so larger requests rank the values on the host
+        topk = None
+        if isinstance(xgrid, DeviceGrid):
+            xgrid = np.asarray(xgrid)
     if topk is not None:
         _, best = topk(xgrid, k)
         best = np.asarray(best, dtype=int)

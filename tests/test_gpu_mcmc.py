@@ -72,6 +72,8 @@ def test_default_model_path_end_to_end():
 
 def test_animated_demo_headless_on_the_device():
     from pybo_amd.demos import animated
-    X, Y, xb = animated.run(niter=20, rng=0, verbose=False)
-    assert X.shape == (23, 1) and np.all(X >= 0.5) and np.all(X <= 2.5)
+    # the demo's own 30 iterations (pybo/demos/animated.py): with a correct hyper-parameter sampler 20 are not
+    # enough for this multimodal function on most seeds (checked against the CPU oracle driving the same loop)
+    X, Y, xb = animated.run(niter=30, rng=0, verbose=False)
+    assert X.shape == (33, 1) and np.all(X >= 0.5) and np.all(X <= 2.5)
     assert abs(X[np.argmax(Y)][0] - animated.XOPT) < 3e-2 and Y.max() > 0.8
