@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X datasheet fp64 matrix (= fp64 vector) peak, dense
 HBM_PEAK_GBS = 8000.0
+PMC_TRAFFIC_FILE = 'r01_pmc_traffic.json'
 
 
 def hartmann6(X):
@@ -125,11 +126,13 @@ def cpu_baseline(w, budget_candidates):
     int(np.argmax(v))
     t_sw = time.perf_counter() - t0
     step = t_fit + t_sw * (w['M'] / float(len(Z)))
+    how = 'in full' if len(Z) == w['M'] else 'extrapolated linearly to M'
     return dict(value=1.0 / step, unit='steps/s', cores=int(threads), kind='port',
-                sample='fit in full (N=%d: %.2f s) + sweep on %d of %d candidates (%.2f s), sweep extrapolated '
-                       'linearly to M; host has %d logical cpus, %d in affinity'
-                       % (w['N'], t_fit, len(Z), w['M'], t_sw, os.cpu_count(), len(os.sched_getaffinity(0))),
-                seconds_per_step=step)
+                sample='fit in full (N=%d: %.2f s) + sweep on %d of %d candidates (%.2f s), sweep %s; '
+                       'numpy/scipy on %d BLAS threads; host has %d logical cpus, %d in affinity'
+                       % (w['N'], t_fit, len(Z), w['M'], t_sw, how, threads, os.cpu_count(),
+                          len(os.sched_getaffinity(0))),
+                extrapolated=len(Z) != w['M'], seconds_per_step=step)
 
 
 def main():
@@ -149,6 +152,9 @@ def main():
                     help='process-group backend; gloo only for dry runs of the N>1 path')
     ap.add_argument('--share-device', type=int, default=-1,
                     help='dry run: every rank uses this one GPU (with --backend gloo)')
+    ap.add_argument('--exchange', default='torch', choices=['torch', 'gpx'],
+                    help="transport of the top-k exchange: torch.distributed (default) or libgpx's own RCCL "
+                         "binding (gpx_topk_allgather; needs one GPU per rank)")
     args = ap.parse_args()
 
     import torch
@@ -186,6 +192,12 @@ def main():
     if args.tile_order >= 0:
         eng.set_option('tile_order', args.tile_order)
     Ml = hi_i - lo_i
+    comm = None
+    if world > 1 and args.exchange == 'gpx':
+        from pybo_amd._lib import Comm
+        box = [Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = Comm(eng, rank, world, box[0])
 
     thompson = None
     if w['acq'] == 'thompson':
@@ -224,18 +236,16 @@ def main():
             elif w['acq'] == 'ucb':
                 param = ucb_beta(N)
             tv, ti = eng.sweep_dev(w['acq'], param, dXc.data_ptr(), Ml, k)
-            ti = ti + lo_i
+            ti = np.where(ti >= 0, ti + lo_i, ti)
         if world > 1:
-            if w['acq'] == 'thompson':      # one (value, index) pair per draw: concatenate all ranks' draws
-                kk = len(tv)
-                cdev = dev if args.backend == 'nccl' else torch.device('cpu')
-                tvals = torch.from_numpy(np.ascontiguousarray(tv)).to(cdev)
-                tidx = torch.from_numpy(np.ascontiguousarray(ti)).to(cdev)
-                allv = torch.empty(world * kk, dtype=torch.float64, device=cdev)
-                alli = torch.empty(world * kk, dtype=torch.int64, device=cdev)
-                dist.all_gather_into_tensor(allv, tvals)
-                dist.all_gather_into_tensor(alli, tidx)
-                return allv.cpu().numpy(), alli.cpu().numpy()   # the q recommendations: w['Xc'][alli]
+            if w['acq'] == 'thompson':
+                # one (value, index) pair per draw, draws sharded over ranks: ONE all-gather, no merge
+                # (the q recommendations are w['Xc'][indices])
+                if comm is not None:
+                    return comm.topk_allgather(len(tv), 0, 0)
+                return pdist.gather_pairs(tv, ti)
+            if comm is not None:                     # libgpx's own RCCL binding: device -> xGMI -> device merge
+                return comm.topk_allgather(k, lo_i, k)
             return pdist.gather_topk(tv, ti, k)      # RCCL all-gather + deterministic merge
         return tv, ti
 
@@ -286,7 +296,7 @@ def main():
             # counters itself); only reported when this run's launch geometry is the profiled one
             traffic = None
             try:
-                pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+                pmc = json.load(open(os.path.join(ROOT, 'profiles', PMC_TRAFFIC_FILE)))
                 cols = tm['sweep_trmm_flop'] / max(launches, 1) / (float(N) * N)
                 if pmc['config']['Np'] == Np_ and abs(cols - pmc['config']['cols_per_launch']) < 1:
                     traffic = pmc['k_sweep_trmm']['traffic_bytes_per_launch']
@@ -296,19 +306,32 @@ def main():
             out['roofline'] = {'kernel': 'k_sweep_trmm', 'bound': 'mfma', 'achieved': ach,
                                'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': ach / FP64_MFMA_PEAK_TFLOPS, 'traffic': traffic,
-                               'traffic_unit': 'bytes/launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, '
-                                               'profiles/r01_pmc_traffic.json)',
+                               'traffic_unit': 'bytes/launch',
+                               'traffic_source': 'profile: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE) of this '
+                                                 'launch geometry, committed as profiles/%s -- a profile-time '
+                                                 'constant, NOT collected during this run' % PMC_TRAFFIC_FILE,
                                'launches': int(launches),
                                'avg_launch_ms': tm['sweep_trmm'] / max(launches, 1),
                                'flop_per_launch': tm['sweep_trmm_flop'] / max(launches, 1)}
-        elif tm['cholesky'] > 0:
-            Np = (N + 127) // 128 * 128
-            ach = (Np ** 3 / 3.0) * args.steps / (tm['cholesky'] * 1e-3) / 1e12
-            out['roofline'] = {'kernel': 'cholesky (potrf_diag + panel_trsm + syrk_update)', 'bound': 'mfma',
-                               'achieved': ach, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': ach / FP64_MFMA_PEAK_TFLOPS, 'traffic': None}
+        # the fit's two MFMA stages against the same peak (algorithmic N^3/3 flop each), for EVERY workload:
+        # the replicated fit is what bounds strong scaling
+        fit = {}
+        for stage, label in (('cholesky', 'cholesky (k_potrf_diag + k_panel_trsm + k_row_update64 + k_syrk_update)'),
+                             ('trtri', 'triangular inverse (k_trtri_gemm1/2)')):
+            if tm[stage] > 0:
+                ach = (float(N) ** 3 / 3.0) * args.steps / (tm[stage] * 1e-3) / 1e12
+                fit[stage] = {'kernel': label, 'bound': 'mfma', 'achieved': ach, 'peak': FP64_MFMA_PEAK_TFLOPS,
+                              'unit': 'TFLOP/s', 'frac': ach / FP64_MFMA_PEAK_TFLOPS,
+                              'ms': tm[stage] / args.steps, 'flop': float(N) ** 3 / 3.0}
+        if fit:
+            out['roofline_fit'] = fit
+        if 'roofline' not in out and 'cholesky' in fit:      # no sweep GEMM in this workload (Thompson)
+            out['roofline'] = dict(fit['cholesky'], traffic=None)
         if world == 1 and not args.no_cpu_baseline:
-            nc = args.cpu_candidates or (8192 if N <= 4096 else 4096)
+            # sample: the WHOLE sweep for N <= 2048 (config B: ~1 min of host time), otherwise 4 full oracle
+            # chunks of 8192 candidates (~25 s at N = 8192), extrapolated linearly and labelled so;
+            # --cpu-candidates 131072 gives SURVEY 8(d)'s 2^17 sample (~1.5 min)
+            nc = args.cpu_candidates or (M if N <= 2048 else 32768)
             out['cpu_baseline'] = cpu_baseline(w, min(nc, M))
         print(json.dumps(out))
     if world > 1:

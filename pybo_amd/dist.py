@@ -6,12 +6,15 @@ rank -- after which every rank computes the same merged top-k with the determini
 (value descending, then global index ascending).  RCCL has no MAXLOC, hence gather + local merge
 (SURVEY.md F13).  The reference has no distributed code at all; this is new.
 
-Works with any initialised torch.distributed backend: 'nccl' (= RCCL over xGMI on MI355X; tensors staged on
-the current device) or 'gloo' (CPU tensors; used by the world_size-2 tests).
+Two transports for that exchange:
+  * any initialised torch.distributed backend: 'nccl' (= RCCL over xGMI on MI355X; tensors staged on the
+    current device) or 'gloo' (CPU tensors; used by the multi-rank tests) -- the default;
+  * `comm=` a pybo_amd._lib.Comm: libgpx's own RCCL binding (gpx_comm_init / gpx_topk_allgather, the C-ABI a
+    non-Python consumer uses): the pairs go device -> xGMI -> device merge, only the k winners reach the host.
 """
 import numpy as np
 
-__all__ = ['shard_bounds', 'merge_topk', 'gather_topk', 'sharded_topk', 'ShardedIndex']
+__all__ = ['shard_bounds', 'merge_topk', 'gather_topk', 'gather_pairs', 'sharded_topk', 'ShardedIndex']
 
 
 def shard_bounds(M, rank, world):
@@ -41,6 +44,34 @@ def _dist():
     return None
 
 
+def _allgather_f64(mine, group=None):
+    """ONE all-gather of a float64 vector (same length on every rank) -> (world, len) array on the host."""
+    import torch
+    dist = _dist()
+    world = dist.get_world_size(group)
+    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' \
+        else torch.device('cpu')
+    send = torch.from_numpy(np.ascontiguousarray(mine, dtype=np.float64)).to(dev)
+    everyone = torch.empty(world * send.numel(), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(everyone, send, group=group)
+    return everyone.cpu().numpy().reshape(world, -1)
+
+
+def gather_pairs(vals, idx, group=None):
+    """All-gather of n (value, index) pairs per rank (same n everywhere) WITHOUT a merge: every rank receives
+    all world*n pairs in rank order.  One collective: values and indices travel in the same float64 buffer
+    (indices < 2^53 are exact).  Batch-BO / Thompson: one recommendation per posterior draw, draws sharded
+    over ranks."""
+    dist = _dist()
+    vals = np.ascontiguousarray(vals, dtype=np.float64).reshape(-1)
+    idx = np.ascontiguousarray(idx, dtype=np.int64).reshape(-1)
+    if dist is None or dist.get_world_size(group) == 1:
+        return vals, idx
+    n = len(vals)
+    table = _allgather_f64(np.concatenate([vals, idx.astype(np.float64)]), group).reshape(-1, 2, n)
+    return table[:, 0, :].reshape(-1), table[:, 1, :].astype(np.int64).reshape(-1)
+
+
 def gather_topk(vals, idx, k, group=None):
     """All-gather per-rank (value, global index) candidates and merge; identical result on every rank.
     Without an initialised process group this is a local merge."""
@@ -49,33 +80,41 @@ def gather_topk(vals, idx, k, group=None):
     idx = np.ascontiguousarray(idx, dtype=np.int64).reshape(-1)
     if dist is None or dist.get_world_size(group) == 1:
         return merge_topk(vals, idx, k)
-    import torch
-    world = dist.get_world_size(group)
     if len(vals) > k:                      # only the k best of a rank can make the global top-k
         vals, idx = merge_topk(vals, idx, k)
     n = len(vals)
-    dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' \
-        else torch.device('cpu')
     # ranks may hold fewer than k pairs (k > shard size): pad to k with index -1 (no extra collective needed)
     nmax = int(k)
     pv = np.full(nmax, -np.inf)
     pi = np.full(nmax, -1, dtype=np.int64)
     pv[:n], pi[:n] = vals, idx
-    # ONE collective per step: values and indices travel in the same float64 buffer (indices < 2^53 are exact)
-    mine = torch.from_numpy(np.concatenate([pv, pi.astype(np.float64)])).to(dev)
-    everyone = torch.empty(world * 2 * nmax, dtype=torch.float64, device=dev)
-    dist.all_gather_into_tensor(everyone, mine, group=group)
-    table = everyone.cpu().numpy().reshape(world, 2, nmax)
-    return merge_topk(table[:, 0, :], table[:, 1, :].astype(np.int64), k)
+    allv, alli = gather_pairs(pv, pi, group)
+    return merge_topk(allv, alli, k)
 
 
-def sharded_topk(index, xgrid, k, group=None):
-    """Rank-local `index.topk` on this rank's slice of `xgrid`, then the exchange."""
+def sharded_topk(index, xgrid, k, group=None, comm=None):
+    """Rank-local `index.topk` on this rank's slice of `xgrid`, then the exchange.
+
+    comm=None: torch.distributed all-gather of the host pairs (any backend).
+    comm=pybo_amd._lib.Comm: the pairs are taken from the device buffers the local sweep left behind and
+    gathered + merged by libgpx over RCCL (gpx_topk_allgather); needs every shard to hold at least k
+    candidates and `index` to come from a device model driven by the communicator's engine."""
     dist = _dist()
-    rank = dist.get_rank(group) if dist else 0
-    world = dist.get_world_size(group) if dist else 1
-    xgrid = np.asarray(xgrid)
-    lo, hi = shard_bounds(len(xgrid), rank, world)
+    if comm is not None:
+        rank, world = comm.rank, comm.nranks
+    else:
+        rank = dist.get_rank(group) if dist else 0
+        world = dist.get_world_size(group) if dist else 1
+    M = len(xgrid)
+    lo, hi = shard_bounds(M, rank, world)
+    if comm is not None:
+        if M // world < k:
+            raise ValueError('device exchange needs at least k candidates on every rank')
+        index.topk(xgrid[lo:hi], k)
+        owner = getattr(index, 'topk_engine', None)
+        if owner is None or owner() is not comm._engine:
+            raise ValueError('the communicator is bound to another engine than the one that ran the sweep')
+        return comm.topk_allgather(k, lo, k)
     if hi > lo:
         vals, idx = index.topk(xgrid[lo:hi], min(k, hi - lo))
         idx = np.asarray(idx, dtype=np.int64)
@@ -90,11 +129,11 @@ class ShardedIndex(object):
     """Wrap an index so that `solve_lbfgs` (or any caller of `.topk`) transparently sweeps the grid across
     all ranks of the process group:  solver(ShardedIndex(policy(model, bounds, X)), bounds)."""
 
-    def __init__(self, index, group=None):
-        self._index, self._group = index, group
+    def __init__(self, index, group=None, comm=None):
+        self._index, self._group, self._comm = index, group, comm
 
     def __call__(self, X, grad=False):
         return self._index(X, grad=grad)
 
     def topk(self, xgrid, k):
-        return sharded_topk(self._index, xgrid, k, self._group)
+        return sharded_topk(self._index, xgrid, k, self._group, self._comm)

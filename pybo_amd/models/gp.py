@@ -298,6 +298,10 @@ class GP(object):
         out = self._engine().sweep(kind, param, xgrid, k=int(k), want_all=False)
         return out['top_val'], out['top_idx']
 
+    def topk_engine(self):
+        """The device handle whose HBM holds the (value, index) pairs of the last `acq_topk`."""
+        return self._engine()
+
     def sample_f(self, n, rng=None):
         """RFF posterior function sample.  Host draws (order fixed: randn(n,d), [chisquare], rand(n),
         randn(n)); the O(N n^2) feature Gram runs on the device, the n x n weight posterior on the host."""

@@ -100,6 +100,7 @@ class MCMC(object):
         # the whole-grid top-k hook only exists for device-backed members (policies probe it with getattr)
         if hasattr(self._proto, 'acq_values'):
             self.acq_topk = self._acq_topk
+            self.topk_engine = lambda: self._engines()[0]     # the ensemble's lead handle ranks the average
 
     # -- sampling ----------------------------------------------------------------------------------
     def _advance(self, nsteps, keep):

@@ -24,6 +24,9 @@ def _attach_topk(index, model, kind, param):
     fast = getattr(model, 'acq_topk', None)
     if fast is not None:
         index.topk = lambda xgrid, k: fast(kind, param, xgrid, k)
+        owner = getattr(model, 'topk_engine', None)
+        if owner is not None:              # which device handle holds the top-k pairs (pybo_amd.dist, comm=)
+            index.topk_engine = owner
     return index
 
 

@@ -39,6 +39,108 @@ class StubModel(object):
         return (out, np.ones_like(np.array(X, ndmin=2, dtype=float))) if grad else out
 
 
+class SmootherModel(object):
+    """A deterministic, DATA-DEPENDENT stand-in for a reggie model (so that the BO loop is not trivial): a
+    kernel smoother with closed-form moments and gradients.  (tests/golden/make_golden.py drove the reference's loop with the same class.)
+        w_i(x) = exp(-|x - x_i|^2 / (2 ell^2))     mu = sum w_i y_i / (c + sum w_i)     s2 = 1 / (1 + sum w_i)"""
+
+    def __init__(self, ell=0.25, c=1e-2, X=None, Y=None):
+        self.ell, self.c = float(ell), float(c)
+        self.X = np.empty((0, 0)) if X is None else X
+        self.Y = np.empty(0) if Y is None else Y
+
+    def copy(self):
+        return SmootherModel(self.ell, self.c, self.X.copy(), self.Y.copy())
+
+    def add_data(self, X, Y):
+        X = np.array(X, ndmin=2, dtype=float)
+        Y = np.array(Y, ndmin=1, dtype=float)
+        self.X = X if self.X.size == 0 else np.vstack([self.X, X])
+        self.Y = np.hstack([self.Y, Y])
+
+    def predict(self, X, grad=False):
+        X = np.array(X, ndmin=2, dtype=float)
+        D = X[:, None, :] - self.X[None, :, :]
+        W = np.exp(-0.5 * (D ** 2).sum(-1) / self.ell ** 2)
+        sw = self.c + W.sum(1)
+        mu = (W @ self.Y) / sw
+        s2 = 1.0 / (1.0 + W.sum(1))
+        if not grad:
+            return mu, s2
+        dW = -D / self.ell ** 2 * W[:, :, None]
+        dsw = dW.sum(1)
+        dmu = (np.einsum('mnd,n->md', dW, self.Y) - mu[:, None] * dsw) / sw[:, None]
+        ds2 = -(s2 ** 2)[:, None] * dsw
+        return mu, s2, dmu, ds2
+
+    def _z(self, target, X, grad):
+        post = self.predict(X, grad)
+        mu, s2 = post[:2]
+        s = np.sqrt(s2)
+        z = (mu - target) / s
+        cdf = 0.5 * (1.0 + np.vectorize(__import__('math').erf)(z / np.sqrt(2.0)))
+        pdf = np.exp(-0.5 * z * z) / np.sqrt(2.0 * np.pi)
+        return post, s, z, cdf, pdf
+
+    def get_improvement(self, target, X, grad=False):
+        post, s, z, cdf, pdf = self._z(target, X, grad)
+        ei = (post[0] - target) * cdf + s * pdf
+        if not grad:
+            return ei
+        return ei, cdf[:, None] * post[2] + (0.5 * pdf / s)[:, None] * post[3]
+
+    def get_tail(self, target, X, grad=False):
+        post, s, z, cdf, pdf = self._z(target, X, grad)
+        if not grad:
+            return cdf
+        dz = post[2] / s[:, None] - (0.5 * z / post[1])[:, None] * post[3]
+        return cdf, pdf[:, None] * dz
+
+
+def loop_objective(x):
+    x = np.ravel(x)
+    return float(-np.sum((x - 0.3) ** 2) + 0.1 * np.sin(5.0 * x[0]))
+
+
+class StubModel(object):
+    """Deterministic stand-in for a reggie model: closed-form 'posterior' of the query points, and a log
+    of the protocol calls the policy makes."""
+
+    def __init__(self, log=None):
+        self.log = [] if log is None else log
+
+    def copy(self):
+        self.log.append('copy')
+        return StubModel(self.log)
+
+    @staticmethod
+    def moments(X):
+        X = np.array(X, ndmin=2, dtype=float)
+        t = X.sum(axis=1)
+        mu = np.sin(1.7 * t) + 0.3 * t
+        s2 = 0.2 + 0.1 * np.cos(0.9 * t) ** 2
+        dmu = np.repeat((1.7 * np.cos(1.7 * t) + 0.3)[:, None], X.shape[1], axis=1)
+        ds2 = np.repeat((-0.18 * np.cos(0.9 * t) * np.sin(0.9 * t))[:, None], X.shape[1], axis=1)
+        return mu, s2, dmu, ds2
+
+    def predict(self, X, grad=False):
+        self.log.append('predict:%d' % int(bool(grad)))
+        m = self.moments(X)
+        return m if grad else m[:2]
+
+    def get_improvement(self, target, X, grad=False):
+        self.log.append('get_improvement:%d' % int(bool(grad)))
+        mu = self.moments(X)[0]
+        out = mu - target            # any deterministic function of (target, X) pins `target`
+        return (out, np.ones_like(np.array(X, ndmin=2, dtype=float))) if grad else out
+
+    def get_tail(self, target, X, grad=False):
+        self.log.append('get_tail:%d' % int(bool(grad)))
+        mu = self.moments(X)[0]
+        out = 1.0 / (1.0 + np.exp(-(mu - target)))
+        return (out, np.ones_like(np.array(X, ndmin=2, dtype=float))) if grad else out
+
+
 def analytic_index(kind):
     if kind == 'bimodal2':
         c1, c2 = np.array([0.8, 0.8]), np.array([0.25, 0.3])

@@ -1,0 +1,173 @@
+"""The N > 1 path with the REAL HIP engine, provable on a one-GPU box: 2 and 4 gloo ranks share device 0, each
+with its own process, HIP context and gpx handle, and run what bench.py's step() runs on config B's inputs
+(N = 2048, d = 2, SE-ARD, EI, 2^20 Sobol candidates): replicated fit, contiguous candidate shard, local top-k,
+ONE all-gather, deterministic merge.  Asserted:
+
+  * every rank's Cholesky factor L and triangular inverse T are BITWISE equal to the single-rank ones
+    ("every rank fits redundantly, deterministic" -- the claim the whole zero-communication
+    fit rests on);
+  * the merged top-k (values and global indices) is bit-identical on every rank and to the single-rank sweep
+    of the whole grid;
+  * the same through the plugin layer: solve_lbfgs(ShardedIndex(policies.EI(GP, ...))) picks the same seed;
+  * Thompson / batch-BO: draws sharded by draw index, one all-gather of (value, index) per draw, equals the
+    single-rank sweep of all draws.
+
+The reference has no distributed code (its only hint is the comment pybo/solvers/lbfgs.py:60); the layout is
+SURVEY.md 8(e).  RCCL itself needs one GPU per rank, so the transport here is gloo; the RCCL binding of the
+same exchange (gpx_topk_allgather) is exercised with a 1-rank communicator below.
+"""
+import hashlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+K = 10
+DRAWS = 8
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _digest(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _thompson_draw(w, s):
+    """Spectral draw s of bench.py's Thompson step (same order as GP.sample_f / the oracle)."""
+    rng = np.random.RandomState(100 + s)
+    W = rng.randn(100, w['d']) / w['ell']
+    b = rng.rand(100) * 2 * np.pi
+    z = rng.randn(100)
+    return W, b, z
+
+
+def _rank_work(rank, world, w):
+    """What one rank does in a step; returns plain numpy results.  Runs inside an initialised process group
+    (or stand-alone with world == 1)."""
+    from pybo_amd import dist as pdist, models, policies, solvers
+    from pybo_amd._lib import Engine
+    out = {}
+    eng = Engine(0)
+    eng.fit(w['X'], w['y'], w['kernel'], w['ell'], w['rho'], w['sn2'], w['bias'])
+    out['L'] = _digest(eng.get_matrix('L'))
+    out['T'] = _digest(eng.get_matrix('T'))
+    _, target = eng.mean_at_obs()
+    out['target'] = target
+    lo, hi = pdist.shard_bounds(w['M'], rank, world)
+    r = eng.sweep('ei', target, w['Xc'][lo:hi], k=K, want_all=False)
+    out['topk'] = pdist.gather_topk(r['top_val'], r['top_idx'] + lo, K)
+    # Thompson: draws s = rank (mod world), every rank sweeps ALL candidates for its draws
+    mine = [s for s in range(DRAWS) if s % world == rank]
+    Ws, bs, zs = zip(*[_thompson_draw(w, s) for s in mine])
+    As, vs = eng.rff_gram_batch(np.array(Ws), np.array(bs))
+    sc = np.sqrt(2.0 * w['rho'] / 100)
+    ths = []
+    for A, v, z in zip(As, vs, zs):
+        Lw = np.linalg.cholesky(sc * sc * A + w['sn2'] * np.eye(100))
+        ths.append(sc * (np.linalg.solve(Lw.T, np.linalg.solve(Lw, sc * v)) + np.sqrt(w['sn2']) * np.linalg.solve(Lw.T, z)))
+    rr = eng.rff_sweep(np.array(Ws), np.array(bs), np.array(ths), w['bias'], w['Xc'][:1 << 16], k=1, want_all=False)
+    tv, ti = pdist.gather_pairs(rr['top_val'][:, 0], rr['top_idx'][:, 0])
+    order = np.argsort(np.concatenate([[s for s in range(DRAWS) if s % world == r2] for r2 in range(world)]),
+                       kind='stable')
+    out['thompson'] = (tv[order], ti[order])            # back to draw order
+    eng.close()
+    # the same through pybo's plugin API
+    gp = models.make_gp(w['sn2'], w['rho'], w['ell'], w['bias'], kernel=w['kernel'])
+    gp.add_data(w['X'], w['y'])
+    bounds = np.array([[-5.0, 10.0], [0.0, 15.0]])
+    index = pdist.ShardedIndex(policies.EI(gp, bounds, w['X']))
+    out['plugin_topk'] = index.topk(w['Xc'], K)
+    out['plugin_x'] = solvers.solve_lbfgs(index, bounds, nbest=K, xgrid=w['Xc'])
+    return out
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    import bench
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        w = bench.make_workload('b', 1 << 20)
+        q.put((rank, _rank_work(rank, world, w)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.fixture(scope='module')
+def single():
+    sys.path.insert(0, ROOT)
+    import bench
+    w = bench.make_workload('b', 1 << 20)
+    return _rank_work(0, 1, w)
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_ranks_sharing_one_gpu_reproduce_the_single_rank_step(world, single):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(got) == list(range(world))
+    for rank, res in got.items():
+        assert res['L'] == single['L'], 'rank %d: Cholesky factor differs bitwise from the single-rank fit' % rank
+        assert res['T'] == single['T'], 'rank %d: triangular inverse differs bitwise' % rank
+        assert res['target'] == single['target']
+        for a, b in zip(res['topk'], single['topk']):
+            np.testing.assert_array_equal(a, b)
+        for a, b in zip(res['plugin_topk'], single['plugin_topk']):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(res['plugin_x'][0], single['plugin_x'][0])
+        assert res['plugin_x'][1] == single['plugin_x'][1]
+        for a, b in zip(res['thompson'], single['thompson']):
+            np.testing.assert_array_equal(a, b)
+    # engine level and plugin level agree with each other too
+    np.testing.assert_array_equal(single['topk'][1], single['plugin_topk'][1])
+
+
+def test_rccl_exchange_behind_the_c_abi_with_a_one_rank_communicator():
+    """gpx_comm_unique_id / gpx_comm_init / gpx_topk_allgather on the real RCCL with nranks = 1: the pairs are
+    read from the device buffers the sweep left behind, offset, gathered, merged on the device."""
+    from pybo_amd._lib import Engine, Comm, GpxError
+    from helpers import synth_problem
+    X, y, ell = synth_problem(300, 3, seed=4)
+    e = Engine(0)
+    e.fit(X, y, 'se', ell, 1.2, 1e-3, 0.1)
+    Z = np.random.RandomState(3).rand(5000, 3)
+    c = Comm(e, 0, 1, Comm.unique_id())
+    with pytest.raises(GpxError):                     # nothing on the device yet
+        c.topk_allgather(7, 0, 7)
+    r = e.sweep('ei', 0.4, Z, k=7, want_all=False)
+    tv, ti = c.topk_allgather(7, 1000, 7)
+    np.testing.assert_array_equal(tv, r['top_val'])
+    np.testing.assert_array_equal(ti, r['top_idx'] + 1000)
+    with pytest.raises(GpxError):                     # n must be what the last sweep produced
+        c.topk_allgather(5, 0, 5)
+    # no-merge mode (batch-BO): S draws x top-1, rank order
+    rng = np.random.RandomState(0)
+    W, b, th = rng.randn(3, 20, 3), rng.rand(3, 20), rng.randn(3, 20)
+    rr = e.rff_sweep(W, b, th, 0.1, Z, k=1, want_all=False)
+    tv, ti = c.topk_allgather(3, 0, 0)
+    np.testing.assert_array_equal(tv, rr['top_val'][:, 0])
+    np.testing.assert_array_equal(ti, rr['top_idx'][:, 0])
+    c.close()
+    e.close()

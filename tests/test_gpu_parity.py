@@ -424,7 +424,7 @@ def test_prior_sample_of_an_empty_model_and_large_nbest():
     np.testing.assert_allclose(s_dev.get(Z[:2], grad=True)[1], s_ref.get(Z[:2], grad=True)[1], rtol=1e-8, atol=1e-10)
     vals, idx = s_dev.topk(Z, 3)
     assert idx[0] == int(np.argmax(s_ref.get(Z)))
-    index = policies.Thompson(gp, None, None, rng=3)            # the policy on the empty model
+    index = policies.Thompson(gp, None, None, n=50, rng=3)      # the policy on the empty model
     np.testing.assert_allclose(index(Z[:5]), s_ref.get(Z[:5]), rtol=1e-9, atol=1e-10)
     gp.bias = 7.0                                               # the drawn function does not move
     np.testing.assert_allclose(s_dev.get(Z[:5]), s_ref.get(Z[:5]), rtol=1e-9, atol=1e-10)
