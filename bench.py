@@ -54,35 +54,40 @@ def make_workload(name, M):
         lo, hi = np.zeros(d), np.ones(d)
         rng = np.random.RandomState(seed)
         X = lo + (hi - lo) * rng.rand(N, d)
-        y = -((X - 0.5) ** 2).sum(1) + 1e-3 * rng.randn(N)
+        f = lambda Z: -((Z - 0.5) ** 2).sum(1)                       # noqa: E731
+        y = f(X) + 1e-3 * rng.randn(N)
         desc = 'north-star: d=8 synthetic quadratic, N=8192 observed, SE-ARD, EI over 2^20 Sobol candidates'
     elif name == 'b':     # BASELINE configs[1]
         N, d, seed, kernel, acq = 2048, 2, 0, 'se', 'ei'
         lo, hi = np.array([-5.0, 0.0]), np.array([10.0, 15.0])
         rng = np.random.RandomState(seed)
         X = lo + (hi - lo) * rng.rand(N, d)
-        y = -branin(X) / 10.0 + 1e-3 * rng.randn(N)
+        f = lambda Z: -branin(Z) / 10.0                               # noqa: E731
+        y = f(X) + 1e-3 * rng.randn(N)
         desc = 'config B: Branin d=2, N=2048 observed, SE-ARD, EI over 2^20 Sobol candidates'
     elif name == 'c':     # BASELINE configs[2]
         N, d, seed, kernel, acq = 8192, 6, 1, 'matern5', 'ucb'
         lo, hi = np.zeros(d), np.ones(d)
         rng = np.random.RandomState(seed)
         X = lo + (hi - lo) * rng.rand(N, d)
-        y = -hartmann6(X) + 1e-3 * rng.randn(N)
+        f = lambda Z: -hartmann6(Z)                                   # noqa: E731
+        y = f(X) + 1e-3 * rng.randn(N)
         desc = 'config C: Hartmann-6, N=8192 observed, Matern-5/2, UCB over 2^20 Sobol candidates'
     elif name == 'd':     # BASELINE configs[3]
         N, d, seed, kernel, acq = 16384, 32, 3, 'se', 'thompson'
         lo, hi = -np.ones(d), np.ones(d)
         rng = np.random.RandomState(seed)
         X = lo + (hi - lo) * rng.rand(N, d)
-        y = -(X ** 2).sum(1) + 1e-3 * rng.randn(N)
+        f = lambda Z: -(Z ** 2).sum(1)                                # noqa: E731
+        y = f(X) + 1e-3 * rng.randn(N)
         desc = 'config D: d=32 quadratic, N=16384 observed, SE-ARD, Thompson (64 RFF draws x 100 features)'
     elif name == 'e':     # BASELINE configs[4]: batch-BO q=8, one Thompson recommendation per GPU
         N, d, seed, kernel, acq = 8192, 6, 1, 'matern5', 'thompson'
         lo, hi = np.zeros(d), np.ones(d)
         rng = np.random.RandomState(seed)
         X = lo + (hi - lo) * rng.rand(N, d)
-        y = -hartmann6(X) + 1e-3 * rng.randn(N)
+        f = lambda Z: -hartmann6(Z)                                   # noqa: E731
+        y = f(X) + 1e-3 * rng.randn(N)
         desc = 'config E: batch-BO q=8 on Hartmann-6, N=8192, Matern-5/2, 8 Thompson draws (100 RFF), one per GPU'
     else:
         raise SystemExit('unknown workload %r' % name)
@@ -91,7 +96,7 @@ def make_workload(name, M):
     sn2 = 1e-4 * rho
     Xc = lo + (hi - lo) * qmc.Sobol(d, scramble=False).random(M)
     return dict(name=name, desc=desc, N=N, d=d, M=M, kernel=kernel, acq=acq, X=X, y=y, ell=ell, rho=rho,
-                sn2=sn2, bias=bias, Xc=Xc)
+                sn2=sn2, bias=bias, Xc=Xc, f=f, lo=lo, hi=hi)
 
 
 def ucb_beta(nobs, delta=0.1, xi=0.2):
@@ -152,6 +157,9 @@ def main():
                     help='process-group backend; gloo only for dry runs of the N>1 path')
     ap.add_argument('--share-device', type=int, default=-1,
                     help='dry run: every rank uses this one GPU (with --backend gloo)')
+    ap.add_argument('--warm-steps', type=int, default=8,
+                    help='also time this many WARM iterations (append one observation + re-score the cached '
+                         'sweep sums); reported separately as warm_step, never as value; 0 = skip')
     ap.add_argument('--exchange', default='torch', choices=['torch', 'gpx'],
                     help="transport of the top-k exchange: torch.distributed (default) or libgpx's own RCCL "
                          "binding (gpx_topk_allgather; needs one GPU per rank)")
@@ -272,6 +280,47 @@ def main():
         elapsed = float(te.item())
     tm = eng.timers(reset=True)
 
+    # ---- warm BO step (reported SEPARATELY; the headline stays the cold step above) ------------------------
+    # Iteration t+1 of the loop with fixed hyper-parameters over the same resident grid: model.add_data(x, y)
+    # -> policy -> solver's grid sweep (pybo/bayesopt.py:262-269).  The engine extends the factor by one row
+    # (gpx_append), corrects the cached per-candidate sums of the last sweep for it (N*M covariance evaluations
+    # instead of the N^2*M product) and re-scores the grid (gpx_sweep_update).  N grows by one per step.
+    warm = None
+    if args.warm_steps > 0 and w['acq'] != 'thompson':
+        eng.set_option('sweep_cache', 1)
+        step()                                          # one cold step fills the cache (untimed)
+        eng.set_option('sweep_cache', 0)
+        rngw = np.random.RandomState(7)
+        Xn = w['lo'] + (w['hi'] - w['lo']) * rngw.rand(args.warm_steps, d)
+        yn = w['f'](Xn) + 1e-3 * rngw.randn(args.warm_steps)
+        eng.timers(reset=True)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.warm_steps):
+            eng.append(Xn[i], yn[i])
+            param = eng.mean_at_obs()[1] if w['acq'] == 'ei' else ucb_beta(N + i + 1)
+            r = eng.sweep_update(w['acq'], param, k=k, want_all=False)
+            tv, ti = r['top_val'], np.where(r['top_idx'] >= 0, r['top_idx'] + lo_i, r['top_idx'])
+            if world > 1:
+                wbest = comm.topk_allgather(k, lo_i, k) if comm is not None else pdist.gather_topk(tv, ti, k)
+            else:
+                wbest = (tv, ti)
+        fence()
+        welapsed = time.perf_counter() - t0
+        if world > 1:
+            te = torch.tensor([welapsed], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            welapsed = float(te.item())
+        tw = eng.timers(reset=True)
+        wsec = welapsed / args.warm_steps
+        warm = {'ms_per_step': wsec * 1e3, 'value': 1.0 / wsec, 'unit': 'steps/s', 'steps': args.warm_steps,
+                'what': 'gpx_append (rank-1 extension of the factor + rank-1 correction of the cached sweep sums) '
+                        '+ EI target / UCB beta + gpx_sweep_update over the same candidates; hyper-parameters '
+                        'fixed, N grows by one per step from %d' % N,
+                'stage_ms_per_step_rank0': {kk: tw[kk] / args.warm_steps for kk in ('append', 'rank1', 'acq_topk')},
+                'selected': {'index': int(wbest[1][0]), 'value': float(wbest[0][0])},
+                'speedup_vs_cold_step': (elapsed / args.steps) / wsec}
+
     if rank == 0:
         Np_ = (N + 127) // 128 * 128
         sec = elapsed / args.steps
@@ -325,6 +374,12 @@ def main():
                               'ms': tm[stage] / args.steps, 'flop': float(N) ** 3 / 3.0}
         if fit:
             out['roofline_fit'] = fit
+        if warm is not None:
+            # algorithmic work of the rank-1 correction: N covariance evaluations per candidate per appended
+            # point; the kernel is fp64-VALU-issue bound like the cross-Gram
+            warm['rank1_cov_evals_per_s'] = float(N) * Ml / (warm['stage_ms_per_step_rank0']['rank1'] * 1e-3) \
+                if warm['stage_ms_per_step_rank0']['rank1'] > 0 else None
+            out['warm_step'] = warm
         if 'roofline' not in out and 'cholesky' in fit:      # no sweep GEMM in this workload (Thompson)
             out['roofline'] = dict(fit['cholesky'], traffic=None)
         if world == 1 and not args.no_cpu_baseline:

@@ -70,7 +70,10 @@ int gpx_version(void);
  *              ring, kept as an independently scheduled witness).  Default 23 = paired super-tiles + schedule 5.
  *              Every setting produces bit-identical results.
  *          "super_m" = rows of the XCD super-tile of 64 workgroups (8 -> 8x8 default, 4 -> 4x16, ...).
- *          "eager_inverse" = 1: form the triangular inverse inside gpx_fit instead of on first use. */
+ *          "eager_inverse" = 1: form the triangular inverse inside gpx_fit instead of on first use.
+ *          "sweep_cache" = 1: full sweeps keep their candidates and reduced sums for gpx_sweep_update;
+ *              0 (default): full sweeps leave an existing cache alone (it stays valid and is still kept current
+ *              by gpx_append); -1: drop the cache. */
 int gpx_set_option(gpx_handle *h, const char *name, int64_t value);
 
 /* ---- GP fit = model.add_data(X, Y)            [pybo/bayesopt.py:114,258,269] ------------- */
@@ -86,8 +89,10 @@ int gpx_fit_dev(gpx_handle *h, const double *dX, int64_t N, int64_t d, const dou
 int gpx_loglik(gpx_handle *h, double *out);
 /* Incremental fit: absorb ONE more observation x (d,), y into the current factorisation in O(N^2)
  * (two memory-bound passes over T and U) instead of refitting -- the per-iteration
- * `model.add_data(x, y)` of the BO loop [pybo/bayesopt.py:269].  GPX_ESTATE when the current 128-block
- * has no padding left (N == ceil(N/128)*128): refit with gpx_fit.  GPX_ENOTPD like gpx_fit. */
+ * `model.add_data(x, y)` of the BO loop [pybo/bayesopt.py:269].  When the current 128-block has no padding
+ * left the factors are re-strided into buffers one block larger (a device copy, no refit).  GPX_ENOTPD like
+ * gpx_fit.  If a sweep cache is live (below) its per-candidate sums are corrected for the new observation in
+ * the same call (one N*M pass). */
 int gpx_append(gpx_handle *h, const double *x, double y);
 /* 0-based index of the failing pivot of the last GPX_ENOTPD fit, else -1. */
 int64_t gpx_fail_pivot(const gpx_handle *h);
@@ -124,6 +129,21 @@ int gpx_sweep(gpx_handle *h, int acq_id, const double *params, int nparams, cons
 int gpx_sweep_dev(gpx_handle *h, int acq_id, const double *params, int nparams, const double *dXc,
                   int64_t M, int64_t k, double *top_val, int64_t *top_idx, double *d_acq_all,
                   double *d_mu, double *d_s2);
+
+/* ---- warm BO step: the NEXT iteration's `index(xgrid)` over the SAME grid with the SAME hyper-parameters
+ *      [pybo/bayesopt.py:262-269 with a fixed `xgrid=` in pybo/solvers/lbfgs.py:42-50].  The reference pays a
+ *      full refit and a full solve again; here, with option "sweep_cache" = 1, a full gpx_sweep* keeps the
+ *      candidates and their reduced sums q = colsum(V^2), p = V^T a in HBM (8 (d + 2) M bytes), every
+ *      gpx_append adds the one new row of V to them (N*M covariance evaluations), and gpx_sweep_update
+ *      re-scores the whole grid in O(M): mu = bias + p, s2 = rho - q, acquisition (the target / beta may
+ *      change from call to call), top-k.  Outputs as in gpx_sweep / gpx_sweep_dev.  GPX_ESTATE without a valid
+ *      cache (never swept, or refitted since: gpx_fit* invalidates it). */
+int gpx_sweep_update(gpx_handle *h, int acq_id, const double *params, int nparams, int64_t k, double *top_val,
+                     int64_t *top_idx, double *acq_all, double *mu, double *s2);
+int gpx_sweep_update_dev(gpx_handle *h, int acq_id, const double *params, int nparams, int64_t k,
+                         double *top_val, int64_t *top_idx, double *d_acq_all, double *d_mu, double *d_s2);
+/* number of candidates in the live sweep cache (0: none) */
+int64_t gpx_sweep_cache_size(const gpx_handle *h);
 
 /* ---- Thompson sampling = model.sample_f(n, rng).get(X)   [pybo/policies/simple.py:44-48] -- */
 /* S random-Fourier-feature posterior draws f_s(x) = bias + sum_j theta[s][j] cos(W[s][j].x + b[s][j])
@@ -208,7 +228,8 @@ int gpx_topk_allgather(gpx_comm *c, int64_t n, int64_t index_offset, int64_t k, 
 /* ---- measurement ------------------------------------------------------------------------ */
 /* Stage timers in milliseconds accumulated since the last reset (HIP events on the handle's
  * stream): [0] gram [1] cholesky [2] trtri [3] alpha [4] cross_gram [5] sweep_trmm [6] acq_topk
- * [7] rff [8] number of sweep_trmm launches [9] sweep_trmm algorithmic flop [10] h2d/d2h copies.
+ * [7] rff [8] number of sweep_trmm launches [9] sweep_trmm algorithmic flop [10] h2d/d2h copies
+ * [11] append (rank-1 extension of the fit) [12] rank-1 correction of the sweep cache.
  * Synchronises the stream.  Returns the number of slots written (<= n). */
 int gpx_timers(gpx_handle *h, double *out, int n, int reset);
 int gpx_sync(gpx_handle *h);

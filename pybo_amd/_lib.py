@@ -35,6 +35,9 @@ SYMBOLS = {
     'gpx_predict': (C.c_int, [_P, _P, _i64, _P, _P, _P, _P]),
     'gpx_sweep': (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _i64, _i64, _P, _P, _P, _P, _P]),
     'gpx_sweep_dev': (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _i64, _i64, _P, _P, _P, _P, _P]),
+    'gpx_sweep_update': (C.c_int, [_P, C.c_int, _P, C.c_int, _i64, _P, _P, _P, _P, _P]),
+    'gpx_sweep_update_dev': (C.c_int, [_P, C.c_int, _P, C.c_int, _i64, _P, _P, _P, _P, _P]),
+    'gpx_sweep_cache_size': (_i64, [_P]),
     'gpx_rff_sweep': (C.c_int, [_P, _P, _P, _P, _i64, _i64, _i64, _dbl, _P, _i64, _i64, _P, _P, _P]),
     'gpx_rff_sweep_dev': (C.c_int, [_P, _P, _P, _P, _i64, _i64, _i64, _dbl, _P, _i64, _i64, _P, _P, _P]),
     'gpx_rff_grad': (C.c_int, [_P, _P, _P, _P, _i64, _i64, _dbl, _P, _i64, _P, _P]),
@@ -61,7 +64,7 @@ COMM_ID_BYTES = 128
 KERNELS = {'se': 0, 'matern5': 1, 'matern3': 2, 'matern1': 3}
 ACQ = {'ei': 0, 'pi': 1, 'ucb': 2, 'mean': 3}
 TIMER_NAMES = ['gram', 'cholesky', 'trtri', 'alpha', 'cross_gram', 'sweep_trmm', 'acq_topk', 'rff',
-               'sweep_trmm_launches', 'sweep_trmm_flop', 'copies']
+               'sweep_trmm_launches', 'sweep_trmm_flop', 'copies', 'append', 'rank1']
 TOPK_MAX = 64
 
 _lib = None
@@ -374,6 +377,23 @@ class Engine(object):
                                         _ptr(tv) if k else None, _ptr(ti) if k else None, _ptr(out),
                                         _ptr(mu), _ptr(s2)))
         return dict(top_val=tv, top_idx=ti, acq=out, mu=mu, s2=s2)
+
+    def sweep_update(self, acq, param, k=0, want_all=True, want_moments=False):
+        """Re-score the cached candidate set (option sweep_cache, kept current by append): O(M)."""
+        M = self.sweep_cache_size()
+        aid = ACQ[acq] if isinstance(acq, str) else int(acq)
+        params = _f64([0.0 if param is None else param])
+        tv = np.empty(k)
+        ti = np.empty(k, dtype=np.int64)
+        out = np.empty(M) if want_all else None
+        mu = np.empty(M) if want_moments else None
+        s2 = np.empty(M) if want_moments else None
+        self._check(self._lib.gpx_sweep_update(self._h, aid, _ptr(params), 1, k, _ptr(tv) if k else None,
+                                               _ptr(ti) if k else None, _ptr(out), _ptr(mu), _ptr(s2)))
+        return dict(top_val=tv, top_idx=ti, acq=out, mu=mu, s2=s2)
+
+    def sweep_cache_size(self):
+        return int(self._lib.gpx_sweep_cache_size(self._h))
 
     def sweep_dev(self, acq, param, dXc_ptr, M, k, d_acq=None, d_mu=None, d_s2=None):
         aid = ACQ[acq] if isinstance(acq, str) else int(acq)

@@ -190,7 +190,7 @@ extern "C" int gpx_destroy(gpx_handle* h) {
     for (auto e : h->pool) hipEventDestroy(e);
     void* ptrs[] = {h->dXs, h->dXraw, h->dy, h->dS, h->dR, h->dT, h->dU, h->da, h->dalpha, h->dinvell,
                     h->dflag, h->dscal, h->dKs, h->dQp, h->dXc, h->dout, h->dblkv, h->dblki,
-                    h->dtopv, h->drff, h->drffs, h->dgrad, h->dens};  // dPp, dtopi alias dQp, dtopv
+                    h->dtopv, h->drff, h->drffs, h->dgrad, h->dens, h->dcZ, h->dcq};  // dPp, dtopi, dcp alias dQp, dtopv, dcq
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
@@ -219,6 +219,12 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             if (value < 0 || value > 23 || ((value >> 2) != 2 && (value >> 2) != 5))
                 return fail(h, GPX_EARG, "tile_order: bits 0-1 tile map (0..3), bits 2-4 k-loop schedule (2 or 5)");
             h->tile_order = (int)value;
+            return GPX_OK;
+        }
+        if (!strcmp(name, "sweep_cache")) {
+            if (value < -1 || value > 1) return fail(h, GPX_EARG, "sweep_cache must be 1, 0 or -1");
+            h->cache_on = (value == 1);
+            if (value < 0) h->cache_valid = false;
             return GPX_OK;
         }
         if (!strcmp(name, "eager_inverse")) {
@@ -327,6 +333,7 @@ static int fit_core(gpx_handle* h, const double* dX, int64_t N, int64_t d, const
     h->stage = 0;
     h->fail_pivot = -1;
     h->last_topn = 0;
+    h->cache_valid = false;      // new data / hyper-parameters: the cached sums describe another posterior
     int rc = alloc_model(h, Np, d);
     if (rc) return rc;
     h->N = N; h->Np = Np; h->d = d; h->kernel_id = kid;
@@ -419,7 +426,25 @@ extern "C" int gpx_loglik(gpx_handle* h, double* out) {
 extern "C" int gpx_append(gpx_handle* h, const double* x, double y) {
     return guarded(h, [&]() -> int {
         if (!h) return GPX_EARG;
-        return gpx::append_host(h, x, y);
+        const int64_t Nold = h->N;
+        int rc;
+        {
+            Span sp(h, T_APPEND);
+            rc = gpx::append_host(h, x, y);
+        }
+        if (rc != GPX_OK) {
+            if (rc != GPX_EARG && rc != GPX_ESTATE) h->cache_valid = false;
+            return rc;
+        }
+        if (h->cache_valid) {
+            // keep the cached per-candidate sums current: one N*M pass instead of the next N^2*M sweep.
+            // (scal / flag / w / the new scaled row are the device-side results of the append just done)
+            Span sp(h, T_RANK1);
+            launch_sweep_rank1(h->stream, h->dXs, Nold, (int)h->d, h->app_w, h->dXs + Nold * h->d, h->dcZ,
+                               h->cache_M, h->dinvell, h->kernel_id, h->rho, h->dscal, h->dflag, h->dcq, h->dcp);
+            HIPCHK(h, hipGetLastError());
+        }
+        return GPX_OK;
     });
 }
 
@@ -548,6 +573,18 @@ static int sweep_core(gpx_handle* h, int acq_id, const double* params, int npara
         d_acq = h->dout;
     }
     const double p0 = (acq_id == GPX_ACQ_MEAN) ? 0.0 : params[0];
+    double* cq = nullptr;
+    double* cp = nullptr;
+    if (h->cache_on) {
+        h->cache_valid = false;
+        if ((rc = ensure(h, h->dcZ, h->cap_cz, M * h->d))) return rc;
+        if ((rc = ensure(h, h->dcq, h->cap_cq, 2 * M))) return rc;
+        h->dcp = h->dcq + h->cap_cq / 2;
+        cq = h->dcq;
+        cp = h->dcp;
+        if (dXc != h->dcZ)
+            HIPCHK(h, hipMemcpyAsync(h->dcZ, dXc, (size_t)M * h->d * 8, hipMemcpyDeviceToDevice, s));
+    }
 
     for (int64_t m0 = 0; m0 < M; m0 += chunk) {
         const int64_t valid = std::min(chunk, M - m0);
@@ -570,8 +607,12 @@ static int sweep_core(gpx_handle* h, int acq_id, const double* params, int npara
         {
             Span sp(h, T_ACQ);
             launch_acq(s, h->dQp, h->dPp, chunk, nP, m0, valid, h->rho, h->bias, acq_id, p0, d_acq, d_mu,
-                       d_s2);
+                       d_s2, cq, cp);
         }
+    }
+    if (h->cache_on) {
+        h->cache_valid = true;
+        h->cache_M = M;
     }
     if (k > 0 && (rc = topk_core(h, d_acq, M, k, top_val, top_idx))) return rc;
     HIPCHK(h, hipGetLastError());
@@ -620,6 +661,74 @@ extern "C" int gpx_sweep(gpx_handle* h, int acq_id, const double* params, int np
         return GPX_OK;
     });
 }
+
+// Re-score the cached candidate set: O(M).  The sums were produced by the last full sweep with option
+// "sweep_cache" = 1 and have been kept current by every gpx_append since.
+static int sweep_update_core(gpx_handle* h, int acq_id, const double* params, int nparams, int64_t k,
+                             double* top_val, int64_t* top_idx, double* d_acq, double* d_mu, double* d_s2) {
+    if (!h->fitted) return fail(h, GPX_ESTATE, "sweep_update: model is not fitted");
+    if (!h->cache_valid)
+        return fail(h, GPX_ESTATE, "sweep_update: no valid sweep cache (set option sweep_cache = 1 and run a full "
+                                   "sweep; a refit invalidates it)");
+    if (acq_id < GPX_ACQ_EI || acq_id > GPX_ACQ_MEAN) return fail(h, GPX_EARG, "sweep_update: unknown acquisition id");
+    if (acq_id != GPX_ACQ_MEAN && (nparams < 1 || !params)) return fail(h, GPX_EARG, "sweep_update: missing acquisition parameter");
+    if (k < 0 || k > TOPK_MAX) return fail(h, GPX_EARG, "sweep_update: k must be in [0, 64]");
+    if (k > 0 && (!top_val || !top_idx)) return fail(h, GPX_EARG, "sweep_update: NULL top-k output");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int64_t M = h->cache_M;
+    int rc;
+    if (!d_acq) {
+        if ((rc = ensure(h, h->dout, h->cap_out, M))) return rc;
+        d_acq = h->dout;
+    }
+    const double p0 = (acq_id == GPX_ACQ_MEAN) ? 0.0 : params[0];
+    {
+        Span sp(h, T_ACQ);
+        launch_acq(h->stream, h->dcq, h->dcp, 0, 0, 0, M, h->rho, h->bias, acq_id, p0, d_acq, d_mu, d_s2, nullptr,
+                   nullptr);
+    }
+    if (k > 0 && (rc = topk_core(h, d_acq, M, k, top_val, top_idx))) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    return GPX_OK;
+}
+
+extern "C" int gpx_sweep_update_dev(gpx_handle* h, int acq_id, const double* params, int nparams, int64_t k,
+                                    double* top_val, int64_t* top_idx, double* d_acq_all, double* d_mu,
+                                    double* d_s2) {
+    return guarded(h, [&]() -> int {
+        if (!h) return GPX_EARG;
+        return sweep_update_core(h, acq_id, params, nparams, k, top_val, top_idx, d_acq_all, d_mu, d_s2);
+    });
+}
+
+extern "C" int gpx_sweep_update(gpx_handle* h, int acq_id, const double* params, int nparams, int64_t k,
+                                double* top_val, int64_t* top_idx, double* acq_all, double* mu, double* s2) {
+    return guarded(h, [&]() -> int {
+        if (!h) return GPX_EARG;
+        if (!h->cache_valid) return fail(h, GPX_ESTATE, "sweep_update: no valid sweep cache");
+        HIPCHK(h, hipSetDevice(h->device));
+        const int64_t M = h->cache_M;
+        int rc;
+        if ((rc = ensure(h, h->dXc, h->cap_xc, 3 * M))) return rc;       // staging [acq M][mu M][s2 M]
+        double* dacq = h->dXc;
+        double* dmu = dacq + M;
+        double* ds2 = dmu + M;
+        rc = sweep_update_core(h, acq_id, params, nparams, k, top_val, top_idx, dacq, mu ? dmu : nullptr,
+                               s2 ? ds2 : nullptr);
+        if (rc) return rc;
+        {
+            Span sp(h, T_COPY);
+            if (acq_all) HIPCHK(h, hipMemcpyAsync(acq_all, dacq, (size_t)M * 8, hipMemcpyDeviceToHost, h->stream));
+            if (mu) HIPCHK(h, hipMemcpyAsync(mu, dmu, (size_t)M * 8, hipMemcpyDeviceToHost, h->stream));
+            if (s2) HIPCHK(h, hipMemcpyAsync(s2, ds2, (size_t)M * 8, hipMemcpyDeviceToHost, h->stream));
+        }
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        return GPX_OK;
+    });
+}
+
+extern "C" int64_t gpx_sweep_cache_size(const gpx_handle* h) { return (h && h->cache_valid) ? h->cache_M : 0; }
 
 extern "C" int gpx_predict(gpx_handle* h, const double* Xc, int64_t M, double* mu, double* s2, double* dmu,
                            double* ds2) {

@@ -15,8 +15,8 @@ constexpr int DMAX = 64;      // max input dimension staged in LDS
 constexpr int TOPK_MAX = 64;  // max k of the device top-k
 
 enum Timer {
-    T_GRAM = 0, T_CHOL, T_TRTRI, T_ALPHA, T_XGRAM, T_TRMM, T_ACQ, T_RFF, T_NLAUNCH, T_FLOP, T_COPY,
-    T_COUNT
+    T_GRAM = 0, T_CHOL, T_TRTRI, T_ALPHA, T_XGRAM, T_TRMM, T_ACQ, T_RFF, T_NLAUNCH, T_FLOP, T_COPY, T_APPEND,
+    T_RANK1, T_COUNT
 };
 
 struct EventPair { hipEvent_t a, b; int slot; };
@@ -88,6 +88,17 @@ struct gpx_handle {
     double* dens = nullptr;   // ensemble sweep: accumulators + member outputs (5 M)
     int64_t cap_ens = 0;
 
+    // sweep cache (warm BO step): candidates and their reduced sums q = colsum(V^2), p = V^T a of the last full
+    // sweep, kept current by gpx_append's rank-1 correction and re-scored by gpx_sweep_update
+    const double* app_w = nullptr;   // scratch of the last gpx_append: w = K^-1 k(X, x_new)
+    bool cache_on = false;       // option "sweep_cache"
+    bool cache_valid = false;
+    int64_t cache_M = 0;
+    double* dcZ = nullptr;       // (M, d) candidates
+    double* dcq = nullptr;       // (M,) q, then p (one allocation: dcp = dcq + cap_cq / 2)
+    double* dcp = nullptr;
+    int64_t cap_cz = 0, cap_cq = 0;
+
     // timers
     std::vector<gpx::EventPair> pending;
     std::vector<hipEvent_t> pool;
@@ -114,9 +125,14 @@ void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double*
                        int64_t cols, const double* a, double* Qp, double* Pp, int64_t ldp,
                        int tile_order, int super_m);
 // reduce partials, form mu/s2/acq for columns [0,cols) of this chunk -> global candidate m0+..
+// nrb = 0: Qp/Pp are reduced per-candidate sums (the sweep cache); qsum/psum (optional) receive the reduced sums
 void launch_acq(hipStream_t s, const double* Qp, const double* Pp, int64_t ldp, int nrb, int64_t m0,
                 int64_t cols_valid, double rho, double bias, int acq_id, double p0, double* acq_out,
-                double* mu_out, double* s2_out);
+                double* mu_out, double* s2_out, double* qsum, double* psum);
+// rank-1 correction of the cached sums after one appended observation (see kernels_sweep.hip)
+void launch_sweep_rank1(hipStream_t s, const double* Xs, int64_t N, int d, const double* w, const double* xnew_s,
+                        const double* Z, int64_t M, const double* invell, int kernel_id, double rho,
+                        const double* scal, const int* flag, double* qsum, double* psum);
 // block-local top-k over vals[0..M) then merge -> topv/topi (k entries)
 void launch_topk(hipStream_t s, const double* vals, int64_t M, int k, double* blkv, int64_t* blki,
                  int64_t nblk, double* topv, int64_t* topi);

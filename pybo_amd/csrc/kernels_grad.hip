@@ -290,12 +290,68 @@ __global__ __launch_bounds__(256) void k_append_scatter(double* __restrict__ R, 
     }
 }
 
+// R, T, U get one more identity-padded 128-block (Np -> Np + 128) when an append finds the current padding
+// used up: a re-strided device copy of the three factors (3 x 8 Np^2 bytes, ~1 ms at N = 8192) instead of the
+// O(N^3) refit round 1 fell back to at every 128th observation.
+__global__ void k_identity_tail(double* __restrict__ R, double* __restrict__ T, double* __restrict__ U, int64_t ld,
+                                int64_t lo, int64_t hi) {
+    const int64_t i = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hi) return;
+    R[i * ld + i] = 1.0;
+    T[i * ld + i] = 1.0;
+    U[i * ld + i] = 1.0;
+}
+
+static int grow_block(gpx_handle* h) {
+    const int64_t Np = h->Np, Nn = Np + NB;
+    hipStream_t s = h->stream;
+    double* nm[4] = {nullptr, nullptr, nullptr, nullptr};     // S (workspace), R, T, U
+    double* nv[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // y, a, alpha, Xs, Xraw
+    const size_t vbytes[5] = {(size_t)Nn * 8, (size_t)Nn * 8, (size_t)Nn * 8, (size_t)Nn * DMAX * 8,
+                              (size_t)Nn * DMAX * 8};
+    auto bail = [&](const char* msg, int code) {
+        for (double* p : nm) if (p) hipFree(p);
+        for (double* p : nv) if (p) hipFree(p);
+        h->err = msg;
+        return code;
+    };
+    for (int i = 0; i < 4; ++i) {
+        if (hipMalloc((void**)&nm[i], (size_t)Nn * Nn * 8) != hipSuccess) return bail("append: device allocation failed", GPX_EOOM);
+        if (hipMemsetAsync(nm[i], 0, (size_t)Nn * Nn * 8, s) != hipSuccess) return bail("append: memset failed", GPX_EHIP);
+    }
+    for (int i = 0; i < 5; ++i) {
+        if (hipMalloc((void**)&nv[i], vbytes[i]) != hipSuccess) return bail("append: device allocation failed", GPX_EOOM);
+        if (hipMemsetAsync(nv[i], 0, vbytes[i], s) != hipSuccess) return bail("append: memset failed", GPX_EHIP);
+    }
+    double* om[4] = {h->dS, h->dR, h->dT, h->dU};
+    for (int i = 1; i < 4; ++i)
+        if (hipMemcpy2DAsync(nm[i], (size_t)Nn * 8, om[i], (size_t)Np * 8, (size_t)Np * 8, (size_t)Np,
+                             hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return bail("append: device copy failed", GPX_EHIP);
+    hipLaunchKernelGGL(k_identity_tail, dim3(1), dim3(NB), 0, s, nm[1], nm[2], nm[3], Nn, Np, Nn);
+    double* ov[5] = {h->dy, h->da, h->dalpha, h->dXs, h->dXraw};
+    const size_t cbytes[5] = {(size_t)Np * 8, (size_t)Np * 8, (size_t)Np * 8, (size_t)Np * h->d * 8,
+                              (size_t)h->N * h->d * 8};
+    for (int i = 0; i < 5; ++i)
+        if (hipMemcpyAsync(nv[i], ov[i], cbytes[i], hipMemcpyDeviceToDevice, s) != hipSuccess)
+            return bail("append: device copy failed", GPX_EHIP);
+    if (hipStreamSynchronize(s) != hipSuccess) return bail("append: growing the factor failed", GPX_EHIP);
+    for (double* p : om) hipFree(p);
+    for (double* p : ov) hipFree(p);
+    h->dS = nm[0]; h->dR = nm[1]; h->dT = nm[2]; h->dU = nm[3];
+    h->dy = nv[0]; h->da = nv[1]; h->dalpha = nv[2]; h->dXs = nv[3]; h->dXraw = nv[4];
+    h->Np = Nn;
+    h->cap_np = Nn;
+    return GPX_OK;
+}
+
 int append_host(gpx_handle* h, const double* x, double ynew) {
     if (!h->fitted) { h->err = "append: model is not fitted"; return GPX_ESTATE; }
     if (!x) { h->err = "append: NULL point"; return GPX_EARG; }
-    if (h->N >= h->Np) { h->err = "append: no padding left in the current 128-block (refit)"; return GPX_ESTATE; }
     if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return GPX_EHIP; }
     if (int rc0 = ensure_inverse(h)) return rc0;     // the rank-1 extension updates T, U, a, alpha in place
+    if (h->N >= h->Np)                               // padding of the last 128-block used up: add a block
+        if (int rc0 = grow_block(h)) return rc0;
     hipStream_t s = h->stream;
     const int64_t Np = h->Np, N = h->N;
     const int d = (int)h->d;
@@ -316,6 +372,7 @@ int append_host(gpx_handle* h, const double* x, double ynew) {
     double* dg = dks + Np;
     double* dr = dg + Np;
     double* dtu = dr + Np;
+    h->app_w = dtu;                                  // w = U r = K^-1 k(X, x): read by the sweep-cache correction
     if (hipMemsetAsync(h->dflag, 0, sizeof(int), s) != hipSuccess ||
         hipMemcpyAsync(dx, x, (size_t)d * 8, hipMemcpyHostToDevice, s) != hipSuccess) {
         h->err = "append: H2D copy failed";

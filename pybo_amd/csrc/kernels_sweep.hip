@@ -252,17 +252,30 @@ __device__ __forceinline__ double norm_pdf(double z) {
     return 0.39894228040143267794 * exp(-0.5 * z * z);
 }
 
+// nrb > 0: Qp/Pp are per-row-block partials (nrb, ldp) of this chunk, reduced here in block order.
+// nrb = 0: Qp/Pp are the already reduced per-candidate sums of the whole grid (the sweep cache), m0 = 0.
+// qsum/psum (optional): the reduced sums are stored per candidate -- the state gpx_append's rank-1 correction
+// keeps current (warm BO step).
 __global__ __launch_bounds__(256) void k_acq(const double* __restrict__ Qp, const double* __restrict__ Pp,
                                              int64_t ldp, int nrb, int64_t m0, int64_t cols_valid,
                                              double rho, double bias, int acq_id, double p0,
                                              double* __restrict__ acq_out, double* __restrict__ mu_out,
-                                             double* __restrict__ s2_out) {
+                                             double* __restrict__ s2_out, double* __restrict__ qsum,
+                                             double* __restrict__ psum) {
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (n >= cols_valid) return;
     double q = 0.0, p = 0.0;
+    if (nrb == 0) {
+        q = Qp[n];
+        p = Pp[n];
+    }
     for (int rb = 0; rb < nrb; ++rb) {
         q += Qp[(int64_t)rb * ldp + n];
         p += Pp[(int64_t)rb * ldp + n];
+    }
+    if (qsum) {
+        qsum[m0 + n] = q;
+        psum[m0 + n] = p;
     }
     const double mu = bias + p;
     const double s2 = fmax(rho - q, 1e-100);
@@ -293,10 +306,119 @@ __global__ __launch_bounds__(256) void k_acq(const double* __restrict__ Qp, cons
 
 void launch_acq(hipStream_t s, const double* Qp, const double* Pp, int64_t ldp, int nrb, int64_t m0,
                 int64_t cols_valid, double rho, double bias, int acq_id, double p0, double* acq_out,
-                double* mu_out, double* s2_out) {
+                double* mu_out, double* s2_out, double* qsum, double* psum) {
     const unsigned g = (unsigned)((cols_valid + 255) / 256);
     hipLaunchKernelGGL(k_acq, dim3(g), dim3(256), 0, s, Qp, Pp, ldp, nrb, m0, cols_valid, rho, bias,
-                       acq_id, p0, acq_out, mu_out, s2_out);
+                       acq_id, p0, acq_out, mu_out, s2_out, qsum, psum);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Warm BO step: rank-1 correction of the cached per-candidate sums after ONE appended observation.
+// With w = K^-1 k(X, x_new), d = posterior std of the new observation (incl. noise), a_new the new entry of a:
+//     v_n = ( k(x_new, z_n) - sum_{i<N} w_i k(x_i, z_n) ) / d        (the new row of V = T K*)
+//     q_n += v_n^2          p_n += v_n a_new
+// i.e. ONE pass of N*M covariance evaluations with a fused row-dot instead of the N^2 M triangular product --
+// what `model.add_data(x, y)` + the next `index(xgrid)` cost in the reference is a full refit and a full solve
+// (pybo/bayesopt.py:269, pybo/solvers/lbfgs.py:50).
+// One workgroup owns 128 candidates and walks all N observed rows in tiles of 64 (fixed order: results do not
+// depend on the launch geometry); thread (ty, tx) accumulates rows ty*8..+7 of each tile for candidates
+// tx*4..+3, the 8 row groups are combined through LDS at the end.
+// scal: [0] d  [1] 1/d  [2] a_new   (written by k_append_dots);  flag != 0: the append failed, do nothing.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sweep_rank1(const double* __restrict__ Xs, int64_t N, int d,
+                                                     const double* __restrict__ w,
+                                                     const double* __restrict__ xnew_s,
+                                                     const double* __restrict__ Z, int64_t M,
+                                                     const double* __restrict__ invell, int kid, double rho,
+                                                     const double* __restrict__ scal,
+                                                     const int* __restrict__ flag, double* __restrict__ qsum,
+                                                     double* __restrict__ psum) {
+    if (*flag != 0) return;
+    __shared__ double xo[XDC][XK];
+    __shared__ double xc[XDC][XN];
+    __shared__ double wv[XK];
+    __shared__ double red[8][XN];
+    const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
+    const int64_t n0 = (int64_t)blockIdx.x * XN;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool onepass = (d <= XDC);          // candidates' coordinates stay in LDS across row tiles
+    if (onepass) {
+        for (int e = t; e < XN * d; e += 256) {
+            const int row = e / d, k = e - row * d;
+            const int64_t gm = n0 + row;
+            xc[k][row] = (gm < M) ? Z[gm * d + k] * invell[k] : 0.0;
+        }
+    }
+    for (int64_t k0 = 0; k0 < N; k0 += XK) {
+        double r2[8][4];
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) r2[a][b] = 0.0;
+        for (int c0 = 0; c0 < d; c0 += XDC) {
+            const int kc = min(XDC, d - c0);
+            __syncthreads();
+            for (int e = t; e < XK * kc; e += 256) {
+                const int row = e / kc, k = e - row * kc;
+                xo[k][row] = (k0 + row < N) ? Xs[(k0 + row) * d + c0 + k] : 0.0;
+            }
+            if (c0 == 0 && t < XK) wv[t] = (k0 + t < N) ? w[k0 + t] : 0.0;
+            if (!onepass) {
+                for (int e = t; e < XN * kc; e += 256) {
+                    const int row = e / kc, k = e - row * kc;
+                    const int64_t gm = n0 + row;
+                    xc[k][row] = (gm < M) ? Z[gm * d + c0 + k] * invell[c0 + k] : 0.0;
+                }
+            }
+            __syncthreads();
+            for (int k = 0; k < kc; ++k) {
+                double a8[8], b4[4];
+#pragma unroll
+                for (int a = 0; a < 8; ++a) a8[a] = xo[k][ty * 8 + a];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) b4[b] = xc[k][tx * 4 + b];
+#pragma unroll
+                for (int a = 0; a < 8; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const double df = a8[a] - b4[b];
+                        r2[a][b] = fma(df, df, r2[a][b]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const double wa = wv[ty * 8 + a];       // 0 beyond N: padded rows contribute nothing
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[b] = fma(wa, kern_eval(kid, r2[a][b], rho), acc[b]);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) red[ty][tx * 4 + b] = acc[b];
+    __syncthreads();
+    if (t < XN) {
+        const int64_t gm = n0 + t;
+        if (gm < M) {
+            double dot = 0.0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) dot += red[g][t];
+            double r2n = 0.0;
+            for (int k = 0; k < d; ++k) {
+                const double df = xnew_s[k] - Z[gm * d + k] * invell[k];
+                r2n = fma(df, df, r2n);
+            }
+            const double v = (kern_eval(kid, r2n, rho) - dot) * scal[1];
+            qsum[gm] = fma(v, v, qsum[gm]);
+            psum[gm] = fma(v, scal[2], psum[gm]);
+        }
+    }
+}
+
+void launch_sweep_rank1(hipStream_t s, const double* Xs, int64_t N, int d, const double* w, const double* xnew_s,
+                        const double* Z, int64_t M, const double* invell, int kernel_id, double rho,
+                        const double* scal, const int* flag, double* qsum, double* psum) {
+    hipLaunchKernelGGL(k_sweep_rank1, dim3((unsigned)((M + XN - 1) / XN)), dim3(256), 0, s, Xs, N, d, w, xnew_s, Z,
+                       M, invell, kernel_id, rho, scal, flag, qsum, psum);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -34,6 +34,7 @@ class _DeviceState(object):
     def __init__(self, device):
         self.engine = None
         self.key = None            # hyper-parameters of the fit the engine holds
+        self.cache_grid = None     # the DeviceGrid whose sweep sums the engine keeps (warm BO step)
         while _ENGINE_POOL and self.engine is None:
             cand = _ENGINE_POOL.pop()
             if cand._h and cand.device == device:      # never hand out a closed handle
@@ -46,8 +47,13 @@ class _DeviceState(object):
         self.nrefs -= 1
         if self.nrefs == 0 and self.engine is not None:
             if self.engine._h and len(_ENGINE_POOL) < 16:
+                try:
+                    self.engine.set_option('sweep_cache', -1)       # the next owner starts without a cache
+                except Exception:
+                    pass
                 _ENGINE_POOL.append(self.engine)
             self.engine = None
+            self.cache_grid = None
 
 
 class Param(object):
@@ -211,7 +217,7 @@ class GP(object):
         self._Y = np.hstack([self._Y, Y])
         if can_append:
             # sole owner of a fitted device state: rank-1 extension per new row (O(N^2)) instead of the
-            # O(N^3) refit; falls through to a refit when a 128-block boundary is crossed
+            # O(N^3) refit (the library grows the factor by a block when the padding of the last one is used up)
             eng = self._state.engine
             done = 0
             try:
@@ -293,7 +299,22 @@ class GP(object):
         """Whole-grid acquisition + top-k on the device: (values (k,), grid indices (k,)).  `xgrid` is a
         host array (uploaded) or a `DeviceGrid` (already in HBM)."""
         if isinstance(xgrid, DeviceGrid):
-            return self._engine().sweep_dev(kind, param, xgrid.ptr, len(xgrid), int(k))
+            # Warm BO step: a grid resident in HBM that this device state has swept before is only RE-SCORED --
+            # the per-candidate sums were kept current by every add_data since (gpx_append's rank-1 correction),
+            # so an iteration costs O(N M) instead of the O(N^2 M) sweep.  Any refit (new hyper-parameters, a
+            # diverging copy) drops the cache and the next call sweeps in full again.
+            eng = self._engine()
+            st = self._state
+            if st.cache_grid is xgrid and eng.sweep_cache_size() == len(xgrid):
+                r = eng.sweep_update(kind, param, k=int(k), want_all=False)
+                return r['top_val'], r['top_idx']
+            eng.set_option('sweep_cache', 1)
+            try:
+                out = eng.sweep_dev(kind, param, xgrid.ptr, len(xgrid), int(k))
+            finally:
+                eng.set_option('sweep_cache', 0)      # other sweeps of this engine must not overwrite the cache
+            st.cache_grid = xgrid
+            return out
         xgrid = np.array(xgrid, ndmin=2, dtype=float)
         out = self._engine().sweep(kind, param, xgrid, k=int(k), want_all=False)
         return out['top_val'], out['top_idx']

@@ -199,3 +199,26 @@ def s2_tol(s2_ref, rho):
 
 def mu_tol(mu_ref, rho):
     return 1e-6 * np.abs(mu_ref) + 1e-9 * np.sqrt(rho)
+
+
+def ei_tol(mu_ref, s2_ref, target, rho):
+    """Tolerance for expected improvement at a candidate = the STATED moment tolerances propagated to first
+    order through EI = (mu - t) Phi(z) + s phi(z), z = (mu - t)/s  (dEI/dmu = Phi(z), dEI/ds2 = phi(z)/(2 s)),
+    plus the direct 1e-6 relative term.  For z << 0, EI ~ s phi(z)/z^2, so the RELATIVE sensitivity is
+    |z| dmu/s + (z^2/2) ds2/s2: at config B (s2/rho down to 1e-7, z down to -5.5 among the candidates within
+    1e-9 of the best EI) moments that are right to 1e-6 leave EI right to ~1.5e-5 only -- for ANY
+    implementation, the oracle included.  DESIGN.md section 6 (tolerance ladder)."""
+    from scipy.special import erfc
+    s = np.sqrt(s2_ref)
+    z = (mu_ref - target) / s
+    cdf = 0.5 * erfc(-z * 0.70710678118654752440)
+    pdf = 0.39894228040143267794 * np.exp(-0.5 * z * z)
+    ei = (mu_ref - target) * cdf + s * pdf
+    return 1e-6 * np.abs(ei) + 1.05 * (cdf * mu_tol(mu_ref, rho) + pdf * s2_tol(s2_ref, rho) / (2.0 * s))
+
+
+def ei_from_moments(mu, s2, target):
+    from scipy.special import erfc
+    s = np.sqrt(s2)
+    z = (mu - target) / s
+    return (mu - target) * 0.5 * erfc(-z * 0.70710678118654752440) + s * 0.39894228040143267794 * np.exp(-0.5 * z * z)

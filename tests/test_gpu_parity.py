@@ -129,7 +129,8 @@ def test_incremental_append_matches_full_fit():
     for i in range(120, 128):                      # fills the padding of the first block
         assert e.append(X[i], y[i])
         n += 1
-    assert not e.append(X[128], y[128])            # boundary: the caller has to refit
+    # (round 1 refused the next append at the block boundary; it now grows the factor by one block instead --
+    # tests/test_gpu_warm.py::test_append_grows_the_factor_across_block_boundaries)
     ref = gp_ref.make_gp(sn2, rho, ell, bias, 'matern5')
     ref.add_data(X[:128], y[:128])
     L = e.get_matrix('L')

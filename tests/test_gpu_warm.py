@@ -1,0 +1,120 @@
+"""Warm BO step (SURVEY N3's sweep-side half): with fixed hyper-parameters and a resident
+candidate set, one more observation adds ONE row to V = T K*, so the per-candidate sums q = colsum(V^2), p = V^T a
+of the last full sweep are corrected in O(N M) by gpx_append and re-scored in O(M) by gpx_sweep_update -- instead of
+the refit + full solve the reference repeats every iteration (pybo/bayesopt.py:262-269 with a fixed `xgrid=` in
+pybo/solvers/lbfgs.py:42-50).  Checked against a from-scratch fit + full sweep on the device AND against the CPU
+oracle after 1, 16 and 200 appends (the factor grows across two 128-block boundaries on the way)."""
+import numpy as np
+import pytest
+
+from oracle import gp_ref
+from helpers import synth_problem, s2_tol, mu_tol
+
+pytestmark = pytest.mark.gpu
+
+
+def _fresh(X, y, kernel, ell, rho, sn2, bias):
+    from pybo_amd._lib import Engine
+    e = Engine(0)
+    e.fit(X, y, kernel, ell, rho, sn2, bias)
+    return e
+
+
+@pytest.mark.parametrize('kernel,N0,d', [('se', 300, 3), ('matern5', 256, 2)])
+def test_sweep_update_tracks_a_full_resweep(kernel, N0, d):
+    from pybo_amd._lib import GpxError
+    X, y, ell = synth_problem(N0 + 200, d, seed=17)
+    rho, sn2, bias = 1.3, 1e-3, 0.2
+    Z = np.random.RandomState(5).rand(3000, d)
+    e = _fresh(X[:N0], y[:N0], kernel, ell, rho, sn2, bias)
+    with pytest.raises(GpxError):
+        e.sweep_update('ei', 0.5, k=5)                      # nothing cached yet
+    e.set_option('sweep_cache', 1)
+    full0 = e.sweep('ei', 0.5, Z, k=10, want_moments=True)
+    e.set_option('sweep_cache', 0)
+    assert e.sweep_cache_size() == len(Z)
+    e.sweep('mean', None, X[:50], k=0)                      # an unrelated sweep leaves the cache alone
+    same = e.sweep_update('ei', 0.5, k=10, want_moments=True)
+    for key in ('acq', 'mu', 's2', 'top_val', 'top_idx'):
+        np.testing.assert_array_equal(same[key], full0[key])        # re-scoring the untouched sums: bitwise
+    n = N0
+    for upto in (N0 + 1, N0 + 16, N0 + 200):
+        while n < upto:
+            assert e.append(X[n], y[n])
+            n += 1
+        assert e.N == n
+        _, target = e.mean_at_obs()
+        warm = e.sweep_update('ei', target, k=10, want_moments=True)
+        cold_e = _fresh(X[:n], y[:n], kernel, ell, rho, sn2, bias)
+        cold = cold_e.sweep('ei', target, Z, k=10, want_moments=True)
+        cold_e.close()
+        ref = gp_ref.make_gp(sn2, rho, ell, bias, kernel)
+        ref.add_data(X[:n], y[:n])
+        mr, sr = ref.predict(Z)
+        for got in (warm, cold):
+            assert np.all(np.abs(got['mu'] - mr) <= mu_tol(mr, rho))
+            assert np.all(np.abs(got['s2'] - sr) <= s2_tol(sr, rho))
+        # warm and cold agree far inside the stated tolerance (same maths, different summation order)
+        assert np.all(np.abs(warm['s2'] - cold['s2']) <= 0.01 * s2_tol(sr, rho))
+        assert np.all(np.abs(warm['mu'] - cold['mu']) <= 0.01 * mu_tol(mr, rho))
+        eir = ref.get_improvement(ref.mean_at_obs().max(), Z)
+        big = eir > 1e-9 * eir.max()
+        np.testing.assert_allclose(warm['acq'][big], eir[big], rtol=1e-6)
+        assert warm['top_idx'][0] == int(np.argmax(eir)) == cold['top_idx'][0]
+        # the target / acquisition may change between re-scorings at no cost
+        ucb = e.sweep_update('ucb', 2.0, k=3)
+        assert ucb['top_idx'][0] == int(np.argmax(mr + np.sqrt(2.0 * sr)))
+    e.fit(X[:N0], y[:N0], kernel, ell, rho, sn2, bias)      # a refit invalidates the cache
+    assert e.sweep_cache_size() == 0
+    with pytest.raises(GpxError):
+        e.sweep_update('ei', 0.5, k=5)
+    e.close()
+
+
+def test_append_grows_the_factor_across_block_boundaries():
+    """Round 1 refused an append at N = 128 j and refitted in O(N^3); now the factors move into buffers one block
+    larger.  N = 256 exactly, 130 appends (two boundaries), compared with a from-scratch fit."""
+    X, y, ell = synth_problem(256 + 130, 2, seed=3)
+    rho, sn2, bias = 1.1, 1e-3, 0.0
+    e = _fresh(X[:256], y[:256], 'se', ell, rho, sn2, bias)
+    for i in range(256, 386):
+        assert e.append(X[i], y[i])
+    ref = gp_ref.make_gp(sn2, rho, ell, bias)
+    ref.add_data(X, y)
+    L = e.get_matrix('L')
+    K = ref.gram()
+    assert np.linalg.norm(L @ L.T - K) <= 1e-13 * np.linalg.norm(K)
+    a, alpha = e.get_vectors()
+    np.testing.assert_allclose(alpha, ref.alpha(), rtol=1e-7, atol=1e-9)
+    Z = np.random.RandomState(0).rand(500, 2)
+    mu, s2 = e.predict(Z)
+    mr, sr = ref.predict(Z)
+    assert np.all(np.abs(mu - mr) <= mu_tol(mr, rho)) and np.all(np.abs(s2 - sr) <= s2_tol(sr, rho))
+    assert abs(e.loglik() - ref.loglikelihood()) <= 1e-9 * abs(ref.loglikelihood())
+    e.close()
+
+
+def test_bo_loop_over_a_device_grid_runs_warm_and_selects_the_same_points():
+    """solve_bayesopt with a user model (fixed hyper-parameters) and a Sobol grid resident in HBM: after the first
+    iteration every acquisition sweep is a re-scoring of the cached sums.  Same queried points as the CPU oracle
+    driving the same loop over the same grid."""
+    from pybo_amd import solve_bayesopt, models, inits
+    bounds = np.array([[0.0, 1.0], [0.0, 1.0]])
+    f = lambda x: float(-np.sum((np.asarray(x) - 0.35) ** 2) + 0.05 * np.sin(9 * x[0]))     # noqa: E731
+    X0 = np.random.RandomState(1).rand(20, 2)
+    y0 = np.array([f(x) for x in X0])
+    grid = inits.init_sobol_device(bounds, 4096)
+    host_grid = np.asarray(grid)
+    gp = models.make_gp(1e-4, 0.2, [0.3, 0.3], float(y0.mean()))
+    ref = gp_ref.make_gp(1e-4, 0.2, [0.3, 0.3], float(y0.mean()))
+    gp.add_data(X0, y0); ref.add_data(X0, y0)
+    xa, ma, ia = solve_bayesopt(f, bounds, model=gp, niter=12, policy='ei', recommender='incumbent',
+                                solver=('lbfgs', {'xgrid': grid, 'nbest': 3}), rng=0)
+    xb, mb, ib = solve_bayesopt(f, bounds, model=ref, niter=12, policy='ei', recommender='incumbent',
+                                solver=('lbfgs', {'xgrid': host_grid, 'nbest': 3}), rng=0)
+    np.testing.assert_allclose(ia.x, ib.x, atol=2e-5)
+    np.testing.assert_allclose(ia.y, ib.y, atol=1e-6)
+    assert ma._state.cache_grid is grid and ma._state.engine.sweep_cache_size() == 4096
+    tm = ma._state.engine.timers()
+    # 12 iterations: ONE full sweep of the grid (the first), then rank-1 corrections
+    assert tm['rank1'] > 0 and tm['append'] > 0
