@@ -157,6 +157,8 @@ def main():
                     help='process-group backend; gloo only for dry runs of the N>1 path')
     ap.add_argument('--share-device', type=int, default=-1,
                     help='dry run: every rank uses this one GPU (with --backend gloo)')
+    ap.add_argument('--opt', action='append', default=[], metavar='NAME=VALUE',
+                    help='engine option (gpx_set_option), e.g. --opt potrf=0; repeatable')
     ap.add_argument('--warm-steps', type=int, default=8,
                     help='also time this many WARM iterations (append one observation + re-score the cached '
                          'sweep sums); reported separately as warm_step, never as value; 0 = skip')
@@ -199,6 +201,9 @@ def main():
         eng.set_option('chunk', args.chunk)
     if args.tile_order >= 0:
         eng.set_option('tile_order', args.tile_order)
+    for kv in args.opt:
+        name, val = kv.split('=')
+        eng.set_option(name, int(val))
     Ml = hi_i - lo_i
     comm = None
     if world > 1 and args.exchange == 'gpx':

@@ -165,7 +165,10 @@ static int create_impl(int device, void* stream, gpx_handle** out) {
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     // the side stream carries only off-critical-path work (far trailing updates): lowest priority, so the
     // serial chain on the caller's stream wins the dispatcher whenever both have workgroups pending
-    if (hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+    bool ok_ev = true;
+    for (auto& e : h->ev_row) ok_ev = ok_ev && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    if (!ok_ev || hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_far, hipEventDisableTiming) != hipSuccess) {
         g_create_err = "gpx_create: side stream / event creation failed";
@@ -194,6 +197,9 @@ extern "C" int gpx_destroy(gpx_handle* h) {
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+    if (h->stream3) { hipStreamSynchronize(h->stream3); hipStreamDestroy(h->stream3); }
+    for (auto e : h->ev_row)
+        if (e) hipEventDestroy(e);
     if (h->ev_chain) hipEventDestroy(h->ev_chain);
     if (h->ev_far) hipEventDestroy(h->ev_far);
     if (h->own_stream) hipStreamDestroy(h->stream);
@@ -225,6 +231,11 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             if (value < -1 || value > 1) return fail(h, GPX_EARG, "sweep_cache must be 1, 0 or -1");
             h->cache_on = (value == 1);
             if (value < 0) h->cache_valid = false;
+            return GPX_OK;
+        }
+        if (!strcmp(name, "potrf")) {
+            if (value != 0 && value != 1) return fail(h, GPX_EARG, "potrf must be 0 or 1");
+            h->potrf_variant = (int)value;
             return GPX_OK;
         }
         if (!strcmp(name, "eager_inverse")) {

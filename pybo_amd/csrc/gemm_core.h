@@ -278,6 +278,86 @@ __device__ __forceinline__ void gemm_tile_64(d4 (&acc)[2][2], const double* __re
         __syncthreads();
     }
 }
+// The same 64x64 tile with K stepped 32 at a time through a SINGLE 40 KB LDS buffer and a TWO-deep register
+// prefetch: the global loads of step t+2 are issued at the top of step t and written to LDS at the end of step
+// t+1.  The chain kernels that use it are bound by the latency of their dependent global loads (K = 512 on the
+// 16-row ring: 32 round trips of ~3.3 us next to the trailing updates), not by MFMA or bandwidth: half as many
+// round trips, each covered by two compute phases instead of one.  k_hi - k_lo must be a multiple of 32.
+__device__ __forceinline__ void gemm_tile_64_g(d4 (&acc)[2][2], const double* __restrict__ A, int64_t lda,
+                                               const double* __restrict__ B, int64_t ldb, int k_lo, int k_hi,
+                                               double* smem) {
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    double* As = smem;                    // [32][LDT64]
+    double* Bs = smem + BK32 * LDT64;     // [32][LDT64]
+    const int lrow = t >> 5;              // 0..7: two k-rows per wave instruction
+    const int lcol = (t & 31) * 2;
+    const int nk = (k_hi - k_lo) / BK32;
+    if (nk <= 0) return;
+    const double* Ap = A + (int64_t)(k_lo + lrow) * lda + lcol;
+    const double* Bp = B + (int64_t)(k_lo + lrow) * ldb + lcol;
+    d2 ra[2][4], rb[2][4];
+#define GPX_GLOAD64(ST)                                                                   \
+    {                                                                                     \
+        _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                   \
+            ra[ST][p] = *reinterpret_cast<const d2*>(Ap + (int64_t)(8 * p) * lda);        \
+            rb[ST][p] = *reinterpret_cast<const d2*>(Bp + (int64_t)(8 * p) * ldb);        \
+        }                                                                                 \
+        Ap += (int64_t)BK32 * lda;                                                        \
+        Bp += (int64_t)BK32 * ldb;                                                        \
+    }
+#define GPX_SWRITE64(ST)                                                                  \
+    {                                                                                     \
+        _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                   \
+            *reinterpret_cast<d2*>(As + (lrow + 8 * p) * LDT64 + lcol) = ra[ST][p];       \
+            *reinterpret_cast<d2*>(Bs + (lrow + 8 * p) * LDT64 + lcol) = rb[ST][p];       \
+        }                                                                                 \
+    }
+    GPX_GLOAD64(0);                       // tile 0
+    GPX_SWRITE64(0);
+    if (nk > 1) GPX_GLOAD64(1);           // tile 1 waits in stage 1
+    __syncthreads();
+    const int fr = lane & 15, fk = lane >> 4;
+    // two steps per trip so that the register stages are compile-time indices
+    for (int kt = 0; kt < nk; kt += 2) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int k = kt + half;
+            if (k >= nk) break;
+            // stage `half` is free (its tile is in LDS): fetch tile k + 2 into it
+            if (k + 2 < nk) {
+                if (half == 0) GPX_GLOAD64(0) else GPX_GLOAD64(1)
+            }
+            const double* as = As + wm * 32 + fr;
+            const double* bs = Bs + wn * 32 + fr;
+#pragma unroll
+            for (int kk = 0; kk < BK32 / 4; ++kk) {
+                const int kr = kk * 4 + fk;
+                double a[2], b[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[i] = as[kr * LDT64 + i * 16];
+                    b[i] = bs[kr * LDT64 + i * 16];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();               // everyone has finished reading the buffer
+            if (k + 1 < nk) {
+                if (half == 0) GPX_SWRITE64(1) else GPX_SWRITE64(0)     // tile k + 1 sits in the OTHER stage
+                __syncthreads();
+            }
+        }
+    }
+#undef GPX_GLOAD64
+#undef GPX_SWRITE64
+}
+
 __device__ __forceinline__ int acc_row64(int i, int r) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     return (w >> 1) * 32 + i * 16 + (lane >> 4) + 4 * r;

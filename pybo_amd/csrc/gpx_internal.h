@@ -27,13 +27,17 @@ struct gpx_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipStream_t stream2 = nullptr;   // library-owned side stream (Cholesky lookahead)
+    hipStream_t stream2 = nullptr;   // library-owned side stream (Cholesky lookahead: far trailing updates, low priority)
+    hipStream_t stream3 = nullptr;   // library-owned side stream (rows 2..4 of the next panel's near update, normal priority)
     hipEvent_t ev_chain = nullptr, ev_far = nullptr;
+    hipEvent_t ev_row[4] = {nullptr, nullptr, nullptr, nullptr};
     std::string err;
 
     // model state
     bool fitted = false;
     int stage = 0;               // 0 none, 1 gram, 2 chol (fitted; T/U/a/alpha not formed yet), 3 + inverse
+    int potrf_variant = 1;       // option "potrf": 0 register-resident pivot pairs (round 1), 1 MFMA-blocked 16 wide
+    bool diag_inv_pending = false;   // the diagonal blocks of T / U hold 16x16 inverses only (k_trtri_diag128 due)
     bool eager_inverse = false;  // option: form the inverse inside the fit (timing experiments)
     int64_t N = 0, Np = 0, d = 0;
     int kernel_id = 0;

@@ -119,6 +119,17 @@ void launch_gram_sym(hipStream_t s, const double* Xs, int64_t N, int64_t Np, int
 // 1/sqrt(x) to fp64 round-off: hardware v_rsq_f64 seed + two Newton steps (no denormal/scale handling
 // needed: pivots of a PD matrix with unit-scale entries; a non-positive or NaN pivot yields NaN/inf,
 // which the uniform pivot check catches one step later)
+#ifndef GPX_PF_NR
+#define GPX_PF_NR 2        // Newton steps after v_rsq_f64 inside factor16 (scripts/potrf_bench.hip builds 1 and 2)
+#endif
+__device__ __forceinline__ double rsqrt_pf(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+#pragma unroll
+    for (int i = 0; i < GPX_PF_NR; ++i) y = fma(y, fma(-hx * y, y, 0.5), y);
+    return y;
+}
+
 __device__ __forceinline__ double rsqrt_nr(double x) {
     double y = __builtin_amdgcn_rsq(x);
     const double hx = 0.5 * x;
@@ -297,6 +308,438 @@ __global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, doub
 }
 
 // ------------------------------------------------------------------------------------------------
+// R2a' (round 2): diagonal-block factorisation, MFMA-blocked 16 wide.  One workgroup = 4 waves.
+//
+// The 128x128 block is 8x8 tiles of 16x16, each living in ONE wave's MFMA accumulators (f64 16x16x4 result
+// layout: lane (g = lane>>4, n = lane&15), register r -> element [g + 4r][n]).  That layout IS the B-operand
+// layout of the same instruction (step kk takes rows 4kk + g), and read as an A operand it is the transpose
+// -- so tiles feed the next MFMA straight from registers.  Wave w owns tile COLUMNS w and 7-w (9 upper tiles).
+// Step jb = 0..7 (right-looking):
+//   1. the owner of tile (jb,jb) factors the augmented [D | I] IN THE WAVE, in place in its accumulators
+//      (factor16 above: 4x4 pivot blocks, scalar 4x4 Cholesky, MFMA rank-4 updates) -- no LDS, no barrier
+//      inside the 16 pivots.  Out: R_d (upper) into the LDS image of R, T_d = R_d^-T (as its transpose,
+//      k-major) into a side array.
+//   2. barrier; every wave: R[jb,c] = T_d * S[jb,c] for its columns c > jb (4 MFMAs, B straight from the
+//      accumulators), written into the LDS image (= the row panel).
+//   3. barrier; trailing update of its tiles (r,c), jb < r <= c: acc -= R[jb,r]^T R[jb,c], both operands k-major
+//      reads of the panel (4 MFMAs per tile).
+// 128 pivots cost 8 x ~1 us of in-wave chain instead of 64 barrier-separated pivot pairs on 256 threads that
+// each carried 64 matrix elements and ~450 issue slots per pair (round 1: 75 us, instruction-issue-bound).
+// The inverse of the whole block is NOT formed here: only the eight 16x16 inverses leave this kernel (into the
+// diagonal tiles of T and U); k_trtri_diag128 below completes T_pp / U_pp.
+// ------------------------------------------------------------------------------------------------
+constexpr int PFP = 136;                  // row pitch (f64) of LDS images of 128-wide rows
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    return u.d;
+}
+
+// In-wave factorisation of one 16x16 tile held in the accumulator layout (D[r] = row g + 4r, column n), together
+// with the same row operations on the identity (I -> T_d = R_d^-T): four steps over 4x4 pivot blocks.
+//   * the 10 entries of the symmetric 4x4 pivot block are v_readlane'd into uniform values and every lane
+//     factors it redundantly in scalars (4 dependent rsqrt chains: this is what is left of the serial chain);
+//   * ALL cross-lane work is matrix instructions: pivot rows  [Rp | Tp] = T44 [D | I](rows of the block)  is one
+//     16x16x4 MFMA each (A = T44 padded to 16 rows, B = the accumulator register that holds those rows), and the
+//     rank-4 update of the remaining rows  [D | I] -= Rp^T [Rp | Tp]  is one MFMA each with A = the pivot rows as
+//     they sit in the lanes (lane (g, n) holds Rp[g][n] = A[m = n][k = g]) and B = the same registers.
+// 128 pivots then cost 32 x (20 readlanes + a 4x4 scalar Cholesky + 4 MFMAs) instead of 128 x (2 + 2 (15 - j))
+// readlanes with a dependent FMA behind each (measured: 3.2 us per 16 pivots for that version).
+// Returns -1, or the local index of the first non-positive pivot.
+__device__ __forceinline__ int factor16(d4& D, d4& I, int g, int n) {
+    int bad = -1;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const double ds = D[s];
+        const double a00 = readlane_f64(ds, 4 * s), a01 = readlane_f64(ds, 4 * s + 1);
+        const double a02 = readlane_f64(ds, 4 * s + 2), a03 = readlane_f64(ds, 4 * s + 3);
+        const double a11 = readlane_f64(ds, 16 + 4 * s + 1), a12 = readlane_f64(ds, 16 + 4 * s + 2);
+        const double a13 = readlane_f64(ds, 16 + 4 * s + 3);
+        const double a22 = readlane_f64(ds, 32 + 4 * s + 2), a23 = readlane_f64(ds, 32 + 4 * s + 3);
+        const double a33 = readlane_f64(ds, 48 + 4 * s + 3);
+        // 4x4 Cholesky A44 = R44^T R44 (upper R44), i_k = 1 / R44[k][k]
+        if (bad < 0 && (!(a00 > 0.0) || !(a00 < 1.0e300))) bad = 4 * s;
+        const double i0 = rsqrt_pf(a00);
+        const double r01 = a01 * i0, r02 = a02 * i0, r03 = a03 * i0;
+        const double p1 = fma(-r01, r01, a11);
+        if (bad < 0 && (!(p1 > 0.0) || !(p1 < 1.0e300))) bad = 4 * s + 1;
+        const double i1 = rsqrt_pf(p1);
+        const double r12 = fma(-r01, r02, a12) * i1, r13 = fma(-r01, r03, a13) * i1;
+        const double p2 = fma(-r12, r12, fma(-r02, r02, a22));
+        if (bad < 0 && (!(p2 > 0.0) || !(p2 < 1.0e300))) bad = 4 * s + 2;
+        const double i2 = rsqrt_pf(p2);
+        const double r23 = fma(-r12, r13, fma(-r02, r03, a23)) * i2;
+        const double p3 = fma(-r23, r23, fma(-r13, r13, fma(-r03, r03, a33)));
+        if (bad < 0 && (!(p3 > 0.0) || !(p3 < 1.0e300))) bad = 4 * s + 3;
+        const double i3 = rsqrt_pf(p3);
+        // T44 = R44^-T (lower): forward substitution on the columns of the identity
+        const double t10 = -(r01 * i0) * i1;
+        const double t20 = -fma(r12, t10, r02 * i0) * i2, t21 = -(r12 * i1) * i2;
+        const double t30 = -fma(r23, t20, fma(r13, t10, r03 * i0)) * i3;
+        const double t31 = -fma(r23, t21, r13 * i1) * i3, t32 = -(r23 * i2) * i3;
+        // A operand of the pivot-row products: A[m][k] = T44[m][k] for m < 4 (lane: m = n, k = g), else 0
+        double ta = 0.0;
+        if (n == 0) ta = (g == 0) ? i0 : 0.0;
+        else if (n == 1) ta = (g == 0) ? t10 : ((g == 1) ? i1 : 0.0);
+        else if (n == 2) ta = (g == 0) ? t20 : ((g == 1) ? t21 : ((g == 2) ? i2 : 0.0));
+        else if (n == 3) ta = (g == 0) ? t30 : ((g == 1) ? t31 : ((g == 2) ? t32 : i3));
+        const d4 zero = (d4){0.0, 0.0, 0.0, 0.0};
+        const d4 pr = __builtin_amdgcn_mfma_f64_16x16x4f64(ta, ds, zero, 0, 0, 0);
+        const d4 pt = __builtin_amdgcn_mfma_f64_16x16x4f64(ta, I[s], zero, 0, 0, 0);
+        // rows 0..3 of the products sit in register 0: lane (g, n) now holds row 4s + g of [R | T]
+        const double rrow = (n >= 4 * s + g) ? pr[0] : 0.0;       // exact zeros left of the diagonal
+        const double trow = pt[0];
+        D[s] = rrow;
+        I[s] = trow;
+        if (s < 3) {
+            const double aop = (n >= 4 * s + 4) ? -rrow : 0.0;    // rows m = n below the pivot block only
+            D = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, rrow, D, 0, 0, 0);
+            I = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, trow, I, 0, 0, 0);
+        }
+    }
+    return bad;
+}
+
+// Pn: the current 16-row panel [16][PFP]; Ud: the current T_d^T [16][16]; Rg / Tg / Ug: the block in global memory
+// (results leave from registers as they are produced: R_d and the panel tiles here, nothing is kept in LDS
+// beyond the panel the trailing update is reading -- 19 KB, so the kernel co-resides with anything).
+template <int JB>
+__device__ __forceinline__ bool pf16_step(d4 (&accA)[8], d4 (&accB)[8], int cA, int cB, double* __restrict__ Pn,
+                                          double* __restrict__ Ud, volatile int* sflag, int w, int lane,
+                                          int64_t p0, int* flag, double* __restrict__ Rg, double* __restrict__ Tg,
+                                          double* __restrict__ Ug, int64_t Np) {
+    const int g = lane >> 4, n = lane & 15;
+    constexpr int OWNER = (JB < 4) ? JB : 7 - JB;
+    if (w == OWNER) {
+        d4 D = (JB < 4) ? accA[JB] : accB[JB];
+        d4 I;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) I[r] = (g + 4 * r == n) ? 1.0 : 0.0;
+        const int bad = factor16(D, I, g, n);
+        if (bad >= 0 && lane == 0) { *flag = (int)(p0 + 16 * JB + bad) + 1; *sflag = 1; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = p0 + 16 * JB + g + 4 * r, col = p0 + 16 * JB + n;
+            Rg[row * Np + col] = D[r];                                    // R_d, zeros below its diagonal
+            Tg[row * Np + col] = I[r];                                    // T_d (lower)
+            Ug[col * Np + row] = I[r];                                    // U_d = T_d^T
+            Ud[n * 16 + g + 4 * r] = I[r];                                // LDS, k-major: Ud[k][m] = T_d[m][k]
+        }
+    }
+    __syncthreads();
+    if (*sflag) return false;
+    if (JB == 7) return true;
+    // row panel: R[jb, c] = T_d S[jb, c]
+    double a[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) a[kk] = Ud[(4 * kk + g) * 16 + n];
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const int c = side ? cB : cA;
+        if (c > JB) {
+            const d4 src = side ? accB[JB] : accA[JB];
+            d4 pnl = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) pnl = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], src[kk], pnl, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Pn[(g + 4 * r) * PFP + 16 * c + n] = pnl[r];
+                Rg[(p0 + 16 * JB + g + 4 * r) * Np + p0 + 16 * c + n] = pnl[r];
+            }
+        }
+    }
+    __syncthreads();
+    // trailing update
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const int c = side ? cB : cA;
+        if (c > JB) {
+            double b[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) b[kk] = -Pn[(4 * kk + g) * PFP + 16 * c + n];
+#pragma unroll
+            for (int r = JB + 1; r < 8; ++r) {
+                if (r <= c) {
+                    double ar[4];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) ar[kk] = Pn[(4 * kk + g) * PFP + 16 * r + n];
+                    d4 acc = side ? accB[r] : accA[r];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[kk], b[kk], acc, 0, 0, 0);
+                    if (side) accB[r] = acc; else accA[r] = acc;
+                }
+            }
+        }
+    }
+    return true;
+}
+
+// DBG (scripts/potrf_bench.hip only): wall-clock stamps of the phases go to `dbg` (thread 0)
+template <bool DBG>
+__global__ __launch_bounds__(256) void k_potrf16(const double* __restrict__ S, double* __restrict__ R,
+                                                 double* __restrict__ T, double* __restrict__ U, int64_t Np,
+                                                 int p, int* __restrict__ flag, long long* __restrict__ dbg) {
+    __shared__ double Pn[16 * PFP];       // the current 16-row panel of R
+    __shared__ double Ud[256];            // the current 16x16 inverse, transposed (k-major A operand)
+    __shared__ int sflag;
+    if (*flag != 0) return;               // an earlier block already failed
+    // The chain kernels run at the highest wave priority: they share compute units with the side streams'
+    // trailing updates, whose waves raise their own priority to 1 around their MFMA phases -- a chain wave at
+    // priority 0 on the same SIMD was measured to run 3x slower (k_potrf16 36 -> 107 us).
+    __builtin_amdgcn_s_setprio(3);
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const int64_t p0 = (int64_t)p * NB;
+    const int cA = w, cB = 7 - w;
+    if (t == 0) sflag = 0;
+    d4 accA[8], accB[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        accA[r] = (d4){0.0, 0.0, 0.0, 0.0};
+        accB[r] = (d4){0.0, 0.0, 0.0, 0.0};
+        if (r <= cA) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) accA[r][q] = S[(p0 + 16 * r + g + 4 * q) * Np + p0 + 16 * cA + n];
+        }
+        if (r <= cB) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) accB[r][q] = S[(p0 + 16 * r + g + 4 * q) * Np + p0 + 16 * cB + n];
+        }
+    }
+    // the block below the diagonal tiles is zero in R and in T's upper / U's lower part: written here, while the
+    // loads above are in flight (tiles (r, c) with r > c for R; T and U only need their off-diagonal tiles
+    // defined once k_trtri_diag128 has run, which writes them in full)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int idx4 = t + 256 * q;
+        const int r = idx4 >> 5, c = (idx4 & 31) * 4;
+        if ((c >> 4) < (r >> 4)) *reinterpret_cast<d4*>(R + (p0 + r) * Np + p0 + c) = (d4){0.0, 0.0, 0.0, 0.0};
+    }
+    if (DBG && t == 0) dbg[0] = wall_clock64();
+    __syncthreads();
+    if (DBG && t == 0) dbg[1] = wall_clock64();
+    bool ok = pf16_step<0>(accA, accB, cA, cB, Pn, Ud, &sflag, w, lane, p0, flag, R, T, U, Np);
+    if (DBG && t == 0) dbg[2] = wall_clock64();
+    if (ok) ok = pf16_step<1>(accA, accB, cA, cB, Pn, Ud, &sflag, w, lane, p0, flag, R, T, U, Np);
+    if (DBG && t == 0) dbg[3] = wall_clock64();
+    if (ok) ok = pf16_step<2>(accA, accB, cA, cB, Pn, Ud, &sflag, w, lane, p0, flag, R, T, U, Np);
+    if (DBG && t == 0) dbg[4] = wall_clock64();
+    if (ok) ok = pf16_step<3>(accA, accB, cA, cB, Pn, Ud, &sflag, w, lane, p0, flag, R, T, U, Np);
+    if (DBG && t == 0) dbg[5] = wall_clock64();
+    if (ok) ok = pf16_step<4>(accA, accB, cA, cB, Pn, Ud, &sflag, w, lane, p0, flag, R, T, U, Np);
+    if (DBG && t == 0) dbg[6] = wall_clock64();
+    if (ok) ok = pf16_step<5>(accA, accB, cA, cB, Pn, Ud, &sflag, w, lane, p0, flag, R, T, U, Np);
+    if (DBG && t == 0) dbg[7] = wall_clock64();
+    if (ok) ok = pf16_step<6>(accA, accB, cA, cB, Pn, Ud, &sflag, w, lane, p0, flag, R, T, U, Np);
+    if (DBG && t == 0) dbg[8] = wall_clock64();
+    if (ok) ok = pf16_step<7>(accA, accB, cA, cB, Pn, Ud, &sflag, w, lane, p0, flag, R, T, U, Np);
+    if (DBG && t == 0) dbg[9] = wall_clock64();
+    if (DBG && t == 0) dbg[10] = wall_clock64();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Triangular inverse of one (or many: blockIdx.x) diagonal 128-block(s) from its factor R_pp and the eight
+// 16x16 inverses k_potrf16 left in the diagonal tiles of T / U: recursive doubling over 16-tiles
+//     T_21 = - T_22 (L_21 T_11),   L_21 = R_12^T
+// on one LDS image that holds R (upper tiles, consumed level by level), T (lower tiles) and U = T^T (upper
+// tiles, written over the R tiles a level has consumed); every MFMA operand is a k-major read of that image.
+// Off the Cholesky's critical path: all diagonal blocks are inverted by ONE launch after the factorisation.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_trtri_diag128(const double* __restrict__ R, double* __restrict__ T,
+                                                       double* __restrict__ U, int64_t Np, int pbase,
+                                                       const int* __restrict__ flag) {
+    __shared__ double Mp[NB * PFP];
+    __shared__ double Ui[8 * 256];
+    if (*flag != 0) return;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const int64_t p0 = (int64_t)(pbase + blockIdx.x) * NB;
+    {
+        // all loads first (16 + 2 x 32 bytes per thread in flight), then the LDS stores
+        d4 v[16], u[2];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int idx4 = t + 256 * q;
+            const int r = idx4 >> 5, c = (idx4 & 31) * 4;
+            const int tr = r >> 4, tc = c >> 4;
+            v[q] = (d4){0.0, 0.0, 0.0, 0.0};
+            if (tc >= tr)      // R above the diagonal tiles, T_d (row-major, zeros above its diagonal) on them
+                v[q] = *reinterpret_cast<const d4*>(((tc > tr) ? R : T) + (p0 + r) * Np + p0 + c);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {       // the diagonal tiles of U: Ui[jb][k][m] = U_d[k][m]
+            const int idx4 = t + 256 * q;
+            const int jb = idx4 >> 6, k = (idx4 >> 2) & 15, m = (idx4 & 3) * 4;
+            u[q] = *reinterpret_cast<const d4*>(U + (p0 + 16 * jb + k) * Np + p0 + 16 * jb + m);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int idx4 = t + 256 * q;
+            *reinterpret_cast<d4*>(Mp + (idx4 >> 5) * PFP + (idx4 & 31) * 4) = v[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<d4*>(Ui + (t + 256 * q) * 4) = u[q];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int hb = 1; hb < 8; hb *= 2) {
+        const int ntile = 4 * hb;                     // (8 / 2hb) groups x hb^2 tiles
+        d4 acc[4];
+        // phase 1: W = L21 T11
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int tt = w + 4 * s;
+            acc[s] = (d4){0.0, 0.0, 0.0, 0.0};
+            if (tt < ntile) {
+                const int grp = tt / (hb * hb), rem = tt - grp * hb * hb;
+                const int g0 = grp * 2 * hb, i = g0 + hb + rem / hb, j = g0 + rem % hb;
+                for (int k = j; k < g0 + hb; ++k) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const double a = Mp[(16 * k + 4 * kk + g) * PFP + 16 * i + n];    // R[k-tile rows][i-tile cols]
+                        const double b = Mp[(16 * k + 4 * kk + g) * PFP + 16 * j + n];    // T11 tile (k, j), k >= j
+                        acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[s], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int tt = w + 4 * s;
+            if (tt < ntile) {
+                const int grp = tt / (hb * hb), rem = tt - grp * hb * hb;
+                const int g0 = grp * 2 * hb, i = g0 + hb + rem / hb, j = g0 + rem % hb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Mp[(16 * i + g + 4 * r) * PFP + 16 * j + n] = acc[s][r];   // W in T21's place
+            }
+        }
+        __syncthreads();
+        // phase 2: T21 = - T22 W
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int tt = w + 4 * s;
+            acc[s] = (d4){0.0, 0.0, 0.0, 0.0};
+            if (tt < ntile) {
+                const int grp = tt / (hb * hb), rem = tt - grp * hb * hb;
+                const int g0 = grp * 2 * hb, i = g0 + hb + rem / hb, j = g0 + rem % hb;
+                for (int k = g0 + hb; k <= i; ++k) {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const double a = (k == i) ? Ui[i * 256 + (4 * kk + g) * 16 + n]                 // T_d of tile i
+                                                  : Mp[(16 * k + 4 * kk + g) * PFP + 16 * i + n];       // U tile (k, i)
+                        const double b = Mp[(16 * k + 4 * kk + g) * PFP + 16 * j + n];                  // W tile (k, j)
+                        acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[s], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();            // everyone has read W and the R12 tiles of this level
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int tt = w + 4 * s;
+            if (tt < ntile) {
+                const int grp = tt / (hb * hb), rem = tt - grp * hb * hb;
+                const int g0 = grp * 2 * hb, i = g0 + hb + rem / hb, j = g0 + rem % hb;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double v = -acc[s][r];
+                    Mp[(16 * i + g + 4 * r) * PFP + 16 * j + n] = v;        // T21
+                    Mp[(16 * j + n) * PFP + 16 * i + g + 4 * r] = v;        // U12 = T21^T over the consumed R12
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int idx4 = t + 256 * q;
+        const int r = idx4 >> 5, c = (idx4 & 31) * 4;
+        const int tr = r >> 4, tc = c >> 4;
+        const d4 m = *reinterpret_cast<const d4*>(Mp + r * PFP + c);
+        const d4 zero = (d4){0.0, 0.0, 0.0, 0.0};
+        d4 uv = zero;
+        if (tr < tc) uv = m;
+        else if (tr == tc) uv = *reinterpret_cast<const d4*>(Ui + tr * 256 + (r & 15) * 16 + (c & 15));
+        const int64_t gidx = (p0 + r) * Np + p0 + c;
+        *reinterpret_cast<d4*>(T + gidx) = (tr >= tc) ? m : zero;
+        *reinterpret_cast<d4*>(U + gidx) = uv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// R2b' (round 2): panel solve  R[p, J] = R_pp^-T S[p, J]  by blocked forward substitution over 16-row tiles,
+// from the factor R_pp and its eight 16x16 diagonal inverses alone -- the inverse of the 128-block is NOT on the
+// Cholesky's critical path any more (round 1 formed it inside the diagonal kernel because this step was a GEMM
+// with T_pp).  One workgroup = 64 columns; each WAVE owns 16 of them and runs the whole substitution on its own:
+// its 8 right-hand-side tiles live in accumulators, the solved tile x_jb feeds
+// the next MFMAs straight from registers as the B operand,
+//     x_jb = T_d(jb) s_jb        s_i -= R[jb, i]^T x_jb   (i > jb)        144 MFMAs per wave.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_panel_solve16(const double* __restrict__ U, const double* __restrict__ S,
+                                                       double* __restrict__ R, int64_t Np, int p,
+                                                       const int* __restrict__ flag) {
+    // NO LDS and no barrier: the A fragments (tiles of R_pp, the 16x16 inverses) are read straight from global
+    // memory / L2 in the k-major fragment layout (lane (g, n) <- row 4kk + g, column n: four 128-byte segments
+    // per instruction), one step ahead of the MFMAs that consume them.  A 155 KB LDS image of R_pp was measured
+    // first: alone it ran in 9.5 us, but it needs an EMPTY compute unit, and next to the side stream's trailing
+    // updates (2 x 72 KB per CU) its launches waited up to 480 us for one.
+    if (*flag != 0) return;
+    __builtin_amdgcn_s_setprio(3);                // chain kernel: see k_potrf16
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const int64_t p0 = (int64_t)p * NB;
+    const int64_t j0 = (int64_t)(p + 1) * NB + (int64_t)blockIdx.x * 64 + 16 * w;
+    const double* Rd = R + p0 * Np + p0;          // R_pp
+    const double* Ud = U + p0 * Np + p0;          // diagonal 16-tiles hold T_d^T
+    d4 X[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) X[r][q] = S[(p0 + 16 * r + g + 4 * q) * Np + j0 + n];
+    double ti[8][4];                               // A fragments of the eight T_d
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) ti[jb][kk] = Ud[(int64_t)(16 * jb + 4 * kk + g) * Np + 16 * jb + n];
+    double acur[7][4], anxt[7][4];                 // A fragments of R[jb, i], i = jb+1 .. 7
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acur[i - 1][kk] = Rd[(int64_t)(4 * kk + g) * Np + 16 * i + n];
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) {
+        if (jb + 1 < 8) {
+#pragma unroll
+            for (int i = jb + 2; i < 8; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    anxt[i - jb - 2][kk] = Rd[(int64_t)(16 * (jb + 1) + 4 * kk + g) * Np + 16 * i + n];
+        }
+        d4 x = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(ti[jb][kk], X[jb][kk], x, 0, 0, 0);
+        X[jb] = x;
+        const d4 xn = -x;
+#pragma unroll
+        for (int i = jb + 1; i < 8; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                X[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(acur[i - jb - 1][kk], xn[kk], X[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acur[i][kk] = anxt[i][kk];
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) R[(p0 + 16 * r + g + 4 * q) * Np + j0 + n] = X[r][q];
+}
+
+// ------------------------------------------------------------------------------------------------
 // R2b: panel solve  R_pJ = T_pp S_pJ  (J > p) as a GEMM:  A(m,k) = T_pp(m,k) = U[p0+k][p0+m]
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GEMM_THREADS) void k_panel_trsm(const double* __restrict__ U,
@@ -359,6 +802,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_row_update64(const double* __r
                                                                double* __restrict__ S, int64_t Np, int kb0,
                                                                int kb1, int I) {
     if (blockIdx.x < blockIdx.y) return;   // strictly below the diagonal inside the diagonal block
+    __builtin_amdgcn_s_setprio(3);         // chain kernel: see k_potrf16
     __shared__ __attribute__((aligned(16))) double smem[GEMM64_LDS_F64];
     const int64_t i0 = (int64_t)I * NB + (int64_t)blockIdx.y * T64;
     const int64_t j0 = (int64_t)I * NB + (int64_t)blockIdx.x * T64;
@@ -367,7 +811,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_row_update64(const double* __r
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
-    gemm_tile_64(acc, R + i0, Np, R + j0, Np, kb0 * NB, kb1 * NB, smem);
+    gemm_tile_64_g(acc, R + i0, Np, R + j0, Np, kb0 * NB, kb1 * NB, smem);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -393,22 +837,36 @@ constexpr int CHOL_W = 4;   // outer panel width in 128-blocks
 void launch_cholesky(gpx_handle* h) {
     const int64_t Np = h->Np;
     const int nP = (int)(Np / NB);
-    hipStream_t s = h->stream, s2 = h->stream2;
+    hipStream_t s = h->stream, s2 = h->stream2, s3 = h->stream3;
     hipMemsetAsync(h->dflag, 0, sizeof(int), s);
     bool mid_pending = false, side_used = false;
+    int near_rows = 0;            // rows P0+1.. of the CURRENT panel whose near update runs on the third stream
     for (int P0 = 0; P0 < nP; P0 += CHOL_W) {
         const int P1 = (P0 + CHOL_W < nP) ? P0 + CHOL_W : nP;
         for (int I = P0; I < P1; ++I) {
+            if (I > P0 && I - P0 <= near_rows)     // this row's share of the previous panel's update (stream 3)
+                hipStreamWaitEvent(s, h->ev_row[I - P0], 0);
             if (I > P0)   // block row I <- contributions of rows P0..I-1 of this panel
                 hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - I)), 2), dim3(GEMM_THREADS), 0, s,
                                    h->dR, h->dS, Np, P0, I, I);
-            hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, s, h->dS, h->dR, h->dT, h->dU, Np, I,
-                               h->dflag);
+            if (h->potrf_variant == 0) {
+                hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, s, h->dS, h->dR, h->dT, h->dU, Np, I,
+                                   h->dflag);
+            } else {
+                hipLaunchKernelGGL(k_potrf16<false>, dim3(1), dim3(256), 0, s, h->dS, h->dR, h->dT, h->dU, Np, I, h->dflag,
+                                   (long long*)nullptr);
+            }
             const int rem = nP - 1 - I;
-            if (rem > 0)
-                hipLaunchKernelGGL(k_panel_trsm, dim3((unsigned)(2 * rem), 2), dim3(GEMM_THREADS), 0, s, h->dU,
-                                   h->dS, h->dR, Np, I);
+            if (rem > 0) {
+                if (h->potrf_variant == 0)
+                    hipLaunchKernelGGL(k_panel_trsm, dim3((unsigned)(2 * rem), 2), dim3(GEMM_THREADS), 0, s, h->dU,
+                                       h->dS, h->dR, Np, I);
+                else
+                    hipLaunchKernelGGL(k_panel_solve16, dim3((unsigned)(2 * rem)), dim3(256), 0, s, h->dU, h->dS, h->dR,
+                                       Np, I, h->dflag);
+            }
         }
+        near_rows = 0;
         if (P1 >= nP) break;
         const int nnear = (P1 + CHOL_W < nP) ? CHOL_W : nP - P1;
         const int m0 = P1 + nnear;                                    // first block row of mid(P)
@@ -416,11 +874,31 @@ void launch_cholesky(gpx_handle* h) {
         const int r0 = m0 + nmid;                                     // first block row of rest(P)
         const int nrest = nP - r0;
         if (mid_pending) hipStreamWaitEvent(s, h->ev_far, 0);        // mid(P-1) (and rest(P-2)) wrote these rows
-        hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)(nP - P1), (unsigned)nnear), dim3(GEMM_THREADS), 0, s,
-                           h->dR, h->dS, Np, P0, P1, P1, P1);
         mid_pending = false;
+        hipEventRecord(h->ev_chain, s);                               // R rows P0..P1-1 are final, mid(P-1) joined
+        if (h->potrf_variant == 0) {
+            hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)(nP - P1), (unsigned)nnear), dim3(GEMM_THREADS), 0, s,
+                               h->dR, h->dS, Np, P0, P1, P1, P1);
+        } else {
+            // near(P) row by row.  Only block row P1 is needed before the next diagonal block can be factored: it is
+            // updated on 64x64 tiles (4x the workgroups, a quarter of the K = 512 tile latency each; the one-launch
+            // 128-tile form cost ~115 us of pure critical path per panel = the latency of ONE workgroup per CU at
+            // half the matrix pipe -- and so did each row launched separately in that form).  The other rows of the
+            // next panel are brought up to date, on 64x64 tiles too, on a third stream WHILE the chain already
+            // works on row P1; the chain waits for row P1 + q just before that row's in-panel update.
+            hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - P1)), 2), dim3(GEMM_THREADS), 0, s, h->dR,
+                               h->dS, Np, P0, P1, P1);
+            if (nnear > 1) {
+                hipStreamWaitEvent(s3, h->ev_chain, 0);
+                for (int q = 1; q < nnear; ++q) {
+                    hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - P1 - q)), 2), dim3(GEMM_THREADS), 0, s3,
+                                       h->dR, h->dS, Np, P0, P1, P1 + q);
+                    hipEventRecord(h->ev_row[q], s3);
+                }
+                near_rows = nnear - 1;
+            }
+        }
         if (nmid > 0) {
-            hipEventRecord(h->ev_chain, s);                           // R rows P0..P1-1 are final
             hipStreamWaitEvent(s2, h->ev_chain, 0);
             hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)(nP - m0), (unsigned)nmid), dim3(GEMM_THREADS), 0, s2,
                                h->dR, h->dS, Np, P0, P1, m0, m0);
@@ -436,6 +914,9 @@ void launch_cholesky(gpx_handle* h) {
         hipEventRecord(h->ev_far, s2);
         hipStreamWaitEvent(s, h->ev_far, 0);
     }
+    // (stream 3 needs no join: every launch on it is followed by an event the main stream has waited on)
+    // variant 1 leaves only the 16x16 inverses in the diagonal blocks of T / U; launch_trtri completes them
+    h->diag_inv_pending = (h->potrf_variant != 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -504,6 +985,10 @@ void launch_trtri(gpx_handle* h) {
     const int64_t Np = h->Np;
     const int nP = (int)(Np / NB);
     hipStream_t s = h->stream;
+    if (h->diag_inv_pending) {     // all diagonal 128-blocks at once, off the factorisation's critical path
+        hipLaunchKernelGGL(k_trtri_diag128, dim3((unsigned)nP), dim3(256), 0, s, h->dR, h->dT, h->dU, Np, 0, h->dflag);
+        h->diag_inv_pending = false;
+    }
     for (int hb = 1; hb < nP; hb *= 2) {
         const int ngroups = (nP + 2 * hb - 1) / (2 * hb);
         dim3 grid((unsigned)hb, (unsigned)hb, (unsigned)ngroups);
