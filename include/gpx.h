@@ -87,6 +87,13 @@ int gpx_fit_dev(gpx_handle *h, const double *dX, int64_t N, int64_t d, const dou
 /* log marginal likelihood of the fitted model, -1/2 a.a - sum log R_ii - N/2 log 2pi: what a
  * hyper-parameter sampler (reggie.MCMC, pybo/bayesopt.py:115) evaluates once per proposal. */
 int gpx_loglik(gpx_handle *h, double *out);
+/* The same quantity for B hyper-parameter vectors at once on the handle's RESIDENT data (any earlier gpx_fit*
+ * put X, y on the device), without touching the handle's own fit: hypers (B, d + 3) row-major
+ * [sn2, rho, ell_1..d, bias] (the argument order of reggie.make_gp, pybo/bayesopt.py:105), out (B,);
+ * -inf where K + sn2 I is not positive definite.  One batched Gram + Cholesky launch chain and one host
+ * synchronisation for the whole batch: the evaluation a hyper-parameter sampler repeats per proposal
+ * (reggie.MCMC(model, n=10, burn=100), pybo/bayesopt.py:115).  1 <= B <= 64. */
+int gpx_loglik_batch(gpx_handle *h, int64_t B, const double *hypers, double *out);
 /* Incremental fit: absorb ONE more observation x (d,), y into the current factorisation in O(N^2)
  * (two memory-bound passes over T and U) instead of refitting -- the per-iteration
  * `model.add_data(x, y)` of the BO loop [pybo/bayesopt.py:269].  When the current 128-block has no padding

@@ -26,6 +26,7 @@ SYMBOLS = {
     'gpx_fit': (C.c_int, [_P, _P, _i64, _i64, _P, C.c_int, _P, _dbl, _dbl, _dbl]),
     'gpx_fit_dev': (C.c_int, [_P, _P, _i64, _i64, _P, C.c_int, _P, _dbl, _dbl, _dbl]),
     'gpx_loglik': (C.c_int, [_P, _P]),
+    'gpx_loglik_batch': (C.c_int, [_P, _i64, _P, _P]),
     'gpx_append': (C.c_int, [_P, _P, _dbl]),
     'gpx_fail_pivot': (_i64, [_P]),
     'gpx_get_matrix': (C.c_int, [_P, C.c_int, _P]),
@@ -314,6 +315,14 @@ class Engine(object):
         out = C.c_double()
         self._check(self._lib.gpx_loglik(self._h, C.byref(out)))
         return out.value
+
+    def loglik_batch(self, hypers):
+        """log p(y | X, theta_b) for B hyper-parameter vectors [sn2, rho, ell_1..d, bias] on the resident data: one
+        batched launch chain, one synchronisation; the engine's own fit is untouched."""
+        hypers = _f64(hypers).reshape(-1, self.d + 3)
+        out = np.empty(len(hypers))
+        self._check(self._lib.gpx_loglik_batch(self._h, len(hypers), _ptr(hypers), _ptr(out)))
+        return out
 
     def append(self, x, y):
         """Rank-1 extension by one observation; returns False when a refit is needed (block boundary)."""

@@ -193,7 +193,7 @@ extern "C" int gpx_destroy(gpx_handle* h) {
     for (auto e : h->pool) hipEventDestroy(e);
     void* ptrs[] = {h->dXs, h->dXraw, h->dy, h->dS, h->dR, h->dT, h->dU, h->da, h->dalpha, h->dinvell,
                     h->dflag, h->dscal, h->dKs, h->dQp, h->dXc, h->dout, h->dblkv, h->dblki,
-                    h->dtopv, h->drff, h->drffs, h->dgrad, h->dens, h->dcZ, h->dcq};  // dPp, dtopi, dcp alias dQp, dtopv, dcq
+                    h->dtopv, h->drff, h->drffs, h->dgrad, h->dens, h->dcZ, h->dcq, h->dbatch};  // dPp, dtopi, dcp alias dQp, dtopv, dcq
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
@@ -431,6 +431,13 @@ extern "C" int gpx_loglik(gpx_handle* h, double* out) {
     return guarded(h, [&]() -> int {
         if (!h) return GPX_EARG;
         return gpx::loglik_host(h, out);
+    });
+}
+
+extern "C" int gpx_loglik_batch(gpx_handle* h, int64_t B, const double* hypers, double* out) {
+    return guarded(h, [&]() -> int {
+        if (!h) return GPX_EARG;
+        return gpx::loglik_batch_host(h, B, hypers, out);
     });
 }
 

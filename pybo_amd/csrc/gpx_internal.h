@@ -103,6 +103,9 @@ struct gpx_handle {
     double* dcp = nullptr;
     int64_t cap_cz = 0, cap_cq = 0;
 
+    double* dbatch = nullptr;    // gpx_loglik_batch: Gram / factor / scaled inputs / a of the batch (one allocation)
+    int64_t cap_batch = 0;
+
     // timers
     std::vector<gpx::EventPair> pending;
     std::vector<hipEvent_t> pool;
@@ -152,6 +155,7 @@ int predict_grad_host(gpx_handle* h, const double* Xc, int64_t M, double* mu, do
 int ensure_inverse(gpx_handle* h);
 
 int loglik_host(gpx_handle* h, double* out);
+int loglik_batch_host(gpx_handle* h, int64_t B, const double* hyp, double* out);   // kernels_fit.hip
 int append_host(gpx_handle* h, const double* x, double ynew);
 int rff_grad_host(gpx_handle* h, const double* W, const double* b, const double* theta, int64_t n, int64_t d,
                   double bias, const double* Xc, int64_t M, double* f, double* g);

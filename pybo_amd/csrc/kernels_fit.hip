@@ -9,6 +9,10 @@
 // the identity so every tile is full and no kernel has bounds checks.  We factor the UPPER triangle:
 // with R row-major, both GEMM operands of the trailing update  S_IJ -= R_pI^T R_pJ  are k-major
 // (see gemm_core.h), which is what keeps the loads coalesced without any transpose.
+#include <math.h>
+
+#include <vector>
+
 #include "gemm_core.h"
 #include "gpx_internal.h"
 #include "gpx_math.h"
@@ -17,10 +21,13 @@ namespace gpx {
 
 // (covariance functions: gpx_math.h)
 // Xs[i][k] = X[i][k] / ell[k] for i < n, 0 for n <= i < np
+// Batched use (gpx_loglik_batch): blockIdx.z = batch element with its own 1/ell (DMAX apart) and its own Xs.
 __global__ void k_scale_x(const double* __restrict__ X, int64_t n, int64_t np, int d,
                           const double* __restrict__ invell, double* __restrict__ Xs) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= np * d) return;
+    invell += (int64_t)blockIdx.z * DMAX;
+    Xs += (int64_t)blockIdx.z * np * d;
     const int64_t i = idx / d;
     const int k = (int)(idx - i * d);
     Xs[idx] = (i < n) ? X[idx] * invell[k] : 0.0;
@@ -41,11 +48,18 @@ void launch_scale_x(hipStream_t s, const double* X, int64_t n, int64_t np, int d
 constexpr int GT = 64;
 constexpr int GDC = 16;  // coordinates staged per pass
 
+// Batched use: blockIdx.z = batch element; hyp (B, 3) = {rho, sn2, bias} per element overrides the scalars.
 __global__ __launch_bounds__(256) void k_gram_sym(const double* __restrict__ Xs, int64_t N, int64_t Np,
                                                   int d, int kid, double rho, double sn2,
-                                                  double* __restrict__ S) {
+                                                  double* __restrict__ S, const double* __restrict__ hyp) {
     const int bi = blockIdx.y, bj = blockIdx.x;
     if ((bi >> 1) > (bj >> 1)) return;  // below the 128-block diagonal: never read
+    if (hyp) {
+        rho = hyp[3 * blockIdx.z];
+        sn2 = hyp[3 * blockIdx.z + 1];
+        Xs += (int64_t)blockIdx.z * Np * d;
+        S += (int64_t)blockIdx.z * Np * Np;
+    }
     __shared__ double xi[GDC][GT];
     __shared__ double xj[GDC][GT];
     const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
@@ -103,7 +117,8 @@ __global__ __launch_bounds__(256) void k_gram_sym(const double* __restrict__ Xs,
 void launch_gram_sym(hipStream_t s, const double* Xs, int64_t N, int64_t Np, int d, int kernel_id,
                      double rho, double sn2, double* S) {
     const unsigned g = (unsigned)(Np / GT);
-    hipLaunchKernelGGL(k_gram_sym, dim3(g, g), dim3(256), 0, s, Xs, N, Np, d, kernel_id, rho, sn2, S);
+    hipLaunchKernelGGL(k_gram_sym, dim3(g, g), dim3(256), 0, s, Xs, N, Np, d, kernel_id, rho, sn2, S,
+                       (const double*)nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -424,7 +439,7 @@ __device__ __forceinline__ bool pf16_step(d4 (&accA)[8], d4 (&accB)[8], int cA, 
         for (int r = 0; r < 4; ++r) {
             const int64_t row = p0 + 16 * JB + g + 4 * r, col = p0 + 16 * JB + n;
             Rg[row * Np + col] = D[r];                                    // R_d, zeros below its diagonal
-            Tg[row * Np + col] = I[r];                                    // T_d (lower)
+            if (Tg) Tg[row * Np + col] = I[r];                            // T_d (lower)
             Ug[col * Np + row] = I[r];                                    // U_d = T_d^T
             Ud[n * 16 + g + 4 * r] = I[r];                                // LDS, k-major: Ud[k][m] = T_d[m][k]
         }
@@ -478,10 +493,18 @@ __device__ __forceinline__ bool pf16_step(d4 (&accA)[8], d4 (&accB)[8], int cA, 
 }
 
 // DBG (scripts/potrf_bench.hip only): wall-clock stamps of the phases go to `dbg` (thread 0)
+// Batched use (gpx_loglik_batch): blockIdx.z = batch element, S / R / U `bs` elements apart, one flag each;
+// T may be NULL (the batched path needs U_d only and keeps it in the dead diagonal blocks of S).
 template <bool DBG>
 __global__ __launch_bounds__(256) void k_potrf16(const double* __restrict__ S, double* __restrict__ R,
                                                  double* __restrict__ T, double* __restrict__ U, int64_t Np,
-                                                 int p, int* __restrict__ flag, long long* __restrict__ dbg) {
+                                                 int p, int* __restrict__ flag, long long* __restrict__ dbg,
+                                                 int64_t bs) {
+    S += (int64_t)blockIdx.z * bs;
+    R += (int64_t)blockIdx.z * bs;
+    U += (int64_t)blockIdx.z * bs;
+    if (T) T += (int64_t)blockIdx.z * bs;
+    flag += blockIdx.z;
     __shared__ double Pn[16 * PFP];       // the current 16-row panel of R
     __shared__ double Ud[256];            // the current 16x16 inverse, transposed (k-major A operand)
     __shared__ int sflag;
@@ -680,7 +703,11 @@ __global__ __launch_bounds__(256) void k_trtri_diag128(const double* __restrict_
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_panel_solve16(const double* __restrict__ U, const double* __restrict__ S,
                                                        double* __restrict__ R, int64_t Np, int p,
-                                                       const int* __restrict__ flag) {
+                                                       const int* __restrict__ flag, int64_t bs) {
+    U += (int64_t)blockIdx.z * bs;       // batched use: blockIdx.z = batch element
+    S += (int64_t)blockIdx.z * bs;
+    R += (int64_t)blockIdx.z * bs;
+    flag += blockIdx.z;
     // NO LDS and no barrier: the A fragments (tiles of R_pp, the 16x16 inverses) are read straight from global
     // memory / L2 in the k-major fragment layout (lane (g, n) <- row 4kk + g, column n: four 128-byte segments
     // per instruction), one step ahead of the MFMAs that consume them.  A 155 KB LDS image of R_pp was measured
@@ -777,9 +804,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_panel_trsm(const double* __res
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(const double* __restrict__ R,
                                                                  double* __restrict__ S, int64_t Np,
-                                                                 int kb0, int kb1, int ib0, int jb0) {
+                                                                 int kb0, int kb1, int ib0, int jb0, int64_t bs) {
     const int I = ib0 + blockIdx.y, J = jb0 + blockIdx.x;
     if (I > J) return;
+    R += (int64_t)blockIdx.z * bs;       // batched use: blockIdx.z = batch element
+    S += (int64_t)blockIdx.z * bs;
     __shared__ __attribute__((aligned(16))) double smem[GEMM_LDS_F64];
     const int64_t i0 = (int64_t)I * NB, j0 = (int64_t)J * NB;
     d4 acc[4][4];
@@ -800,8 +829,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(const double* _
 // grid (2*(nP-I), 2): blockIdx.y = row half, blockIdx.x = 64-column tile counted from the diagonal block.
 __global__ __launch_bounds__(GEMM_THREADS) void k_row_update64(const double* __restrict__ R,
                                                                double* __restrict__ S, int64_t Np, int kb0,
-                                                               int kb1, int I) {
+                                                               int kb1, int I, int64_t bs) {
     if (blockIdx.x < blockIdx.y) return;   // strictly below the diagonal inside the diagonal block
+    R += (int64_t)blockIdx.z * bs;         // batched use: blockIdx.z = batch element
+    S += (int64_t)blockIdx.z * bs;
     __builtin_amdgcn_s_setprio(3);         // chain kernel: see k_potrf16
     __shared__ __attribute__((aligned(16))) double smem[GEMM64_LDS_F64];
     const int64_t i0 = (int64_t)I * NB + (int64_t)blockIdx.y * T64;
@@ -848,13 +879,13 @@ void launch_cholesky(gpx_handle* h) {
                 hipStreamWaitEvent(s, h->ev_row[I - P0], 0);
             if (I > P0)   // block row I <- contributions of rows P0..I-1 of this panel
                 hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - I)), 2), dim3(GEMM_THREADS), 0, s,
-                                   h->dR, h->dS, Np, P0, I, I);
+                                   h->dR, h->dS, Np, P0, I, I, (int64_t)0);
             if (h->potrf_variant == 0) {
                 hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, s, h->dS, h->dR, h->dT, h->dU, Np, I,
                                    h->dflag);
             } else {
                 hipLaunchKernelGGL(k_potrf16<false>, dim3(1), dim3(256), 0, s, h->dS, h->dR, h->dT, h->dU, Np, I, h->dflag,
-                                   (long long*)nullptr);
+                                   (long long*)nullptr, (int64_t)0);
             }
             const int rem = nP - 1 - I;
             if (rem > 0) {
@@ -863,7 +894,7 @@ void launch_cholesky(gpx_handle* h) {
                                        h->dS, h->dR, Np, I);
                 else
                     hipLaunchKernelGGL(k_panel_solve16, dim3((unsigned)(2 * rem)), dim3(256), 0, s, h->dU, h->dS, h->dR,
-                                       Np, I, h->dflag);
+                                       Np, I, h->dflag, (int64_t)0);
             }
         }
         near_rows = 0;
@@ -878,7 +909,7 @@ void launch_cholesky(gpx_handle* h) {
         hipEventRecord(h->ev_chain, s);                               // R rows P0..P1-1 are final, mid(P-1) joined
         if (h->potrf_variant == 0) {
             hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)(nP - P1), (unsigned)nnear), dim3(GEMM_THREADS), 0, s,
-                               h->dR, h->dS, Np, P0, P1, P1, P1);
+                               h->dR, h->dS, Np, P0, P1, P1, P1, (int64_t)0);
         } else {
             // near(P) row by row.  Only block row P1 is needed before the next diagonal block can be factored: it is
             // updated on 64x64 tiles (4x the workgroups, a quarter of the K = 512 tile latency each; the one-launch
@@ -887,12 +918,12 @@ void launch_cholesky(gpx_handle* h) {
             // next panel are brought up to date, on 64x64 tiles too, on a third stream WHILE the chain already
             // works on row P1; the chain waits for row P1 + q just before that row's in-panel update.
             hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - P1)), 2), dim3(GEMM_THREADS), 0, s, h->dR,
-                               h->dS, Np, P0, P1, P1);
+                               h->dS, Np, P0, P1, P1, (int64_t)0);
             if (nnear > 1) {
                 hipStreamWaitEvent(s3, h->ev_chain, 0);
                 for (int q = 1; q < nnear; ++q) {
                     hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - P1 - q)), 2), dim3(GEMM_THREADS), 0, s3,
-                                       h->dR, h->dS, Np, P0, P1, P1 + q);
+                                       h->dR, h->dS, Np, P0, P1, P1 + q, (int64_t)0);
                     hipEventRecord(h->ev_row[q], s3);
                 }
                 near_rows = nnear - 1;
@@ -901,13 +932,13 @@ void launch_cholesky(gpx_handle* h) {
         if (nmid > 0) {
             hipStreamWaitEvent(s2, h->ev_chain, 0);
             hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)(nP - m0), (unsigned)nmid), dim3(GEMM_THREADS), 0, s2,
-                               h->dR, h->dS, Np, P0, P1, m0, m0);
+                               h->dR, h->dS, Np, P0, P1, m0, m0, (int64_t)0);
             hipEventRecord(h->ev_far, s2);
             mid_pending = true;
             side_used = true;
             if (nrest > 0)
                 hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)nrest, (unsigned)nrest), dim3(GEMM_THREADS), 0, s2,
-                                   h->dR, h->dS, Np, P0, P1, r0, r0);
+                                   h->dR, h->dS, Np, P0, P1, r0, r0, (int64_t)0);
         }
     }
     if (side_used) {   // join: everything queued on the side stream is done before the caller's stream goes on
@@ -1027,6 +1058,158 @@ void launch_alpha(gpx_handle* h) {
                        h->bias, 0, h->da);
     hipLaunchKernelGGL(k_tri_matvec, dim3(g), dim3(256), 0, h->stream, h->dU, h->Np, h->N, h->da, 0.0,
                        1, h->dalpha);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batched log marginal likelihoods: B hyper-parameter vectors on the handle's resident data, ONE launch chain
+// (batch element = blockIdx.z of the Gram / Cholesky kernels above) and ONE host synchronisation -- what a
+// hyper-parameter sampler asks for, proposal after proposal (reggie.MCMC(gp, n=10, burn=100) refits ~60 + 10
+// times per model.add_data, pybo/bayesopt.py:115,269).  Neither the triangular inverse nor the handle's own
+// factorisation is touched: a = R^-T (y - bias) comes from a blocked forward substitution with the 16x16
+// inverses k_potrf16 leaves behind (kept in the dead diagonal blocks of the batch's Gram buffer).
+//     out_b = -1/2 a.a - sum_i log R_ii - N/2 log(2 pi)          (R&W eq. 2.30),   -inf if not positive definite
+// One workgroup per batch element walks the 128-blocks in order:
+//     r_p   = (y_p - bias) - sum_{k < p0} R[k][p0 + j] a[k]      two threads per column j, coalesced rows of R
+//     R_pp^T x = r_p  by substitution over the eight 16-tiles:  x_jb = T_d r_jb ;  r[c] -= R[jb rows][c] . x_jb
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_loglik_fwd(const double* __restrict__ R, const double* __restrict__ Ud,
+                                                    int64_t bs, int64_t Np, int64_t N, const double* __restrict__ y,
+                                                    const double* __restrict__ hyp, const int* __restrict__ flag,
+                                                    double* __restrict__ a, double* __restrict__ out) {
+    __shared__ double r[NB], x[16], part[2][NB], red[4];
+    const int z = blockIdx.x, t = threadIdx.x;
+    R += (int64_t)z * bs;
+    Ud += (int64_t)z * bs;
+    a += (int64_t)z * Np;
+    if (flag[z] != 0) {
+        if (t == 0) out[z] = -__builtin_huge_val();
+        return;
+    }
+    const double bias = hyp[3 * z + 2];
+    const int nP = (int)(Np / NB);
+    const int j = t & 127, half = t >> 7;
+    double q = 0.0, ld = 0.0;
+    for (int p = 0; p < nP; ++p) {
+        const int64_t p0 = (int64_t)p * NB;
+        double acc = 0.0;
+        for (int64_t k = half; k < p0; k += 2) acc = fma(R[k * Np + p0 + j], a[k], acc);
+        part[half][j] = acc;
+        __syncthreads();
+        if (t < NB) {
+            const int64_t gi = p0 + t;
+            r[t] = ((gi < N) ? y[gi] - bias : 0.0) - (part[0][t] + part[1][t]);
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int jb = 0; jb < 8; ++jb) {
+            if (t < 16) {                       // x_jb = T_d r_jb,  T_d[m][k] = Ud[(16jb + k) Np + 16jb + m]
+                double v = 0.0;
+                for (int k = 0; k <= t; ++k)
+                    v = fma(Ud[(p0 + 16 * jb + k) * Np + p0 + 16 * jb + t], r[16 * jb + k], v);
+                x[t] = v;
+                a[p0 + 16 * jb + t] = v;
+                const double dg = R[(p0 + 16 * jb + t) * Np + p0 + 16 * jb + t];
+                if (p0 + 16 * jb + t < N) { q = fma(v, v, q); ld += log(dg); }
+            }
+            __syncthreads();
+            if (t < NB && t >= 16 * (jb + 1)) {
+                double v = r[t];
+                for (int k = 0; k < 16; ++k) v = fma(-R[(p0 + 16 * jb + k) * Np + p0 + t], x[k], v);
+                r[t] = v;
+            }
+            __syncthreads();
+        }
+        __threadfence_block();                  // a[] of this block is read by every thread in the next one
+        __syncthreads();
+    }
+    // only threads 0..15 carry partial sums (one wave)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        q += __shfl_xor(q, off);
+        ld += __shfl_xor(ld, off);
+    }
+    if (t == 0) { red[0] = q; red[1] = ld; }
+    __syncthreads();
+    if (t == 0) out[z] = -0.5 * red[0] - red[1] - 0.5 * (double)N * 1.83787706640934548356;
+}
+
+int loglik_batch_host(gpx_handle* h, int64_t B, const double* hyp, double* out) {
+    if (h->stage < 1) { h->err = "loglik_batch: no data on the device (fit first)"; return GPX_ESTATE; }
+    if (!hyp || !out || B < 1 || B > 64) { h->err = "loglik_batch: need 1 <= B <= 64 hyper-parameter vectors"; return GPX_EARG; }
+    const int64_t N = h->N, Np = h->Np, d = h->d, bs = Np * Np;
+    const int nP = (int)(Np / NB);
+    if ((double)B * (double)bs * 16.0 > 16.0e9) { h->err = "loglik_batch: B * N^2 too large for the batch buffers"; return GPX_EARG; }
+    std::vector<double> stage((size_t)B * (3 + DMAX), 0.0);     // [hyp B x 3 = rho, sn2, bias][invell B x DMAX]
+    for (int64_t b = 0; b < B; ++b) {
+        const double* v = hyp + b * (d + 3);                    // sn2, rho, ell[d], bias
+        const double sn2 = v[0], rho = v[1], bias = v[2 + d];
+        bool ok = (rho > 0) && (sn2 >= 0) && std::isfinite(rho) && std::isfinite(sn2) && std::isfinite(bias);
+        for (int64_t k = 0; k < d; ++k) ok = ok && (v[2 + k] > 0) && std::isfinite(v[2 + k]);
+        if (!ok) { h->err = "loglik_batch: need finite rho > 0, sn2 >= 0, ell > 0, bias"; return GPX_EARG; }
+        stage[(size_t)b * 3] = rho;
+        stage[(size_t)b * 3 + 1] = sn2;
+        stage[(size_t)b * 3 + 2] = bias;
+        for (int64_t k = 0; k < d; ++k) stage[(size_t)B * 3 + b * DMAX + k] = 1.0 / v[2 + k];
+    }
+    if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return GPX_EHIP; }
+    hipStream_t s = h->stream;
+    // one allocation: [S B bs][R B bs][Xs B Np d][a B Np][hyp 3B][invell B DMAX][out B][flag B ints]
+    const int64_t need = 2 * B * bs + B * Np * d + B * Np + B * (3 + DMAX) + B + (B + 1) / 2 + 8;
+    if (need > h->cap_batch) {
+        if (h->dbatch) hipFree(h->dbatch);
+        h->dbatch = nullptr;
+        h->cap_batch = 0;
+        if (hipMalloc((void**)&h->dbatch, (size_t)need * 8) != hipSuccess) { h->err = "loglik_batch: device allocation failed"; return GPX_EOOM; }
+        h->cap_batch = need;
+    }
+    double* bS = h->dbatch;
+    double* bR = bS + B * bs;
+    double* bXs = bR + B * bs;
+    double* ba = bXs + B * Np * d;
+    double* bhyp = ba + B * Np;
+    double* binv = bhyp + 3 * B;
+    double* bout = binv + B * DMAX;
+    int* bflag = reinterpret_cast<int*>(bout + B);
+    if (hipMemcpyAsync(bhyp, stage.data(), stage.size() * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemsetAsync(bflag, 0, (size_t)B * sizeof(int), s) != hipSuccess) {
+        h->err = "loglik_batch: H2D copy failed";
+        return GPX_EHIP;
+    }
+    const unsigned Bz = (unsigned)B;
+    {
+        const int64_t tot = Np * d;
+        hipLaunchKernelGGL(k_scale_x, dim3((unsigned)((tot + 255) / 256), 1, Bz), dim3(256), 0, s, h->dXraw, N, Np,
+                           (int)d, binv, bXs);
+        const unsigned g = (unsigned)(Np / GT);
+        hipLaunchKernelGGL(k_gram_sym, dim3(g, g, Bz), dim3(256), 0, s, bXs, N, Np, (int)d, h->kernel_id, 1.0, 0.0, bS,
+                           (const double*)bhyp);
+    }
+    // right-looking blocked factorisation, every launch over the whole batch; single stream, no lookahead (the
+    // sizes a sampler works at are a few blocks)
+    for (int P0 = 0; P0 < nP; P0 += CHOL_W) {
+        const int P1 = (P0 + CHOL_W < nP) ? P0 + CHOL_W : nP;
+        for (int I = P0; I < P1; ++I) {
+            if (I > P0)
+                hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - I)), 2, Bz), dim3(GEMM_THREADS), 0, s, bR, bS,
+                                   Np, P0, I, I, bs);
+            hipLaunchKernelGGL(k_potrf16<false>, dim3(1, 1, Bz), dim3(256), 0, s, bS, bR, (double*)nullptr, bS, Np, I,
+                               bflag, (long long*)nullptr, bs);
+            const int rem = nP - 1 - I;
+            if (rem > 0)
+                hipLaunchKernelGGL(k_panel_solve16, dim3((unsigned)(2 * rem), 1, Bz), dim3(256), 0, s, bS, bS, bR, Np, I,
+                                   bflag, bs);
+        }
+        if (P1 < nP)
+            hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)(nP - P1), (unsigned)(nP - P1), Bz), dim3(GEMM_THREADS), 0, s,
+                               bR, bS, Np, P0, P1, P1, P1, bs);
+    }
+    hipLaunchKernelGGL(k_loglik_fwd, dim3(Bz), dim3(256), 0, s, bR, bS, bs, Np, N, h->dy, bhyp, bflag, ba, bout);
+    if (hipMemcpyAsync(out, bout, (size_t)B * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) {
+        h->err = "loglik_batch: kernel or D2H copy failed";
+        return GPX_EHIP;
+    }
+    return GPX_OK;
 }
 
 // out (N,N) row-major = transpose of the leading N x N part of src (Np,Np) keeping only the part

@@ -265,6 +265,16 @@ class GP(object):
         """log p(y | X, hyper-parameters) of the current fit, computed on the device."""
         return self._engine().loglik()
 
+    def loglik_at(self, thetas):
+        """log p(y | X, theta_b) for the rows of `thetas` ([log sn2, log rho, log ell_1..d, bias]) in ONE batched
+        device call (gpx_loglik_batch) on the resident data; the model and its fit are left untouched.  -inf
+        where the covariance is not positive definite.  This is what the hyper-parameter sampler evaluates per
+        proposal."""
+        thetas = np.array(thetas, dtype=float, ndmin=2)
+        d = len(self.ell)
+        hyp = np.column_stack([np.exp(thetas[:, 0]), np.exp(thetas[:, 1]), np.exp(thetas[:, 2:2 + d]), thetas[:, 2 + d]])
+        return self._engine().loglik_batch(hyp)
+
     def acq_values(self, kind, param, xgrid):
         """Acquisition values over a whole grid (device sweep, values copied back)."""
         return self._engine().sweep(kind, param, np.array(xgrid, ndmin=2, dtype=float), k=0)['acq']

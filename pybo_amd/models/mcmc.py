@@ -16,11 +16,15 @@ stated in full:
     between the sides as in Neal's fig. 3), then shrinkage;
   * `burn` updates are discarded at construction, then `n` are kept; `add_data` continues the chain from
     its last state and keeps the next `n` samples (no new burn-in).
-Each log-likelihood evaluation is one fit of the member model -- on the device for `pybo_amd.models.GP`
-(`gpx_fit` + `gpx_loglik`).  This file is host logic only and works with ANY member model that offers
+Each log-likelihood evaluation is one fit of the member model; for the device model `pybo_amd.models.GP` the
+sampler's evaluations go through `loglik_at` -> `gpx_loglik_batch` (batched Gram + Cholesky + forward substitution
+on the resident data, the two ends of a stepping-out round in one call), the kept members are fitted with
+`gpx_fit`.  This file is host logic only and works with ANY member model that offers
 `hyper_vector() / set_hyper_vector(theta) / loglikelihood() / params / copy() / add_data()`, which is how
 the CPU tests drive it with the oracle model.
 """
+import math
+
 import numpy as np
 
 from ..utils import rstate
@@ -29,56 +33,134 @@ from .priors import log_prior
 __all__ = ['MCMC']
 
 
-def _log_target(model, theta):
-    """log posterior density of the transformed hyper-parameters (-inf outside the support)."""
+def _log_prior_part(model, theta):
+    """log prior density + log-Jacobian of the transformed hyper-parameters (-inf outside the support)."""
     d = len(theta) - 3
     if not np.all(np.isfinite(theta)) or np.any(np.abs(theta[:2 + d]) > 60.0):
         return -np.inf
-    sn2, rho, ell, bias = np.exp(theta[0]), np.exp(theta[1]), np.exp(theta[2:2 + d]), theta[2 + d]
+    sn2, rho, ell, bias = math.exp(theta[0]), math.exp(theta[1]), np.exp(theta[2:2 + d]), float(theta[2 + d])
     pr = model.params
     lp = (log_prior(pr['like.sn2'].prior, sn2) + log_prior(pr['kern.rho'].prior, rho) +
           log_prior(pr['kern.ell'].prior, ell) + log_prior(pr['mean.bias'].prior, bias))
-    if not np.isfinite(lp):
+    if not math.isfinite(lp):
         return -np.inf
-    lp += float(np.sum(theta[:2 + d]))            # Jacobian of x = exp(theta)
-    try:
-        model.set_hyper_vector(theta)
-        return lp + model.loglikelihood()
-    except np.linalg.LinAlgError:
-        return -np.inf
+    return lp + float(np.sum(theta[:2 + d]))      # Jacobian of x = exp(theta)
 
 
-def _slice_update(logp, theta, lp, rng, scale, max_out=16):
+def _log_targets(model, thetas):
+    """log posterior densities of several hyper-parameter states.  A device model evaluates all likelihoods in ONE
+    batched call that leaves the model untouched (`loglik_at` -> gpx_loglik_batch: one launch chain and one host
+    synchronisation instead of a refit + log-likelihood round trip per state); any other model is refitted per
+    state.  The values do not depend on how the states are grouped into calls."""
+    out = np.array([_log_prior_part(model, th) for th in thetas], dtype=float)
+    live = np.flatnonzero(np.isfinite(out))
+    if len(live) == 0:
+        return out
+    batch = getattr(model, 'loglik_at', None)
+    if batch is not None:
+        out[live] += batch(np.array([thetas[i] for i in live]))
+        return out
+    for i in live:
+        try:
+            model.set_hyper_vector(thetas[i])
+            out[i] += model.loglikelihood()
+        except np.linalg.LinAlgError:
+            out[i] = -np.inf
+    return out
+
+
+def _log_target(model, theta):
+    return float(_log_targets(model, [theta])[0])
+
+
+def _slice_update(logp, theta, lp, rng, scale, max_out=16, logp_many=None, spec=4):
     """One slice-sampling update (Neal 2003, fig. 3 + fig. 5) of `theta` along a random direction
     scale * N(0, I); returns (theta', lp').  `logp` is the log target density (callable), `lp` its value at
     `theta`.  `scale` is a vector that must NOT depend on the current state: the direction has to be drawn
     from the same distribution at theta and at theta' for the update to leave the target invariant.
     The bracket grows by stepping out in unit steps with the total number of expansions capped at `max_out`
-    and split at random between the two sides (Neal's J/K rule), then shrinks towards the current point."""
+    and split at random between the two sides (Neal's J/K rule), then shrinks towards the current point.
+
+    `logp_many` (optional): evaluates several states in one call (a batched device call).  Both phases are then
+    SPECULATED without changing the chain: the stepping-out points of a side are lo-1, lo-2, ... whatever the
+    densities turn out to be, and a shrinkage candidate only depends on the SIGN of the previous one (t < 0 moves
+    the lower end, otherwise the upper one), never on its density -- so the next `spec` points of either phase
+    are known in advance, are evaluated together, and the first decisive one is used.  The random stream is
+    rewound to exactly what the sequential procedure would have consumed: same states, same draws, same result."""
     direction = scale * rng.randn(len(theta))
     level = lp + np.log(rng.rand())
     r = rng.rand()
     lo, hi = -r, 1.0 - r
     nlo = int(np.floor(max_out * rng.rand()))
     nhi = (max_out - 1) - nlo
-    while nlo > 0 and logp(theta + lo * direction) > level:
-        lo -= 1.0
-        nlo -= 1
-    while nhi > 0 and logp(theta + hi * direction) > level:
-        hi += 1.0
-        nhi -= 1
+    if logp_many is None:
+        while nlo > 0 and logp(theta + lo * direction) > level:
+            lo -= 1.0
+            nlo -= 1
+        while nhi > 0 and logp(theta + hi * direction) > level:
+            hi += 1.0
+            nhi -= 1
+    else:
+        grow_lo, grow_hi = nlo > 0, nhi > 0
+        per_side = max(1, spec // 2)
+        while grow_lo or grow_hi:
+            klo = min(per_side, nlo) if grow_lo else 0
+            khi = min(per_side, nhi) if grow_hi else 0
+            pts = [theta + (lo - i) * direction for i in range(klo)] + [theta + (hi + i) * direction for i in range(khi)]
+            vals = np.asarray(logp_many(pts))
+            for v in vals[:klo]:                 # the ends lo, lo-1, ...: expand while the density is above the level
+                if v > level:
+                    lo -= 1.0
+                    nlo -= 1
+                else:
+                    grow_lo = False
+                    break
+            grow_lo = grow_lo and nlo > 0
+            for v in vals[klo:]:
+                if v > level:
+                    hi += 1.0
+                    nhi -= 1
+                else:
+                    grow_hi = False
+                    break
+            grow_hi = grow_hi and nhi > 0
     while True:
-        t = lo + (hi - lo) * rng.rand()
-        cand = theta + t * direction
-        lpc = logp(cand)
-        if lpc > level:
-            return cand, lpc
-        if t < 0:
-            lo = t
-        else:
-            hi = t
-        if hi - lo < 1e-12:                      # numerically collapsed bracket: stay put
+        if logp_many is None:
+            t = lo + (hi - lo) * rng.rand()
+            cand = theta + t * direction
+            lpc = logp(cand)
+            if lpc > level:
+                return cand, lpc
+            if t < 0:
+                lo = t
+            else:
+                hi = t
+            if hi - lo < 1e-12:                  # numerically collapsed bracket: stay put
+                return theta, lp
+            continue
+        # speculate the next `spec` shrinkage candidates (each follows from the sign of the one before)
+        state = rng.get_state()
+        l2, h2, ts, dead = lo, hi, [], -1
+        for i in range(spec):
+            t = l2 + (h2 - l2) * rng.rand()
+            ts.append(t)
+            if t < 0:
+                l2 = t
+            else:
+                h2 = t
+            if h2 - l2 < 1e-12:
+                dead = i                         # the sequential procedure would give up after rejecting this one
+                break
+        vals = np.asarray(logp_many([theta + t * direction for t in ts]))
+        hit = next((i for i, v in enumerate(vals) if v > level), -1)
+        used = (hit + 1) if hit >= 0 else len(ts)
+        rng.set_state(state)
+        rng.rand(used)                           # consume exactly the draws the sequential procedure would have
+        if hit >= 0:
+            return theta + ts[hit] * direction, float(vals[hit])
+        if dead >= 0:
             return theta, lp
+        lo, hi = l2, h2
 
 
 class MCMC(object):
@@ -110,8 +192,10 @@ class MCMC(object):
                 raise ValueError('MCMC: the initial hyper-parameters have zero posterior density')
         kept = []
         logp = lambda th: _log_target(self._proto, th)      # noqa: E731
+        many = (lambda ths: _log_targets(self._proto, ths)) if hasattr(self._proto, 'loglik_at') else None
         for _ in range(nsteps):
-            self._theta, self._lp = _slice_update(logp, self._theta, self._lp, self._rng, self._scale)
+            self._theta, self._lp = _slice_update(logp, self._theta, self._lp, self._rng, self._scale,
+                                                  logp_many=many)
             kept.append(self._theta.copy())
         if keep:
             members = []

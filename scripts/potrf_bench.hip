@@ -88,12 +88,12 @@ int main() {
         hipMemcpy(dS, A.data(), bytes, hipMemcpyHostToDevice);
         hipMemset(dR, 0, bytes); hipMemset(dT, 0, bytes); hipMemset(dU, 0, bytes);
         if (variant == 2)       // the block inverse completes what k_potrf16 leaves behind
-            hipLaunchKernelGGL(k_potrf16<false>, dim3(1), dim3(256), 0, 0, dS, dR, dT, dU, Np, p, dflag, (long long*)nullptr);
+            hipLaunchKernelGGL(k_potrf16<false>, dim3(1), dim3(256), 0, 0, dS, dR, dT, dU, Np, p, dflag, (long long*)nullptr, (int64_t)0);
         hipDeviceSynchronize();
         hipEventRecord(e0, 0);
         for (int r = 0; r < reps; ++r) {
             if (variant == 0) hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, 0, dS, dR, dT, dU, Np, p, dflag);
-            if (variant == 1) hipLaunchKernelGGL(k_potrf16<true>, dim3(1), dim3(256), 0, 0, dS, dR, dT, dU, Np, p, dflag, ddbg);
+            if (variant == 1) hipLaunchKernelGGL(k_potrf16<true>, dim3(1), dim3(256), 0, 0, dS, dR, dT, dU, Np, p, dflag, ddbg, (int64_t)0);
             if (variant == 2) hipLaunchKernelGGL(k_trtri_diag128, dim3(1), dim3(256), 0, 0, dR, dT, dU, Np, p, dflag);
         }
         hipEventRecord(e1, 0);

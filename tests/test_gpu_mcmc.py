@@ -77,3 +77,39 @@ def test_animated_demo_headless_on_the_device():
     X, Y, xb = animated.run(niter=30, rng=0, verbose=False)
     assert X.shape == (33, 1) and np.all(X >= 0.5) and np.all(X <= 2.5)
     assert abs(X[np.argmax(Y)][0] - animated.XOPT) < 3e-2 and Y.max() > 0.8
+
+
+@pytest.mark.parametrize('N,d,kernel', [(40, 1, 'se'), (128, 2, 'matern5'), (300, 3, 'se'), (700, 2, 'matern3')])
+def test_batched_loglik_matches_oracle_and_leaves_the_fit_alone(N, d, kernel):
+    """gpx_loglik_batch: B hyper-parameter vectors, one launch chain; against the oracle's refit per vector, against
+    the single-vector device path, independent of the grouping, -inf for a non-PD covariance."""
+    from pybo_amd import models
+    X, y, ell = synth_problem(N, d, seed=N + 1)
+    gp = models.make_gp(1e-3, 1.4, ell, 0.2, kernel=kernel)
+    gp.add_data(X, y)
+    ref = gp_ref.make_gp(1e-3, 1.4, ell, 0.2, kernel)
+    ref.add_data(X, y)
+    rng = np.random.RandomState(N)
+    th0 = gp.hyper_vector()
+    thetas = th0 + 0.4 * rng.randn(9, len(th0))
+    got = gp.loglik_at(thetas)
+    want = []
+    for th in thetas:
+        ref.set_hyper_vector(th)
+        want.append(ref.loglikelihood())
+    np.testing.assert_allclose(got, want, rtol=1e-9)
+    np.testing.assert_array_equal(gp.loglik_at(thetas[3:5]), got[3:5])        # grouping does not matter
+    np.testing.assert_array_equal(gp.loglik_at(thetas[7]), got[7:8])
+    # the model's own fit is untouched
+    np.testing.assert_array_equal(gp.hyper_vector(), th0)
+    ref.set_hyper_vector(th0)
+    assert abs(gp.loglikelihood() - ref.loglikelihood()) < 1e-9 * abs(ref.loglikelihood())
+    Z = rng.rand(50, d)
+    np.testing.assert_allclose(gp.predict(Z)[0], ref.predict(Z)[0], rtol=1e-6, atol=1e-8)
+    # duplicated inputs without noise: not positive definite -> -inf for that vector only
+    gp2 = models.make_gp(1e-3, 1.0, ell, 0.0, kernel=kernel)
+    gp2.add_data(np.vstack([X[:20], X[:3]]), np.hstack([y[:20], y[:3]]))
+    bad = gp2.hyper_vector()
+    bad[0] = -800.0                                                           # sn2 = exp(-800) = 0
+    out = gp2.loglik_at(np.array([gp2.hyper_vector(), bad]))
+    assert np.isfinite(out[0]) and out[1] == -np.inf

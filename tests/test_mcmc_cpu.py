@@ -153,3 +153,31 @@ def test_direction_scale_is_frozen_at_construction():
     np.testing.assert_array_equal(s._scale, want)          # the chain's own rho moved, the scale did not
     np.testing.assert_array_equal(pickle.loads(pickle.dumps(s))._scale, want)
     np.testing.assert_array_equal(s.copy()._scale, want)
+
+
+@pytest.mark.parametrize('spec', [1, 2, 4, 7])
+def test_speculative_batched_slice_update_is_the_sequential_one(spec):
+    """With a batched density (`logp_many`, the device path) the stepping-out ends and the next `spec` shrinkage
+    candidates are evaluated together; the chain, the returned densities and the random stream must be EXACTLY
+    those of the one-at-a-time procedure."""
+    from pybo_amd.models.mcmc import _slice_update
+    mean = np.array([0.0, 1.0, -2.0])
+    A = np.array([[1.5, 0.0, 0.0], [0.6, 0.8, 0.0], [0.0, 1.0, 3.0]])
+    P = np.linalg.inv(A @ A.T)
+    calls = []
+    logp = lambda th: float(-0.5 * (th - mean) @ P @ (th - mean))      # noqa: E731
+
+    def many(ths):
+        calls.append(len(ths))
+        return np.array([logp(t) for t in ths])
+    r1, r2 = np.random.RandomState(3), np.random.RandomState(3)
+    scale = np.array([1.0, 1.0, 3.0])
+    a, la = mean.copy(), 0.0
+    b, lb = mean.copy(), 0.0
+    for _ in range(800):
+        a, la = _slice_update(logp, a, la, r1, scale)
+        b, lb = _slice_update(logp, b, lb, r2, scale, logp_many=many, spec=spec)
+        assert np.array_equal(a, b) and la == lb
+    assert r1.rand() == r2.rand()
+    if spec >= 4:
+        assert np.mean(calls) > 1.5          # the batches really carry several states
