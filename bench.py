@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X datasheet fp64 matrix (= fp64 vector) peak, dense
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILE = 'r01_pmc_traffic.json'
+PMC_TRAFFIC_FILE = 'r02_pmc_traffic.json'
 
 
 def hartmann6(X):
@@ -370,7 +370,7 @@ def main():
         # the fit's two MFMA stages against the same peak (algorithmic N^3/3 flop each), for EVERY workload:
         # the replicated fit is what bounds strong scaling
         fit = {}
-        for stage, label in (('cholesky', 'cholesky (k_potrf_diag + k_panel_trsm + k_row_update64 + k_syrk_update)'),
+        for stage, label in (('cholesky', 'cholesky (k_potrf16 + k_panel_solve16 + k_row_update64 + k_syrk_update)'),
                              ('trtri', 'triangular inverse (k_trtri_gemm1/2)')):
             if tm[stage] > 0:
                 ach = (float(N) ** 3 / 3.0) * args.steps / (tm[stage] * 1e-3) / 1e12

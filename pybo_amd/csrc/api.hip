@@ -233,11 +233,6 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             if (value < 0) h->cache_valid = false;
             return GPX_OK;
         }
-        if (!strcmp(name, "potrf")) {
-            if (value != 0 && value != 1) return fail(h, GPX_EARG, "potrf must be 0 or 1");
-            h->potrf_variant = (int)value;
-            return GPX_OK;
-        }
         if (!strcmp(name, "eager_inverse")) {
             if (value != 0 && value != 1) return fail(h, GPX_EARG, "eager_inverse must be 0 or 1");
             h->eager_inverse = (value != 0);

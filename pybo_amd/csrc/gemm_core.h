@@ -213,75 +213,12 @@ __device__ __forceinline__ int acc_col(int j) {
 // ------------------------------------------------------------------------------------------------
 constexpr int T64 = 64;
 constexpr int LDT64 = T64 + 16;
-constexpr int GEMM64_LDS_F64 = 2 * 2 * BK * LDT64;   // 40,960 B
+constexpr int GEMM64_LDS_F64 = 2 * BK32 * LDT64;    // [A|B][32][LDT64] = 40,960 B
 
-__device__ __forceinline__ void gemm_tile_64(d4 (&acc)[2][2], const double* __restrict__ A, int64_t lda,
-                                             const double* __restrict__ B, int64_t ldb, int k_lo, int k_hi,
-                                             double* smem) {
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int w = t >> 6;
-    const int wm = w >> 1, wn = w & 1;
-    double* As = smem;                    // [2][BK][LDT64]
-    double* Bs = smem + 2 * BK * LDT64;
-    const int lrow = t >> 5;              // 0..7: two k-rows per wave instruction (2 x 512 B)
-    const int lcol = (t & 31) * 2;
-    d2 ra[2], rb[2];
-    const int nk = (k_hi - k_lo) / BK;
-    if (nk <= 0) return;
-    const double* Ap = A + (int64_t)(k_lo + lrow) * lda + lcol;
-    const double* Bp = B + (int64_t)(k_lo + lrow) * ldb + lcol;
-    auto gload = [&]() {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            ra[p] = *reinterpret_cast<const d2*>(Ap + (int64_t)(8 * p) * lda);
-            rb[p] = *reinterpret_cast<const d2*>(Bp + (int64_t)(8 * p) * ldb);
-        }
-        Ap += (int64_t)BK * lda;
-        Bp += (int64_t)BK * ldb;
-    };
-    auto swrite = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            *reinterpret_cast<d2*>(As + buf * BK * LDT64 + (lrow + 8 * p) * LDT64 + lcol) = ra[p];
-            *reinterpret_cast<d2*>(Bs + buf * BK * LDT64 + (lrow + 8 * p) * LDT64 + lcol) = rb[p];
-        }
-    };
-    gload();
-    swrite(0);
-    if (nk > 1) gload();
-    __syncthreads();
-    const int fr = lane & 15, fk = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) {
-            swrite(buf ^ 1);
-            if (kt + 2 < nk) gload();
-        }
-        const double* as = As + buf * BK * LDT64 + wm * 32 + fr;
-        const double* bs = Bs + buf * BK * LDT64 + wn * 32 + fr;
-#pragma unroll
-        for (int kk = 0; kk < BK / 4; ++kk) {
-            const int kr = kk * 4 + fk;
-            double a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = as[kr * LDT64 + i * 16];
-                b[i] = bs[kr * LDT64 + i * 16];
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-}
-// The same 64x64 tile with K stepped 32 at a time through a SINGLE 40 KB LDS buffer and a TWO-deep register
-// prefetch: the global loads of step t+2 are issued at the top of step t and written to LDS at the end of step
-// t+1.  The chain kernels that use it are bound by the latency of their dependent global loads (K = 512 on the
-// 16-row ring: 32 round trips of ~3.3 us next to the trailing updates), not by MFMA or bandwidth: half as many
+// K is stepped 32 at a time through a SINGLE 40 KB LDS buffer with a TWO-deep register prefetch: the global loads
+// of step t+2 are issued at the top of step t and written to LDS at the end of step t+1.  The chain kernels that
+// use it are bound by the latency of their dependent global loads, not by MFMA or bandwidth (round 1's 16-row
+// ring with a one-step prefetch: K = 512 = 32 round trips of ~3.3 us next to the trailing updates): half as many
 // round trips, each covered by two compute phases instead of one.  k_hi - k_lo must be a multiple of 32.
 __device__ __forceinline__ void gemm_tile_64_g(d4 (&acc)[2][2], const double* __restrict__ A, int64_t lda,
                                                const double* __restrict__ B, int64_t ldb, int k_lo, int k_hi,

@@ -36,7 +36,6 @@ struct gpx_handle {
     // model state
     bool fitted = false;
     int stage = 0;               // 0 none, 1 gram, 2 chol (fitted; T/U/a/alpha not formed yet), 3 + inverse
-    int potrf_variant = 1;       // option "potrf": 0 register-resident pivot pairs (round 1), 1 MFMA-blocked 16 wide
     bool diag_inv_pending = false;   // the diagonal blocks of T / U hold 16x16 inverses only (k_trtri_diag128 due)
     bool eager_inverse = false;  // option: form the inverse inside the fit (timing experiments)
     int64_t N = 0, Np = 0, d = 0;

@@ -121,19 +121,9 @@ void launch_gram_sym(hipStream_t s, const double* Xs, int64_t N, int64_t Np, int
                        (const double*)nullptr);
 }
 
-// ------------------------------------------------------------------------------------------------
-// R2a: diagonal-block factorisation + inversion, one workgroup, the 128x128 block REGISTER-resident.
-// Thread (tr, tc) of a 16x16 grid owns the 8x8 elements M[tr+16a][tc+16b] (64 f64 = 128 VGPR), so the
-// rank-1 update of a pivot step is 64 register FMAs; the only shared traffic per step is the pivot row,
-// published through a double-buffered 128-entry LDS vector (one barrier per pivot).
-// Right-looking Cholesky on the upper triangle (rows of R); the same row operations applied to the
-// identity give T_pp = R_pp^-T in the strict lower triangle (Gauss-Jordan style), so one array holds both:
-//   step j:  d = sqrt(M[j][j]);  row j: R part (c > j) and T part (c < j) scaled by 1/d, T[j][j] = 1/d;
-//            rows r > j:  M[r][c] -= R[j][r] * rowj[c]   for c >= r (Cholesky) and c <= j (inverse).
-// ------------------------------------------------------------------------------------------------
-// 1/sqrt(x) to fp64 round-off: hardware v_rsq_f64 seed + two Newton steps (no denormal/scale handling
-// needed: pivots of a PD matrix with unit-scale entries; a non-positive or NaN pivot yields NaN/inf,
-// which the uniform pivot check catches one step later)
+// 1/sqrt(x) to fp64 round-off: hardware v_rsq_f64 seed (measured: 5.2e-8 relative) + Newton steps (4.1e-15 after
+// one, 2.5e-16 after two -- scripts/potrf_bench.hip).  No denormal / scale handling needed: pivots of a PD matrix
+// with unit-scale entries; a non-positive or NaN pivot is caught by the uniform pivot check before it is used.
 #ifndef GPX_PF_NR
 #define GPX_PF_NR 2        // Newton steps after v_rsq_f64 inside factor16 (scripts/potrf_bench.hip builds 1 and 2)
 #endif
@@ -143,183 +133,6 @@ __device__ __forceinline__ double rsqrt_pf(double x) {
 #pragma unroll
     for (int i = 0; i < GPX_PF_NR; ++i) y = fma(y, fma(-hx * y, y, 0.5), y);
     return y;
-}
-
-__device__ __forceinline__ double rsqrt_nr(double x) {
-    double y = __builtin_amdgcn_rsq(x);
-    const double hx = 0.5 * x;
-    y = fma(y, fma(-hx * y, y, 0.5), y);
-    y = fma(y, fma(-hx * y, y, 0.5), y);
-    return y;
-}
-
-// Sixteen pivots j = 16*JS .. 16*JS+15, taken TWO AT A TIME, with the slice index JS a compile-time
-// constant so that every mask that depends on "which 16-row/16-column slice" folds away: slices a < JS are
-// finished (no code), columns b < JS are always left of the pivots (inverse part), b > JS always right of
-// them (Cholesky part), and the never-updated gap JS < b < a emits no FMA at all.
-//
-// Pair step (j, j+1): the two pivot rows p1 = M[j][:], p2 = M[j+1][:] are published UNSCALED in LDS (p2 not yet
-// touched by pivot j).  Every thread forms the 2x2 pivot block in closed form
-//     inv1 = 1/sqrt(p1[j]),  l = p1[j+1]*inv1 (= R[j][j+1]),  inv2 = 1/sqrt(p2[j+1] - l^2)
-// the two scaled pivot rows  row1 = p1*inv1,  row2 = (p2 - l*row1)*inv2  (with the identity columns of the
-// inverse part: T[j][j] = inv1, T[j+1][j] = -l*inv1*inv2, T[j+1][j+1] = inv2), and applies the rank-2 update
-//     M[r][c] -= R1[r]*row1[c] + R2[r]*row2[c]          (R2 = 0 for r = j+1: that row only sees pivot j)
-// i.e. one barrier and one LDS round trip per TWO pivots for the same FMA count.  Rows are left unscaled
-// in registers; their 1/d is remembered in dinv[] and applied at write-back.
-// Returns false (uniformly) on a non-positive pivot.
-template <int JS>
-__device__ __forceinline__ bool potrf_phase(double (&m)[8][8], double (&dinv)[8],
-                                            double (*rowbuf)[2][NB + 8], int tr, int tc, bool up_diag,
-                                            int64_t p0, int* flag) {
-#pragma unroll 1
-    for (int jj = 0; jj < 16; jj += 2) {
-        const int j = JS * 16 + jj;
-        const int par = (j >> 1) & 1;
-        const double* p1 = rowbuf[par][0];
-        const double* p2 = rowbuf[par][1];
-        const double piv1 = p1[j];
-        if (!(piv1 > 0.0) || !(piv1 < 1.0e300)) {  // also catches NaN; uniform
-            if (threadIdx.x == 0) *flag = (int)(p0 + j) + 1;
-            return false;
-        }
-        const double inv1 = rsqrt_nr(piv1);
-        const double l = p1[j + 1] * inv1;
-        const double piv2 = fma(-l, l, p2[j + 1]);
-        if (!(piv2 > 0.0) || !(piv2 < 1.0e300)) {
-            if (threadIdx.x == 0) *flag = (int)(p0 + j + 1) + 1;
-            return false;
-        }
-        const double inv2 = rsqrt_nr(piv2);
-        const int cj = tc + 16 * JS, rj = tr + 16 * JS;
-        // scaled pivot rows per owned column; for slice JS split into Cholesky (R*) and inverse (T*) parts
-        double row1[8], row2[8];
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            if (b == JS) continue;
-            row1[b] = p1[tc + 16 * b] * inv1;
-            row2[b] = fma(-l, row1[b], p2[tc + 16 * b]) * inv2;
-        }
-        double R1, R2, T1, T2;
-        {
-            const double q1 = p1[cj] * inv1;
-            const double q2 = fma(-l, q1, p2[cj]) * inv2;
-            R1 = (cj > j) ? q1 : 0.0;                       // includes c = j+1: R[j][j+1] = l
-            R2 = (cj > j + 1) ? q2 : 0.0;
-            T1 = (cj < j) ? q1 : ((cj == j) ? inv1 : 0.0);
-            T2 = (cj < j) ? q2 : ((cj == j) ? (-l * inv1) * inv2 : ((cj == j + 1) ? inv2 : 0.0));
-        }
-        double mu1[8], mu2[8];
-#pragma unroll
-        for (int a = JS; a < 8; ++a) {
-            const int r = tr + 16 * a;
-            const double q1 = p1[r] * inv1;                 // R[j][r]
-            mu1[a] = -q1;
-            mu2[a] = -(fma(-l, q1, p2[r]) * inv2);          // R[j+1][r]
-        }
-        if (!(rj > j)) mu1[JS] = 0.0;                       // rows of slice JS at or above pivot j
-        if (!(rj > j + 1)) mu2[JS] = 0.0;                   // row j+1 is only eliminated by pivot j
-        dinv[JS] = (rj == j) ? inv1 : ((rj == j + 1) ? inv2 : dinv[JS]);
-        const int jn = j + 2;
-#pragma unroll
-        for (int a = JS; a < 8; ++a) {
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                double v1, v2;
-                bool live = true;
-                if (b < JS) {                      // inverse part, c < j
-                    v1 = row1[b]; v2 = row2[b];
-                } else if (b == JS) {
-                    if (a == JS) { v1 = up_diag ? R1 : T1; v2 = up_diag ? R2 : T2; }
-                    else { v1 = T1; v2 = T2; }     // b < a: inverse part
-                } else {                           // b > JS: right of the pivots
-                    if (b > a) { v1 = row1[b]; v2 = row2[b]; }
-                    else if (b == a) { v1 = up_diag ? row1[b] : 0.0; v2 = up_diag ? row2[b] : 0.0; }
-                    else { live = false; v1 = 0.0; v2 = 0.0; }   // JS < b < a: never touched
-                }
-                if (live) m[a][b] = fma(mu2[a], v2, fma(mu1[a], v1, m[a][b]));
-            }
-            if (a == JS || a == JS + 1) {          // publish the next pivot pair, rows jn and jn+1 (unscaled)
-                const int r = tr + 16 * a;
-                if (r == jn || r == jn + 1) {
-                    double* wb = rowbuf[par ^ 1][r - jn];
-#pragma unroll
-                    for (int b = 0; b < 8; ++b) wb[tc + 16 * b] = m[a][b];
-                }
-            }
-        }
-        __syncthreads();
-    }
-    return true;
-}
-
-__global__ __launch_bounds__(256) void k_potrf_diag(double* __restrict__ S, double* __restrict__ R,
-                                                    double* __restrict__ T, double* __restrict__ U,
-                                                    int64_t Np, int p, int* __restrict__ flag) {
-    __shared__ double rowbuf[2][2][NB + 8];   // [parity][first|second pivot row of the pair][column]
-    if (*flag != 0) return;  // an earlier panel already failed
-    const int t = threadIdx.x;
-    const int tr = t >> 4, tc = t & 15;
-    const int64_t p0 = (int64_t)p * NB;
-    double m[8][8];
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const int r = tr + 16 * a, c = tc + 16 * b;
-            m[a][b] = (c >= r) ? S[(p0 + r) * Np + p0 + c] : 0.0;
-        }
-    // publish rows 0 and 1
-    if (tr < 2) {
-#pragma unroll
-        for (int b = 0; b < 8; ++b) rowbuf[0][tr][tc + 16 * b] = m[0][b];
-    }
-    __syncthreads();
-
-    // Element (r,c) = (tr+16a, tc+16b) is in the Cholesky part iff c >= r, i.e. b > a, or b == a and
-    // tc >= tr (a per-thread constant).
-    const bool up_diag = (tc >= tr);
-    double dinv[8];   // 1/d of each owned row, filled when the row is a pivot; applied at write-back
-#pragma unroll
-    for (int a = 0; a < 8; ++a) dinv[a] = 1.0;
-
-    if (!potrf_phase<0>(m, dinv, rowbuf, tr, tc, up_diag, p0, flag)) return;
-    if (!potrf_phase<1>(m, dinv, rowbuf, tr, tc, up_diag, p0, flag)) return;
-    if (!potrf_phase<2>(m, dinv, rowbuf, tr, tc, up_diag, p0, flag)) return;
-    if (!potrf_phase<3>(m, dinv, rowbuf, tr, tc, up_diag, p0, flag)) return;
-    if (!potrf_phase<4>(m, dinv, rowbuf, tr, tc, up_diag, p0, flag)) return;
-    if (!potrf_phase<5>(m, dinv, rowbuf, tr, tc, up_diag, p0, flag)) return;
-    if (!potrf_phase<6>(m, dinv, rowbuf, tr, tc, up_diag, p0, flag)) return;
-    if (!potrf_phase<7>(m, dinv, rowbuf, tr, tc, up_diag, p0, flag)) return;
-    // rows were left unscaled: R[j][c>j] = m*inv_j, T[j][c<j] = m*inv_j, R[j][j] = piv*inv_j = d_j
-    // (for the second row of a pair the register already holds row - l*row1, its own pivot included)
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) m[a][b] *= dinv[a];
-    // write back: R (upper), T (lower) and U = T^T (upper), zeros elsewhere in the block
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const int r = tr + 16 * a, c = tc + 16 * b;
-            const double v = m[a][b];
-            const int64_t g = (p0 + r) * Np + p0 + c;    // (r, c)
-            const int64_t gt = (p0 + c) * Np + p0 + r;   // (c, r)
-            if (c > r) {
-                R[g] = v;
-                T[g] = 0.0;
-                U[gt] = 0.0;
-            } else if (c < r) {
-                R[g] = 0.0;
-                T[g] = v;
-                U[gt] = v;
-            } else {
-                const double dinv = 1.0 / v;
-                R[g] = v;
-                T[g] = dinv;
-                U[g] = dinv;
-            }
-        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -767,33 +580,6 @@ __global__ __launch_bounds__(256) void k_panel_solve16(const double* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
-// R2b: panel solve  R_pJ = T_pp S_pJ  (J > p) as a GEMM:  A(m,k) = T_pp(m,k) = U[p0+k][p0+m]
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GEMM_THREADS) void k_panel_trsm(const double* __restrict__ U,
-                                                             const double* __restrict__ S,
-                                                             double* __restrict__ R, int64_t Np, int p) {
-    // 64x64 tiles: blockIdx.y = 64-row half of the block row, blockIdx.x = 64-column tile right of the
-    // diagonal block.  T_pp is lower triangular (U_pp[k][m] = 0 for k > m): the upper half needs k < 64 only.
-    __shared__ __attribute__((aligned(16))) double smem[GEMM64_LDS_F64];
-    const int64_t p0 = (int64_t)p * NB;
-    const int mh = blockIdx.y;
-    const int64_t j0 = (int64_t)(p + 1) * NB + (int64_t)blockIdx.x * T64;
-    d4 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
-    gemm_tile_64(acc, U + p0 * Np + p0 + mh * T64, Np, S + p0 * Np + j0, Np, 0, (mh + 1) * T64, smem);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                R[(p0 + mh * T64 + acc_row64(i, r)) * Np + j0 + acc_col64(j)] = acc[i][j][r];
-}
-
-// ------------------------------------------------------------------------------------------------
 // R2c: symmetric update  S_IJ -= sum_{k in [kb0,kb1)} R_kI^T R_kJ  for tiles I = ib0+by <= J = ib0+bx
 // (the syrk/gemm on fp64 MFMA).  Used two ways by the two-level blocked factorisation below:
 //   * in-panel "row update" (grid (nP-I, 1), ib0 = I): brings block row I up to date with the rows of the
@@ -880,22 +666,12 @@ void launch_cholesky(gpx_handle* h) {
             if (I > P0)   // block row I <- contributions of rows P0..I-1 of this panel
                 hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - I)), 2), dim3(GEMM_THREADS), 0, s,
                                    h->dR, h->dS, Np, P0, I, I, (int64_t)0);
-            if (h->potrf_variant == 0) {
-                hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(256), 0, s, h->dS, h->dR, h->dT, h->dU, Np, I,
-                                   h->dflag);
-            } else {
-                hipLaunchKernelGGL(k_potrf16<false>, dim3(1), dim3(256), 0, s, h->dS, h->dR, h->dT, h->dU, Np, I, h->dflag,
-                                   (long long*)nullptr, (int64_t)0);
-            }
+            hipLaunchKernelGGL(k_potrf16<false>, dim3(1), dim3(256), 0, s, h->dS, h->dR, h->dT, h->dU, Np, I, h->dflag,
+                               (long long*)nullptr, (int64_t)0);
             const int rem = nP - 1 - I;
-            if (rem > 0) {
-                if (h->potrf_variant == 0)
-                    hipLaunchKernelGGL(k_panel_trsm, dim3((unsigned)(2 * rem), 2), dim3(GEMM_THREADS), 0, s, h->dU,
-                                       h->dS, h->dR, Np, I);
-                else
-                    hipLaunchKernelGGL(k_panel_solve16, dim3((unsigned)(2 * rem)), dim3(256), 0, s, h->dU, h->dS, h->dR,
-                                       Np, I, h->dflag, (int64_t)0);
-            }
+            if (rem > 0)
+                hipLaunchKernelGGL(k_panel_solve16, dim3((unsigned)(2 * rem)), dim3(256), 0, s, h->dU, h->dS, h->dR, Np,
+                                   I, h->dflag, (int64_t)0);
         }
         near_rows = 0;
         if (P1 >= nP) break;
@@ -907,10 +683,7 @@ void launch_cholesky(gpx_handle* h) {
         if (mid_pending) hipStreamWaitEvent(s, h->ev_far, 0);        // mid(P-1) (and rest(P-2)) wrote these rows
         mid_pending = false;
         hipEventRecord(h->ev_chain, s);                               // R rows P0..P1-1 are final, mid(P-1) joined
-        if (h->potrf_variant == 0) {
-            hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)(nP - P1), (unsigned)nnear), dim3(GEMM_THREADS), 0, s,
-                               h->dR, h->dS, Np, P0, P1, P1, P1, (int64_t)0);
-        } else {
+        {
             // near(P) row by row.  Only block row P1 is needed before the next diagonal block can be factored: it is
             // updated on 64x64 tiles (4x the workgroups, a quarter of the K = 512 tile latency each; the one-launch
             // 128-tile form cost ~115 us of pure critical path per panel = the latency of ONE workgroup per CU at
@@ -946,8 +719,8 @@ void launch_cholesky(gpx_handle* h) {
         hipStreamWaitEvent(s, h->ev_far, 0);
     }
     // (stream 3 needs no join: every launch on it is followed by an event the main stream has waited on)
-    // variant 1 leaves only the 16x16 inverses in the diagonal blocks of T / U; launch_trtri completes them
-    h->diag_inv_pending = (h->potrf_variant != 0);
+    // only the 16x16 inverses are in the diagonal blocks of T / U so far; launch_trtri completes them
+    h->diag_inv_pending = true;
 }
 
 // ------------------------------------------------------------------------------------------------
