@@ -3,6 +3,7 @@
 // HIP-event timers.  No exception leaves this file.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -231,6 +232,11 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             if (value < -1 || value > 1) return fail(h, GPX_EARG, "sweep_cache must be 1, 0 or -1");
             h->cache_on = (value == 1);
             if (value < 0) h->cache_valid = false;
+            return GPX_OK;
+        }
+        if (!strcmp(name, "chol_w")) {
+            if (value != 0 && (value < 2 || value > 8)) return fail(h, GPX_EARG, "chol_w must be 0 (by size) or in [2, 8]");
+            h->chol_w = (int)value;
             return GPX_OK;
         }
         if (!strcmp(name, "eager_inverse")) {

@@ -30,7 +30,8 @@ struct gpx_handle {
     hipStream_t stream2 = nullptr;   // library-owned side stream (Cholesky lookahead: far trailing updates, low priority)
     hipStream_t stream3 = nullptr;   // library-owned side stream (rows 2..4 of the next panel's near update, normal priority)
     hipEvent_t ev_chain = nullptr, ev_far = nullptr;
-    hipEvent_t ev_row[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_row[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int chol_w = 0;               // outer panel width of the factorisation in 128-blocks (2..8; 0 = by size)
     std::string err;
 
     // model state
