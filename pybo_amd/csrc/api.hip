@@ -275,7 +275,7 @@ static int check_fit_args(gpx_handle* h, const void* X, int64_t N, int64_t d, co
     if (!h) return GPX_EARG;
     if (!X || !y || !ell) return fail(h, GPX_EARG, "fit: NULL pointer");
     if (N < 1) return fail(h, GPX_EARG, "fit: N must be >= 1");
-    if (d < 1 || d > DMAX) return fail(h, GPX_EARG, "fit: d must be in [1, 64]");
+    if (d < 1 || d > DMAX) return fail(h, GPX_EARG, "fit: d must be in [1, 1024]");
     if (kid < GPX_KERN_SE_ARD || kid > GPX_KERN_MATERN12) return fail(h, GPX_EARG, "fit: unknown kernel id");
     if (!(rho > 0) || !(sn2 >= 0) || !std::isfinite(rho) || !std::isfinite(sn2))
         return fail(h, GPX_EARG, "fit: need finite rho > 0 and sn2 >= 0");
@@ -286,7 +286,9 @@ static int check_fit_args(gpx_handle* h, const void* X, int64_t N, int64_t d, co
 }
 
 static int alloc_model(gpx_handle* h, int64_t Np, int64_t d) {
-    if (Np > h->cap_np) {
+    if (Np > h->cap_np || d > h->cap_d) {
+        Np = std::max(Np, h->cap_np);
+        d = std::max(d, h->cap_d);
         double** mats[] = {&h->dS, &h->dR, &h->dT, &h->dU};
         for (auto m : mats) {
             if (*m) HIPCHK(h, hipFree(*m));
@@ -298,6 +300,7 @@ static int alloc_model(gpx_handle* h, int64_t Np, int64_t d) {
             *v = nullptr;
         }
         h->cap_np = 0;
+        h->cap_d = 0;
         for (auto m : mats) {
             HIPCHK(h, hipMalloc((void**)m, (size_t)Np * Np * 8));
             // never-written regions (e.g. the upper off-diagonal blocks of T) are never read by a
@@ -307,11 +310,11 @@ static int alloc_model(gpx_handle* h, int64_t Np, int64_t d) {
         HIPCHK(h, hipMalloc((void**)&h->dy, (size_t)Np * 8));
         HIPCHK(h, hipMalloc((void**)&h->da, (size_t)Np * 8));
         HIPCHK(h, hipMalloc((void**)&h->dalpha, (size_t)Np * 8));
-        HIPCHK(h, hipMalloc((void**)&h->dXs, (size_t)Np * DMAX * 8));
-        HIPCHK(h, hipMalloc((void**)&h->dXraw, (size_t)Np * DMAX * 8));
+        HIPCHK(h, hipMalloc((void**)&h->dXs, (size_t)Np * d * 8));
+        HIPCHK(h, hipMalloc((void**)&h->dXraw, (size_t)Np * d * 8));
         h->cap_np = Np;
+        h->cap_d = d;
     }
-    (void)d;
     return GPX_OK;
 }
 
@@ -767,7 +770,8 @@ static int rff_core(gpx_handle* h, const double* W, const double* b, const doubl
                     int64_t n, int64_t d, double bias, const double* dXc, int64_t M, int64_t k,
                     double* top_val, int64_t* top_idx, double* d_vals) {
     if (!W || !b || !theta || !dXc) return fail(h, GPX_EARG, "rff_sweep: NULL pointer");
-    if (S < 1 || n < 1 || d < 1 || d > DMAX || M < 1) return fail(h, GPX_EARG, "rff_sweep: bad sizes");
+    if (S < 1 || n < 1 || d < 1 || M < 1) return fail(h, GPX_EARG, "rff_sweep: bad sizes");
+    if (d > DMAX_RFF) return fail(h, GPX_EARG, "rff_sweep: the Thompson kernels take d <= 64 (feature tiles in LDS)");
     if (k < 0 || k > TOPK_MAX) return fail(h, GPX_EARG, "rff_sweep: k must be in [0, 64]");
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
@@ -874,6 +878,7 @@ extern "C" int gpx_rff_gram_batch(gpx_handle* h, const double* W, const double* 
         if (!h) return GPX_EARG;
         if (h->stage < 1) return fail(h, GPX_ESTATE, "rff_gram: no data on the device (fit first)");
         if (!W || !b || !A || !v || n < 1 || S < 1) return fail(h, GPX_EARG, "rff_gram: bad arguments");
+        if (h->d > DMAX_RFF) return fail(h, GPX_EARG, "rff_gram: the Thompson kernels take d <= 64 (feature tiles in LDS)");
         HIPCHK(h, hipSetDevice(h->device));
         hipStream_t s = h->stream;
         const int64_t d = h->d, Np = h->Np, N = h->N;

@@ -11,7 +11,8 @@ namespace gpx {
 
 constexpr int NB = 128;       // factorisation block = GEMM tile edge
 constexpr int TBH = 128;      // host-side copy of the GEMM tile edge (gemm_core.h TB)
-constexpr int DMAX = 64;      // max input dimension staged in LDS
+constexpr int DMAX = 1024;    // max input dimension (buffer sizing only: the kernels walk coordinates 16 at a time)
+constexpr int DMAX_RFF = 64;  // max input dimension of the Thompson / RFF kernels (their feature tiles [d][144] live in LDS)
 constexpr int TOPK_MAX = 64;  // max k of the device top-k
 
 enum Timer {
@@ -46,8 +47,8 @@ struct gpx_handle {
     int64_t fail_pivot = -1;
 
     // device buffers (capacity tracked in elements)
-    int64_t cap_np = 0;
-    double* dXs = nullptr;    // (Np, d) observed points scaled by 1/ell, padded rows = 0
+    int64_t cap_np = 0, cap_d = 0;
+    double* dXs = nullptr;    // (Np, d) observed points scaled by 1/ell, padded rows = 0 (allocated (cap_np, cap_d))
     double* dXraw = nullptr;  // (N, d) observed points as given
     double* dy = nullptr;     // (Np,) y (padded 0)
     double* dS = nullptr;     // (Np,Np) working Gram matrix (upper), later trtri workspace

@@ -307,8 +307,8 @@ static int grow_block(gpx_handle* h) {
     hipStream_t s = h->stream;
     double* nm[4] = {nullptr, nullptr, nullptr, nullptr};     // S (workspace), R, T, U
     double* nv[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // y, a, alpha, Xs, Xraw
-    const size_t vbytes[5] = {(size_t)Nn * 8, (size_t)Nn * 8, (size_t)Nn * 8, (size_t)Nn * DMAX * 8,
-                              (size_t)Nn * DMAX * 8};
+    const size_t vbytes[5] = {(size_t)Nn * 8, (size_t)Nn * 8, (size_t)Nn * 8, (size_t)Nn * h->cap_d * 8,
+                              (size_t)Nn * h->cap_d * 8};
     auto bail = [&](const char* msg, int code) {
         for (double* p : nm) if (p) hipFree(p);
         for (double* p : nv) if (p) hipFree(p);
@@ -355,8 +355,9 @@ int append_host(gpx_handle* h, const double* x, double ynew) {
     hipStream_t s = h->stream;
     const int64_t Np = h->Np, N = h->N;
     const int d = (int)h->d;
-    // scratch: [x d (padded to 64)][ks Np][g Np][r Np][tu Np]
-    const int64_t need = 64 + 4 * Np;
+    // scratch: [x d (padded to a multiple of 64)][ks Np][g Np][r Np][tu Np]
+    const int64_t xpad = (d + 63) / 64 * 64;
+    const int64_t need = xpad + 4 * Np;
     if (need > h->cap_grad) {
         if (h->dgrad) hipFree(h->dgrad);
         h->dgrad = nullptr;
@@ -368,7 +369,7 @@ int append_host(gpx_handle* h, const double* x, double ynew) {
         h->cap_grad = need;
     }
     double* dx = h->dgrad;
-    double* dks = dx + 64;
+    double* dks = dx + xpad;
     double* dg = dks + Np;
     double* dr = dg + Np;
     double* dtu = dr + Np;

@@ -140,7 +140,7 @@ def test_grid_errors():
     with pytest.raises(GpxError):
         g.rows([16])
     with pytest.raises(GpxError):
-        DeviceGrid('uniform', np.zeros((65, 2)), 4)         # d > 64
+        DeviceGrid('uniform', np.zeros((1025, 2)), 4)       # d > 1024
 
 
 def test_sweeps_over_a_device_grid_equal_sweeps_over_the_host_copy():

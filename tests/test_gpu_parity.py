@@ -256,7 +256,8 @@ def test_topk_edge_cases():
 
 
 def test_nan_candidates_rank_last_and_max_dimension():
-    # d = 64 is the largest supported input dimension; 65 is refused
+    # d = 64 is the largest input dimension of the Thompson kernels; the exact-GP path goes on to 1024
+    # (test_high_dimensional_inputs) and refuses 1025
     from pybo_amd._lib import GpxError, GPX_EARG
     X, y, ell = synth_problem(130, 64, seed=8)
     ref = gp_ref.make_gp(1e-3, 1.0, ell * 4, 0.0)
@@ -268,7 +269,7 @@ def test_nan_candidates_rank_last_and_max_dimension():
     mr, sr = ref.predict(Z)
     assert np.all(np.abs(mu - mr) <= mu_tol(mr, 1.0)) and np.all(np.abs(s2 - sr) <= s2_tol(sr, 1.0))
     with pytest.raises(GpxError) as ei:
-        e.fit(np.random.rand(10, 65), np.random.rand(10), 'se', np.ones(65), 1.0, 1e-3, 0.0)
+        e.fit(np.random.rand(10, 1025), np.random.rand(10), 'se', np.ones(1025), 1.0, 1e-3, 0.0)
     assert ei.value.code == GPX_EARG
     # a NaN coordinate poisons that candidate only; it ranks below every finite value
     e.fit(X, y, 'se', ell * 4, 1.0, 1e-3, 0.0)
@@ -410,6 +411,44 @@ def test_model_protocol_matches_oracle_and_is_copy_on_write():
     np.testing.assert_allclose(g2.predict(Z[:5])[0], before, rtol=1e-9, atol=1e-10)
     g2.params['kern.rho'].set_prior('lognormal', 0.0, 1.0)
     assert pickle.loads(pickle.dumps(g2)).params['kern.rho'].prior[0] == 'lognormal'
+
+
+def test_high_dimensional_inputs():
+    """the exact-GP path had a d <= 64 limit the reference does not have.  The kernels
+    walk coordinates 16 at a time, so only buffer sizes depended on it: d = 100 through fit / sweep / gradients /
+    append / batched likelihood.  (The Thompson kernels keep d <= 64: their feature tiles live in LDS.)"""
+    from pybo_amd._lib import GpxError
+    d, N = 100, 200
+    rng = np.random.RandomState(8)
+    X = rng.rand(N + 3, d)
+    y = np.sin(X[:, :5].sum(1)) + 0.01 * rng.randn(N + 3)
+    ell = 1.5 + rng.rand(d)
+    rho, sn2, bias = 1.1, 1e-3, 0.1
+    e = _engine()
+    e.fit(X[:N], y[:N], 'matern5', ell, rho, sn2, bias)
+    ref = gp_ref.make_gp(sn2, rho, ell, bias, 'matern5')
+    ref.add_data(X[:N], y[:N])
+    Z = rng.rand(700, d)
+    r = e.sweep('ei', 0.3, Z, k=5, want_moments=True)
+    mr, sr = ref.predict(Z)
+    assert np.all(np.abs(r['mu'] - mr) <= mu_tol(mr, rho)) and np.all(np.abs(r['s2'] - sr) <= s2_tol(sr, rho))
+    assert r['top_idx'][0] == int(np.argmax(ref.get_improvement(0.3, Z)))
+    got, want = e.predict(Z[:9], grad=True), ref.predict(Z[:9], grad=True)
+    np.testing.assert_allclose(got[2], want[2], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(got[3], want[3], rtol=1e-6, atol=1e-8)
+    for i in range(N, N + 3):
+        assert e.append(X[i], y[i])
+    ref.add_data(X[N:], y[N:])
+    mr, sr = ref.predict(Z[:50])
+    mu, s2 = e.predict(Z[:50])
+    assert np.all(np.abs(mu - mr) <= mu_tol(mr, rho)) and np.all(np.abs(s2 - sr) <= s2_tol(sr, rho))
+    hyp = np.concatenate([[sn2, rho], ell, [bias]])
+    assert abs(e.loglik_batch(hyp[None])[0] - ref.loglikelihood()) <= 1e-9 * abs(ref.loglikelihood())
+    with pytest.raises(GpxError):
+        e.rff_gram(rng.randn(20, d), rng.rand(20))
+    with pytest.raises(GpxError):
+        e.fit(np.zeros((4, 1025)), np.zeros(4), 'se', np.ones(1025), 1.0, 1e-3, 0.0)
+    e.close()
 
 
 def test_prior_sample_of_an_empty_model_and_large_nbest():
