@@ -611,18 +611,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(const double* _
             }
 }
 
-// In-panel row update on 64x64 tiles: block row I (two 64-row halves) <- rows kb0..kb1-1 of R.
-// grid (2*(nP-I), 2): blockIdx.y = row half, blockIdx.x = 64-column tile counted from the diagonal block.
+// Row update on 64x64 tiles: block rows I .. I+nrows-1 (two 64-row halves each) <- rows kb0..kb1-1 of R.
+// grid (2*(nP-I), 2*nrows): blockIdx.y = 2 * (row - I) + row half, blockIdx.x = 64-column tile counted from that
+// row's diagonal block.  `prio`: wave priority -- 3 on the chain (see k_potrf16), lower for the launches that run
+// beside it on the third stream.
 __global__ __launch_bounds__(GEMM_THREADS) void k_row_update64(const double* __restrict__ R,
                                                                double* __restrict__ S, int64_t Np, int kb0,
-                                                               int kb1, int I, int64_t bs) {
-    if (blockIdx.x < blockIdx.y) return;   // strictly below the diagonal inside the diagonal block
+                                                               int kb1, int I, int64_t bs, int nP, int prio) {
+    const int row = I + (int)(blockIdx.y >> 1), half = (int)(blockIdx.y & 1);
+    if ((int)blockIdx.x < half || (int)blockIdx.x >= 2 * (nP - row)) return;   // below the diagonal / past the end
     R += (int64_t)blockIdx.z * bs;         // batched use: blockIdx.z = batch element
     S += (int64_t)blockIdx.z * bs;
-    __builtin_amdgcn_s_setprio(3);         // chain kernel: see k_potrf16
+    if (prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (prio == 2) __builtin_amdgcn_s_setprio(2);
     __shared__ __attribute__((aligned(16))) double smem[GEMM64_LDS_F64];
-    const int64_t i0 = (int64_t)I * NB + (int64_t)blockIdx.y * T64;
-    const int64_t j0 = (int64_t)I * NB + (int64_t)blockIdx.x * T64;
+    const int64_t i0 = (int64_t)row * NB + (int64_t)half * T64;
+    const int64_t j0 = (int64_t)row * NB + (int64_t)blockIdx.x * T64;
     d4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -665,11 +669,11 @@ void launch_cholesky(gpx_handle* h) {
     for (int P0 = 0; P0 < nP; P0 += CW) {
         const int P1 = (P0 + CW < nP) ? P0 + CW : nP;
         for (int I = P0; I < P1; ++I) {
-            if (I > P0 && I - P0 <= near_rows)     // this row's share of the previous panel's update (stream 3)
-                hipStreamWaitEvent(s, h->ev_row[I - P0], 0);
+            if (I == P0 + 1 && near_rows > 0)      // rows P0+1.. got the previous panel's update on stream 3
+                hipStreamWaitEvent(s, h->ev_row[0], 0);
             if (I > P0)   // block row I <- contributions of rows P0..I-1 of this panel
                 hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - I)), 2), dim3(GEMM_THREADS), 0, s,
-                                   h->dR, h->dS, Np, P0, I, I, (int64_t)0);
+                                   h->dR, h->dS, Np, P0, I, I, (int64_t)0, nP, 3);
             hipLaunchKernelGGL(k_potrf16<false>, dim3(1), dim3(256), 0, s, h->dS, h->dR, h->dT, h->dU, Np, I, h->dflag,
                                (long long*)nullptr, (int64_t)0);
             const int rem = nP - 1 - I;
@@ -692,17 +696,16 @@ void launch_cholesky(gpx_handle* h) {
             // updated on 64x64 tiles (4x the workgroups, a quarter of the K = 512 tile latency each; the one-launch
             // 128-tile form cost ~115 us of pure critical path per panel = the latency of ONE workgroup per CU at
             // half the matrix pipe -- and so did each row launched separately in that form).  The other rows of the
-            // next panel are brought up to date, on 64x64 tiles too, on a third stream WHILE the chain already
-            // works on row P1; the chain waits for row P1 + q just before that row's in-panel update.
+            // next panel are brought up to date, on 64x64 tiles too, by ONE launch on a third stream (wave priority 2,
+            // below the chain's 3) WHILE the chain already works on row P1; the chain waits for its event just
+            // before row P1 + 1's in-panel update.
             hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - P1)), 2), dim3(GEMM_THREADS), 0, s, h->dR,
-                               h->dS, Np, P0, P1, P1, (int64_t)0);
-            if (nnear > 1) {
+                               h->dS, Np, P0, P1, P1, (int64_t)0, nP, 3);
+            if (nnear > 1) {       // rows P1+1 .. in ONE launch at a lower wave priority, one event
                 hipStreamWaitEvent(s3, h->ev_chain, 0);
-                for (int q = 1; q < nnear; ++q) {
-                    hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - P1 - q)), 2), dim3(GEMM_THREADS), 0, s3,
-                                       h->dR, h->dS, Np, P0, P1, P1 + q, (int64_t)0);
-                    hipEventRecord(h->ev_row[q], s3);
-                }
+                hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - P1 - 1)), (unsigned)(2 * (nnear - 1))),
+                                   dim3(GEMM_THREADS), 0, s3, h->dR, h->dS, Np, P0, P1, P1 + 1, (int64_t)0, nP, 2);
+                hipEventRecord(h->ev_row[0], s3);
                 near_rows = nnear - 1;
             }
         }
@@ -968,7 +971,7 @@ int loglik_batch_host(gpx_handle* h, int64_t B, const double* hyp, double* out) 
         for (int I = P0; I < P1; ++I) {
             if (I > P0)
                 hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - I)), 2, Bz), dim3(GEMM_THREADS), 0, s, bR, bS,
-                                   Np, P0, I, I, bs);
+                                   Np, P0, I, I, bs, nP, 0);
             hipLaunchKernelGGL(k_potrf16<false>, dim3(1, 1, Bz), dim3(256), 0, s, bS, bR, (double*)nullptr, bS, Np, I,
                                bflag, (long long*)nullptr, bs);
             const int rem = nP - 1 - I;

@@ -48,7 +48,7 @@ def test_config_b_full_grid_properties_and_subsample_parity():
     # oracle parity on a sub-sample of the grid + the selected candidate
     ref = gp_ref.make_gp(sn2, rho, ell, bias)
     ref.add_data(X, y)
-    pick = np.unique(np.concatenate([np.arange(0, M, 1024), r['top_idx']]))
+    pick = np.unique(np.concatenate([np.arange(0, M, 512), r['top_idx']]))
     mr, sr = ref.predict(Z[pick])
     assert np.all(np.abs(mu[pick] - mr) <= mu_tol(mr, rho))
     assert np.all(np.abs(s2[pick] - sr) <= s2_tol(sr, rho))
