@@ -127,7 +127,10 @@ __device__ __forceinline__ void gemm_tile_128_b(d4 (&acc)[4][4], const double* _
 // workgroup to keep the matrix pipe busy meanwhile.
 constexpr int BK32 = 32;
 
-template <bool PRIO>
+// NEGA: the A operand is negated on its way into LDS, i.e. acc += -(A^T-panel) * B: the symmetric updates start
+// their accumulators from the S tile they update (loaded while the first k-steps are in flight) and store
+// S - sum A B directly, instead of a dependent read-modify-write round trip after the k-loop.
+template <bool PRIO, bool NEGA = false>
 __device__ __forceinline__ void gemm_tile_128_g(d4 (&acc)[4][4], const double* __restrict__ A, int64_t lda,
                                                 const double* __restrict__ B, int64_t ldb, int k_lo,
                                                 int k_hi, double* smem) {
@@ -157,7 +160,7 @@ __device__ __forceinline__ void gemm_tile_128_g(d4 (&acc)[4][4], const double* _
     auto swrite = [&]() {
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            *reinterpret_cast<d2*>(As + (lrow + 4 * p) * LDT + lcol) = ra[p];
+            *reinterpret_cast<d2*>(As + (lrow + 4 * p) * LDT + lcol) = NEGA ? -ra[p] : ra[p];
             *reinterpret_cast<d2*>(Bs + (lrow + 4 * p) * LDT + lcol) = rb[p];
         }
     };
@@ -215,41 +218,47 @@ constexpr int T64 = 64;
 constexpr int LDT64 = T64 + 16;
 constexpr int GEMM64_LDS_F64 = 2 * BK32 * LDT64;    // [A|B][32][LDT64] = 40,960 B
 
-// K is stepped 32 at a time through a SINGLE 40 KB LDS buffer with a TWO-deep register prefetch: the global loads
+// 64x64 tile engine of the Cholesky's chain kernels (row updates): K is stepped 32 at a time through a SINGLE
+// 40 KB LDS buffer with a TWO-deep register prefetch: the global loads
 // of step t+2 are issued at the top of step t and written to LDS at the end of step t+1.  The chain kernels that
 // use it are bound by the latency of their dependent global loads, not by MFMA or bandwidth (round 1's 16-row
 // ring with a one-step prefetch: K = 512 = 32 round trips of ~3.3 us next to the trailing updates): half as many
 // round trips, each covered by two compute phases instead of one.  k_hi - k_lo must be a multiple of 32.
-__device__ __forceinline__ void gemm_tile_64_g(d4 (&acc)[2][2], const double* __restrict__ A, int64_t lda,
+// Workgroup = 512 threads = 8 waves (2 x 4), wave tile 32 x 16 = 2 MFMA accumulators: the kernels that use this tile
+// are latency-bound per k-step, so the MFMA work of a step is spread over twice the waves of the 128-tile engine.
+constexpr int GEMM64_THREADS = 512;
+
+template <bool NEGA = false>
+__device__ __forceinline__ void gemm_tile_64_g(d4 (&acc)[2], const double* __restrict__ A, int64_t lda,
                                                const double* __restrict__ B, int64_t ldb, int k_lo, int k_hi,
                                                double* smem) {
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int w = t >> 6;
-    const int wm = w >> 1, wn = w & 1;
+    const int wm = w >> 2, wn = w & 3;
     double* As = smem;                    // [32][LDT64]
     double* Bs = smem + BK32 * LDT64;     // [32][LDT64]
-    const int lrow = t >> 5;              // 0..7: two k-rows per wave instruction
+    const int lrow = t >> 5;              // 0..15: two k-rows per wave instruction
     const int lcol = (t & 31) * 2;
     const int nk = (k_hi - k_lo) / BK32;
     if (nk <= 0) return;
     const double* Ap = A + (int64_t)(k_lo + lrow) * lda + lcol;
     const double* Bp = B + (int64_t)(k_lo + lrow) * ldb + lcol;
-    d2 ra[2][4], rb[2][4];
+    d2 ra[2][2], rb[2][2];
 #define GPX_GLOAD64(ST)                                                                   \
     {                                                                                     \
-        _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                   \
-            ra[ST][p] = *reinterpret_cast<const d2*>(Ap + (int64_t)(8 * p) * lda);        \
-            rb[ST][p] = *reinterpret_cast<const d2*>(Bp + (int64_t)(8 * p) * ldb);        \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                   \
+            ra[ST][p] = *reinterpret_cast<const d2*>(Ap + (int64_t)(16 * p) * lda);       \
+            rb[ST][p] = *reinterpret_cast<const d2*>(Bp + (int64_t)(16 * p) * ldb);       \
         }                                                                                 \
         Ap += (int64_t)BK32 * lda;                                                        \
         Bp += (int64_t)BK32 * ldb;                                                        \
     }
 #define GPX_SWRITE64(ST)                                                                  \
     {                                                                                     \
-        _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                   \
-            *reinterpret_cast<d2*>(As + (lrow + 8 * p) * LDT64 + lcol) = ra[ST][p];       \
-            *reinterpret_cast<d2*>(Bs + (lrow + 8 * p) * LDT64 + lcol) = rb[ST][p];       \
+        _Pragma("unroll") for (int p = 0; p < 2; ++p) {                                   \
+            *reinterpret_cast<d2*>(As + (lrow + 16 * p) * LDT64 + lcol) = NEGA ? -ra[ST][p] : ra[ST][p]; \
+            *reinterpret_cast<d2*>(Bs + (lrow + 16 * p) * LDT64 + lcol) = rb[ST][p];      \
         }                                                                                 \
     }
     GPX_GLOAD64(0);                       // tile 0
@@ -268,21 +277,14 @@ __device__ __forceinline__ void gemm_tile_64_g(d4 (&acc)[2][2], const double* __
                 if (half == 0) GPX_GLOAD64(0) else GPX_GLOAD64(1)
             }
             const double* as = As + wm * 32 + fr;
-            const double* bs = Bs + wn * 32 + fr;
+            const double* bs = Bs + wn * 16 + fr;
 #pragma unroll
             for (int kk = 0; kk < BK32 / 4; ++kk) {
                 const int kr = kk * 4 + fk;
-                double a[2], b[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    a[i] = as[kr * LDT64 + i * 16];
-                    b[i] = bs[kr * LDT64 + i * 16];
-                }
+                const double b = bs[kr * LDT64];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(as[kr * LDT64 + i * 16], b, acc[i], 0, 0, 0);
             }
             __syncthreads();               // everyone has finished reading the buffer
             if (k + 1 < nk) {
@@ -297,11 +299,11 @@ __device__ __forceinline__ void gemm_tile_64_g(d4 (&acc)[2][2], const double* __
 
 __device__ __forceinline__ int acc_row64(int i, int r) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    return (w >> 1) * 32 + i * 16 + (lane >> 4) + 4 * r;
+    return (w >> 2) * 32 + i * 16 + (lane >> 4) + 4 * r;
 }
-__device__ __forceinline__ int acc_col64(int j) {
+__device__ __forceinline__ int acc_col64() {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    return (w & 1) * 32 + j * 16 + (lane & 15);
+    return (w & 3) * 16 + (lane & 15);
 }
 
 }  // namespace gpx

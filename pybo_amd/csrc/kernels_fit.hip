@@ -597,25 +597,28 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(const double* _
     S += (int64_t)blockIdx.z * bs;
     __shared__ __attribute__((aligned(16))) double smem[GEMM_LDS_F64];
     const int64_t i0 = (int64_t)I * NB, j0 = (int64_t)J * NB;
+    // accumulators start from the S tile (its loads overlap the first k-steps), A enters negated: acc = S - A B
     d4 acc[4][4];
-    acc_zero(acc);
-    gemm_tile_128_g<true>(acc, R + i0, Np, R + j0, Np, kb0 * NB, kb1 * NB, smem);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double* q = S + (i0 + acc_row(i, r)) * Np + j0 + acc_col(j);
-                *q -= acc[i][j][r];
-            }
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = S[(i0 + acc_row(i, r)) * Np + j0 + acc_col(j)];
+    gemm_tile_128_g<true, true>(acc, R + i0, Np, R + j0, Np, kb0 * NB, kb1 * NB, smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(i0 + acc_row(i, r)) * Np + j0 + acc_col(j)] = acc[i][j][r];
 }
 
 // Row update on 64x64 tiles: block rows I .. I+nrows-1 (two 64-row halves each) <- rows kb0..kb1-1 of R.
 // grid (2*(nP-I), 2*nrows): blockIdx.y = 2 * (row - I) + row half, blockIdx.x = 64-column tile counted from that
 // row's diagonal block.  `prio`: wave priority -- 3 on the chain (see k_potrf16), lower for the launches that run
 // beside it on the third stream.
-__global__ __launch_bounds__(GEMM_THREADS) void k_row_update64(const double* __restrict__ R,
+__global__ __launch_bounds__(GEMM64_THREADS) void k_row_update64(const double* __restrict__ R,
                                                                double* __restrict__ S, int64_t Np, int kb0,
                                                                int kb1, int I, int64_t bs, int nP, int prio) {
     const int row = I + (int)(blockIdx.y >> 1), half = (int)(blockIdx.y & 1);
@@ -627,21 +630,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void k_row_update64(const double* __r
     __shared__ __attribute__((aligned(16))) double smem[GEMM64_LDS_F64];
     const int64_t i0 = (int64_t)row * NB + (int64_t)half * T64;
     const int64_t j0 = (int64_t)row * NB + (int64_t)blockIdx.x * T64;
-    d4 acc[2][2];
+    d4 acc[2];             // start from the S tile, A enters negated: acc = S - A B (no read-modify-write tail)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
-    gemm_tile_64_g(acc, R + i0, Np, R + j0, Np, kb0 * NB, kb1 * NB, smem);
+        for (int r = 0; r < 4; ++r) acc[i][r] = S[(i0 + acc_row64(i, r)) * Np + j0 + acc_col64()];
+    gemm_tile_64_g<true>(acc, R + i0, Np, R + j0, Np, kb0 * NB, kb1 * NB, smem);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double* q = S + (i0 + acc_row64(i, r)) * Np + j0 + acc_col64(j);
-                *q -= acc[i][j][r];
-            }
+        for (int r = 0; r < 4; ++r) S[(i0 + acc_row64(i, r)) * Np + j0 + acc_col64()] = acc[i][r];
 }
 
 constexpr int CHOL_W = 4;   // outer panel width in 128-blocks
@@ -672,7 +670,7 @@ void launch_cholesky(gpx_handle* h) {
             if (I == P0 + 1 && near_rows > 0)      // rows P0+1.. got the previous panel's update on stream 3
                 hipStreamWaitEvent(s, h->ev_row[0], 0);
             if (I > P0)   // block row I <- contributions of rows P0..I-1 of this panel
-                hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - I)), 2), dim3(GEMM_THREADS), 0, s,
+                hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - I)), 2), dim3(GEMM64_THREADS), 0, s,
                                    h->dR, h->dS, Np, P0, I, I, (int64_t)0, nP, 3);
             hipLaunchKernelGGL(k_potrf16<false>, dim3(1), dim3(256), 0, s, h->dS, h->dR, h->dT, h->dU, Np, I, h->dflag,
                                (long long*)nullptr, (int64_t)0);
@@ -699,12 +697,12 @@ void launch_cholesky(gpx_handle* h) {
             // next panel are brought up to date, on 64x64 tiles too, by ONE launch on a third stream (wave priority 2,
             // below the chain's 3) WHILE the chain already works on row P1; the chain waits for its event just
             // before row P1 + 1's in-panel update.
-            hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - P1)), 2), dim3(GEMM_THREADS), 0, s, h->dR,
+            hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - P1)), 2), dim3(GEMM64_THREADS), 0, s, h->dR,
                                h->dS, Np, P0, P1, P1, (int64_t)0, nP, 3);
             if (nnear > 1) {       // rows P1+1 .. in ONE launch at a lower wave priority, one event
                 hipStreamWaitEvent(s3, h->ev_chain, 0);
                 hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - P1 - 1)), (unsigned)(2 * (nnear - 1))),
-                                   dim3(GEMM_THREADS), 0, s3, h->dR, h->dS, Np, P0, P1, P1 + 1, (int64_t)0, nP, 2);
+                                   dim3(GEMM64_THREADS), 0, s3, h->dR, h->dS, Np, P0, P1, P1 + 1, (int64_t)0, nP, 2);
                 hipEventRecord(h->ev_row[0], s3);
                 near_rows = nnear - 1;
             }
@@ -970,7 +968,7 @@ int loglik_batch_host(gpx_handle* h, int64_t B, const double* hyp, double* out) 
         const int P1 = (P0 + CHOL_W < nP) ? P0 + CHOL_W : nP;
         for (int I = P0; I < P1; ++I) {
             if (I > P0)
-                hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - I)), 2, Bz), dim3(GEMM_THREADS), 0, s, bR, bS,
+                hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - I)), 2, Bz), dim3(GEMM64_THREADS), 0, s, bR, bS,
                                    Np, P0, I, I, bs, nP, 0);
             hipLaunchKernelGGL(k_potrf16<false>, dim3(1, 1, Bz), dim3(256), 0, s, bS, bR, (double*)nullptr, bS, Np, I,
                                bflag, (long long*)nullptr, bs);
