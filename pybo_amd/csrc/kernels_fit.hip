@@ -660,8 +660,8 @@ void launch_cholesky(gpx_handle* h) {
     hipMemsetAsync(h->dflag, 0, sizeof(int), s);
     // outer panel width in 128-blocks: wider panels halve the read-modify-write traffic of the big trailing updates
     // (throughput-bound sizes), narrower ones keep the in-panel row updates short (chain-bound sizes); measured at
-    // N = 8192 / 16384: W = 3: 7.08 / 35.2 ms, 4: 7.18 / 33.4, 6: 7.32 / 31.7, 8: 7.75 / 32.0
-    const int CW = h->chol_w ? h->chol_w : (nP >= 96 ? 6 : CHOL_W);
+    // N = 8192 / 16384 (final kernels): W = 3: 6.59 / 30.8 ms, 4: 6.68 / 30.4, 5: 6.74 / 29.7, 6: 7.00 / 30.1
+    const int CW = h->chol_w ? h->chol_w : (nP >= 96 ? 5 : CHOL_W);
     bool mid_pending = false, side_used = false;
     int near_rows = 0;            // rows P0+1.. of the CURRENT panel whose near update runs on the third stream
     for (int P0 = 0; P0 < nP; P0 += CW) {
