@@ -152,6 +152,7 @@ def main():
     ap.add_argument('--tile-order', type=int, default=-1)
     ap.add_argument('--draws', type=int, default=0, help='Thompson draws (default: 64 for workload d, 8 for e)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-refine', action='store_true', help='skip the separately reported L-BFGS refinement')
     ap.add_argument('--cpu-candidates', type=int, default=0, help='candidates in the CPU sample (0 = auto)')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help='process-group backend; gloo only for dry runs of the N>1 path')
@@ -326,6 +327,50 @@ def main():
                 'selected': {'index': int(wbest[1][0]), 'value': float(wbest[0][0])},
                 'speedup_vs_cold_step': (elapsed / args.steps) / wsec}
 
+    # ---- the solver's refinement (A7) and the recommender (A8), reported SEPARATELY (excluded from the
+    # headline): L-BFGS-B from the sweep's seeds with device gradients, exactly what solve_lbfgs does after the
+    # grid sweep (pybo/solvers/lbfgs.py:56-68) -- the reference's behaviour (only the best seed's refinement is
+    # returned, so only that one is computed) and the all-seeds variant in lock-step.
+    refine = None
+    if rank == 0 and w['acq'] in ('ei', 'ucb') and not args.no_refine:
+        import scipy.optimize
+        from scipy.special import erfc
+        from pybo_amd.solvers.lbfgs import _refine_lockstep
+        eng.fit_dev(dX.data_ptr(), N, d, dy.data_ptr(), w['kernel'], w['ell'], w['rho'], w['sn2'], w['bias'])
+        param = eng.mean_at_obs()[1] if w['acq'] == 'ei' else ucb_beta(N)
+        tv, ti = eng.sweep_dev(w['acq'], param, dXc.data_ptr(), Ml, k)
+        seeds = w['Xc'][lo_i + ti]
+        box = np.stack([w['lo'], w['hi']], axis=1)
+        ncall = [0]
+
+        def index(X, grad=True):
+            ncall[0] += 1
+            mu, s2, dmu, ds2 = eng.predict(np.array(X, ndmin=2, dtype=float), grad=True)
+            if w['acq'] == 'ucb':
+                return mu + np.sqrt(param * s2), dmu + 0.5 * np.sqrt(param / s2)[:, None] * ds2
+            s = np.sqrt(s2)
+            z = (mu - param) / s
+            cdf = 0.5 * erfc(-z * 0.70710678118654752440)
+            pdf = 0.39894228040143267794 * np.exp(-0.5 * z * z)
+            return (mu - param) * cdf + s * pdf, cdf[:, None] * dmu + (0.5 * pdf / s)[:, None] * ds2
+
+        def negated(x):
+            fx, gx = index(x[None])
+            return -fx[0], -gx[0]
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        x1, f1 = scipy.optimize.fmin_l_bfgs_b(negated, seeds[0], bounds=box)[:2]
+        t_first, c_first = time.perf_counter() - t0, ncall[0]
+        ncall[0] = 0
+        t0 = time.perf_counter()
+        res = _refine_lockstep(index, seeds, box)
+        t_all, c_all = time.perf_counter() - t0, ncall[0]
+        refine = {'what': 'L-BFGS-B refinement of the sweep seeds with device gradients (gpx_predict with grad); '
+                          'not part of the headline step',
+                  'first_seed': {'ms': t_first * 1e3, 'gradient_calls': c_first, 'value': float(-f1)},
+                  'all_%d_seeds_lockstep' % len(seeds): {'ms': t_all * 1e3, 'batched_gradient_calls': c_all,
+                                                         'best_value': float(-min(r[1] for r in res))}}
+
     if rank == 0:
         Np_ = (N + 127) // 128 * 128
         sec = elapsed / args.steps
@@ -379,6 +424,8 @@ def main():
                               'ms': tm[stage] / args.steps, 'flop': float(N) ** 3 / 3.0}
         if fit:
             out['roofline_fit'] = fit
+        if refine is not None:
+            out['refine'] = refine
         if warm is not None:
             # algorithmic work of the rank-1 correction: N covariance evaluations per candidate per appended
             # point; the kernel is fp64-VALU-issue bound like the cross-Gram

@@ -88,3 +88,71 @@ def test_world2_sharded_topk_equals_global(M, k):
         np.testing.assert_array_equal(idx, order)
         np.testing.assert_array_equal(vals, table[order])
         np.testing.assert_array_equal(i2, order)
+
+
+def _pairs_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        # batch-BO: each rank holds the (value, index) winners of ITS draws; one all-gather, rank order, no merge
+        vals = np.array([10.0 * rank + 0.5, 10.0 * rank + 1.5, -np.inf])
+        idx = np.array([1000 * rank + 7, 2 ** 40 + rank, -1], dtype=np.int64)
+        q.put((rank,) + tuple(pdist.gather_pairs(vals, idx)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gather_pairs_is_one_collective_in_rank_order():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pairs_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, vals, idx in got:
+        np.testing.assert_array_equal(vals, [0.5, 1.5, -np.inf, 10.5, 11.5, -np.inf])
+        np.testing.assert_array_equal(idx, [7, 2 ** 40, -1, 1007, 2 ** 40 + 1, -1])       # indices beyond 2^32 survive
+
+
+def test_device_exchange_branch_checks_its_preconditions():
+    """sharded_topk(comm=...) (libgpx's own RCCL exchange) without a GPU: the communicator must be bound to the
+    engine that ran the sweep, and every shard must hold at least k candidates."""
+    class Eng(object):
+        pass
+
+    class FakeComm(object):
+        def __init__(self, engine, rank, nranks):
+            self._engine, self.rank, self.nranks, self.calls = engine, rank, nranks, []
+
+        def topk_allgather(self, n, off, k):
+            self.calls.append((n, off, k))
+            return np.arange(k, dtype=float), np.arange(k, dtype=np.int64)
+
+    eng, other = Eng(), Eng()
+    seen = []
+
+    def index(X, grad=False):
+        return np.zeros(len(X))
+
+    def topk(xgrid, k):
+        seen.append((len(xgrid), k))
+        return np.zeros(k), np.arange(k)
+    index.topk = topk
+    index.topk_engine = lambda: eng
+    grid = np.arange(100.0)[:, None]
+    comm = FakeComm(eng, rank=1, nranks=4)
+    v, i = pdist.ShardedIndex(index, comm=comm).topk(grid, 5)
+    assert seen == [(25, 5)] and comm.calls == [(5, 25, 5)] and len(v) == 5
+    with pytest.raises(ValueError):
+        pdist.sharded_topk(index, grid, 30, comm=comm)                 # 25 candidates per shard < k
+    with pytest.raises(ValueError):
+        pdist.sharded_topk(index, grid, 5, comm=FakeComm(other, 1, 4))  # bound to another engine
+    del index.topk_engine
+    with pytest.raises(ValueError):
+        pdist.sharded_topk(index, grid, 5, comm=comm)                  # a host index has no device pairs
