@@ -117,7 +117,7 @@ static void harvest(gpx_handle* h) {
 }
 
 // ---- lifetime ---------------------------------------------------------------------------------
-extern "C" int gpx_version(void) { return 100; }
+extern "C" int gpx_version(void) { return 200; }
 
 extern "C" const char* gpx_last_error(const gpx_handle* h) {
     return h ? h->err.c_str() : g_create_err.c_str();

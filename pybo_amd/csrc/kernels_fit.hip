@@ -790,6 +790,56 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trtri_gemm2(const double* _
             }
 }
 
+// The same two products on 64x64 tiles (8 waves, gemm_tile_64_g) for the levels that do not fill the chip with
+// 128x128 tiles: there the makespan was ONE workgroup walking the longest K (hb = 16 at N = 8192: 512 tiles,
+// K up to 2048, 480 us for 18 GFLOP = 38 TFLOP/s against 67 at the last level).  Four times the workgroups, a
+// quarter of the MFMA work each, and the triangular structure of T11 / T22 is followed at 64-row granularity.
+__global__ __launch_bounds__(GEMM64_THREADS) void k_trtri_gemm1_64(const double* __restrict__ R,
+                                                                  const double* __restrict__ T,
+                                                                  double* __restrict__ W, int64_t Np, int nP,
+                                                                  int hb) {
+    const int g = blockIdx.z, bm = blockIdx.x, bn = blockIdx.y;        // 64-row / 64-column tile indices
+    const int r1 = g * 2 * hb, r2 = r1 + hb;
+    if (r2 >= nP) return;
+    const int size2 = min(hb, nP - r2);
+    if (bm >= 2 * size2) return;
+    __shared__ __attribute__((aligned(16))) double smem[GEMM64_LDS_F64];
+    const int64_t r1e = (int64_t)r1 * NB, r2e = (int64_t)r2 * NB;
+    const int64_t m0 = r2e + (int64_t)bm * T64, n0 = r1e + (int64_t)bn * T64;
+    d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}};
+    gemm_tile_64_g<false>(acc, R + r1e * Np + m0, Np, T + r1e * Np + n0, Np, bn * T64, hb * NB, smem);   // T11[k][n] = 0 for k < n
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) W[(m0 + acc_row64(i, r)) * Np + n0 + acc_col64()] = acc[i][r];
+}
+
+__global__ __launch_bounds__(GEMM64_THREADS) void k_trtri_gemm2_64(const double* __restrict__ W,
+                                                                  double* __restrict__ T,
+                                                                  double* __restrict__ U, int64_t Np, int nP,
+                                                                  int hb) {
+    const int g = blockIdx.z, bm = 2 * hb - 1 - (int)blockIdx.y, bn = blockIdx.x;   // heaviest (largest bm) first
+    const int r1 = g * 2 * hb, r2 = r1 + hb;
+    if (r2 >= nP) return;
+    const int size2 = min(hb, nP - r2);
+    if (bm >= 2 * size2) return;
+    __shared__ __attribute__((aligned(16))) double smem[GEMM64_LDS_F64];
+    const int64_t r1e = (int64_t)r1 * NB, r2e = (int64_t)r2 * NB;
+    const int64_t m0 = r2e + (int64_t)bm * T64, n0 = r1e + (int64_t)bn * T64;
+    d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}};
+    // A(m,k) = T_22(m,k) = U[r2e+k][m0+m], zero for k > m  ->  k in [0, (bm + 1) * 64)
+    gemm_tile_64_g<false>(acc, U + r2e * Np + m0, Np, W + r2e * Np + n0, Np, 0, (bm + 1) * T64, smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t gm = m0 + acc_row64(i, r), gn = n0 + acc_col64();
+            const double v = -acc[i][r];
+            T[gm * Np + gn] = v;
+            U[gn * Np + gm] = v;
+        }
+}
+
 void launch_trtri(gpx_handle* h) {
     const int64_t Np = h->Np;
     const int nP = (int)(Np / NB);
@@ -800,9 +850,15 @@ void launch_trtri(gpx_handle* h) {
     }
     for (int hb = 1; hb < nP; hb *= 2) {
         const int ngroups = (nP + 2 * hb - 1) / (2 * hb);
-        dim3 grid((unsigned)hb, (unsigned)hb, (unsigned)ngroups);
-        hipLaunchKernelGGL(k_trtri_gemm1, grid, dim3(GEMM_THREADS), 0, s, h->dR, h->dT, h->dS, Np, nP, hb);
-        hipLaunchKernelGGL(k_trtri_gemm2, grid, dim3(GEMM_THREADS), 0, s, h->dS, h->dT, h->dU, Np, nP, hb);
+        if ((int64_t)hb * hb * ngroups >= 1024) {         // enough 128x128 tiles to fill the chip twice over
+            dim3 grid((unsigned)hb, (unsigned)hb, (unsigned)ngroups);
+            hipLaunchKernelGGL(k_trtri_gemm1, grid, dim3(GEMM_THREADS), 0, s, h->dR, h->dT, h->dS, Np, nP, hb);
+            hipLaunchKernelGGL(k_trtri_gemm2, grid, dim3(GEMM_THREADS), 0, s, h->dS, h->dT, h->dU, Np, nP, hb);
+        } else {
+            dim3 grid((unsigned)(2 * hb), (unsigned)(2 * hb), (unsigned)ngroups);
+            hipLaunchKernelGGL(k_trtri_gemm1_64, grid, dim3(GEMM64_THREADS), 0, s, h->dR, h->dT, h->dS, Np, nP, hb);
+            hipLaunchKernelGGL(k_trtri_gemm2_64, grid, dim3(GEMM64_THREADS), 0, s, h->dS, h->dT, h->dU, Np, nP, hb);
+        }
     }
 }
 
