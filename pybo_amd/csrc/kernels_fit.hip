@@ -646,9 +646,10 @@ constexpr int CHOL_W = 4;   // outer panel width in 128-blocks
 
 // Two-level blocked right-looking factorisation with lookahead.  U(Q, P) = update of panel Q's block rows
 // with the factored rows of panel P (K = W*128); chain(Q) needs every U(Q, P < Q).
-//   chain(P)   rows P0..P1-1 one by one: row update (left-looking inside the panel) -> k_potrf_diag ->
-//              k_panel_trsm.  Serial and latency-bound (~100 us per 128-block), uses a handful of CUs.
-//   near(P)    U(P+1, P): on the main stream, chain(P+1) needs it.
+//   chain(P)   rows P0..P1-1 one by one: row update (left-looking inside the panel, 64x64 tiles) -> k_potrf16 ->
+//              k_panel_solve16.  Serial and latency-bound (~85-100 us per 128-block), uses a handful of CUs.
+//   near(P)    U(P+1, P), row by row on 64x64 tiles: its first block row on the main stream (the next diagonal
+//              block needs it), the other rows in one launch on a third stream while the chain works on that row.
 //   mid(P)     U(P+2, P): first thing on the side stream; near(P+1) touches the same rows and waits for it.
 //   rest(P)    U(Q >= P+3, P): the bulk, streams back-to-back on the (low-priority) side stream and only
 //              has to be finished before mid(P+1) -- which follows it in stream order anyway.
