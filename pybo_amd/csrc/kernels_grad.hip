@@ -17,7 +17,7 @@
 
 namespace gpx {
 
-constexpr int GB = 8;  // candidates per batch
+constexpr int GB = 16;  // candidates per pass over T and U (the 10 lock-step L-BFGS seeds of solve_lbfgs fit in one)
 
 __device__ __forceinline__ void kern_and_grad(int kid, double r2, double rho, double& k, double& g) {
     switch (kid) {
@@ -72,15 +72,18 @@ __global__ __launch_bounds__(256) void k_kstar(const double* __restrict__ Xs, in
 }
 
 // out[m][row] = sum_j Mx[row][j] * in[m][j], j in [0,row] (mode 0, lower) or [row,N) (mode 1, upper)
+// MBT: compile-time bucket (>= mb) so that a single right-hand side (gpx_append, one L-BFGS instance) does not pay
+// for the 16-wide register loop of a full batch
+template <int MBT>
 __global__ __launch_bounds__(256) void k_tri_matvec_multi(const double* __restrict__ Mx, int64_t Np, int64_t N,
                                                           const double* __restrict__ in, int mb, int mode,
                                                           double* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= Np) return;
-    double acc[GB];
+    double acc[MBT];
 #pragma unroll
-    for (int m = 0; m < GB; ++m) acc[m] = 0.0;
+    for (int m = 0; m < MBT; ++m) acc[m] = 0.0;
     if (row < N) {
         const int64_t lo = (mode == 0) ? 0 : row;
         const int64_t hi = (mode == 0) ? row + 1 : N;
@@ -88,17 +91,29 @@ __global__ __launch_bounds__(256) void k_tri_matvec_multi(const double* __restri
         for (int64_t j = lo + lane; j < hi; j += 64) {
             const double t = mr[j];
 #pragma unroll
-            for (int m = 0; m < GB; ++m)
+            for (int m = 0; m < MBT; ++m)
                 if (m < mb) acc[m] = fma(t, in[(int64_t)m * Np + j], acc[m]);
         }
     }
 #pragma unroll
-    for (int m = 0; m < GB; ++m) {
+    for (int m = 0; m < MBT; ++m) {
         double a = acc[m];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
         if (lane == 0 && m < mb) out[(int64_t)m * Np + row] = a;
     }
+}
+
+static void launch_tri_matvec_multi(hipStream_t s, unsigned rows4, const double* Mx, int64_t Np, int64_t N,
+                                    const double* in, int mb, int mode, double* out) {
+    if (mb <= 1)
+        hipLaunchKernelGGL(k_tri_matvec_multi<1>, dim3(rows4), dim3(256), 0, s, Mx, Np, N, in, mb, mode, out);
+    else if (mb <= 4)
+        hipLaunchKernelGGL(k_tri_matvec_multi<4>, dim3(rows4), dim3(256), 0, s, Mx, Np, N, in, mb, mode, out);
+    else if (mb <= 8)
+        hipLaunchKernelGGL(k_tri_matvec_multi<8>, dim3(rows4), dim3(256), 0, s, Mx, Np, N, in, mb, mode, out);
+    else
+        hipLaunchKernelGGL(k_tri_matvec_multi<GB>, dim3(rows4), dim3(256), 0, s, Mx, Np, N, in, mb, mode, out);
 }
 
 __device__ __forceinline__ double block_sum(double v, double* sh) {
@@ -193,8 +208,8 @@ int predict_grad_host(gpx_handle* h, const double* Xc, int64_t M, double* mu, do
         }
         hipLaunchKernelGGL(k_kstar, dim3((unsigned)((Np + 255) / 256), (unsigned)mb), dim3(256), 0, s, h->dXs,
                            N, Np, d, dX, h->dinvell, h->kernel_id, h->rho, dks, dg);
-        hipLaunchKernelGGL(k_tri_matvec_multi, dim3(rows4), dim3(256), 0, s, h->dT, Np, N, dks, mb, 0, dV);
-        hipLaunchKernelGGL(k_tri_matvec_multi, dim3(rows4), dim3(256), 0, s, h->dU, Np, N, dV, mb, 1, dw);
+        launch_tri_matvec_multi(s, rows4, h->dT, Np, N, dks, mb, 0, dV);
+        launch_tri_matvec_multi(s, rows4, h->dU, Np, N, dV, mb, 1, dw);
         hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)(d + 1), (unsigned)mb), dim3(256), 0, s, h->dXs, N, Np,
                            d, dX, h->dinvell, dg, dV, dw, h->da, h->dalpha, h->rho, h->bias, dout);
         if (hipMemcpyAsync(host.data(), dout, (size_t)mb * per * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -382,10 +397,10 @@ int append_host(gpx_handle* h, const double* x, double ynew) {
     const unsigned rows4 = (unsigned)((Np + 3) / 4);
     hipLaunchKernelGGL(k_kstar, dim3((unsigned)((Np + 255) / 256), 1), dim3(256), 0, s, h->dXs, N, Np, d, dx,
                        h->dinvell, h->kernel_id, h->rho, dks, dg);
-    hipLaunchKernelGGL(k_tri_matvec_multi, dim3(rows4), dim3(256), 0, s, h->dT, Np, N, dks, 1, 0, dr);
+    launch_tri_matvec_multi(s, rows4, h->dT, Np, N, dks, 1, 0, dr);
     hipLaunchKernelGGL(k_append_dots, dim3(1), dim3(256), 0, s, dr, h->da, N, h->rho + h->sn2, ynew - h->bias,
                        h->dscal, h->dflag);
-    hipLaunchKernelGGL(k_tri_matvec_multi, dim3(rows4), dim3(256), 0, s, h->dU, Np, N, dr, 1, 1, dtu);
+    launch_tri_matvec_multi(s, rows4, h->dU, Np, N, dr, 1, 1, dtu);
     hipLaunchKernelGGL(k_append_scatter, dim3((unsigned)((N + 1 + 255) / 256)), dim3(256), 0, s, h->dR, h->dT,
                        h->dU, Np, N, dr, dtu, h->dscal, h->da, h->dalpha, h->dy, ynew, h->dXs, h->dXraw, d, dx,
                        h->dinvell, h->dflag);
