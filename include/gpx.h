@@ -99,7 +99,8 @@ int gpx_loglik_batch(gpx_handle *h, int64_t B, const double *hypers, double *out
 /* Incremental fit: absorb ONE more observation x (d,), y into the current factorisation in O(N^2)
  * (two memory-bound passes over T and U) instead of refitting -- the per-iteration
  * `model.add_data(x, y)` of the BO loop [pybo/bayesopt.py:269].  When the current 128-block has no padding
- * left the factors are re-strided into buffers one block larger (a device copy, no refit).  GPX_ENOTPD like
+ * left the factors are re-strided to one more block inside buffers allocated with head-room (a device copy, no
+ * refit; a reallocation only when the head-room is used up).  GPX_ENOTPD like
  * gpx_fit.  If a sweep cache is live (below) its per-candidate sums are corrected for the new observation in
  * the same call (one N*M pass). */
 int gpx_append(gpx_handle *h, const double *x, double y);

@@ -287,7 +287,9 @@ static int check_fit_args(gpx_handle* h, const void* X, int64_t N, int64_t d, co
 
 static int alloc_model(gpx_handle* h, int64_t Np, int64_t d) {
     if (Np > h->cap_np || d > h->cap_d) {
-        Np = std::max(Np, h->cap_np);
+        // head-room of at least one block (1/16 of the size beyond that): gpx_append can then grow the factor across
+        // a 128-block boundary by re-striding inside the existing buffers, without an allocation
+        Np = std::max(Np + std::max<int64_t>(NB, Np / 16 / NB * NB), h->cap_np);
         d = std::max(d, h->cap_d);
         double** mats[] = {&h->dS, &h->dR, &h->dT, &h->dU};
         for (auto m : mats) {

@@ -320,10 +320,34 @@ __global__ void k_identity_tail(double* __restrict__ R, double* __restrict__ T, 
 static int grow_block(gpx_handle* h) {
     const int64_t Np = h->Np, Nn = Np + NB;
     hipStream_t s = h->stream;
+    if (Nn <= h->cap_np) {
+        // The buffers were allocated with head-room (alloc_model): only the leading dimension changes.  The three
+        // factors are re-strided OUT OF PLACE by rotating through the workspace -- R -> S's buffer, T -> R's old
+        // one, U -> T's old one, U's old buffer becomes the workspace -- all in stream order, no allocation and no
+        // host synchronisation (a fresh allocation of 4 x 0.55 GB was measured at up to 60 ms on this path).
+        double* buf[4] = {h->dS, h->dR, h->dT, h->dU};          // destination i receives source i + 1
+        bool ok = true;
+        for (int i = 0; i < 3 && ok; ++i) {
+            ok = hipMemsetAsync(buf[i], 0, (size_t)Nn * Nn * 8, s) == hipSuccess &&
+                 hipMemcpy2DAsync(buf[i], (size_t)Nn * 8, buf[i + 1], (size_t)Np * 8, (size_t)Np * 8, (size_t)Np,
+                                  hipMemcpyDeviceToDevice, s) == hipSuccess;
+        }
+        // padding of the new block: zero rows of the scaled inputs and of y / a / alpha (they sit past the old Np)
+        ok = ok && hipMemsetAsync(h->dXs + Np * h->d, 0, (size_t)NB * h->d * 8, s) == hipSuccess &&
+             hipMemsetAsync(h->dy + Np, 0, (size_t)NB * 8, s) == hipSuccess &&
+             hipMemsetAsync(h->da + Np, 0, (size_t)NB * 8, s) == hipSuccess &&
+             hipMemsetAsync(h->dalpha + Np, 0, (size_t)NB * 8, s) == hipSuccess;
+        if (!ok) { h->err = "append: growing the factor failed"; return GPX_EHIP; }
+        hipLaunchKernelGGL(k_identity_tail, dim3(1), dim3(NB), 0, s, buf[0], buf[1], buf[2], Nn, Np, Nn);
+        h->dR = buf[0]; h->dT = buf[1]; h->dU = buf[2]; h->dS = buf[3];
+        h->Np = Nn;
+        return GPX_OK;
+    }
+    const int64_t cap = Nn + std::max<int64_t>(NB, Nn / 16 / NB * NB);      // head-room for the next growths
     double* nm[4] = {nullptr, nullptr, nullptr, nullptr};     // S (workspace), R, T, U
     double* nv[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // y, a, alpha, Xs, Xraw
-    const size_t vbytes[5] = {(size_t)Nn * 8, (size_t)Nn * 8, (size_t)Nn * 8, (size_t)Nn * h->cap_d * 8,
-                              (size_t)Nn * h->cap_d * 8};
+    const size_t vbytes[5] = {(size_t)cap * 8, (size_t)cap * 8, (size_t)cap * 8, (size_t)cap * h->cap_d * 8,
+                              (size_t)cap * h->cap_d * 8};
     auto bail = [&](const char* msg, int code) {
         for (double* p : nm) if (p) hipFree(p);
         for (double* p : nv) if (p) hipFree(p);
@@ -331,7 +355,7 @@ static int grow_block(gpx_handle* h) {
         return code;
     };
     for (int i = 0; i < 4; ++i) {
-        if (hipMalloc((void**)&nm[i], (size_t)Nn * Nn * 8) != hipSuccess) return bail("append: device allocation failed", GPX_EOOM);
+        if (hipMalloc((void**)&nm[i], (size_t)cap * cap * 8) != hipSuccess) return bail("append: device allocation failed", GPX_EOOM);
         if (hipMemsetAsync(nm[i], 0, (size_t)Nn * Nn * 8, s) != hipSuccess) return bail("append: memset failed", GPX_EHIP);
     }
     for (int i = 0; i < 5; ++i) {
@@ -356,7 +380,7 @@ static int grow_block(gpx_handle* h) {
     h->dS = nm[0]; h->dR = nm[1]; h->dT = nm[2]; h->dU = nm[3];
     h->dy = nv[0]; h->da = nv[1]; h->dalpha = nv[2]; h->dXs = nv[3]; h->dXraw = nv[4];
     h->Np = Nn;
-    h->cap_np = Nn;
+    h->cap_np = cap;
     return GPX_OK;
 }
 
