@@ -160,6 +160,9 @@ def main():
                     help='dry run: every rank uses this one GPU (with --backend gloo)')
     ap.add_argument('--opt', action='append', default=[], metavar='NAME=VALUE',
                     help='engine option (gpx_set_option), e.g. --opt potrf=0; repeatable')
+    ap.add_argument('--warm-batch', type=int, default=1,
+                    help='observations appended per warm step (q of a batch-BO add_data(X, Y)); their cache '
+                         'corrections share one pass over the candidates')
     ap.add_argument('--warm-steps', type=int, default=8,
                     help='also time this many WARM iterations (append one observation + re-score the cached '
                          'sweep sums); reported separately as warm_step, never as value; 0 = skip')
@@ -297,14 +300,16 @@ def main():
         step()                                          # one cold step fills the cache (untimed)
         eng.set_option('sweep_cache', 0)
         rngw = np.random.RandomState(7)
-        Xn = w['lo'] + (w['hi'] - w['lo']) * rngw.rand(args.warm_steps, d)
-        yn = w['f'](Xn) + 1e-3 * rngw.randn(args.warm_steps)
+        wq = max(1, args.warm_batch)
+        Xn = w['lo'] + (w['hi'] - w['lo']) * rngw.rand(args.warm_steps * wq, d)
+        yn = w['f'](Xn) + 1e-3 * rngw.randn(args.warm_steps * wq)
         eng.timers(reset=True)
         fence()
         t0 = time.perf_counter()
         for i in range(args.warm_steps):
-            eng.append(Xn[i], yn[i])
-            param = eng.mean_at_obs()[1] if w['acq'] == 'ei' else ucb_beta(N + i + 1)
+            for j in range(i * wq, (i + 1) * wq):
+                eng.append(Xn[j], yn[j])
+            param = eng.mean_at_obs()[1] if w['acq'] == 'ei' else ucb_beta(N + (i + 1) * wq)
             r = eng.sweep_update(w['acq'], param, k=k, want_all=False)
             tv, ti = r['top_val'], np.where(r['top_idx'] >= 0, r['top_idx'] + lo_i, r['top_idx'])
             if world > 1:
@@ -322,7 +327,8 @@ def main():
         warm = {'ms_per_step': wsec * 1e3, 'value': 1.0 / wsec, 'unit': 'steps/s', 'steps': args.warm_steps,
                 'what': 'gpx_append (rank-1 extension of the factor + rank-1 correction of the cached sweep sums) '
                         '+ EI target / UCB beta + gpx_sweep_update over the same candidates; hyper-parameters '
-                        'fixed, N grows by one per step from %d' % N,
+                        'fixed, N grows by %d per step from %d' % (wq, N),
+                'appends_per_step': wq,
                 'stage_ms_per_step_rank0': {kk: tw[kk] / args.warm_steps for kk in ('append', 'rank1', 'acq_topk')},
                 'selected': {'index': int(wbest[1][0]), 'value': float(wbest[0][0])},
                 'speedup_vs_cold_step': (elapsed / args.steps) / wsec}
@@ -427,9 +433,10 @@ def main():
         if refine is not None:
             out['refine'] = refine
         if warm is not None:
-            # algorithmic work of the rank-1 correction: N covariance evaluations per candidate per appended
-            # point; the kernel is fp64-VALU-issue bound like the cross-Gram
-            warm['rank1_cov_evals_per_s'] = float(N) * Ml / (warm['stage_ms_per_step_rank0']['rank1'] * 1e-3) \
+            # work of the cache correction: N covariance evaluations per candidate per PASS (up to 8 appended
+            # points share a pass); the kernel is fp64-VALU-issue bound like the cross-Gram
+            passes = -(-warm['appends_per_step'] // 8)
+            warm['rank1_cov_evals_per_s'] = float(N) * Ml * passes / (warm['stage_ms_per_step_rank0']['rank1'] * 1e-3) \
                 if warm['stage_ms_per_step_rank0']['rank1'] > 0 else None
             out['warm_step'] = warm
         if 'roofline' not in out and 'cholesky' in fit:      # no sweep GEMM in this workload (Thompson)

@@ -144,9 +144,11 @@ int gpx_sweep_dev(gpx_handle *h, int acq_id, const double *params, int nparams, 
  *      [pybo/bayesopt.py:262-269 with a fixed `xgrid=` in pybo/solvers/lbfgs.py:42-50].  The reference pays a
  *      full refit and a full solve again; here, with option "sweep_cache" = 1, a full gpx_sweep* keeps the
  *      candidates and their reduced sums q = colsum(V^2), p = V^T a in HBM (8 (d + 2) M bytes), every
- *      gpx_append adds the one new row of V to them (N*M covariance evaluations), and gpx_sweep_update
- *      re-scores the whole grid in O(M): mu = bias + p, s2 = rho - q, acquisition (the target / beta may
- *      change from call to call), top-k.  Outputs as in gpx_sweep / gpx_sweep_dev.  GPX_ESTATE without a valid
+ *      gpx_append adds the one new row of V to them (N*M covariance evaluations; the corrections of up to 8
+ *      appended points -- one batch-BO add_data(X, Y) -- are queued and share one pass over the candidates,
+ *      made when the queue is full or by the next gpx_sweep_update), and gpx_sweep_update re-scores the whole
+ *      grid in O(M): mu = bias + p, s2 = rho - q, acquisition (the target / beta may change from call to
+ *      call), top-k.  Outputs as in gpx_sweep / gpx_sweep_dev.  GPX_ESTATE without a valid
  *      cache (never swept, or refitted since: gpx_fit* invalidates it). */
 int gpx_sweep_update(gpx_handle *h, int acq_id, const double *params, int nparams, int64_t k, double *top_val,
                      int64_t *top_idx, double *acq_all, double *mu, double *s2);
@@ -239,7 +241,7 @@ int gpx_topk_allgather(gpx_comm *c, int64_t n, int64_t index_offset, int64_t k, 
 /* Stage timers in milliseconds accumulated since the last reset (HIP events on the handle's
  * stream): [0] gram [1] cholesky [2] trtri [3] alpha [4] cross_gram [5] sweep_trmm [6] acq_topk
  * [7] rff [8] number of sweep_trmm launches [9] sweep_trmm algorithmic flop [10] h2d/d2h copies
- * [11] append (rank-1 extension of the fit) [12] rank-1 correction of the sweep cache.
+ * [11] append (rank-1 extension of the fit) [12] correction passes over the sweep cache.
  * Synchronises the stream.  Returns the number of slots written (<= n). */
 int gpx_timers(gpx_handle *h, double *out, int n, int reset);
 int gpx_sync(gpx_handle *h);

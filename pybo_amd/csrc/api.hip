@@ -194,7 +194,7 @@ extern "C" int gpx_destroy(gpx_handle* h) {
     for (auto e : h->pool) hipEventDestroy(e);
     void* ptrs[] = {h->dXs, h->dXraw, h->dy, h->dS, h->dR, h->dT, h->dU, h->da, h->dalpha, h->dinvell,
                     h->dflag, h->dscal, h->dKs, h->dQp, h->dXc, h->dout, h->dblkv, h->dblki,
-                    h->dtopv, h->drff, h->drffs, h->dgrad, h->dens, h->dcZ, h->dcq, h->dbatch};  // dPp, dtopi, dcp alias dQp, dtopv, dcq
+                    h->dtopv, h->drff, h->drffs, h->dgrad, h->dens, h->dcZ, h->dcq, h->dbatch, h->dpend};  // dPp, dtopi, dcp alias dQp, dtopv, dcq
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
@@ -231,7 +231,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
         if (!strcmp(name, "sweep_cache")) {
             if (value < -1 || value > 1) return fail(h, GPX_EARG, "sweep_cache must be 1, 0 or -1");
             h->cache_on = (value == 1);
-            if (value < 0) h->cache_valid = false;
+            if (value < 0) { h->cache_valid = false; h->npend = 0; }
             return GPX_OK;
         }
         if (!strcmp(name, "chol_w")) {
@@ -351,6 +351,7 @@ static int fit_core(gpx_handle* h, const double* dX, int64_t N, int64_t d, const
     h->fail_pivot = -1;
     h->last_topn = 0;
     h->cache_valid = false;      // new data / hyper-parameters: the cached sums describe another posterior
+    h->npend = 0;
     int rc = alloc_model(h, Np, d);
     if (rc) return rc;
     h->N = N; h->Np = Np; h->d = d; h->kernel_id = kid;
@@ -440,6 +441,21 @@ extern "C" int gpx_loglik(gpx_handle* h, double* out) {
     });
 }
 
+// Apply the cache corrections of the observations appended since the last flush: ONE pass over the candidates
+// (kernels_sweep.hip: k_sweep_rankq).
+static int flush_pending(gpx_handle* h) {
+    if (h->npend == 0) return GPX_OK;
+    if (h->cache_valid) {
+        Span sp(h, T_RANK1);
+        launch_sweep_rankq(h->stream, h->dXs, h->N, (int)h->d, h->dpend, h->pend_ld, h->npend,
+                           h->dpend + (int64_t)PEND_MAX * h->pend_ld, h->dcZ, h->cache_M, h->dinvell, h->kernel_id,
+                           h->rho, h->dcq, h->dcp);
+        HIPCHK(h, hipGetLastError());
+    }
+    h->npend = 0;
+    return GPX_OK;
+}
+
 extern "C" int gpx_loglik_batch(gpx_handle* h, int64_t B, const double* hypers, double* out) {
     return guarded(h, [&]() -> int {
         if (!h) return GPX_EARG;
@@ -457,16 +473,31 @@ extern "C" int gpx_append(gpx_handle* h, const double* x, double y) {
             rc = gpx::append_host(h, x, y);
         }
         if (rc != GPX_OK) {
-            if (rc != GPX_EARG && rc != GPX_ESTATE) h->cache_valid = false;
+            if (rc != GPX_EARG && rc != GPX_ESTATE) { h->cache_valid = false; h->npend = 0; }
             return rc;
         }
         if (h->cache_valid) {
-            // keep the cached per-candidate sums current: one N*M pass instead of the next N^2*M sweep.
-            // (scal / flag / w / the new scaled row are the device-side results of the append just done)
-            Span sp(h, T_RANK1);
-            launch_sweep_rank1(h->stream, h->dXs, Nold, (int)h->d, h->app_w, h->dXs + Nold * h->d, h->dcZ,
-                               h->cache_M, h->dinvell, h->kernel_id, h->rho, h->dscal, h->dflag, h->dcq, h->dcp);
+            // keep the cached per-candidate sums current: the correction for this observation (one N*M pass
+            // instead of the next N^2*M sweep) is queued and applied together with up to PEND_MAX - 1 others --
+            // at the next gpx_sweep_update, or here when the queue is full.  (scal / w are the device-side
+            // results of the append just done.)
+            if (h->npend > 0 && h->N > h->pend_ld) {             // the factor outgrew the rows: apply what is queued
+                h->N = Nold;                                     // (the queued rows know nothing of the new point)
+                const int rc2 = flush_pending(h);
+                h->N = Nold + 1;
+                if (rc2) return rc2;
+            }
+            if (h->npend == 0 && h->cap_np > h->pend_ld) {
+                if (h->dpend) HIPCHK(h, hipFree(h->dpend));
+                h->dpend = nullptr;
+                h->pend_ld = 0;
+                HIPCHK(h, hipMalloc((void**)&h->dpend, (size_t)PEND_MAX * (h->cap_np + 2) * 8));
+                h->pend_ld = h->cap_np;
+            }
+            launch_pend_store(h->stream, h->app_w, Nold, h->pend_ld, h->dscal, h->dpend + (int64_t)h->npend * h->pend_ld,
+                              h->dpend + (int64_t)PEND_MAX * h->pend_ld + 2 * h->npend);
             HIPCHK(h, hipGetLastError());
+            if (++h->npend == PEND_MAX) return flush_pending(h);
         }
         return GPX_OK;
     });
@@ -601,6 +632,7 @@ static int sweep_core(gpx_handle* h, int acq_id, const double* params, int npara
     double* cp = nullptr;
     if (h->cache_on) {
         h->cache_valid = false;
+        h->npend = 0;
         if ((rc = ensure(h, h->dcZ, h->cap_cz, M * h->d))) return rc;
         if ((rc = ensure(h, h->dcq, h->cap_cq, 2 * M))) return rc;
         h->dcp = h->dcq + h->cap_cq / 2;
@@ -701,6 +733,7 @@ static int sweep_update_core(gpx_handle* h, int acq_id, const double* params, in
     HIPCHK(h, hipSetDevice(h->device));
     const int64_t M = h->cache_M;
     int rc;
+    if ((rc = flush_pending(h))) return rc;
     if (!d_acq) {
         if ((rc = ensure(h, h->dout, h->cap_out, M))) return rc;
         d_acq = h->dout;

@@ -14,6 +14,7 @@ constexpr int TBH = 128;      // host-side copy of the GEMM tile edge (gemm_core
 constexpr int DMAX = 1024;    // max input dimension (buffer sizing only: the kernels walk coordinates 16 at a time)
 constexpr int DMAX_RFF = 64;  // max input dimension of the Thompson / RFF kernels (their feature tiles [d][144] live in LDS)
 constexpr int TOPK_MAX = 64;  // max k of the device top-k
+constexpr int PEND_MAX = 8;   // appended observations per pass of the sweep-cache correction
 
 enum Timer {
     T_GRAM = 0, T_CHOL, T_TRTRI, T_ALPHA, T_XGRAM, T_TRMM, T_ACQ, T_RFF, T_NLAUNCH, T_FLOP, T_COPY, T_APPEND,
@@ -103,6 +104,10 @@ struct gpx_handle {
     double* dcq = nullptr;       // (M,) q, then p (one allocation: dcp = dcq + cap_cq / 2)
     double* dcp = nullptr;
     int64_t cap_cz = 0, cap_cq = 0;
+    // appended observations whose cache correction is still due (applied together, at most PEND_MAX per pass)
+    double* dpend = nullptr;     // [PEND_MAX][pend_ld] weight rows, then [PEND_MAX][2] {1/d, a_new}
+    int64_t pend_ld = 0;
+    int npend = 0;
 
     double* dbatch = nullptr;    // gpx_loglik_batch: Gram / factor / scaled inputs / a of the batch (one allocation)
     int64_t cap_batch = 0;
@@ -137,10 +142,12 @@ void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double*
 void launch_acq(hipStream_t s, const double* Qp, const double* Pp, int64_t ldp, int nrb, int64_t m0,
                 int64_t cols_valid, double rho, double bias, int acq_id, double p0, double* acq_out,
                 double* mu_out, double* s2_out, double* qsum, double* psum);
-// rank-1 correction of the cached sums after one appended observation (see kernels_sweep.hip)
-void launch_sweep_rank1(hipStream_t s, const double* Xs, int64_t N, int d, const double* w, const double* xnew_s,
-                        const double* Z, int64_t M, const double* invell, int kernel_id, double rho,
-                        const double* scal, const int* flag, double* qsum, double* psum);
+// correction of the cached sums after q <= 8 appended observations in one pass (see kernels_sweep.hip)
+void launch_pend_store(hipStream_t s, const double* w, int64_t Nj, int64_t ldw, const double* scal, double* row,
+                       double* pscal_j);
+void launch_sweep_rankq(hipStream_t s, const double* Xs, int64_t Ntot, int d, const double* Wq, int64_t ldw, int q,
+                        const double* pscal, const double* Z, int64_t M, const double* invell, int kernel_id,
+                        double rho, double* qsum, double* psum);
 // block-local top-k over vals[0..M) then merge -> topv/topi (k entries)
 void launch_topk(hipStream_t s, const double* vals, int64_t M, int k, double* blkv, int64_t* blki,
                  int64_t nblk, double* topv, int64_t* topi);

@@ -313,34 +313,39 @@ void launch_acq(hipStream_t s, const double* Qp, const double* Pp, int64_t ldp, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Warm BO step: rank-1 correction of the cached per-candidate sums after ONE appended observation.
-// With w = K^-1 k(X, x_new), d = posterior std of the new observation (incl. noise), a_new the new entry of a:
-//     v_n = ( k(x_new, z_n) - sum_{i<N} w_i k(x_i, z_n) ) / d        (the new row of V = T K*)
-//     q_n += v_n^2          p_n += v_n a_new
-// i.e. ONE pass of N*M covariance evaluations with a fused row-dot instead of the N^2 M triangular product --
+// Warm BO step: correction of the cached per-candidate sums after q appended observations (q <= Q).
+// With w_j = K_j^-1 k(X_j, x_j) (K_j, X_j: the model just before point j was appended), d_j the posterior std of
+// observation j (incl. noise) and a_j the new entry of a:
+//     v_jn = ( k(x_j, z_n) - sum_{i < N_j} w_ji k(x_i, z_n) ) / d_j        (the new row j of V = T K*)
+//     q_n += sum_j v_jn^2          p_n += sum_j v_jn a_j
+// i.e. ONE pass of N*M covariance evaluations with q fused row-dots instead of the N^2 M triangular product --
 // what `model.add_data(x, y)` + the next `index(xgrid)` cost in the reference is a full refit and a full solve
-// (pybo/bayesopt.py:269, pybo/solvers/lbfgs.py:50).
-// One workgroup owns 128 candidates and walks all N observed rows in tiles of 64 (fixed order: results do not
+// (pybo/bayesopt.py:269, pybo/solvers/lbfgs.py:50).  The q points of one `add_data(X, Y)` call share the pass:
+// the covariance evaluations dominate (46 fp64 instructions each against one FMA per extra point).
+// Wq (q, ldw): row j = [w_j (N_j entries), -1 at position N_j (the point's own row of Xs), zeros], so that
+// v_jn = - (Wq_j . k(X_all, z_n)) / d_j with one dot over all Ntot = N_0 + q rows.  pscal (q, 2) = {1/d_j, a_j}.
+// One workgroup owns 128 candidates and walks all observed rows in tiles of 64 (fixed order: results do not
 // depend on the launch geometry); thread (ty, tx) accumulates rows ty*8..+7 of each tile for candidates
 // tx*4..+3, the 8 row groups are combined through LDS at the end.
-// scal: [0] d  [1] 1/d  [2] a_new   (written by k_append_dots);  flag != 0: the append failed, do nothing.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_sweep_rank1(const double* __restrict__ Xs, int64_t N, int d,
-                                                     const double* __restrict__ w,
-                                                     const double* __restrict__ xnew_s,
+template <int Q>
+__global__ __launch_bounds__(256) void k_sweep_rankq(const double* __restrict__ Xs, int64_t Ntot, int d,
+                                                     const double* __restrict__ Wq, int64_t ldw, int q,
+                                                     const double* __restrict__ pscal,
                                                      const double* __restrict__ Z, int64_t M,
                                                      const double* __restrict__ invell, int kid, double rho,
-                                                     const double* __restrict__ scal,
-                                                     const int* __restrict__ flag, double* __restrict__ qsum,
-                                                     double* __restrict__ psum) {
-    if (*flag != 0) return;
+                                                     double* __restrict__ qsum, double* __restrict__ psum) {
     __shared__ double xo[XDC][XK];
     __shared__ double xc[XDC][XN];
-    __shared__ double wv[XK];
+    __shared__ double wv[Q][XK];
     __shared__ double red[8][XN];
     const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
     const int64_t n0 = (int64_t)blockIdx.x * XN;
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    double acc[Q][4];
+#pragma unroll
+    for (int j = 0; j < Q; ++j)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[j][b] = 0.0;
     const bool onepass = (d <= XDC);          // candidates' coordinates stay in LDS across row tiles
     if (onepass) {
         for (int e = t; e < XN * d; e += 256) {
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(256) void k_sweep_rank1(const double* __restrict__ 
             xc[k][row] = (gm < M) ? Z[gm * d + k] * invell[k] : 0.0;
         }
     }
-    for (int64_t k0 = 0; k0 < N; k0 += XK) {
+    for (int64_t k0 = 0; k0 < Ntot; k0 += XK) {
         double r2[8][4];
 #pragma unroll
         for (int a = 0; a < 8; ++a)
@@ -360,9 +365,14 @@ __global__ __launch_bounds__(256) void k_sweep_rank1(const double* __restrict__ 
             __syncthreads();
             for (int e = t; e < XK * kc; e += 256) {
                 const int row = e / kc, k = e - row * kc;
-                xo[k][row] = (k0 + row < N) ? Xs[(k0 + row) * d + c0 + k] : 0.0;
+                xo[k][row] = (k0 + row < Ntot) ? Xs[(k0 + row) * d + c0 + k] : 0.0;
             }
-            if (c0 == 0 && t < XK) wv[t] = (k0 + t < N) ? w[k0 + t] : 0.0;
+            if (c0 == 0) {
+                for (int e = t; e < Q * XK; e += 256) {
+                    const int j = e / XK, row = e - j * XK;
+                    wv[j][row] = (j < q && k0 + row < Ntot) ? Wq[(int64_t)j * ldw + k0 + row] : 0.0;
+                }
+            }
             if (!onepass) {
                 for (int e = t; e < XN * kc; e += 256) {
                     const int row = e / kc, k = e - row * kc;
@@ -388,37 +398,72 @@ __global__ __launch_bounds__(256) void k_sweep_rank1(const double* __restrict__ 
         }
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
-            const double wa = wv[ty * 8 + a];       // 0 beyond N: padded rows contribute nothing
+            double kv[4];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[b] = fma(wa, kern_eval(kid, r2[a][b], rho), acc[b]);
+            for (int b = 0; b < 4; ++b) kv[b] = kern_eval(kid, r2[a][b], rho);
+#pragma unroll
+            for (int j = 0; j < Q; ++j) {
+                const double wa = wv[j][ty * 8 + a];      // 0 beyond a point's own row: contributes nothing
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[j][b] = fma(wa, kv[b], acc[j][b]);
+            }
         }
     }
+    double dq = 0.0, dp = 0.0;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) red[ty][tx * 4 + b] = acc[b];
-    __syncthreads();
-    if (t < XN) {
-        const int64_t gm = n0 + t;
-        if (gm < M) {
+    for (int j = 0; j < Q; ++j) {
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 4; ++b) red[ty][tx * 4 + b] = acc[j][b];
+        __syncthreads();
+        if (t < XN && j < q) {
             double dot = 0.0;
 #pragma unroll
             for (int g = 0; g < 8; ++g) dot += red[g][t];
-            double r2n = 0.0;
-            for (int k = 0; k < d; ++k) {
-                const double df = xnew_s[k] - Z[gm * d + k] * invell[k];
-                r2n = fma(df, df, r2n);
-            }
-            const double v = (kern_eval(kid, r2n, rho) - dot) * scal[1];
-            qsum[gm] = fma(v, v, qsum[gm]);
-            psum[gm] = fma(v, scal[2], psum[gm]);
+            const double v = -dot * pscal[2 * j];
+            dq = fma(v, v, dq);
+            dp = fma(v, pscal[2 * j + 1], dp);
+        }
+    }
+    if (t < XN) {
+        const int64_t gm = n0 + t;
+        if (gm < M) {
+            qsum[gm] += dq;
+            psum[gm] += dp;
         }
     }
 }
 
-void launch_sweep_rank1(hipStream_t s, const double* Xs, int64_t N, int d, const double* w, const double* xnew_s,
-                        const double* Z, int64_t M, const double* invell, int kernel_id, double rho,
-                        const double* scal, const int* flag, double* qsum, double* psum) {
-    hipLaunchKernelGGL(k_sweep_rank1, dim3((unsigned)((M + XN - 1) / XN)), dim3(256), 0, s, Xs, N, d, w, xnew_s, Z,
-                       M, invell, kernel_id, rho, scal, flag, qsum, psum);
+// row j of the pending-correction table: [w (Nj entries), -1, zeros up to ldw]; pscal_j = {1/d, a_new}
+__global__ void k_pend_store(const double* __restrict__ w, int64_t Nj, int64_t ldw, const double* __restrict__ scal,
+                             double* __restrict__ row, double* __restrict__ pscal_j) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ldw) row[i] = (i < Nj) ? w[i] : ((i == Nj) ? -1.0 : 0.0);
+    if (i == 0) {
+        pscal_j[0] = scal[1];
+        pscal_j[1] = scal[2];
+    }
+}
+
+void launch_pend_store(hipStream_t s, const double* w, int64_t Nj, int64_t ldw, const double* scal, double* row,
+                       double* pscal_j) {
+    hipLaunchKernelGGL(k_pend_store, dim3((unsigned)((ldw + 255) / 256)), dim3(256), 0, s, w, Nj, ldw, scal, row,
+                       pscal_j);
+}
+
+void launch_sweep_rankq(hipStream_t s, const double* Xs, int64_t Ntot, int d, const double* Wq, int64_t ldw, int q,
+                        const double* pscal, const double* Z, int64_t M, const double* invell, int kernel_id,
+                        double rho, double* qsum, double* psum) {
+    const dim3 grid((unsigned)((M + XN - 1) / XN));
+    if (q == 1)
+        hipLaunchKernelGGL(k_sweep_rankq<1>, grid, dim3(256), 0, s, Xs, Ntot, d, Wq, ldw, q, pscal, Z, M, invell,
+                           kernel_id, rho, qsum, psum);
+    else if (q <= 4)
+        hipLaunchKernelGGL(k_sweep_rankq<4>, grid, dim3(256), 0, s, Xs, Ntot, d, Wq, ldw, q, pscal, Z, M, invell,
+                           kernel_id, rho, qsum, psum);
+    else
+        hipLaunchKernelGGL(k_sweep_rankq<8>, grid, dim3(256), 0, s, Xs, Ntot, d, Wq, ldw, q, pscal, Z, M, invell,
+                           kernel_id, rho, qsum, psum);
 }
 
 // ------------------------------------------------------------------------------------------------
