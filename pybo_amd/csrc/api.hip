@@ -239,6 +239,11 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             h->chol_w = (int)value;
             return GPX_OK;
         }
+        if (!strcmp(name, "x_skip")) {       // diagnostic only: see launch_cholesky
+            if (value < 0 || value > 7) return fail(h, GPX_EARG, "x_skip: bits 0..2");
+            h->x_skip = (int)value;
+            return GPX_OK;
+        }
         if (!strcmp(name, "eager_inverse")) {
             if (value != 0 && value != 1) return fail(h, GPX_EARG, "eager_inverse must be 0 or 1");
             h->eager_inverse = (value != 0);

@@ -663,6 +663,9 @@ void launch_cholesky(gpx_handle* h) {
     // (throughput-bound sizes), narrower ones keep the in-panel row updates short (chain-bound sizes); measured at
     // N = 8192 / 16384 (final kernels): W = 3: 6.59 / 30.8 ms, 4: 6.68 / 30.4, 5: 6.74 / 29.7, 6: 7.00 / 30.1
     const int CW = h->chol_w ? h->chol_w : (nP >= 96 ? 5 : CHOL_W);
+    // diagnostic (option "x_skip", scripts/chol_parts.py): leave out the far updates (bit 0), the chain kernels
+    // (bit 1) or the near updates (bit 2) to time the parts alone -- the results are then NOT a factorisation
+    const bool far = !(h->x_skip & 1), chain = !(h->x_skip & 2), near = !(h->x_skip & 4);
     bool mid_pending = false, side_used = false;
     int near_rows = 0;            // rows P0+1.. of the CURRENT panel whose near update runs on the third stream
     for (int P0 = 0; P0 < nP; P0 += CW) {
@@ -670,13 +673,14 @@ void launch_cholesky(gpx_handle* h) {
         for (int I = P0; I < P1; ++I) {
             if (I == P0 + 1 && near_rows > 0)      // rows P0+1.. got the previous panel's update on stream 3
                 hipStreamWaitEvent(s, h->ev_row[0], 0);
-            if (I > P0)   // block row I <- contributions of rows P0..I-1 of this panel
+            if (I > P0 && chain)   // block row I <- contributions of rows P0..I-1 of this panel
                 hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - I)), 2), dim3(GEMM64_THREADS), 0, s,
                                    h->dR, h->dS, Np, P0, I, I, (int64_t)0, nP, 3);
-            hipLaunchKernelGGL(k_potrf16<false>, dim3(1), dim3(256), 0, s, h->dS, h->dR, h->dT, h->dU, Np, I, h->dflag,
+            if (chain)
+                hipLaunchKernelGGL(k_potrf16<false>, dim3(1), dim3(256), 0, s, h->dS, h->dR, h->dT, h->dU, Np, I, h->dflag,
                                (long long*)nullptr, (int64_t)0);
             const int rem = nP - 1 - I;
-            if (rem > 0)
+            if (rem > 0 && chain)
                 hipLaunchKernelGGL(k_panel_solve16, dim3((unsigned)(2 * rem)), dim3(256), 0, s, h->dU, h->dS, h->dR, Np,
                                    I, h->dflag, (int64_t)0);
         }
@@ -698,9 +702,10 @@ void launch_cholesky(gpx_handle* h) {
             // next panel are brought up to date, on 64x64 tiles too, by ONE launch on a third stream (wave priority 2,
             // below the chain's 3) WHILE the chain already works on row P1; the chain waits for its event just
             // before row P1 + 1's in-panel update.
-            hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - P1)), 2), dim3(GEMM64_THREADS), 0, s, h->dR,
-                               h->dS, Np, P0, P1, P1, (int64_t)0, nP, 3);
-            if (nnear > 1) {       // rows P1+1 .. in ONE launch at a lower wave priority, one event
+            if (near)
+                hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - P1)), 2), dim3(GEMM64_THREADS), 0, s, h->dR,
+                                   h->dS, Np, P0, P1, P1, (int64_t)0, nP, 3);
+            if (nnear > 1 && near) {       // rows P1+1 .. in ONE launch at a lower wave priority, one event
                 hipStreamWaitEvent(s3, h->ev_chain, 0);
                 hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - P1 - 1)), (unsigned)(2 * (nnear - 1))),
                                    dim3(GEMM64_THREADS), 0, s3, h->dR, h->dS, Np, P0, P1, P1 + 1, (int64_t)0, nP, 2);
@@ -710,12 +715,13 @@ void launch_cholesky(gpx_handle* h) {
         }
         if (nmid > 0) {
             hipStreamWaitEvent(s2, h->ev_chain, 0);
-            hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)(nP - m0), (unsigned)nmid), dim3(GEMM_THREADS), 0, s2,
+            if (far)
+                hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)(nP - m0), (unsigned)nmid), dim3(GEMM_THREADS), 0, s2,
                                h->dR, h->dS, Np, P0, P1, m0, m0, (int64_t)0);
             hipEventRecord(h->ev_far, s2);
             mid_pending = true;
             side_used = true;
-            if (nrest > 0)
+            if (nrest > 0 && far)
                 hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)nrest, (unsigned)nrest), dim3(GEMM_THREADS), 0, s2,
                                    h->dR, h->dS, Np, P0, P1, r0, r0, (int64_t)0);
         }
