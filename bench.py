@@ -449,6 +449,7 @@ def main():
             out['cpu_baseline'] = cpu_baseline(w, min(nc, M))
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()       # rank 0 may still be in the (untimed) refinement block: leave together
         dist.destroy_process_group()
 
 
