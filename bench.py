@@ -236,14 +236,10 @@ def main():
                 bs.append(rng.rand(100) * 2 * np.pi)
                 zs.append(rng.randn(100))
             Ws, bs = np.array(Ws), np.array(bs)
-            As, vs = eng.rff_gram_batch(Ws, bs)          # feature Grams of all local draws, one device call
             sc = np.sqrt(2.0 * w['rho'] / 100)
-            ths = []
-            for A, v, z in zip(As, vs, zs):              # 100 x 100 weight posteriors on the host
-                L = np.linalg.cholesky(sc * sc * A + w['sn2'] * np.eye(100))
-                ths.append(sc * (np.linalg.solve(L.T, np.linalg.solve(L, sc * v)) +
-                                 np.sqrt(w['sn2']) * np.linalg.solve(L.T, z)))
-            tv, ti = eng.rff_sweep_dev(Ws, bs, np.array(ths), w['bias'],
+            # feature Grams and the 100 x 100 weight posteriors of all local draws: one device call
+            ths = eng.rff_posterior(Ws, bs, np.array(zs), sc)
+            tv, ti = eng.rff_sweep_dev(Ws, bs, ths, w['bias'],
                                        dXc_full.data_ptr(), M, 1)
             tv, ti = tv[:, 0], ti[:, 0]
         else:

@@ -178,6 +178,13 @@ int gpx_rff_gram(gpx_handle *h, const double *W, const double *b, int64_t n, dou
 /* the same for S draws in one call: W (S,n,d), b (S,n) -> A (S,n,n), v (S,n) */
 int gpx_rff_gram_batch(gpx_handle *h, const double *W, const double *b, int64_t S, int64_t n, double *A,
                        double *v);
+/* the weight posterior of S draws WITHOUT leaving the device (the n x n solve inside sample_f,
+ * pybo/policies/simple.py:48): feature Grams as above, then per draw
+ *     B = sc^2 A + sn2 I = L L^T,    theta = sc ( B^-1 (sc v) + sqrt(sn2) L^-T z )
+ * with z (S,n) the caller's standard-normal draws, sc = sqrt(2 rho / n) and sn2 the fitted noise variance (> 0);
+ * theta (S,n) comes back ready for gpx_rff_sweep* / gpx_rff_grad.  n <= 127.  GPX_ENOTPD if a B is not PD. */
+int gpx_rff_posterior(gpx_handle *h, const double *W, const double *b, const double *z, int64_t S, int64_t n,
+                      double sc, double *theta);
 
 /* ---- hyper-parameter ensemble = pybo's DEFAULT model, reggie.MCMC(gp, n=10)
  *      [pybo/bayesopt.py:115]: every index is the average over the n member GPs.  `members` are fitted

@@ -44,6 +44,7 @@ SYMBOLS = {
     'gpx_rff_grad': (C.c_int, [_P, _P, _P, _P, _i64, _i64, _dbl, _P, _i64, _P, _P]),
     'gpx_rff_gram': (C.c_int, [_P, _P, _P, _i64, _P, _P]),
     'gpx_rff_gram_batch': (C.c_int, [_P, _P, _P, _i64, _i64, _P, _P]),
+    'gpx_rff_posterior': (C.c_int, [_P, _P, _P, _P, _i64, _i64, _dbl, _P]),
     'gpx_ensemble_sweep': (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _P, _i64, _i64, _P, _P, _P, _P, _P]),
     'gpx_ensemble_sweep_dev': (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _P, _i64, _i64, _P, _P, _P, _P, _P]),
     'gpx_grid_create': (C.c_int, [C.c_int, C.c_int, _P, _i64, _i64, C.c_uint64, _i64, _P, C.c_int, C.POINTER(_P)]),
@@ -459,6 +460,16 @@ class Engine(object):
         v = np.empty((S, n))
         self._check(self._lib.gpx_rff_gram_batch(self._h, _ptr(W), _ptr(b), S, n, _ptr(A), _ptr(v)))
         return A, v
+
+    def rff_posterior(self, W, b, z, sc):
+        """Weights theta (S, n) of S posterior draws: feature Grams and the n x n solves on the device."""
+        W = _f64(W)
+        S, n, d = W.shape
+        b = _f64(b).reshape(S, n)
+        z = _f64(z).reshape(S, n)
+        theta = np.empty((S, n))
+        self._check(self._lib.gpx_rff_posterior(self._h, _ptr(W), _ptr(b), _ptr(z), S, n, float(sc), _ptr(theta)))
+        return theta
 
     def rff_sweep(self, W, b, theta, bias, Xc, k=0, want_all=True):
         W = _f64(W)

@@ -912,6 +912,44 @@ extern "C" int gpx_rff_grad(gpx_handle* h, const double* W, const double* b, con
     });
 }
 
+// feature Grams of S draws (n < 128 features each) on the device: dA (S,n,n), dv (S,n) inside h->drff, followed by
+// `extra` spare doubles (*dextra) for the caller
+static int rff_gram_batch_dev(gpx_handle* h, const double* W, const double* b, int64_t S, int64_t n, int64_t extra,
+                              double** dA_out, double** dv_out, double** dextra) {
+    hipStream_t s = h->stream;
+    const int64_t d = h->d, Np = h->Np, N = h->N;
+    int rc;
+    // batched MFMA path: feature tiles [S][dp][128] k-major, phases [S][128]
+    const int64_t dp = (d + 3) / 4 * 4;
+    const int64_t nW = S * dp * TBH, nV = S * TBH;
+    std::vector<double> stage((size_t)(nW + nV), 0.0);
+    for (int64_t q = 0; q < S; ++q)
+        for (int64_t j = 0; j < n; ++j) {
+            for (int64_t kk = 0; kk < d; ++kk) stage[(size_t)((q * dp + kk) * TBH + j)] = W[(q * n + j) * d + kk];
+            stage[(size_t)(nW + q * TBH + j)] = b[q * n + j];
+        }
+    // device: [Wt nW][bt nV][A S*n*n][v S*n][extra]
+    const int64_t need = nW + nV + S * n * n + S * n + extra;
+    if ((rc = ensure(h, h->drff, h->cap_rff, need))) return rc;
+    if ((rc = ensure(h, h->drffs, h->cap_rffs, rff_gram_batch_scratch(S, Np)))) return rc;
+    double* dWt = h->drff;
+    double* dbt = dWt + nW;
+    double* dA = dbt + nV;
+    double* dv = dA + S * n * n;
+    HIPCHK(h, hipMemcpyAsync(dWt, stage.data(), stage.size() * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipStreamSynchronize(s));   // `stage` is a local buffer
+    {
+        Span sp(h, T_RFF);
+        launch_rff_gram_batch(s, h->dXraw, N, Np, (int)d, (int)dp, dWt, dbt, (int)S, (int)n, h->dy, h->bias,
+                              h->drffs, dA, dv);
+    }
+    HIPCHK(h, hipGetLastError());
+    *dA_out = dA;
+    *dv_out = dv;
+    if (dextra) *dextra = dv + S * n;
+    return GPX_OK;
+}
+
 extern "C" int gpx_rff_gram_batch(gpx_handle* h, const double* W, const double* b, int64_t S, int64_t n,
                                   double* A, double* v) {
     return guarded(h, [&]() -> int {
@@ -947,34 +985,44 @@ extern "C" int gpx_rff_gram_batch(gpx_handle* h, const double* W, const double* 
             HIPCHK(h, hipGetLastError());
             return GPX_OK;
         }
-        // batched MFMA path: feature tiles [S][dp][128] k-major, phases [S][128]
-        const int64_t dp = (d + 3) / 4 * 4;
-        const int64_t nW = S * dp * TBH, nV = S * TBH;
-        std::vector<double> stage((size_t)(nW + nV), 0.0);
-        for (int64_t q = 0; q < S; ++q)
-            for (int64_t j = 0; j < n; ++j) {
-                for (int64_t kk = 0; kk < d; ++kk) stage[(size_t)((q * dp + kk) * TBH + j)] = W[(q * n + j) * d + kk];
-                stage[(size_t)(nW + q * TBH + j)] = b[q * n + j];
-            }
-        // device: [Wt nW][bt nV][A S*n*n][v S*n]
-        const int64_t need = nW + nV + S * n * n + S * n;
-        if ((rc = ensure(h, h->drff, h->cap_rff, need))) return rc;
-        if ((rc = ensure(h, h->drffs, h->cap_rffs, rff_gram_batch_scratch(S, Np)))) return rc;
-        double* dWt = h->drff;
-        double* dbt = dWt + nW;
-        double* dA = dbt + nV;
-        double* dv = dA + S * n * n;
-        HIPCHK(h, hipMemcpyAsync(dWt, stage.data(), stage.size() * 8, hipMemcpyHostToDevice, s));
-        HIPCHK(h, hipStreamSynchronize(s));   // `stage` is a local buffer
-        {
-            Span sp(h, T_RFF);
-            launch_rff_gram_batch(s, h->dXraw, N, Np, (int)d, (int)dp, dWt, dbt, (int)S, (int)n, h->dy, h->bias,
-                                  h->drffs, dA, dv);
-        }
+        double *dA, *dv;
+        if ((rc = rff_gram_batch_dev(h, W, b, S, n, 0, &dA, &dv, nullptr))) return rc;
         HIPCHK(h, hipMemcpyAsync(A, dA, (size_t)S * n * n * 8, hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipMemcpyAsync(v, dv, (size_t)S * n * 8, hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipStreamSynchronize(s));
         HIPCHK(h, hipGetLastError());
+        return GPX_OK;
+    });
+}
+
+extern "C" int gpx_rff_posterior(gpx_handle* h, const double* W, const double* b, const double* z, int64_t S,
+                                 int64_t n, double sc, double* theta) {
+    return guarded(h, [&]() -> int {
+        if (!h) return GPX_EARG;
+        if (h->stage < 1) return fail(h, GPX_ESTATE, "rff_posterior: no data on the device (fit first)");
+        if (!W || !b || !z || !theta || n < 1 || S < 1) return fail(h, GPX_EARG, "rff_posterior: bad arguments");
+        if (n >= TBH) return fail(h, GPX_EARG, "rff_posterior: n <= 127 features (the weight posterior lives in LDS)");
+        if (!(sc > 0.0) || !(h->sn2 > 0.0)) return fail(h, GPX_EARG, "rff_posterior: needs sc > 0 and a noise variance > 0");
+        if (h->d > DMAX_RFF) return fail(h, GPX_EARG, "rff_posterior: the Thompson kernels take d <= 64");
+        HIPCHK(h, hipSetDevice(h->device));
+        hipStream_t s = h->stream;
+        int rc;
+        double *dA, *dv, *dz;
+        if ((rc = rff_gram_batch_dev(h, W, b, S, n, 2 * S * n, &dA, &dv, &dz))) return rc;
+        double* dth = dz + S * n;
+        int* pflag = h->dflag + 8;                    // its own word: the factorisation's flag stays untouched
+        HIPCHK(h, hipMemsetAsync(pflag, 0, sizeof(int), s));
+        HIPCHK(h, hipMemcpyAsync(dz, z, (size_t)S * n * 8, hipMemcpyHostToDevice, s));
+        {
+            Span sp(h, T_RFF);
+            launch_rff_posterior(s, dA, dv, dz, (int)S, (int)n, sc, h->sn2, dth, pflag);
+        }
+        int flag = 0;
+        HIPCHK(h, hipMemcpyAsync(theta, dth, (size_t)S * n * 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(&flag, pflag, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+        HIPCHK(h, hipGetLastError());
+        if (flag != 0) return fail(h, GPX_ENOTPD, "rff_posterior: the feature Gram of a draw is not positive definite");
         return GPX_OK;
     });
 }

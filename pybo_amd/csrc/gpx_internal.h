@@ -173,6 +173,8 @@ int rff_grad_host(gpx_handle* h, const double* W, const double* b, const double*
 void launch_rff_mfma(hipStream_t s, const double* Wt, const double* bt, const double* tt, int S, int nfb, int d,
                      int dp, double bias, const double* Xc, int64_t M, double* vals);
 int64_t rff_gram_batch_scratch(int64_t S, int64_t Np);
+void launch_rff_posterior(hipStream_t s, const double* A, const double* v, const double* z, int S, int n, double sc,
+                          double sn2, double* theta, int* flag);
 void launch_rff_gram_batch(hipStream_t s, const double* Xraw, int64_t N, int64_t Np, int d, int dp,
                            const double* Wt, const double* bt, int S, int n, const double* y, double bias,
                            double* scratch, double* A, double* v);

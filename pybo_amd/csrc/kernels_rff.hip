@@ -264,6 +264,68 @@ __global__ __launch_bounds__(256) void k_rff_gram_rd(const double* __restrict__ 
 }
 
 // scratch: Phi (S*Np*128) | part (S*RFF_SPLIT*128*128)
+// ------------------------------------------------------------------------------------------------
+// Weight posterior of the random-feature model, one workgroup per draw, everything in LDS:
+//     B = sc^2 A + sn2 I = L L^T,     theta = sc L^-T ( L^-1 (sc v) + sqrt(sn2) z )
+// (= sc (B^-1 sc v + sqrt(sn2) L^-T z): posterior mean + a N(0, sn2 B^-1) draw -- the n x n solve inside
+// model.sample_f(n, rng), pybo/policies/simple.py:48).  Right-looking Cholesky on the AUGMENTED lower triangle
+// [B; (sc v)^T]: the extra row leaves the loop as L^-1 (sc v), so only the back substitution follows.
+// n <= 127 (the batched feature path), row pitch odd => conflict-free column walks.  2n + n barriers.
+// ------------------------------------------------------------------------------------------------
+constexpr int RFP_NMAX = 127;
+__global__ __launch_bounds__(256) void k_rff_posterior(const double* __restrict__ A, const double* __restrict__ v,
+                                                       const double* __restrict__ z, int n, double sc, double sn2,
+                                                       double* __restrict__ theta, int* __restrict__ flag) {
+    __shared__ double Bm[(RFP_NMAX + 1) * (RFP_NMAX + 2)];
+    __shared__ int bad;
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    const int ld = (n + 1) | 1;
+    const int64_t q = blockIdx.x;
+    A += q * n * n;
+    v += q * n;
+    z += q * n;
+    theta += q * n;
+    for (int e = t; e < n * n; e += 256) {
+        const int i = e / n, j = e - i * n;
+        if (j <= i) Bm[i * ld + j] = sc * sc * A[e] + ((i == j) ? sn2 : 0.0);
+    }
+    for (int j = t; j < n; j += 256) Bm[n * ld + j] = sc * v[j];
+    if (t == 0) bad = 0;
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {
+        const double piv = Bm[j * ld + j];
+        if (!(piv > 0.0) || !(piv < 1.0e300)) {          // uniform: every thread reads the same value
+            if (t == 0) { bad = 1; atomicCAS(flag, 0, j + 1); }
+            break;
+        }
+        const double rinv = 1.0 / sqrt(piv);
+        for (int i = j + 1 + t; i <= n; i += 256) Bm[i * ld + j] *= rinv;
+        __syncthreads();
+        if (t == 0) Bm[j * ld + j] = piv * rinv;
+        for (int i = j + 1 + ty; i <= n; i += 16) {
+            const double li = Bm[i * ld + j];
+            const int khi = (i < n) ? i : n - 1;         // the augmented row has no diagonal entry
+            for (int k = j + 1 + tx; k <= khi; k += 16) Bm[i * ld + k] = fma(-li, Bm[k * ld + j], Bm[i * ld + k]);
+        }
+        __syncthreads();
+    }
+    if (bad) return;
+    // w = L^-1 (sc v) + sqrt(sn2) z, in place in the augmented row; then theta = sc L^-T w
+    const double sn = sqrt(sn2);
+    for (int j = t; j < n; j += 256) Bm[n * ld + j] = fma(sn, z[j], Bm[n * ld + j]);
+    for (int j = n - 1; j >= 0; --j) {
+        __syncthreads();
+        const double tj = Bm[n * ld + j] / Bm[j * ld + j];
+        for (int k = t; k < j; k += 256) Bm[n * ld + k] = fma(-Bm[j * ld + k], tj, Bm[n * ld + k]);
+        if (t == 0) theta[j] = sc * tj;
+    }
+}
+
+void launch_rff_posterior(hipStream_t s, const double* A, const double* v, const double* z, int S, int n, double sc,
+                          double sn2, double* theta, int* flag) {
+    hipLaunchKernelGGL(k_rff_posterior, dim3((unsigned)S), dim3(256), 0, s, A, v, z, n, sc, sn2, theta, flag);
+}
+
 int64_t rff_gram_batch_scratch(int64_t S, int64_t Np) { return S * Np * TB + S * RFF_SPLIT * TB * TB; }
 
 void launch_rff_gram_batch(hipStream_t s, const double* Xraw, int64_t N, int64_t Np, int d, int dp,

@@ -335,7 +335,7 @@ class GP(object):
 
     def sample_f(self, n, rng=None):
         """RFF posterior function sample.  Host draws (order fixed: randn(n,d), [chisquare], rand(n),
-        randn(n)); the O(N n^2) feature Gram runs on the device, the n x n weight posterior on the host."""
+        randn(n)); the O(N n^2) feature Gram and (n < 128) the n x n weight posterior run on the device."""
         rng = rstate(rng)
         d = len(self.ell)
         W = rng.randn(n, d)
@@ -349,7 +349,10 @@ class GP(object):
         sc = np.sqrt(2.0 * self.rho / n)
         if self.ndata == 0:
             return RFFSampleDevice(self, W, b, sc * z)
-        A, v = self._engine().rff_gram(W, b)
+        if n < 128:      # feature Gram AND the n x n weight posterior on the device (gpx_rff_posterior)
+            theta = self._engine().rff_posterior(W[None], b[None], z[None], sc)[0]
+            return RFFSampleDevice(self, W, b, theta)
+        A, v = self._engine().rff_gram(W, b)           # wide feature maps: the n x n solve on the host
         Am = (sc * sc) * A + self.sn2 * np.eye(n)
         L = np.linalg.cholesky(Am)
         mean = np.linalg.solve(L.T, np.linalg.solve(L, sc * v))

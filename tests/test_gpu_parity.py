@@ -314,6 +314,7 @@ def test_gradients_at_training_inputs_are_finite(kernel):
 # ---- Thompson / RFF -------------------------------------------------------------------------------
 @pytest.mark.parametrize('kernel', ['se', 'matern5'])
 def test_rff_paths_match_oracle(kernel):
+    from pybo_amd._lib import GpxError
     e, ref, (X, y, ell, rho, sn2, bias) = _pair(200, 3, kernel, seed=31)
     kid = gp_ref.KERNEL_IDS[kernel]
     S, n = 3, 100
@@ -332,6 +333,21 @@ def test_rff_paths_match_oracle(kernel):
         Cq = np.cos(X @ Ws[q].T + bs[q])
         np.testing.assert_allclose(Ab[q], Cq.T @ Cq, rtol=1e-11, atol=1e-10)
         np.testing.assert_allclose(vb[q], Cq.T @ (y - bias), rtol=1e-11, atol=1e-10)
+    # the n x n weight posterior on the device (gpx_rff_posterior) vs the oracle's: same draws, replayed
+    zs = []
+    for q in range(S):
+        rng = np.random.RandomState(100 + q)
+        Wq, bq = gp_ref.rff_draw_spectral(kid, n, 3, ell, rng)
+        np.testing.assert_array_equal(Wq, Ws[q])
+        zs.append(rng.randn(n))
+    th_dev = e.rff_posterior(np.array(Ws), np.array(bs), np.array(zs), np.sqrt(2.0 * rho / n))
+    for q in range(S):
+        # cond(B) ~ 1e6-1e8 here: both solves carry ~cond * eps relative error
+        np.testing.assert_allclose(th_dev[q], ths[q], rtol=0, atol=1e-7 * np.abs(ths[q]).max())
+    with pytest.raises(GpxError):
+        e.rff_posterior(np.zeros((1, 128, 3)), np.zeros((1, 128)), np.zeros((1, 128)), 0.1)     # n <= 127
+    with pytest.raises(GpxError):
+        e.rff_posterior(np.array(Ws), np.array(bs), np.array(zs), 0.0)                          # sc > 0
     # wide feature maps (n >= 128) take the per-draw path
     wide = ref.sample_f(130, rng=5)
     Cw = np.cos(X @ wide.W.T + wide.b)
