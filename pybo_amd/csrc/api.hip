@@ -162,6 +162,25 @@ static int create_impl(int device, void* stream, gpx_handle** out) {
         }
         h->own_stream = true;
     }
+    // (the factorisation's side streams and events are created on first use: gpx::ensure_side_streams)
+    // one allocation for the small per-handle device scalars
+    if (hipMalloc((void**)&h->dsmall, 64 + 16 * 8 + DMAX * 8) != hipSuccess) {
+        g_create_err = "gpx_create: device allocation failed";
+        delete h;
+        return GPX_EOOM;
+    }
+    h->dflag = reinterpret_cast<int*>(h->dsmall);
+    h->dscal = reinterpret_cast<double*>(h->dsmall + 64);
+    h->dinvell = h->dscal + 16;
+    *out = h;
+    return GPX_OK;
+}
+
+// The blocked factorisation's lookahead streams and events, created when a fit first needs them (more than one
+// outer panel): a handle that only ever holds small models -- the members and proposals of the hyper-parameter
+// sampler -- never pays for two HSA queues (stream creation dominated gpx_create: ~8 ms per handle).
+int gpx::ensure_side_streams(gpx_handle* h) {
+    if (h->stream2) return GPX_OK;
     int prio_lo = 0, prio_hi = 0;   // numerically lowest value = highest priority
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     // the side stream carries only off-critical-path work (far trailing updates): lowest priority, so the
@@ -171,18 +190,8 @@ static int create_impl(int device, void* stream, gpx_handle** out) {
     if (!ok_ev || hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_far, hipEventDisableTiming) != hipSuccess) {
-        g_create_err = "gpx_create: side stream / event creation failed";
-        delete h;
-        return GPX_EHIP;
-    }
-    if (hipMalloc((void**)&h->dflag, 64) != hipSuccess || hipMalloc((void**)&h->dscal, 16 * 8) != hipSuccess ||
-        hipMalloc((void**)&h->dinvell, DMAX * 8) != hipSuccess) {
-        g_create_err = "gpx_create: device allocation failed";
-        delete h;
-        return GPX_EOOM;
-    }
-    *out = h;
+        hipEventCreateWithFlags(&h->ev_far, hipEventDisableTiming) != hipSuccess)
+        return fail(h, GPX_EHIP, "side stream / event creation failed");
     return GPX_OK;
 }
 
@@ -192,8 +201,7 @@ extern "C" int gpx_destroy(gpx_handle* h) {
     hipStreamSynchronize(h->stream);
     for (auto& p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : h->pool) hipEventDestroy(e);
-    void* ptrs[] = {h->dXs, h->dXraw, h->dy, h->dS, h->dR, h->dT, h->dU, h->da, h->dalpha, h->dinvell,
-                    h->dflag, h->dscal, h->dKs, h->dQp, h->dXc, h->dout, h->dblkv, h->dblki,
+    void* ptrs[] = {h->dXs, h->dXraw, h->dy, h->dS, h->dR, h->dT, h->dU, h->da, h->dalpha, h->dsmall, h->dKs, h->dQp, h->dXc, h->dout, h->dblkv, h->dblki,
                     h->dtopv, h->drff, h->drffs, h->dgrad, h->dens, h->dcZ, h->dcq, h->dbatch, h->dpend};  // dPp, dtopi, dcp alias dQp, dtopv, dcq
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -379,6 +387,8 @@ static int fit_core(gpx_handle* h, const double* dX, int64_t N, int64_t d, const
     if (stage >= 2) {
         {
             Span sp(h, T_CHOL);
+            // more than one outer panel: the lookahead needs its streams (see launch_cholesky)
+            if (h->Np / NB > (h->chol_w ? h->chol_w : 4) && (rc = ensure_side_streams(h))) return rc;
             launch_cholesky(h);
         }
         int flag = 0;

@@ -60,6 +60,7 @@ struct gpx_handle {
     double* da = nullptr;     // (Np,) a = T (y - bias)
     double* dalpha = nullptr; // (Np,) alpha = U a
     double* dinvell = nullptr;// (DMAX,) 1/ell
+    char* dsmall = nullptr;   // ONE allocation behind dflag / dscal / dinvell
     int* dflag = nullptr;     // [0] = failing pivot + 1 (0 = ok)
     double* dscal = nullptr;  // small scalar scratch (16 doubles)
 
@@ -126,6 +127,7 @@ void launch_scale_x(hipStream_t s, const double* X, int64_t n, int64_t np, int d
                     double* Xs);
 void launch_gram_sym(hipStream_t s, const double* Xs, int64_t N, int64_t Np, int d, int kernel_id,
                      double rho, double sn2, double* S);
+int ensure_side_streams(gpx_handle* h);   // api.hip: streams 2 / 3 + events, on first use
 void launch_cholesky(gpx_handle* h);   // S -> R, diag blocks of T/U; sets dflag
 void launch_trtri(gpx_handle* h);      // R, diag blocks -> T, U (uses S as workspace)
 void launch_alpha(gpx_handle* h);      // a = T (y - bias); alpha = U a

@@ -26,6 +26,7 @@ __all__ = ['GP', 'make_gp']
 
 _KERNELS = ('se', 'matern5', 'matern3', 'matern1')
 _ENGINE_POOL = []      # engines whose last owner died; reused so steady-state BO never re-allocates
+_POOL_SMALL_N = 1024   # handles that last held at most this many observations count as small (<= ~35 MB)
 
 
 class _DeviceState(object):
@@ -46,7 +47,14 @@ class _DeviceState(object):
     def release(self):
         self.nrefs -= 1
         if self.nrefs == 0 and self.engine is not None:
-            if self.engine._h and len(_ENGINE_POOL) < 16:
+            # keep the handle for the next model: creating and destroying one costs ~8 ms each (HSA queue,
+            # allocations), which was 80 % of a default solve_bayesopt run -- the hyper-parameter sampler turns over
+            # ~30 member / proposal models per iteration.  Handles of small models are cheap to keep (a few MB);
+            # at most 4 large ones (their factor and sweep buffers stay allocated) wait in the pool.
+            small = self.engine.N <= _POOL_SMALL_N
+            room = (sum(1 for e in _ENGINE_POOL if e.N <= _POOL_SMALL_N) < 64) if small \
+                else (sum(1 for e in _ENGINE_POOL if e.N > _POOL_SMALL_N) < 4)
+            if self.engine._h and room:
                 try:
                     self.engine.set_option('sweep_cache', -1)       # the next owner starts without a cache
                 except Exception:

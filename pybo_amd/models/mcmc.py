@@ -173,16 +173,28 @@ class MCMC(object):
         self._scale[-1] = np.sqrt(np.exp(self._theta[1]))   # bias moves on the INITIAL signal std (frozen)
         self._lp = None
         self._members = []
-        self._bind_hooks()
         if self._proto.ndata > 0:
             self._advance(int(burn), keep=False)
             self._advance(self._n, keep=True)
 
-    def _bind_hooks(self):
-        # the whole-grid top-k hook only exists for device-backed members (policies probe it with getattr)
-        if hasattr(self._proto, 'acq_values'):
-            self.acq_topk = self._acq_topk
-            self.topk_engine = lambda: self._engines()[0]     # the ensemble's lead handle ranks the average
+    # The whole-grid top-k hooks only exist for device-backed members (policies probe them with getattr).  They are
+    # properties, not attributes bound at construction: an instance that stores its own bound method is a reference
+    # cycle, and every BO step makes several ensemble copies -- their 10 member handles each then wait for the cyclic
+    # collector instead of going back to the handle pool at once.
+    @property
+    def acq_topk(self):
+        if not hasattr(self._proto, 'acq_values'):
+            raise AttributeError('acq_topk')
+        return self._acq_topk
+
+    @property
+    def topk_engine(self):
+        if not hasattr(self._proto, 'acq_values'):
+            raise AttributeError('topk_engine')
+        return self._lead_engine
+
+    def _lead_engine(self):
+        return self._engines()[0]                # the ensemble's lead handle ranks the average
 
     # -- sampling ----------------------------------------------------------------------------------
     def _advance(self, nsteps, keep):
@@ -234,7 +246,6 @@ class MCMC(object):
         new._scale = self._scale.copy()
         new._lp = self._lp
         new._members = [m.copy() for m in self._members]
-        new._bind_hooks()
         return new
 
     def add_data(self, X, Y):
@@ -308,7 +319,6 @@ class MCMC(object):
 
     # -- pickling: hyper-parameter states + data, members are rebuilt on load -------------------------
     def __getstate__(self):
-        # (the bound acq_topk hook is re-created on load)
         return dict(proto=self._proto, n=self._n, rng=self._rng, theta=self._theta, scale=self._scale,
                     samples=[np.array(m.hyper_vector()) for m in self._members])
 
@@ -321,4 +331,3 @@ class MCMC(object):
             m = self._proto.copy()
             m.set_hyper_vector(th)
             self._members.append(m)
-        self._bind_hooks()

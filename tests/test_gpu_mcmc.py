@@ -113,3 +113,23 @@ def test_batched_loglik_matches_oracle_and_leaves_the_fit_alone(N, d, kernel):
     bad[0] = -800.0                                                           # sn2 = exp(-800) = 0
     out = gp2.loglik_at(np.array([gp2.hyper_vector(), bad]))
     assert np.isfinite(out[0]) and out[1] == -np.inf
+
+
+def test_a_default_run_reuses_its_device_handles(monkeypatch):
+    """pybo's default model turns over ~30 member / proposal models per iteration; their handles must come from
+    the pool (creating + destroying one costs ~5-15 ms: it was 80 % of a default run before the pool kept up)."""
+    import pybo_amd
+    from pybo_amd import _lib
+    from helpers import branin
+    bounds = np.array([[-5.0, 10.0], [0.0, 15.0]])
+    f = lambda x: -branin(np.atleast_2d(x))[0] / 10.0          # noqa: E731
+    pybo_amd.solve_bayesopt(f, bounds, niter=4, rng=0)         # fills the pool
+    made = [0]
+    orig = _lib.Engine.__init__
+
+    def counting(self, *a, **kw):
+        made[0] += 1
+        orig(self, *a, **kw)
+    monkeypatch.setattr(_lib.Engine, '__init__', counting)
+    pybo_amd.solve_bayesopt(f, bounds, niter=8, rng=1)
+    assert made[0] <= 8, 'handles created in a steady-state run: %d' % made[0]
