@@ -243,6 +243,9 @@ class GP(object):
 
     def predict(self, X, grad=False):
         X = np.array(X, ndmin=2, dtype=float)
+        if X.shape[0] == 0:                      # empty in, empty out (numpy semantics; no device call)
+            e1, e2 = np.zeros(0), np.zeros((0, X.shape[1]))
+            return (e1, e1.copy(), e2, e2.copy()) if grad else (e1, e1.copy())
         if self.ndata == 0:
             M, d = X.shape
             mu, s2 = np.full(M, self.bias), np.full(M, self.rho)
@@ -294,6 +297,8 @@ class GP(object):
         X = np.array(X, ndmin=2, dtype=float)
         if self.ndata == 0:
             raise RuntimeError('the model has no data yet')
+        if X.shape[0] == 0:
+            return (np.zeros(0), np.zeros((0, X.shape[1]))) if grad else np.zeros(0)
         if not grad:
             return self._engine().sweep(kind, target, X, k=0)['acq']
         mu, s2, dmu, ds2 = self._engine().predict(X, grad=True)

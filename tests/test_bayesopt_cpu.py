@@ -132,3 +132,4 @@ def test_lockstep_refinement_surfaces_index_errors():
     with pytest.raises(ValueError, match='index failed'):
         solvers.solve_lbfgs(broken, [[0, 1], [0, 1]], nbest=3, xgrid=np.random.RandomState(0).rand(20, 2),
                             select='best')
+

@@ -553,3 +553,19 @@ def test_direct_hyperparameter_assignment_triggers_a_refit():
     ref.add_data(X, y)
     mu, s2 = gp.predict(Z); mr, sr = ref.predict(Z)
     assert np.all(np.abs(mu - mr) <= mu_tol(mr, 1.7)) and np.all(np.abs(s2 - sr) <= s2_tol(sr, 1.7))
+
+
+def test_device_model_returns_empty_for_empty_input():
+    """`predict` / `get_improvement` / `get_tail` of a (0, d) batch: empty arrays, as numpy code would give (the
+    library itself refuses M = 0)."""
+    from pybo_amd.models import make_gp
+    m = make_gp(1e-3, 1.0, [0.3, 0.3], 0.0)
+    m.add_data(np.random.RandomState(0).rand(5, 2), np.arange(5.0))
+    Z = np.zeros((0, 2))
+    mu, s2 = m.predict(Z)
+    assert mu.shape == s2.shape == (0,)
+    mu, s2, dmu, ds2 = m.predict(Z, grad=True)
+    assert dmu.shape == ds2.shape == (0, 2)
+    assert m.get_improvement(0.3, Z).shape == (0,)
+    f, g = m.get_tail(0.3, Z, grad=True)
+    assert f.shape == (0,) and g.shape == (0, 2)
