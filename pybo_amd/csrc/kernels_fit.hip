@@ -231,36 +231,50 @@ __device__ __forceinline__ int factor16(d4& D, d4& I, int g, int n) {
     return bad;
 }
 
-// Pn: the current 16-row panel [16][PFP]; Ud: the current T_d^T [16][16]; Rg / Tg / Ug: the block in global memory
-// (results leave from registers as they are produced: R_d and the panel tiles here, nothing is kept in LDS
-// beyond the panel the trailing update is reading -- 19 KB, so the kernel co-resides with anything).
-template <int JB>
-__device__ __forceinline__ bool pf16_step(d4 (&accA)[8], d4 (&accB)[8], int cA, int cB, double* __restrict__ Pn,
-                                          double* __restrict__ Ud, volatile int* sflag, int w, int lane,
-                                          int64_t p0, int* flag, double* __restrict__ Rg, double* __restrict__ Tg,
-                                          double* __restrict__ Ug, int64_t Np) {
-    const int g = lane >> 4, n = lane & 15;
-    constexpr int OWNER = (JB < 4) ? JB : 7 - JB;
-    if (w == OWNER) {
-        d4 D = (JB < 4) ? accA[JB] : accB[JB];
-        d4 I;
+// ---- the steps of k_potrf16, with LOOKAHEAD over the diagonal tiles --------------------------------------------
+// Pn[2]: the 16-row panels of the current and the previous step ([16][PFP] each); Ud: the current T_d^T [16][16];
+// Rg / Tg / Ug: the block in global memory (results leave from registers as they are produced).
+//   factor   the owner of tile (jb, jb) factors it in the wave (factor16) and publishes T_d^T;
+//   panel    every wave forms R[jb, c] = T_d S[jb, c] for its columns c > jb (LDS panel jb & 1 + global);
+//   trail    trailing update with panel jb -- except that the wave that owns tile (jb+1, jb+1) brings only THAT
+//            tile up to date, factors it at once (next to the other waves' trailing updates instead of after them:
+//            the in-wave chain of factor16 is 2.6 of a step's 4.4 us and three waves idled through it), fixes its
+//            other tile of row jb+1 (the next panel needs it) and DEFERS the rest of its trailing tiles: it applies
+//            panel jb to them one step later, together with panel jb+1 (updates commute; the previous panel stays
+//            in the other LDS buffer for exactly that long).
+__device__ __forceinline__ bool pf16_factor(d4& D, int jb, int g, int n, double* __restrict__ Ud, volatile int* sflag,
+                                            int64_t p0, int* flag, double* __restrict__ Rg, double* __restrict__ Tg,
+                                            double* __restrict__ Ug, int64_t Np, int lane) {
+    d4 I;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) I[r] = (g + 4 * r == n) ? 1.0 : 0.0;
-        const int bad = factor16(D, I, g, n);
-        if (bad >= 0 && lane == 0) { *flag = (int)(p0 + 16 * JB + bad) + 1; *sflag = 1; }
+    for (int r = 0; r < 4; ++r) I[r] = (g + 4 * r == n) ? 1.0 : 0.0;
+    const int bad = factor16(D, I, g, n);
+    if (bad >= 0 && lane == 0) { *flag = (int)(p0 + 16 * jb + bad) + 1; *sflag = 1; }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t row = p0 + 16 * JB + g + 4 * r, col = p0 + 16 * JB + n;
-            Rg[row * Np + col] = D[r];                                    // R_d, zeros below its diagonal
-            if (Tg) Tg[row * Np + col] = I[r];                            // T_d (lower)
-            Ug[col * Np + row] = I[r];                                    // U_d = T_d^T
-            Ud[n * 16 + g + 4 * r] = I[r];                                // LDS, k-major: Ud[k][m] = T_d[m][k]
-        }
+    for (int r = 0; r < 4; ++r) {
+        const int64_t row = p0 + 16 * jb + g + 4 * r, col = p0 + 16 * jb + n;
+        Rg[row * Np + col] = D[r];                                    // R_d, zeros below its diagonal
+        if (Tg) Tg[row * Np + col] = I[r];                            // T_d (lower)
+        Ug[col * Np + row] = I[r];                                    // U_d = T_d^T
+        Ud[n * 16 + g + 4 * r] = I[r];                                // LDS, k-major: Ud[k][m] = T_d[m][k]
     }
-    __syncthreads();
-    if (*sflag) return false;
-    if (JB == 7) return true;
-    // row panel: R[jb, c] = T_d S[jb, c]
+    return bad < 0;
+}
+
+// acc(r, c) -= R[jb, r]^T R[jb, c] from the panel `P` (both operands k-major reads of it)
+__device__ __forceinline__ void pf16_tile_update(d4& acc, const double* __restrict__ P, int r, int c, int g, int n) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(P[(4 * kk + g) * PFP + 16 * r + n], -P[(4 * kk + g) * PFP + 16 * c + n],
+                                                   acc, 0, 0, 0);
+}
+
+template <int JB>
+__device__ __forceinline__ void pf16_panel(d4 (&accA)[8], d4 (&accB)[8], int cA, int cB, double* __restrict__ Pn,
+                                           const double* __restrict__ Ud, int lane, int64_t p0,
+                                           double* __restrict__ Rg, int64_t Np) {
+    const int g = lane >> 4, n = lane & 15;
+    double* P = Pn + (JB & 1) * 16 * PFP;
     double a[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) a[kk] = Ud[(4 * kk + g) * 16 + n];
@@ -274,35 +288,56 @@ __device__ __forceinline__ bool pf16_step(d4 (&accA)[8], d4 (&accB)[8], int cA, 
             for (int kk = 0; kk < 4; ++kk) pnl = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], src[kk], pnl, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                Pn[(g + 4 * r) * PFP + 16 * c + n] = pnl[r];
+                P[(g + 4 * r) * PFP + 16 * c + n] = pnl[r];
                 Rg[(p0 + 16 * JB + g + 4 * r) * Np + p0 + 16 * c + n] = pnl[r];
             }
         }
     }
-    __syncthreads();
-    // trailing update
+}
+
+// returns false if the looked-ahead factorisation hit a non-positive pivot (sflag is set for the other waves)
+template <int JB>
+__device__ __forceinline__ void pf16_trail(d4 (&accA)[8], d4 (&accB)[8], int cA, int cB, double* __restrict__ Pn,
+                                           double* __restrict__ Ud, volatile int* sflag, int w, int lane, int64_t p0,
+                                           int* flag, double* __restrict__ Rg, double* __restrict__ Tg,
+                                           double* __restrict__ Ug, int64_t Np) {
+    const int g = lane >> 4, n = lane & 15;
+    constexpr int NX = JB + 1;                                    // the tile row the next step factors
+    constexpr int OWN_NX = (NX < 4) ? NX : 7 - NX;                // wave that owns tile (NX, NX)
+    constexpr int OWN_JB = (JB < 4) ? JB : 7 - JB;                // ... and the one that deferred at step JB - 1
+    const double* Pc = Pn + (JB & 1) * 16 * PFP;                  // this step's panel
+    const double* Pp = Pn + ((JB + 1) & 1) * 16 * PFP;            // the previous one (for deferred updates)
+    const bool pend = (JB >= 1) && (w == OWN_JB);                 // this wave skipped panel JB-1 for rows >= JB+1
+    if (w == OWN_NX) {
+        // the next diagonal tile first, factored at once
+        d4& D = (NX < 4) ? accA[NX] : accB[NX];
+        if (pend) pf16_tile_update(D, Pp, NX, NX, g, n);
+        pf16_tile_update(D, Pc, NX, NX, g, n);
+        pf16_factor(D, NX, g, n, Ud, sflag, p0, flag, Rg, Tg, Ug, Np, lane);
+        // its other tile of row NX feeds the next panel; everything below waits one step
+        const int co = (NX < 4) ? cB : cA;
+        if (co > NX) {
+            d4& E = (NX < 4) ? accB[NX] : accA[NX];
+            if (pend) pf16_tile_update(E, Pp, NX, co, g, n);
+            pf16_tile_update(E, Pc, NX, co, g, n);
+        }
+    } else {
 #pragma unroll
-    for (int side = 0; side < 2; ++side) {
-        const int c = side ? cB : cA;
-        if (c > JB) {
-            double b[4];
+        for (int side = 0; side < 2; ++side) {
+            const int c = side ? cB : cA;
+            if (c > JB) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) b[kk] = -Pn[(4 * kk + g) * PFP + 16 * c + n];
-#pragma unroll
-            for (int r = JB + 1; r < 8; ++r) {
-                if (r <= c) {
-                    double ar[4];
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) ar[kk] = Pn[(4 * kk + g) * PFP + 16 * r + n];
-                    d4 acc = side ? accB[r] : accA[r];
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ar[kk], b[kk], acc, 0, 0, 0);
-                    if (side) accB[r] = acc; else accA[r] = acc;
+                for (int r = JB + 1; r < 8; ++r) {
+                    if (r <= c) {
+                        d4 acc = side ? accB[r] : accA[r];
+                        if (pend) pf16_tile_update(acc, Pp, r, c, g, n);
+                        pf16_tile_update(acc, Pc, r, c, g, n);
+                        if (side) accB[r] = acc; else accA[r] = acc;
+                    }
                 }
             }
         }
     }
-    return true;
 }
 
 // DBG (scripts/potrf_bench.hip only): wall-clock stamps of the phases go to `dbg` (thread 0)
@@ -318,7 +353,7 @@ __global__ __launch_bounds__(256) void k_potrf16(const double* __restrict__ S, d
     U += (int64_t)blockIdx.z * bs;
     if (T) T += (int64_t)blockIdx.z * bs;
     flag += blockIdx.z;
-    __shared__ double Pn[16 * PFP];       // the current 16-row panel of R
+    __shared__ double Pn[2 * 16 * PFP];   // the 16-row panels of the current and the previous step
     __shared__ double Ud[256];            // the current 16x16 inverse, transposed (k-major A operand)
     __shared__ int sflag;
     if (*flag != 0) return;               // an earlier block already failed
@@ -357,21 +392,25 @@ __global__ __launch_bounds__(256) void k_potrf16(const double* __restrict__ S, d
     if (DBG && t == 0) dbg[0] = wall_clock64();
     __syncthreads();
     if (DBG && t == 0) dbg[1] = wall_clock64();
-    bool ok = pf16_step<0>(accA, accB, cA, cB, Pn, Ud, &sflag, w, lane, p0, flag, R, T, U, Np);
-    if (DBG && t == 0) dbg[2] = wall_clock64();
-    if (ok) ok = pf16_step<1>(accA, accB, cA, cB, Pn, Ud, &sflag, w, lane, p0, flag, R, T, U, Np);
-    if (DBG && t == 0) dbg[3] = wall_clock64();
-    if (ok) ok = pf16_step<2>(accA, accB, cA, cB, Pn, Ud, &sflag, w, lane, p0, flag, R, T, U, Np);
-    if (DBG && t == 0) dbg[4] = wall_clock64();
-    if (ok) ok = pf16_step<3>(accA, accB, cA, cB, Pn, Ud, &sflag, w, lane, p0, flag, R, T, U, Np);
-    if (DBG && t == 0) dbg[5] = wall_clock64();
-    if (ok) ok = pf16_step<4>(accA, accB, cA, cB, Pn, Ud, &sflag, w, lane, p0, flag, R, T, U, Np);
-    if (DBG && t == 0) dbg[6] = wall_clock64();
-    if (ok) ok = pf16_step<5>(accA, accB, cA, cB, Pn, Ud, &sflag, w, lane, p0, flag, R, T, U, Np);
-    if (DBG && t == 0) dbg[7] = wall_clock64();
-    if (ok) ok = pf16_step<6>(accA, accB, cA, cB, Pn, Ud, &sflag, w, lane, p0, flag, R, T, U, Np);
-    if (DBG && t == 0) dbg[8] = wall_clock64();
-    if (ok) ok = pf16_step<7>(accA, accB, cA, cB, Pn, Ud, &sflag, w, lane, p0, flag, R, T, U, Np);
+    // tile (0, 0) is factored before the loop; every later diagonal tile inside the previous step's trailing phase
+    if (w == 0) pf16_factor(accA[0], 0, g, n, Ud, &sflag, p0, flag, R, T, U, Np, lane);
+    __syncthreads();
+#define GPX_PF_STEP(JB)                                                                                     \
+    if (!sflag) {                                                                                           \
+        pf16_panel<JB>(accA, accB, cA, cB, Pn, Ud, lane, p0, R, Np);                                        \
+        __syncthreads();                                                                                    \
+        pf16_trail<JB>(accA, accB, cA, cB, Pn, Ud, &sflag, w, lane, p0, flag, R, T, U, Np);                 \
+        __syncthreads();                                                                                    \
+    }                                                                                                       \
+    if (DBG && t == 0) dbg[2 + JB] = wall_clock64();
+    GPX_PF_STEP(0)
+    GPX_PF_STEP(1)
+    GPX_PF_STEP(2)
+    GPX_PF_STEP(3)
+    GPX_PF_STEP(4)
+    GPX_PF_STEP(5)
+    GPX_PF_STEP(6)
+#undef GPX_PF_STEP
     if (DBG && t == 0) dbg[9] = wall_clock64();
     if (DBG && t == 0) dbg[10] = wall_clock64();
 }
