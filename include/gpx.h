@@ -73,7 +73,11 @@ int gpx_version(void);
  *          "eager_inverse" = 1: form the triangular inverse inside gpx_fit instead of on first use.
  *          "sweep_cache" = 1: full sweeps keep their candidates and reduced sums for gpx_sweep_update;
  *              0 (default): full sweeps leave an existing cache alone (it stays valid and is still kept current
- *              by gpx_append); -1: drop the cache. */
+ *              by gpx_append); -1: drop the cache.
+ *          "chol_w" = outer panel width of the blocked factorisation in 128-blocks (2..8; 0 = by size, default).
+ *          "x_skip" = DIAGNOSTIC (scripts/chol_parts.py): leave out the far updates (bit 0), the chain kernels
+ *              (bit 1) or the near updates (bit 2) of the factorisation to time its parts alone -- the result is
+ *              then NOT a factorisation; 0 (default) = everything. */
 int gpx_set_option(gpx_handle *h, const char *name, int64_t value);
 
 /* ---- GP fit = model.add_data(X, Y)            [pybo/bayesopt.py:114,258,269] ------------- */
