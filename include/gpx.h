@@ -203,6 +203,13 @@ int gpx_ensemble_sweep(gpx_handle *const *members, int n_members, int acq_id, co
 int gpx_ensemble_sweep_dev(gpx_handle *const *members, int n_members, int acq_id, const double *params,
                            int nparams, const double *dXc, int64_t M, int64_t k, double *top_val,
                            int64_t *top_idx, double *d_acq_all, double *d_mu, double *d_s2);
+/* per-member posterior moments AND gradients at M points (host buffers), member-major: mu, s2 (n_members, M);
+ * dmu, ds2 (n_members, M, d) -- the `f(x, grad=True)` calls of the L-BFGS refinement on the default model
+ * [pybo/solvers/lbfgs.py:56-58 over pybo/bayesopt.py:115]; the members' latency-bound kernels run concurrently on
+ * their own streams (one call instead of n_members gpx_predict calls) and the caller forms the average it needs
+ * (mixture moments for UCB / mean, the mean of the members' EI / PI and their gradients). */
+int gpx_ensemble_predict(gpx_handle *const *members, int n_members, const double *Xc, int64_t M, double *mu,
+                         double *s2, double *dmu, double *ds2);
 
 /* ---- candidate grid generated and kept in HBM = the solver's grid
  *      xgrid = init_uniform(bounds, ngrid, rng)   [pybo/solvers/lbfgs.py:45; pybo/inits/methods.py:24-38]

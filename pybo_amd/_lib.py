@@ -47,6 +47,7 @@ SYMBOLS = {
     'gpx_rff_posterior': (C.c_int, [_P, _P, _P, _P, _i64, _i64, _dbl, _P]),
     'gpx_ensemble_sweep': (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _P, _i64, _i64, _P, _P, _P, _P, _P]),
     'gpx_ensemble_sweep_dev': (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int, _P, _i64, _i64, _P, _P, _P, _P, _P]),
+    'gpx_ensemble_predict': (C.c_int, [_P, C.c_int, _P, _i64, _P, _P, _P, _P]),
     'gpx_grid_create': (C.c_int, [C.c_int, C.c_int, _P, _i64, _i64, C.c_uint64, _i64, _P, C.c_int, C.POINTER(_P)]),
     'gpx_grid_data': (_P, [_P]),
     'gpx_grid_rows': (C.c_int, [_P, _P, _i64, _P]),
@@ -441,6 +442,19 @@ class Engine(object):
                                                  _ptr(tv) if k else None, _ptr(ti) if k else None, _ptr(out),
                                                  _ptr(mu), _ptr(s2)))
         return dict(top_val=tv, top_idx=ti, acq=out, mu=mu, s2=s2)
+
+    @staticmethod
+    def ensemble_predict(engines, Xc):
+        """Per-member moments and gradients at the rows of Xc in ONE call (gpx_ensemble_predict):
+        mu, s2 (n, M); dmu, ds2 (n, M, d)."""
+        lead = engines[0]
+        handles = (_P * len(engines))(*[e._h for e in engines])
+        Xc = _f64(Xc).reshape(-1, lead.d)
+        n, M, d = len(engines), len(Xc), lead.d
+        mu, s2 = np.empty((n, M)), np.empty((n, M))
+        dmu, ds2 = np.empty((n, M, d)), np.empty((n, M, d))
+        lead._check(lead._lib.gpx_ensemble_predict(handles, n, _ptr(Xc), M, _ptr(mu), _ptr(s2), _ptr(dmu), _ptr(ds2)))
+        return mu, s2, dmu, ds2
 
     # -- Thompson --------------------------------------------------------------------------------
     def rff_gram(self, W, b):

@@ -205,6 +205,7 @@ extern "C" int gpx_destroy(gpx_handle* h) {
                     h->dtopv, h->drff, h->drffs, h->dgrad, h->dens, h->dcZ, h->dcq, h->dbatch, h->dpend};  // dPp, dtopi, dcp alias dQp, dtopv, dcq
     for (void* p : ptrs)
         if (p) hipFree(p);
+    if (h->hpin) hipHostFree(h->hpin);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
     if (h->stream3) { hipStreamSynchronize(h->stream3); hipStreamDestroy(h->stream3); }
     for (auto e : h->ev_row)
@@ -1102,6 +1103,16 @@ static int ensemble_check(gpx_handle* const* members, int n) {
             return GPX_EARG;
         }
     return GPX_OK;
+}
+
+extern "C" int gpx_ensemble_predict(gpx_handle* const* members, int n_members, const double* Xc, int64_t M,
+                                    double* mu, double* s2, double* dmu, double* ds2) {
+    if (ensemble_check(members, n_members)) return GPX_EARG;
+    gpx_handle* h = members[0];
+    return guarded(h, [&]() -> int {
+        if (!mu || !s2 || !dmu || !ds2) return fail(h, GPX_EARG, "ensemble_predict: all four outputs are required");
+        return gpx::ensemble_predict_grad_host(members, n_members, Xc, M, mu, s2, dmu, ds2);
+    });
 }
 
 extern "C" int gpx_ensemble_sweep_dev(gpx_handle* const* members, int n_members, int acq_id, const double* params,

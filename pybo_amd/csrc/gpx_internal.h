@@ -60,6 +60,8 @@ struct gpx_handle {
     double* da = nullptr;     // (Np,) a = T (y - bias)
     double* dalpha = nullptr; // (Np,) alpha = U a
     double* dinvell = nullptr;// (DMAX,) 1/ell
+    double* hpin = nullptr;   // pinned host staging of predict-with-gradients (GB points)
+    int64_t cap_hpin = 0;
     char* dsmall = nullptr;   // ONE allocation behind dflag / dscal / dinvell
     int* dflag = nullptr;     // [0] = failing pivot + 1 (0 = ok)
     double* dscal = nullptr;  // small scalar scratch (16 doubles)
@@ -159,6 +161,8 @@ void launch_topk_merge(hipStream_t s, double* vals, int64_t* idx, int64_t n, int
 int64_t topk_blocks(int64_t M);
 
 // predict with gradients (small M path)
+int ensemble_predict_grad_host(gpx_handle* const* mem, int n, const double* Xc, int64_t M, double* mu, double* s2,
+                               double* dmu, double* ds2);
 int predict_grad_host(gpx_handle* h, const double* Xc, int64_t M, double* mu, double* s2, double* dmu,
                       double* ds2);
 

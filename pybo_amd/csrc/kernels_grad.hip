@@ -170,12 +170,11 @@ __global__ __launch_bounds__(256) void k_grad_reduce(const double* __restrict__ 
     }
 }
 
-int predict_grad_host(gpx_handle* h, const double* Xc, int64_t M, double* mu, double* s2, double* dmu,
-                      double* ds2) {
-    if (!h->fitted) { h->err = "predict: model is not fitted"; return GPX_ESTATE; }
-    if (!Xc || M < 1) { h->err = "predict: need M >= 1 points"; return GPX_EARG; }
+// One chunk (mb <= GB points) of predict-with-gradients, ENQUEUED on the handle's stream: upload, the four kernels,
+// download into the handle's pinned staging buffer.  No synchronisation: the ensemble entry point enqueues a chunk on
+// every member's stream before it waits for any of them.
+static int predict_grad_enqueue(gpx_handle* h, const double* Xc, int mb) {
     if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return GPX_EHIP; }
-    if (int rc0 = ensure_inverse(h)) return rc0;
     hipStream_t s = h->stream;
     const int64_t Np = h->Np, N = h->N;
     const int d = (int)h->d;
@@ -192,42 +191,94 @@ int predict_grad_host(gpx_handle* h, const double* Xc, int64_t M, double* mu, do
         }
         h->cap_grad = need;
     }
+    if (GB * per > h->cap_hpin) {     // pinned: a pageable destination would make the download synchronous
+        if (h->hpin) hipHostFree(h->hpin);
+        h->hpin = nullptr;
+        h->cap_hpin = 0;
+        if (hipHostMalloc((void**)&h->hpin, (size_t)GB * per * 8, hipHostMallocDefault) != hipSuccess) {
+            h->err = "predict: pinned host allocation failed";
+            return GPX_EOOM;
+        }
+        h->cap_hpin = GB * per;
+    }
     double* dX = h->dgrad;
     double* dks = dX + GB * d;
     double* dg = dks + GB * Np;
     double* dV = dg + GB * Np;
     double* dw = dV + GB * Np;
     double* dout = dw + GB * Np;
-    std::vector<double> host((size_t)GB * per);
     const unsigned rows4 = (unsigned)((Np + 3) / 4);
-    for (int64_t m0 = 0; m0 < M; m0 += GB) {
-        const int mb = (int)std::min<int64_t>(GB, M - m0);
-        if (hipMemcpyAsync(dX, Xc + m0 * d, (size_t)mb * d * 8, hipMemcpyHostToDevice, s) != hipSuccess) {
-            h->err = "predict: H2D copy failed";
-            return GPX_EHIP;
-        }
-        hipLaunchKernelGGL(k_kstar, dim3((unsigned)((Np + 255) / 256), (unsigned)mb), dim3(256), 0, s, h->dXs,
-                           N, Np, d, dX, h->dinvell, h->kernel_id, h->rho, dks, dg);
-        launch_tri_matvec_multi(s, rows4, h->dT, Np, N, dks, mb, 0, dV);
-        launch_tri_matvec_multi(s, rows4, h->dU, Np, N, dV, mb, 1, dw);
-        hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)(d + 1), (unsigned)mb), dim3(256), 0, s, h->dXs, N, Np,
-                           d, dX, h->dinvell, dg, dV, dw, h->da, h->dalpha, h->rho, h->bias, dout);
-        if (hipMemcpyAsync(host.data(), dout, (size_t)mb * per * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
-            hipStreamSynchronize(s) != hipSuccess) {
-            h->err = "predict: D2H copy failed";
-            return GPX_EHIP;
-        }
-        for (int m = 0; m < mb; ++m) {
-            const double* o = host.data() + (size_t)m * per;
-            mu[m0 + m] = o[0];
-            s2[m0 + m] = o[1];
-            for (int j = 0; j < d; ++j) {
-                dmu[(m0 + m) * d + j] = o[2 + j];
-                ds2[(m0 + m) * d + j] = o[2 + d + j];
-            }
+    if (hipMemcpyAsync(dX, Xc, (size_t)mb * d * 8, hipMemcpyHostToDevice, s) != hipSuccess) {
+        h->err = "predict: H2D copy failed";
+        return GPX_EHIP;
+    }
+    hipLaunchKernelGGL(k_kstar, dim3((unsigned)((Np + 255) / 256), (unsigned)mb), dim3(256), 0, s, h->dXs,
+                       N, Np, d, dX, h->dinvell, h->kernel_id, h->rho, dks, dg);
+    launch_tri_matvec_multi(s, rows4, h->dT, Np, N, dks, mb, 0, dV);
+    launch_tri_matvec_multi(s, rows4, h->dU, Np, N, dV, mb, 1, dw);
+    hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)(d + 1), (unsigned)mb), dim3(256), 0, s, h->dXs, N, Np,
+                       d, dX, h->dinvell, dg, dV, dw, h->da, h->dalpha, h->rho, h->bias, dout);
+    if (hipMemcpyAsync(h->hpin, dout, (size_t)mb * per * 8, hipMemcpyDeviceToHost, s) != hipSuccess) {
+        h->err = "predict: D2H copy failed";
+        return GPX_EHIP;
+    }
+    return GPX_OK;
+}
+
+// wait for the chunk and scatter it into the caller's arrays
+static int predict_grad_collect(gpx_handle* h, int mb, double* mu, double* s2, double* dmu, double* ds2) {
+    if (hipStreamSynchronize(h->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+        h->err = "predict: kernel launch or copy failed";
+        return GPX_EHIP;
+    }
+    const int d = (int)h->d;
+    const int64_t per = 2 + 2 * d;
+    for (int m = 0; m < mb; ++m) {
+        const double* o = h->hpin + (size_t)m * per;
+        mu[m] = o[0];
+        s2[m] = o[1];
+        for (int j = 0; j < d; ++j) {
+            dmu[(int64_t)m * d + j] = o[2 + j];
+            ds2[(int64_t)m * d + j] = o[2 + d + j];
         }
     }
-    if (hipGetLastError() != hipSuccess) { h->err = "predict: kernel launch failed"; return GPX_EHIP; }
+    return GPX_OK;
+}
+
+int predict_grad_host(gpx_handle* h, const double* Xc, int64_t M, double* mu, double* s2, double* dmu,
+                      double* ds2) {
+    if (!h->fitted) { h->err = "predict: model is not fitted"; return GPX_ESTATE; }
+    if (!Xc || M < 1) { h->err = "predict: need M >= 1 points"; return GPX_EARG; }
+    if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return GPX_EHIP; }
+    if (int rc0 = ensure_inverse(h)) return rc0;
+    const int d = (int)h->d;
+    for (int64_t m0 = 0; m0 < M; m0 += GB) {
+        const int mb = (int)std::min<int64_t>(GB, M - m0);
+        if (int rc = predict_grad_enqueue(h, Xc + m0 * d, mb)) return rc;
+        if (int rc = predict_grad_collect(h, mb, mu + m0, s2 + m0, dmu + m0 * d, ds2 + m0 * d)) return rc;
+    }
+    return GPX_OK;
+}
+
+// The same for every member of a hyper-parameter ensemble: outputs (n, M) / (n, M, d), member-major.  Each chunk is
+// enqueued on ALL members' streams before the first wait, so the members' latency-bound kernels overlap.
+int ensemble_predict_grad_host(gpx_handle* const* mem, int n, const double* Xc, int64_t M, double* mu, double* s2,
+                               double* dmu, double* ds2) {
+    gpx_handle* h0 = mem[0];
+    if (!Xc || M < 1) { h0->err = "ensemble_predict: need M >= 1 points"; return GPX_EARG; }
+    const int d = (int)h0->d;
+    for (int i = 0; i < n; ++i) {
+        if (!mem[i]->fitted) { h0->err = "ensemble_predict: a member is not fitted"; return GPX_ESTATE; }
+        if (int rc0 = ensure_inverse(mem[i])) { if (mem[i] != h0) h0->err = mem[i]->err; return rc0; }
+    }
+    for (int64_t m0 = 0; m0 < M; m0 += GB) {
+        const int mb = (int)std::min<int64_t>(GB, M - m0);
+        for (int i = 0; i < n; ++i)
+            if (int rc = predict_grad_enqueue(mem[i], Xc + m0 * d, mb)) { if (mem[i] != h0) h0->err = mem[i]->err; return rc; }
+        for (int i = 0; i < n; ++i)
+            if (int rc = predict_grad_collect(mem[i], mb, mu + i * M + m0, s2 + i * M + m0, dmu + (i * M + m0) * d,
+                                              ds2 + (i * M + m0) * d)) { if (mem[i] != h0) h0->err = mem[i]->err; return rc; }
+    }
     return GPX_OK;
 }
 

@@ -26,6 +26,7 @@ the CPU tests drive it with the oracle model.
 import math
 
 import numpy as np
+from scipy.special import erfc
 
 from ..utils import rstate
 from .priors import log_prior
@@ -258,6 +259,17 @@ class MCMC(object):
             raise RuntimeError('the model has no data yet')
         return self._members
 
+    def _member_grads(self, X):
+        """(mu, s2, dmu, ds2) of every member, member-major: one device call for device members
+        (gpx_ensemble_predict: their kernels overlap on the members' streams), a loop otherwise."""
+        X = np.array(X, ndmin=2, dtype=float)
+        engines = self._engines() if len(X) else None
+        if engines is not None:
+            from .._lib import Engine
+            return Engine.ensemble_predict(engines, X)
+        posts = [m.predict(X, True) for m in self._need()]
+        return tuple(np.array([p[i] for p in posts]) for i in range(4))
+
     def predict(self, X, grad=False):
         engines = None if grad else self._engines()
         if engines is not None:                      # mixture moments formed on the device
@@ -265,15 +277,16 @@ class MCMC(object):
             out = Engine.ensemble_sweep(engines, 'mean', None, np.array(X, ndmin=2, dtype=float), k=0,
                                         want_all=False, want_moments=True)
             return out['mu'], out['s2']
-        posts = [m.predict(X, grad) for m in self._need()]
-        mus = np.array([p[0] for p in posts])
-        s2s = np.array([p[1] for p in posts])
+        if grad:
+            mus, s2s, dmus, ds2s = self._member_grads(X)
+        else:
+            posts = [m.predict(X, False) for m in self._need()]
+            mus = np.array([p[0] for p in posts])
+            s2s = np.array([p[1] for p in posts])
         mu = mus.mean(axis=0)
         s2 = np.maximum((s2s + mus ** 2).mean(axis=0) - mu ** 2, 0.0)
         if not grad:
             return mu, s2
-        dmus = np.array([p[2] for p in posts])
-        ds2s = np.array([p[3] for p in posts])
         dmu = dmus.mean(axis=0)
         ds2 = (ds2s + 2.0 * mus[:, :, None] * dmus).mean(axis=0) - 2.0 * mu[:, None] * dmu
         return mu, s2, dmu, ds2
@@ -284,6 +297,20 @@ class MCMC(object):
             from .._lib import Engine
             kind = {'get_improvement': 'ei', 'get_tail': 'pi'}[name]
             return Engine.ensemble_sweep(engines, kind, target, np.array(X, ndmin=2, dtype=float), k=0)['acq']
+        if grad and self._engines() is not None and len(np.atleast_2d(X)):
+            # device members: all members' moments and gradients in one call, the closed forms vectorised over them
+            mu, s2, dmu, ds2 = self._member_grads(X)
+            s = np.sqrt(s2)
+            z = (mu - target) / s
+            cdf = 0.5 * erfc(-z * 0.70710678118654752440)
+            pdf = 0.39894228040143267794 * np.exp(-0.5 * z * z)
+            if name == 'get_improvement':
+                val = (mu - target) * cdf + s * pdf
+                g = cdf[:, :, None] * dmu + (0.5 * pdf / s)[:, :, None] * ds2
+            else:
+                val = cdf
+                g = pdf[:, :, None] * (dmu / s[:, :, None] - (0.5 * z / s2)[:, :, None] * ds2)
+            return val.mean(axis=0), g.mean(axis=0)
         outs = [getattr(m, name)(target, X, grad) for m in self._need()]
         if not grad:
             return np.mean(outs, axis=0)

@@ -205,3 +205,38 @@ def test_lockstep_refinement_on_the_device_equals_sequential():
     xb, fb_ = solvers.solve_lbfgs(index, bounds, nbest=5, xgrid=grid, select='best', batched=True)
     np.testing.assert_array_equal(xa, xb)
     assert fa == fb_
+
+
+@pytest.mark.parametrize('N,d,kernel,M', [(150, 2, 'se', 5), (300, 3, 'matern5', 37)])
+def test_ensemble_predict_equals_the_members_own_gradients(N, d, kernel, M):
+    """gpx_ensemble_predict: every member's moments and gradients in one call (the members' kernels overlap on their
+    own streams) are BITWISE what gpx_predict gives member by member, and match the oracle; the ensemble's
+    get_improvement / get_tail / predict with grad=True built on it equal the member loop."""
+    from pybo_amd._lib import Engine, GpxError
+    from pybo_amd.models.mcmc import MCMC
+    dev, ref = _members(N, d, kernel, seed=7 * N + d)
+    Z = np.random.RandomState(9).rand(M, d)
+    engines = [g._engine() for g in dev]
+    mu, s2, dmu, ds2 = Engine.ensemble_predict(engines, Z)
+    assert mu.shape == (len(dev), M) and ds2.shape == (len(dev), M, d)
+    for i, (g, r) in enumerate(zip(dev, ref)):
+        own = g._engine().predict(Z, grad=True)
+        for got, o in zip((mu[i], s2[i], dmu[i], ds2[i]), own):
+            np.testing.assert_array_equal(got, o)
+        want = r.predict(Z, grad=True)
+        np.testing.assert_allclose(dmu[i], want[2], rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(ds2[i], want[3], rtol=1e-6, atol=1e-8)
+    ens = MCMC.__new__(MCMC)                       # an ensemble over exactly these members (no sampling)
+    ens._proto, ens._members = dev[0], dev
+    for name, target in (('get_improvement', 0.4), ('get_tail', 0.3)):
+        f, gr = getattr(ens, name)(target, Z, grad=True)
+        loop = [getattr(m, name)(target, Z, True) for m in dev]
+        np.testing.assert_allclose(f, np.mean([o[0] for o in loop], axis=0), rtol=1e-13, atol=1e-300)
+        np.testing.assert_allclose(gr, np.mean([o[1] for o in loop], axis=0), rtol=1e-12, atol=1e-15)
+    got = ens.predict(Z, grad=True)
+    posts = [m.predict(Z, True) for m in dev]
+    mus, dmus = np.array([p[0] for p in posts]), np.array([p[2] for p in posts])
+    np.testing.assert_allclose(got[0], mus.mean(0), rtol=1e-14)
+    np.testing.assert_allclose(got[2], dmus.mean(0), rtol=1e-13, atol=1e-16)
+    with pytest.raises(GpxError):
+        Engine.ensemble_predict(engines, np.zeros((0, d)))
