@@ -142,13 +142,14 @@ __device__ __forceinline__ double rsqrt_pf(double x) {
 // layout: lane (g = lane>>4, n = lane&15), register r -> element [g + 4r][n]).  That layout IS the B-operand
 // layout of the same instruction (step kk takes rows 4kk + g), and read as an A operand it is the transpose
 // -- so tiles feed the next MFMA straight from registers.  Wave w owns tile COLUMNS w and 7-w (9 upper tiles).
-// Step jb = 0..7 (right-looking):
+// Step jb = 0..7 (right-looking; the order in time is 2, 3 + 1 of the NEXT tile -- see the lookahead note at
+// pf16_factor / pf16_panel / pf16_trail):
 //   1. the owner of tile (jb,jb) factors the augmented [D | I] IN THE WAVE, in place in its accumulators
-//      (factor16 above: 4x4 pivot blocks, scalar 4x4 Cholesky, MFMA rank-4 updates) -- no LDS, no barrier
-//      inside the 16 pivots.  Out: R_d (upper) into the LDS image of R, T_d = R_d^-T (as its transpose,
-//      k-major) into a side array.
+//      (factor16 below: 4x4 pivot blocks, scalar 4x4 Cholesky, MFMA rank-4 updates) -- no LDS, no barrier
+//      inside the 16 pivots.  Out: R_d (upper) to global memory, T_d = R_d^-T (as its transpose, k-major) into
+//      a small LDS array.
 //   2. barrier; every wave: R[jb,c] = T_d * S[jb,c] for its columns c > jb (4 MFMAs, B straight from the
-//      accumulators), written into the LDS image (= the row panel).
+//      accumulators), written into the LDS row panel and to global memory.
 //   3. barrier; trailing update of its tiles (r,c), jb < r <= c: acc -= R[jb,r]^T R[jb,c], both operands k-major
 //      reads of the panel (4 MFMAs per tile).
 // 128 pivots cost 8 x ~1 us of in-wave chain instead of 64 barrier-separated pivot pairs on 256 threads that
