@@ -628,14 +628,8 @@ __global__ __launch_bounds__(256) void k_panel_solve16(const double* __restrict_
 //     S tile is read-modified-written once per W panels instead of once per panel (the K = 128 version
 //     is HBM-bound: 8 flop/B against a machine balance of ~12).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(const double* __restrict__ R,
-                                                                 double* __restrict__ S, int64_t Np,
-                                                                 int kb0, int kb1, int ib0, int jb0, int64_t bs) {
-    const int I = ib0 + blockIdx.y, J = jb0 + blockIdx.x;
-    if (I > J) return;
-    R += (int64_t)blockIdx.z * bs;       // batched use: blockIdx.z = batch element
-    S += (int64_t)blockIdx.z * bs;
-    __shared__ __attribute__((aligned(16))) double smem[GEMM_LDS_F64];
+__device__ __forceinline__ void syrk_tile(const double* __restrict__ R, double* __restrict__ S, int64_t Np, int kb0,
+                                          int kb1, int I, int J, double* smem) {
     const int64_t i0 = (int64_t)I * NB, j0 = (int64_t)J * NB;
     // accumulators start from the S tile (its loads overlap the first k-steps), A enters negated: acc = S - A B
     d4 acc[4][4];
@@ -652,6 +646,36 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(const double* _
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) S[(i0 + acc_row(i, r)) * Np + j0 + acc_col(j)] = acc[i][j][r];
+}
+
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(const double* __restrict__ R,
+                                                                 double* __restrict__ S, int64_t Np,
+                                                                 int kb0, int kb1, int ib0, int jb0, int64_t bs) {
+    const int I = ib0 + blockIdx.y, J = jb0 + blockIdx.x;
+    if (I > J) return;
+    R += (int64_t)blockIdx.z * bs;       // batched use: blockIdx.z = batch element
+    S += (int64_t)blockIdx.z * bs;
+    __shared__ __attribute__((aligned(16))) double smem[GEMM_LDS_F64];
+    syrk_tile(R, S, Np, kb0, kb1, I, J, smem);
+}
+
+// The same over the upper triangle of the t x t block region at (ib0, ib0) as a ONE-dimensional grid of exactly
+// t (t + 1) / 2 workgroups (row r holds the t - r tiles J = r .. t-1).  Workgroups go to the XCDs round-robin by
+// their linear index; in the square grid above (index = row * t + column, the lower half returning at once) a
+// region with t = 0 mod 8 sends whole tile COLUMNS to one XCD, and column J holds J + 1 tiles: at t = 56 the
+// busiest XCD carried 224 tiles against 175 on the idlest and set the launch's duration (the per-launch rate of the
+// trailing updates swung between 33 and 57 TFLOP/s with t mod 8 -- profiles/r02_far_update_launches.txt).
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update_tri(const double* __restrict__ R,
+                                                                     double* __restrict__ S, int64_t Np, int kb0,
+                                                                     int kb1, int ib0, int t) {
+    const int idx = blockIdx.x;
+    int r = (int)((2.0 * t + 1.0 - sqrt((2.0 * t + 1.0) * (2.0 * t + 1.0) - 8.0 * idx)) * 0.5);
+    if (r < 0) r = 0;
+    while (r > 0 && r * t - r * (r - 1) / 2 > idx) --r;             // (the float estimate is off by at most one)
+    while ((r + 1) * t - (r + 1) * r / 2 <= idx) ++r;
+    const int c = r + idx - (r * t - r * (r - 1) / 2);
+    __shared__ __attribute__((aligned(16))) double smem[GEMM_LDS_F64];
+    syrk_tile(R, S, Np, kb0, kb1, ib0 + r, ib0 + c, smem);
 }
 
 // Row update on 64x64 tiles: block rows I .. I+nrows-1 (two 64-row halves each) <- rows kb0..kb1-1 of R.
@@ -762,8 +786,8 @@ void launch_cholesky(gpx_handle* h) {
             mid_pending = true;
             side_used = true;
             if (nrest > 0 && far)
-                hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)nrest, (unsigned)nrest), dim3(GEMM_THREADS), 0, s2,
-                                   h->dR, h->dS, Np, P0, P1, r0, r0, (int64_t)0);
+                hipLaunchKernelGGL(k_syrk_update_tri, dim3((unsigned)(nrest * (nrest + 1) / 2)), dim3(GEMM_THREADS), 0,
+                                   s2, h->dR, h->dS, Np, P0, P1, r0, nrest);
         }
     }
     if (side_used) {   // join: everything queued on the side stream is done before the caller's stream goes on
