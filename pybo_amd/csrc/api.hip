@@ -189,8 +189,10 @@ int gpx::ensure_side_streams(gpx_handle* h) {
     for (auto& e : h->ev_row) ok_ev = ok_ev && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     if (!ok_ev || hipStreamCreateWithPriority(&h->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithPriority(&h->stream4, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_chain, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_far, hipEventDisableTiming) != hipSuccess)
+        hipEventCreateWithFlags(&h->ev_far, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_rest, hipEventDisableTiming) != hipSuccess)
         return fail(h, GPX_EHIP, "side stream / event creation failed");
     return GPX_OK;
 }
@@ -208,6 +210,8 @@ extern "C" int gpx_destroy(gpx_handle* h) {
     if (h->hpin) hipHostFree(h->hpin);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
     if (h->stream3) { hipStreamSynchronize(h->stream3); hipStreamDestroy(h->stream3); }
+    if (h->stream4) { hipStreamSynchronize(h->stream4); hipStreamDestroy(h->stream4); }
+    if (h->ev_rest) hipEventDestroy(h->ev_rest);
     for (auto e : h->ev_row)
         if (e) hipEventDestroy(e);
     if (h->ev_chain) hipEventDestroy(h->ev_chain);

@@ -31,7 +31,8 @@ struct gpx_handle {
     bool own_stream = false;
     hipStream_t stream2 = nullptr;   // library-owned side stream (Cholesky lookahead: far trailing updates, low priority)
     hipStream_t stream3 = nullptr;   // library-owned side stream (rows 2..4 of the next panel's near update, normal priority)
-    hipEvent_t ev_chain = nullptr, ev_far = nullptr;
+    hipStream_t stream4 = nullptr;   // library-owned side stream (mid(P): the next-but-one panel's rows, low priority)
+    hipEvent_t ev_chain = nullptr, ev_far = nullptr, ev_rest = nullptr;
     hipEvent_t ev_row[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int x_skip = 0;               // diagnostic: time parts of the factorisation alone (see launch_cholesky)
     int chol_w = 0;               // outer panel width of the factorisation in 128-blocks (2..8; 0 = by size)

@@ -714,9 +714,10 @@ constexpr int CHOL_W = 4;   // outer panel width in 128-blocks
 //              k_panel_solve16.  Serial and latency-bound (~85-100 us per 128-block), uses a handful of CUs.
 //   near(P)    U(P+1, P), row by row on 64x64 tiles: its first block row on the main stream (the next diagonal
 //              block needs it), the other rows in one launch on a third stream while the chain works on that row.
-//   mid(P)     U(P+2, P): first thing on the side stream; near(P+1) touches the same rows and waits for it.
-//   rest(P)    U(Q >= P+3, P): the bulk, streams back-to-back on the (low-priority) side stream and only
-//              has to be finished before mid(P+1) -- which follows it in stream order anyway.
+//   mid(P)     U(P+2, P) on a fourth (low-priority) stream, after rest(P-1), which wrote the same rows; near(P+1)
+//              touches those rows next and waits for it.
+//   rest(P)    U(Q >= P+3, P): the bulk, back-to-back on the (low-priority) side stream, concurrently with mid(P)
+//              (disjoint block rows); it only has to be finished before mid(P+1) and rest(P+1).
 // So the critical path never waits for a whole trailing update, only for the W block rows it is about to use.
 void launch_cholesky(gpx_handle* h) {
     const int64_t Np = h->Np;
@@ -730,7 +731,8 @@ void launch_cholesky(gpx_handle* h) {
     // diagnostic (option "x_skip", scripts/chol_parts.py): leave out the far updates (bit 0), the chain kernels
     // (bit 1) or the near updates (bit 2) to time the parts alone -- the results are then NOT a factorisation
     const bool far = !(h->x_skip & 1), chain = !(h->x_skip & 2), near = !(h->x_skip & 4);
-    bool mid_pending = false, side_used = false;
+    bool mid_pending = false, side_used = false, rest_used = false;
+    hipStream_t s4 = h->stream4;
     int near_rows = 0;            // rows P0+1.. of the CURRENT panel whose near update runs on the third stream
     for (int P0 = 0; P0 < nP; P0 += CW) {
         const int P1 = (P0 + CW < nP) ? P0 + CW : nP;
@@ -778,21 +780,31 @@ void launch_cholesky(gpx_handle* h) {
             }
         }
         if (nmid > 0) {
-            hipStreamWaitEvent(s2, h->ev_chain, 0);
+            // mid(P) and rest(P) touch disjoint block rows and both follow rest(P-1) (which wrote all of them): they
+            // run CONCURRENTLY, mid on a fourth stream -- alone on the side stream its <= 4 x 56 tiles (one workgroup
+            // per CU) held the chip for 150-190 us per panel before the big update could start.
+            hipStreamWaitEvent(s4, h->ev_chain, 0);
+            if (rest_used) hipStreamWaitEvent(s4, h->ev_rest, 0);          // rest(P-1) wrote mid(P)'s rows
             if (far)
-                hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)(nP - m0), (unsigned)nmid), dim3(GEMM_THREADS), 0, s2,
+                hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)(nP - m0), (unsigned)nmid), dim3(GEMM_THREADS), 0, s4,
                                h->dR, h->dS, Np, P0, P1, m0, m0, (int64_t)0);
-            hipEventRecord(h->ev_far, s2);
+            hipEventRecord(h->ev_far, s4);
             mid_pending = true;
             side_used = true;
-            if (nrest > 0 && far)
-                hipLaunchKernelGGL(k_syrk_update_tri, dim3((unsigned)(nrest * (nrest + 1) / 2)), dim3(GEMM_THREADS), 0,
-                                   s2, h->dR, h->dS, Np, P0, P1, r0, nrest);
+            if (nrest > 0) {
+                hipStreamWaitEvent(s2, h->ev_chain, 0);
+                if (far)
+                    hipLaunchKernelGGL(k_syrk_update_tri, dim3((unsigned)(nrest * (nrest + 1) / 2)), dim3(GEMM_THREADS),
+                                       0, s2, h->dR, h->dS, Np, P0, P1, r0, nrest);
+                hipEventRecord(h->ev_rest, s2);
+                rest_used = true;
+            }
         }
     }
-    if (side_used) {   // join: everything queued on the side stream is done before the caller's stream goes on
-        hipEventRecord(h->ev_far, s2);
+    if (side_used) {   // join: everything queued on the side streams is done before the caller's stream goes on
+        hipEventRecord(h->ev_far, s4);
         hipStreamWaitEvent(s, h->ev_far, 0);
+        if (rest_used) hipStreamWaitEvent(s, h->ev_rest, 0);
     }
     // (stream 3 needs no join: every launch on it is followed by an event the main stream has waited on)
     // only the 16x16 inverses are in the diagonal blocks of T / U so far; launch_trtri completes them
