@@ -1,0 +1,51 @@
+"""The bench.py contract the driver relies on, end to end on the device at a reduced candidate count: ONE JSON line
+with the metric / value / roofline / cpu_baseline fields (single rank), and the N > 1 launch path through
+torch.distributed.run (two gloo ranks sharing the one GPU of the box: same selected candidate as the single rank)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMMON = ['--workload', 'b', '--candidates', '131072', '--steps', '2', '--warmup', '1', '--warm-steps', '2']
+
+
+def _line(cmd):
+    out = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600,
+                         stdin=subprocess.DEVNULL)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    # (the gloo transport of the two-rank run prints its own "[Gloo] Rank ..." lines; bench.py prints ONE line)
+    lines = [l for l in out.stdout.decode().splitlines() if l.strip() and not l.startswith('[Gloo]')]
+    assert len(lines) == 1, lines                      # exactly one line on stdout, and it is JSON
+    return json.loads(lines[0])
+
+
+def test_single_rank_line_has_the_contract_fields():
+    o = _line([sys.executable, 'bench.py'] + COMMON + ['--cpu-candidates', '8192'])
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in o, key
+    assert o['n_gpus'] == 1 and o['steps'] == 2 and o['warmup'] == 1 and o['dtype'] == 'f64' and o['unit'] == 'steps/s'
+    assert abs(o['value'] * o['ms_per_step'] / 1e3 - 1.0) < 1e-9 and o['higher_is_better'] is True
+    assert o['vs_baseline'] is None and 'workload' in o['config'] and 'model' not in o['config']
+    r = o['roofline']
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    assert 0.05 < r['frac'] < 1.0
+    c = o['cpu_baseline']
+    assert c['kind'] == 'port' and c['cores'] >= 1 and c['value'] > 0 and 'sample' in c
+    assert {'cholesky', 'trtri'} <= set(o['roofline_fit']) and o['warm_step']['ms_per_step'] > 0
+    assert o['selected']['index'] >= 0
+
+
+def test_two_ranks_through_torch_distributed_run_select_the_same_candidate():
+    one = _line([sys.executable, 'bench.py'] + COMMON + ['--no-cpu-baseline', '--no-refine'])
+    two = _line([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+                 '--master-addr', '127.0.0.1', '--master-port', '29577', 'bench.py', '--gpus', '2', '--backend', 'gloo',
+                 '--share-device', '0'] + COMMON + ['--no-cpu-baseline', '--no-refine'])
+    assert two['n_gpus'] == 2 and two['scaling'] == 'strong'
+    assert two['selected'] == one['selected']          # bit-identical merged top-1 (value and global index)
+    assert two['warm_step']['selected'] == one['warm_step']['selected']
