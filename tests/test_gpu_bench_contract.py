@@ -3,6 +3,7 @@ with the metric / value / roofline / cpu_baseline fields (single rank), and the 
 torch.distributed.run (two gloo ranks sharing the one GPU of the box: same selected candidate as the single rank)."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -12,6 +13,14 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COMMON = ['--workload', 'b', '--candidates', '131072', '--steps', '2', '--warmup', '1', '--warm-steps', '2']
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def _line(cmd):
@@ -44,7 +53,7 @@ def test_single_rank_line_has_the_contract_fields():
 def test_two_ranks_through_torch_distributed_run_select_the_same_candidate():
     one = _line([sys.executable, 'bench.py'] + COMMON + ['--no-cpu-baseline', '--no-refine'])
     two = _line([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
-                 '--master-addr', '127.0.0.1', '--master-port', '29577', 'bench.py', '--gpus', '2', '--backend', 'gloo',
+                 '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), 'bench.py', '--gpus', '2', '--backend', 'gloo',
                  '--share-device', '0'] + COMMON + ['--no-cpu-baseline', '--no-refine'])
     assert two['n_gpus'] == 2 and two['scaling'] == 'strong'
     assert two['selected'] == one['selected']          # bit-identical merged top-1 (value and global index)
