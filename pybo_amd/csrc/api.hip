@@ -861,7 +861,7 @@ static int rff_core(gpx_handle* h, const double* W, const double* b, const doubl
     }
     {
         Span sp(h, T_RFF);
-        launch_rff_mfma(s, dWt, dbt, dtt, (int)S, (int)nfb, (int)d, (int)dp, bias, dXc, M, d_vals);
+        launch_rff_mfma(s, dWt, dbt, dtt, (int)S, (int)nfb, (int)n, (int)d, (int)dp, bias, dXc, M, d_vals);
     }
     if (k > 0) {
         const int64_t nblk = topk_blocks(M);

@@ -177,7 +177,7 @@ int rff_grad_host(gpx_handle* h, const double* W, const double* b, const double*
                   double bias, const double* Xc, int64_t M, double* f, double* g);
 
 // launchers (kernels_rff.hip)
-void launch_rff_mfma(hipStream_t s, const double* Wt, const double* bt, const double* tt, int S, int nfb, int d,
+void launch_rff_mfma(hipStream_t s, const double* Wt, const double* bt, const double* tt, int S, int nfb, int n, int d,
                      int dp, double bias, const double* Xc, int64_t M, double* vals);
 int64_t rff_gram_batch_scratch(int64_t S, int64_t Np);
 void launch_rff_posterior(hipStream_t s, const double* A, const double* v, const double* z, int S, int n, double sc,

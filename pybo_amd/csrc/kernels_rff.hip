@@ -49,20 +49,23 @@ __device__ __forceinline__ double cos_cw(double z) {
 
 // Wt:  [S][nfb][dp][128]   feature tiles, k-major (zero padded);  bt, tt: [S][nfb][128]
 // grid (ceil(M/128)): one workgroup per 128-candidate tile, looping over all S draws.
+// Wave layout 4 x 1: wave w owns candidate rows 32w .. 32w+31 and ALL 128 feature columns of the tile (2 x 8
+// accumulators), so that the 16-column groups beyond the draw's n features are skipped by every wave alike --
+// n = 100 (the Thompson default) uses 7 of 8 groups: 12.5 % fewer MFMAs and cosines than the padded tile; with the
+// 2 x 2 layout of the GEMM engine only the waves of the right half could have skipped, and the workgroup would
+// have waited for the others.  A row's sum over the features then lives in ONE wave (16-lane reduction, no LDS).
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_rff_mfma(const double* __restrict__ Wt,
                                                               const double* __restrict__ bt,
-                                                              const double* __restrict__ tt, int S, int nfb,
+                                                              const double* __restrict__ tt, int S, int nfb, int n,
                                                               int d, int dp, double bias,
                                                               const double* __restrict__ Xc, int64_t M,
                                                               double* __restrict__ vals) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];   // At[dp][LDT] | Bt[dp][LDT] | red[2][128]
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // At[dp][LDT] | Bt[dp][LDT]
     // (single-buffered feature tile: 2*dp*144*8 B = 74 KB at d = 32, so TWO workgroups share a CU and hide
     //  each other's tile loads and cosine chains; a double-buffered tile would leave one workgroup per CU)
     double* At = lds;
     double* Bt = lds + dp * LDT;
-    double* red = Bt + dp * LDT;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int wm = w >> 1, wn = w & 1;
     const int64_t m0 = (int64_t)blockIdx.x * TB;
     // candidate tile, transposed into k-major once (lane <-> candidate: conflict-free LDS stores)
     for (int e = t; e < TB * dp; e += GEMM_THREADS) {
@@ -80,49 +83,54 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_rff_mfma(const double* __re
             *reinterpret_cast<d2*>(dst + k * LDT + c) = *reinterpret_cast<const d2*>(Wtile + (int64_t)k * TB + c);
         }
     };
-    double rowsum[4][4];
+    double rowsum[2][4];
     for (int tile = 0; tile < ntile; ++tile) {
         const int fb = tile % nfb, s = tile / nfb;
+        const int nv = min(TB, n - fb * TB);          // features of this tile that exist
+        const int jt = (nv + 15) >> 4;                // ... in 16-column groups (uniform)
         load_b(tile);
         __syncthreads();   // feature tile (and, first time, the candidate tile) complete
         if (fb == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rowsum[i][r] = 0.0;
         }
-        d4 acc[4][4];
-        acc_zero(acc);
-        const double* as = At + wm * 64 + fr;
-        const double* bs = Bt + wn * 64 + fr;
+        d4 acc[2][8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+        const double* as = At + w * 32 + fr;
+        const double* bs = Bt + fr;
         for (int kk = 0; kk < dp / 4; ++kk) {
             const int kr = kk * 4 + fk;
-            double a[4], b[4];
+            const double a0 = as[kr * LDT], a1 = as[kr * LDT + 16];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = as[kr * LDT + i * 16];
-                b[i] = bs[kr * LDT + i * 16];
+            for (int j = 0; j < 8; ++j) {
+                if (j < jt) {
+                    const double b = bs[kr * LDT + j * 16];
+                    acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1][j], 0, 0, 0);
+                }
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        const double* bb = bt + (int64_t)tile * TB + wn * 64 + fr;
-        const double* th = tt + (int64_t)tile * TB + wn * 64 + fr;
+        const double* bb = bt + (int64_t)tile * TB + fr;
+        const double* th = tt + (int64_t)tile * TB + fr;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const double bj = bb[j * 16], tj = th[j * 16];
+        for (int j = 0; j < 8; ++j) {
+            if (j < jt) {
+                const double bj = bb[j * 16], tj = th[j * 16];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) rowsum[i][r] = fma(tj, cos_cw(acc[i][j][r] + bj), rowsum[i][r]);
+                    for (int r = 0; r < 4; ++r) rowsum[i][r] = fma(tj, cos_cw(acc[i][j][r] + bj), rowsum[i][r]);
+            }
         }
         if (fb == nfb - 1) {
-            // draw s complete: reduce over the 16 lanes sharing a row, then over the two column-waves
+            // draw s complete: reduce over the 16 lanes sharing a row; the row lives in this wave alone
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     double v = rowsum[i][r];
@@ -130,26 +138,22 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_rff_mfma(const double* __re
                     v += __shfl_xor(v, 2);
                     v += __shfl_xor(v, 4);
                     v += __shfl_xor(v, 8);
-                    if (fr == 0) red[wn * TB + wm * 64 + i * 16 + fk + 4 * r] = v;
+                    const int64_t gm = m0 + w * 32 + i * 16 + fk + 4 * r;
+                    if (fr == 0 && gm < M) vals[(int64_t)s * M + gm] = bias + v;
                 }
-            __syncthreads();
-            if (t < TB) {
-                const int64_t gm = m0 + t;
-                if (gm < M) vals[(int64_t)s * M + gm] = bias + red[t] + red[TB + t];
-            }
         }
-        __syncthreads();   // everyone is done with this feature tile (and red): it may be overwritten
+        __syncthreads();   // everyone is done with this feature tile: it may be overwritten
     }
 }
 
 // device staging layout for the MFMA path: [Wt S*nfb*dp*128][bt S*nfb*128][tt S*nfb*128]
-void launch_rff_mfma(hipStream_t s, const double* Wt, const double* bt, const double* tt, int S, int nfb, int d,
+void launch_rff_mfma(hipStream_t s, const double* Wt, const double* bt, const double* tt, int S, int nfb, int n, int d,
                      int dp, double bias, const double* Xc, int64_t M, double* vals) {
     dim3 grid((unsigned)((M + TB - 1) / TB));
-    const size_t ldsb = (size_t)(2 * dp * LDT + 2 * TB) * sizeof(double);
+    const size_t ldsb = (size_t)(2 * dp * LDT) * sizeof(double);
     if (ldsb > 64 * 1024)
         hipFuncSetAttribute((const void*)k_rff_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    hipLaunchKernelGGL(k_rff_mfma, grid, dim3(GEMM_THREADS), ldsb, s, Wt, bt, tt, S, nfb, d, dp, bias, Xc, M,
+    hipLaunchKernelGGL(k_rff_mfma, grid, dim3(GEMM_THREADS), ldsb, s, Wt, bt, tt, S, nfb, n, d, dp, bias, Xc, M,
                        vals);
 }
 
