@@ -187,6 +187,30 @@ def test_rff_posterior_sample_tracks_the_posterior_mean():
     np.testing.assert_allclose(g[:, 0], (fp - fm) / 2e-6, rtol=1e-5, atol=1e-7)
 
 
+def test_rff_posterior_draws_have_the_posterior_variance():
+    """sample_f is a POSTERIOR draw (reggie's semantics are recalled, not pinned: SURVEY F-notes): across many
+    independent draws the pointwise mean and variance must be the exact GP posterior's, also away from the data,
+    where the variance is large -- a sampler that returned the mean, or prior draws, fails this."""
+    rng = np.random.RandomState(3)
+    X = 0.5 * rng.rand(30, 1)                                 # data in [0, 0.5] only
+    y = np.sin(6.0 * X[:, 0]) + 0.05 * rng.randn(30)
+    gp = gp_ref.make_gp(2.5e-3, 1.0, [0.15], 0.0)
+    gp.add_data(X, y)
+    Z = np.linspace(0.1, 1.0, 19)[:, None]                    # interpolation and extrapolation
+    mu, s2 = gp.predict(Z)
+    S = 300
+    draws = np.array([gp.sample_f(600, rng=1000 + s).get(Z) for s in range(S)])
+    sd = np.sqrt(s2)
+    # mean: within 4 standard errors (+ the random-feature approximation error of the kernel, ~ 1/sqrt(n))
+    assert np.all(np.abs(draws.mean(0) - mu) <= 4.0 * sd / np.sqrt(S) + 0.05)
+    # variance: where the posterior is not degenerate the ratio is 1 within Monte-Carlo + feature-map error
+    wide = s2 > 0.05
+    assert wide.sum() >= 5 and (~wide).sum() >= 3
+    ratio = draws.var(0, ddof=1)[wide] / s2[wide]
+    assert np.all((ratio > 0.7) & (ratio < 1.35)), ratio
+    assert np.all(draws.var(0, ddof=1)[~wide] < 0.1)          # and tight where the data pin the function
+
+
 def test_topk_rule():
     v = np.array([1.0, 3.0, np.nan, 3.0, 2.0, -np.inf])
     assert list(gp_ref.topk_desc(v, 4)) == [1, 3, 4, 0]
