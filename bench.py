@@ -106,38 +106,146 @@ def ucb_beta(nobs, delta=0.1, xi=0.2):
 
 def cpu_baseline(w, budget_candidates):
     """Time the CPU restatement (oracle/, numpy+scipy on the host's BLAS threads) on a bounded sample:
-    the fit in full, the sweep on `budget_candidates` of the M candidates, extrapolated linearly."""
+    the fit in full, the sweep on `budget_candidates` of the M candidates, extrapolated linearly.
+    Returns (the cpu_baseline record, the oracle's values on the sample for the parity record)."""
     from oracle import gp_ref
+    threads, limiter = len(os.sched_getaffinity(0)), None
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
+        if os.environ.get('OMP_NUM_THREADS') == '1' and int(os.environ.get('WORLD_SIZE', '1')) > 1:
+            # torch.distributed.run pins OMP_NUM_THREADS=1 for multi-rank launches; the baseline (rank 0 only, the
+            # other ranks idle in a barrier) gets the host's cores back
+            limiter = threadpool_limits(limits=threads)
         threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
     except Exception:
-        threads = len(os.sched_getaffinity(0))
+        pass
     t0 = time.perf_counter()
     ref = gp_ref.make_gp(w['sn2'], w['rho'], w['ell'], w['bias'], w['kernel'])
     ref.add_data(w['X'], w['y'])
     t_fit = time.perf_counter() - t0
     Z = w['Xc'][:budget_candidates]
+    vals = {}
     t0 = time.perf_counter()
-    if w['acq'] == 'ei':
-        target = ref.mean_at_obs().max()
-        v = ref.get_improvement(target, Z)
-    elif w['acq'] == 'ucb':
+    if w['acq'] in ('ei', 'ucb'):
         mu, s2 = ref.predict(Z)
-        v = mu + np.sqrt(ucb_beta(w['N']) * s2)
+        if w['acq'] == 'ei':                    # the arithmetic of GPRef.get_improvement on the moments just formed
+            target = ref.mean_at_obs().max()
+            s = np.sqrt(s2)
+            z = (mu - target) / s
+            v = (mu - target) * gp_ref.norm_cdf(z) + s * gp_ref.norm_pdf(z)
+            vals['target'] = float(target)
+        else:
+            v = mu + np.sqrt(ucb_beta(w['N']) * s2)
+        vals.update(mu=mu, s2=s2)
     else:
         smp = ref.sample_f(100, rng=100)
         v = smp.get(Z)
-    int(np.argmax(v))
+    vals.update(acq=v, best=int(np.argmax(v)))
     t_sw = time.perf_counter() - t0
+    if limiter is not None:
+        limiter.restore_original_limits()
     step = t_fit + t_sw * (w['M'] / float(len(Z)))
     how = 'in full' if len(Z) == w['M'] else 'extrapolated linearly to M'
-    return dict(value=1.0 / step, unit='steps/s', cores=int(threads), kind='port',
-                sample='fit in full (N=%d: %.2f s) + sweep on %d of %d candidates (%.2f s), sweep %s; '
-                       'numpy/scipy on %d BLAS threads; host has %d logical cpus, %d in affinity'
-                       % (w['N'], t_fit, len(Z), w['M'], t_sw, how, threads, os.cpu_count(),
-                          len(os.sched_getaffinity(0))),
-                extrapolated=len(Z) != w['M'], seconds_per_step=step)
+    rec = dict(value=1.0 / step, unit='steps/s', cores=int(threads), kind='port',
+               sample='fit in full (N=%d: %.2f s) + sweep on %d of %d candidates (%.2f s), sweep %s; '
+                      'numpy/scipy on %d BLAS threads; host has %d logical cpus, %d in affinity'
+                      % (w['N'], t_fit, len(Z), w['M'], t_sw, how, threads, os.cpu_count(),
+                         len(os.sched_getaffinity(0))),
+               extrapolated=len(Z) != w['M'], seconds_per_step=step)
+    return rec, vals
+
+
+def parity_record(w, ref_vals, dev_vals):
+    """What BASELINE.md section 4 promised beside the CPU timing: the device's values against the oracle's on the
+    candidates the oracle was timed on -- max relative error of mu, s2 and the acquisition, and whether both pick
+    the same candidate of the sample.  Relative errors use the stated tolerance ladder's floors:
+    |d mu| / (|mu| + 1e-3 sqrt(rho)), |d s2| / (s2 + 1e-4 rho), acquisition where it is within 1e-9 of its maximum."""
+    rho = w['rho']
+    out = {'n_compared': int(len(ref_vals['acq'])), 'against': 'oracle/gp_ref.py on the cpu_baseline sample'}
+    if 'mu' in ref_vals:
+        mr, sr = ref_vals['mu'], ref_vals['s2']
+        out['max_rel_mu'] = float(np.max(np.abs(dev_vals['mu'] - mr) / (np.abs(mr) + 1e-3 * np.sqrt(rho))))
+        out['max_rel_s2'] = float(np.max(np.abs(dev_vals['s2'] - sr) / (sr + 1e-4 * rho)))
+        out['moments_within_stated_tolerance'] = bool(
+            np.all(np.abs(dev_vals['mu'] - mr) <= 1e-6 * np.abs(mr) + 1e-9 * np.sqrt(rho)) and
+            np.all(np.abs(dev_vals['s2'] - sr) <= 1e-6 * sr + 1e-10 * rho))
+    ar, ad = ref_vals['acq'], dev_vals['acq']
+    live = np.abs(ar) > 1e-9 * np.max(np.abs(ar))
+    out['max_rel_acq'] = float(np.max(np.abs(ad[live] - ar[live]) / np.abs(ar[live])))
+    out['n_acq_compared'] = int(live.sum())
+    out['selected_index_matches'] = bool(int(np.argmax(ad)) == ref_vals['best'])
+    out['selected_index'] = {'oracle': ref_vals['best'], 'device': int(np.argmax(ad))}
+    if 'target' in ref_vals:
+        out['abs_err_target'] = float(abs(dev_vals['target'] - ref_vals['target']))
+    return out
+
+
+def plugin_step(w, nsteps, k):
+    """One BO iteration THROUGH THE PLUGIN API at the workload size, end to end: `pybo_amd.solve_bayesopt` resumed
+    from a checkpoint that holds the N observations (model + trace, the reference's own resume path,
+    pybo/bayesopt.py:236-262), policy by name, solver 'lbfgs' over a grid resident in HBM, recommender 'latent',
+    checkpoint written every iteration.  An iteration = policy (model.copy + target) + solver (grid stage + L-BFGS-B
+    refinement of the best seed) + objective + model.add_data + recommender + checkpoint.  Timed from the objective
+    calls: the span between two consecutive calls is one full iteration's work (the tail of one, the head of the
+    next).  The first span (cold) contains the unpickled model's refit and the full N^2 M sweep; from then on the
+    grid stage is a warm re-score."""
+    import tempfile
+    import pybo_amd
+    from pybo_amd import models, inits
+    from pybo_amd.bayesopt import safe_dump, Info
+    N, d, M = w['N'], w['d'], w['M']
+    bounds = np.stack([w['lo'], w['hi']], axis=1)
+    gp = models.make_gp(w['sn2'], w['rho'], w['ell'], w['bias'], kernel=w['kernel'])
+    gp._X, gp._Y = np.array(w['X']), np.array(w['y'])         # data only: the run below starts from the pickle
+    grid = inits.DeviceGrid('sobol', bounds, M)                # the points of w['Xc'], generated in HBM
+    rng = np.random.RandomState(11)
+    stamps = []
+
+    def objective(x):
+        stamps.append(time.perf_counter())
+        return float(w['f'](np.array(x, ndmin=2))[0] + 1e-3 * rng.randn())
+
+    policy = 'ei' if w['acq'] == 'ei' else 'ucb'
+    with tempfile.TemporaryDirectory() as tmp:
+        log = os.path.join(tmp, 'bo.pkl')
+        safe_dump(gp, Info(list(w['X']), list(w['y']), list(w['X'])), log)
+        del gp
+        t0 = time.perf_counter()
+        xbest, model, info = pybo_amd.solve_bayesopt(objective, bounds, niter=N + nsteps, policy=policy,
+                                                     solver=('lbfgs', {'xgrid': grid, 'nbest': k}),
+                                                     recommender='latent', log=log)
+        t1 = time.perf_counter()
+        ckpt_bytes = os.path.getsize(log)
+    spans = np.diff(stamps)
+    rec = {'what': 'pybo_amd.solve_bayesopt resumed at N observations, policy %r, solver lbfgs over a DeviceGrid of '
+                   '%d Sobol points, recommender latent, checkpoint every iteration; spans between consecutive '
+                   'objective calls' % (policy, M),
+           'iterations': int(nsteps), 'N_start': int(N),
+           'cold_ms': (stamps[0] - t0) * 1e3,
+           'cold_what': 'checkpoint load + fit + policy + full sweep + refinement up to the first objective call',
+           'tail_ms': (t1 - stamps[-1]) * 1e3,
+           'checkpoint_bytes': int(ckpt_bytes), 'selected_last': [float(v) for v in info.x[-1]]}
+    if len(spans):
+        rec['warm_ms'] = float(np.mean(spans) * 1e3)
+        rec['warm_ms_each'] = [float(s * 1e3) for s in spans]
+    return rec
+
+
+def self_launch(ngpus):
+    """`python bench.py --gpus N` without a launcher (the driver's command shape): start N ranks of this very
+    command through torch.distributed.run on a free local port, one GPU per rank; rank 0 prints the ONE JSON line
+    on the inherited stdout.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ngpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env, stdin=subprocess.DEVNULL)
 
 
 def main():
@@ -169,7 +277,14 @@ def main():
     ap.add_argument('--exchange', default='torch', choices=['torch', 'gpx'],
                     help="transport of the top-k exchange: torch.distributed (default) or libgpx's own RCCL "
                          "binding (gpx_topk_allgather; needs one GPU per rank)")
+    ap.add_argument('--plugin-steps', type=int, default=4,
+                    help='also time this many iterations of pybo_amd.solve_bayesopt THROUGH THE PLUGIN API at the '
+                         'workload size (cold + warm; reported separately as plugin_step); 0 = skip')
     args = ap.parse_args()
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # invoked as `python bench.py --gpus N`: start the N ranks ourselves
+        raise SystemExit(self_launch(args.gpus))
 
     import torch
     rank = int(os.environ.get('RANK', '0'))
@@ -437,12 +552,35 @@ def main():
             out['warm_step'] = warm
         if 'roofline' not in out and 'cholesky' in fit:      # no sweep GEMM in this workload (Thompson)
             out['roofline'] = dict(fit['cholesky'], traffic=None)
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
             # sample: the WHOLE sweep for N <= 2048 (config B: ~1 min of host time), otherwise 4 full oracle
             # chunks of 8192 candidates (~25 s at N = 8192), extrapolated linearly and labelled so;
-            # --cpu-candidates 131072 gives SURVEY 8(d)'s 2^17 sample (~1.5 min)
-            nc = args.cpu_candidates or (M if N <= 2048 else 32768)
-            out['cpu_baseline'] = cpu_baseline(w, min(nc, M))
+            # --cpu-candidates 131072 gives SURVEY 8(d)'s 2^17 sample (~1.5 min).  With N > 1 ranks rank 0 times it
+            # (on the candidates at the head of its own shard) while the others wait in the closing barrier.
+            nc = min(args.cpu_candidates or (M if N <= 2048 else 32768), Ml if w['acq'] != 'thompson' else M)
+            out['cpu_baseline'], ref_vals = cpu_baseline(w, nc)
+            # the same candidates on the device, outside any timed region: every bench line is also a parity check
+            eng.fit_dev(dX.data_ptr(), N, d, dy.data_ptr(), w['kernel'], w['ell'], w['rho'], w['sn2'], w['bias'])
+            dev_vals = {}
+            if w['acq'] == 'thompson':
+                rng = np.random.RandomState(100)
+                Wd = rng.randn(100, d)
+                if nu is not None:
+                    Wd = Wd * np.sqrt(2.0 * nu / rng.chisquare(2.0 * nu, size=100))[:, None]
+                Wd, bd, zd = Wd / w['ell'], rng.rand(100) * 2 * np.pi, rng.randn(100)
+                th = eng.rff_posterior(Wd[None], bd[None], zd[None], np.sqrt(2.0 * w['rho'] / 100))
+                dev_vals['acq'] = eng.rff_sweep(Wd[None], bd[None], th, w['bias'], w['Xc'][:nc], k=0)['vals'][0]
+            else:
+                param = eng.mean_at_obs()[1] if w['acq'] == 'ei' else ucb_beta(N)
+                buf = torch.empty(3, nc, dtype=torch.float64, device=dev)
+                eng.sweep_dev(w['acq'], param, dXc.data_ptr(), nc, 0, d_acq=buf[0].data_ptr(),
+                              d_mu=buf[1].data_ptr(), d_s2=buf[2].data_ptr())
+                eng.sync()
+                hb = buf.cpu().numpy()
+                dev_vals.update(acq=hb[0], mu=hb[1], s2=hb[2], target=float(param))
+            out['parity'] = parity_record(w, ref_vals, dev_vals)
+        if args.plugin_steps > 0 and world == 1 and w['acq'] in ('ei', 'ucb'):
+            out['plugin_step'] = plugin_step(w, args.plugin_steps, k)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()       # rank 0 may still be in the (untimed) refinement block: leave together

@@ -126,6 +126,13 @@ int gpx_fit_stage(gpx_handle *h, const double *X, int64_t N, int64_t d, const do
 /* posterior (latent) mean at the N observed points, closed form y - sn2*alpha.
  * = model.predict(X_obs)[0]                     [pybo/policies/simple.py:21,35]            */
 int gpx_mean_at_obs(gpx_handle *h, double *mu_host, double *mu_max);
+/* posterior (latent) variance at the N observed points, closed form sn2 - sn2^2 [K^-1]_ii with
+ * [K^-1]_ii = sum_m U[i][m]^2 (one HBM-read pass over U = R^-1; a sweep over X_obs is an N x N x N product).
+ * = model.predict(X_obs)[1]                     [pybo/policies/simple.py:21,35; pybo/recommenders.py:34] */
+int gpx_var_at_obs(gpx_handle *h, double *s2_host);
+/* rows (a multiple of 128) the handle's factor buffers are allocated for: 4 matrices of capacity^2 doubles stay
+ * on the device until gpx_destroy -- what a pool of handles should be sized by. */
+int64_t gpx_capacity(const gpx_handle *h);
 
 /* ---- posterior moments = model.predict(X, grad) [pybo/policies/simple.py:64] ------------- */
 /* Xc (M,d) -> mu (M,), s2 (M,) latent variance; dmu, ds2 (M,d) optional (NULL to skip). */
@@ -216,7 +223,8 @@ int gpx_ensemble_predict(gpx_handle *const *members, int n_members, const double
  *      or a Sobol' grid                            [pybo/inits/methods.py:62-77]
  *      without the host array and its PCIe upload; pass gpx_grid_data() to the *_dev sweeps.
  * GPX_GRID_UNIFORM: counter-based Philox4x32-10, key = seed, counter = element-pair index; element 2c, 2c+1
- *      of the row-major (M,d) array = the two 53-bit uniforms of output c; x = lo + u*(hi-lo).
+ *      of the row-major (first+M,d) array = the two 53-bit uniforms of output c; x = lo + u*(hi-lo); rows
+ *      first .. first+M-1 of that array are generated (a shard of a grid holds the numbers the whole grid holds).
  * GPX_GRID_SOBOL: unscrambled Sobol' points first .. first+M-1 in Gray-code order (the order of
  *      scipy.stats.qmc.Sobol), from caller-supplied direction numbers sv (d, bits) uint32, 1 <= bits <= 32.
  * bounds (d,2) row-major [lo, hi].  Errors of the grid calls are read with gpx_last_error(NULL). */

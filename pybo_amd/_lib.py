@@ -33,6 +33,8 @@ SYMBOLS = {
     'gpx_get_vectors': (C.c_int, [_P, _P, _P]),
     'gpx_fit_stage': (C.c_int, [_P, _P, _i64, _i64, _P, C.c_int, _P, _dbl, _dbl, _dbl, C.c_int]),
     'gpx_mean_at_obs': (C.c_int, [_P, _P, _P]),
+    'gpx_var_at_obs': (C.c_int, [_P, _P]),
+    'gpx_capacity': (_i64, [_P]),
     'gpx_predict': (C.c_int, [_P, _P, _i64, _P, _P, _P, _P]),
     'gpx_sweep': (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _i64, _i64, _P, _P, _P, _P, _P]),
     'gpx_sweep_dev': (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _i64, _i64, _P, _P, _P, _P, _P]),
@@ -156,7 +158,8 @@ class DeviceGrid(object):
             rc = self._lib.gpx_grid_create(int(device), 1, _ptr(bounds), n, d, 0, int(first),
                                            sv.ctypes.data_as(_P), bits, C.byref(g))
         elif kind == 'uniform':
-            rc = self._lib.gpx_grid_create(int(device), 0, _ptr(bounds), n, d, int(seed), 0, None, 0, C.byref(g))
+            rc = self._lib.gpx_grid_create(int(device), 0, _ptr(bounds), n, d, int(seed), int(first), None, 0,
+                                           C.byref(g))
         else:
             raise ValueError("grid kind must be 'sobol' or 'uniform'")
         if rc != GPX_OK:
@@ -177,7 +180,23 @@ class DeviceGrid(object):
             raise GpxError(rc, (self._lib.gpx_last_error(None) or b'').decode())
         return out
 
+    def view(self, lo, hi):
+        """Rows [lo, hi) as a grid of their own, without a copy; the same object for the same range (a model keys
+        its warm sweep cache on the grid object it swept)."""
+        lo, hi = int(lo), int(hi)
+        if not 0 <= lo <= hi <= len(self):
+            raise IndexError('grid view out of range')
+        views = self.__dict__.setdefault('_views', {})
+        if (lo, hi) not in views:
+            views[(lo, hi)] = DeviceGridView(self, lo, hi)
+        return views[(lo, hi)]
+
     def __getitem__(self, idx):
+        if isinstance(idx, slice):                  # grid[lo:hi] (pybo_amd.dist shards a grid this way)
+            lo, hi, step = idx.indices(len(self))
+            if step == 1:
+                return self.view(lo, max(lo, hi))   # contiguous: stays on the device
+            return self.rows(np.arange(lo, hi, step, dtype=np.int64))
         if np.isscalar(idx):
             return self.rows([idx])[0]
         return self.rows(idx)
@@ -200,6 +219,81 @@ class DeviceGrid(object):
             self.close()
         except Exception:
             pass
+
+
+class DeviceGridView(DeviceGrid):
+    """Rows [lo, hi) of a DeviceGrid as a grid of their own (no copy: a pointer into the parent's HBM array) -- what
+    a rank of the multi-process layout sweeps when every rank holds the whole grid (pybo_amd.dist.sharded_topk)."""
+
+    def __init__(self, parent, lo, hi):
+        self._lib = parent._lib
+        self._parent, self._lo = parent, int(lo)
+        self._g = None
+        self.kind, self.bounds, self.device = parent.kind, parent.bounds, parent.device
+        self.shape = (int(hi) - int(lo), parent.shape[1])
+        self.ptr = parent.ptr + int(lo) * parent.shape[1] * 8
+
+    def rows(self, idx):
+        idx = np.ascontiguousarray(np.atleast_1d(idx), dtype=np.int64)
+        if len(idx) and (idx.min() < 0 or idx.max() >= len(self)):
+            raise IndexError('grid row out of range')
+        return self._parent.rows(idx + self._lo)
+
+    def __array__(self, dtype=None, copy=None):
+        out = self._parent.rows(np.arange(self._lo, self._lo + len(self), dtype=np.int64))
+        return out if dtype is None else out.astype(dtype)
+
+    def close(self):
+        self.ptr = None
+
+
+class ShardedDeviceGrid(object):
+    """ONE logical (n, d) grid laid out over several devices for pybo_amd.models.ShardedGP: shard p = rows
+    shard_bounds(n, p, P) generated and kept on devices[p] (Sobol': the same points of the sequence; uniform: the same
+    Philox stream -- the concatenation of the shards IS the single-device grid, bit for bit).  Behaves like a
+    read-only (n, d) array for the solver: len(), .shape, grid[idx] (rows fetched from their owners)."""
+
+    def __init__(self, kind, bounds, n, devices, seed=0, first=0):
+        n, devices = int(n), [int(dv) for dv in devices]
+        P = len(devices)
+        self.kind, self.devices = kind, devices
+        self.shards = []
+        for p, dv in enumerate(devices):
+            lo, hi = (n * p) // P, (n * (p + 1)) // P
+            g = DeviceGrid(kind, bounds, hi - lo, seed=seed, first=int(first) + lo, device=dv) if hi > lo else None
+            self.shards.append((lo, hi, g))
+        self.bounds = np.array(bounds, dtype=float, ndmin=2)
+        self.shape = (n, len(self.bounds))
+
+    def __len__(self):
+        return self.shape[0]
+
+    def rows(self, idx):
+        idx = np.ascontiguousarray(np.atleast_1d(idx), dtype=np.int64)
+        out = np.empty((len(idx), self.shape[1]))
+        if len(idx) and (idx.min() < 0 or idx.max() >= len(self)):
+            raise IndexError('grid row out of range')
+        for lo, hi, g in self.shards:
+            mine = np.flatnonzero((idx >= lo) & (idx < hi))
+            if len(mine):
+                out[mine] = g.rows(idx[mine] - lo)
+        return out
+
+    def __getitem__(self, idx):
+        if isinstance(idx, slice):
+            return self.rows(np.arange(*idx.indices(len(self)), dtype=np.int64))
+        if np.isscalar(idx):
+            return self.rows([idx])[0]
+        return self.rows(idx)
+
+    def __array__(self, dtype=None, copy=None):
+        out = np.concatenate([np.asarray(g) for _, _, g in self.shards if g is not None])
+        return out if dtype is None else out.astype(dtype)
+
+    def close(self):
+        for _, _, g in self.shards:
+            if g is not None:
+                g.close()
 
 
 class Comm(object):
@@ -357,6 +451,15 @@ class Engine(object):
         mx = C.c_double()
         self._check(self._lib.gpx_mean_at_obs(self._h, _ptr(mu), C.byref(mx)))
         return mu, mx.value
+
+    def var_at_obs(self):
+        s2 = np.empty(self.N)
+        self._check(self._lib.gpx_var_at_obs(self._h, _ptr(s2)))
+        return s2
+
+    def capacity(self):
+        """Rows the handle's factor buffers are allocated for (they stay allocated until the handle is closed)."""
+        return int(self._lib.gpx_capacity(self._h))
 
     # -- posterior / sweep -----------------------------------------------------------------------
     def predict(self, Xc, grad=False):

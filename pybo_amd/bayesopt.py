@@ -52,9 +52,14 @@ def safe_dump(model, info, filename=None):
     """Persist (model, trace); a None filename disables checkpointing."""
     if filename is None:
         return
+    if _spmd_rank() != 0:                # SPMD runs: the ranks hold the same state, one of them writes it
+        return
+    # the trace goes to disk as three arrays, not as lists of thousands of small ones (pickling a list of 8192
+    # (d,) arrays costs ~25 ms per iteration, more than a warm BO step); safe_load turns them back into lists
+    packed = tuple(np.array(col, dtype=float) for col in info)
     scratch = '{}.part{}'.format(filename, os.getpid())
     with open(scratch, 'wb') as fh:
-        pickle.dump((model, info), fh, protocol=pickle.HIGHEST_PROTOCOL)
+        pickle.dump((model, _PackedTrace(*packed)), fh, protocol=pickle.HIGHEST_PROTOCOL)
     os.replace(scratch, filename)
 
 
@@ -63,7 +68,56 @@ def safe_load(filename=None):
     if filename is None or not os.path.exists(filename):
         return None, Info([], [], [])
     with open(filename, 'rb') as fh:
-        return pickle.load(fh)
+        model, info = pickle.load(fh)
+    if isinstance(info, _PackedTrace):
+        info = Info(list(info.x), [float(v) for v in info.y], list(info.xbest))
+    return model, info
+
+
+_PackedTrace = collections.namedtuple('_PackedTrace', ['x', 'y', 'xbest'])
+
+
+class _Rows(list):
+    """The trace columns x / xbest: a list of (d,) points, as in the reference (`info.x.append(x)`,
+    pybo/bayesopt.py:271), that ALSO keeps its rows in one growing array and hands that to numpy (`__array__`):
+    every policy and recommender call starts with np.array(X) of the whole trace -- 3 ms for a list of 8192 small
+    arrays, 10 us for the mirror."""
+
+    def __init__(self, rows=()):
+        list.__init__(self)
+        self._buf, self._n = None, 0
+        self.extend(rows)
+
+    def append(self, x):
+        x = np.asarray(x, dtype=float)
+        if self._buf is None:
+            self._buf = np.empty((16,) + x.shape)
+        if x.shape != self._buf.shape[1:]:
+            raise ValueError('trace rows must have the same shape')
+        if self._n == len(self._buf):
+            grown = np.empty((2 * len(self._buf),) + self._buf.shape[1:])
+            grown[:self._n] = self._buf[:self._n]
+            self._buf = grown
+        self._buf[self._n] = x
+        self._n += 1
+        list.append(self, self._buf[self._n - 1])
+
+    def extend(self, rows):
+        for x in rows:
+            self.append(x)
+
+    def __array__(self, dtype=None, copy=None):
+        out = self._buf[:self._n] if self._buf is not None else np.empty((0,))
+        return out if dtype is None else out.astype(dtype)
+
+    def __reduce__(self):
+        return (_Rows, (list(np.array(self)),))
+
+
+def _spmd_rank():
+    from . import dist as pdist
+    d = pdist._dist()
+    return d.get_rank() if d is not None else 0
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -78,9 +132,12 @@ def _heuristic_hypers(y, bounds):
                 bias=float(np.mean(y)) if len(y) else 0.0)
 
 
-def init_model(f, bounds, ninit=None, design='latin', log=None, rng=None, kernel='se'):
-    """Evaluate an initial design (resumable through `log`) and return a GP fitted to it."""
+def init_model(f, bounds, ninit=None, design='latin', log=None, rng=None, kernel='se', devices=None):
+    """Evaluate an initial design (resumable through `log`) and return a GP fitted to it.  `devices`: a list of
+    GPUs for a one-process multi-device model (models.ShardedGP)."""
     from . import models
+    from .dist import spmd_objective
+    f = f if getattr(f, 'spmd', False) else spmd_objective(f)      # SPMD runs: rank 0 evaluates, everyone receives
     rng = rstate(rng)
     bounds = np.array(bounds, dtype=float, ndmin=2)
     stored_model, trace = safe_load(log)
@@ -97,7 +154,7 @@ def init_model(f, bounds, ninit=None, design='latin', log=None, rng=None, kernel
         safe_dump(None, trace, filename=log)
 
     hyp = _heuristic_hypers(trace.y, bounds)
-    gp = models.make_gp(hyp['sn2'], hyp['rho'], hyp['ell'], hyp['bias'], kernel=kernel)
+    gp = models.make_gp(hyp['sn2'], hyp['rho'], hyp['ell'], hyp['bias'], kernel=kernel, devices=devices)
     gp.params['like.sn2'].set_prior('horseshoe', 0.1)
     gp.params['kern.rho'].set_prior('lognormal', np.log(hyp['rho']), 1.0)
     gp.params['kern.ell'].set_prior('uniform', hyp['ell'] / 100, hyp['ell'] * 10)
@@ -194,8 +251,13 @@ def solve_bayesopt(objective, bounds, model=None, niter=100, policy='ei', solver
     get_improvement / get_tail / sample_f); default: a `pybo_amd.models.GP` from `init_model`.
     Returns (xbest, model, Info(x, y, xbest)) with the Info fields as arrays.
     """
+    from .dist import spmd_objective
     rng = rstate(rng)
     bounds = np.array(bounds, dtype=float, ndmin=2)
+    # the reference evaluates the objective once per iteration in one process (bayesopt.py:268).  Under an
+    # initialised torch.distributed group (one rank per GPU, every rank running this loop) rank 0 evaluates and
+    # broadcasts, so every rank absorbs the same observation and the replicated models stay bitwise equal.
+    objective = spmd_objective(objective)
     policy = get_component(policy, policies, rng)
     solver = get_component(solver, solvers, rng, lstrip='solve_')
     recommender = get_component(recommender, recommenders, rng, lstrip='best_')
@@ -207,6 +269,7 @@ def solve_bayesopt(objective, bounds, model=None, niter=100, policy='ei', solver
         model = init_model(objective, bounds, ninit, log=log, rng=rng)   # trace stays as loaded above
     else:
         model = model.copy()             # never mutate the caller's model
+    trace = Info(_Rows(trace.x), list(trace.y), _Rows(trace.xbest))
 
     if not trace.x:                      # seed the trace with the centre of the box
         x0 = inits.init_middle(bounds)[0]

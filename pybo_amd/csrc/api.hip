@@ -169,6 +169,13 @@ static int create_impl(int device, void* stream, gpx_handle** out) {
         delete h;
         return GPX_EOOM;
     }
+    if (hipHostMalloc((void**)&h->hinv, (size_t)DMAX * 8, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_inv, hipEventDisableTiming) != hipSuccess) {
+        g_create_err = "gpx_create: pinned host allocation failed";
+        hipFree(h->dsmall);
+        delete h;
+        return GPX_EOOM;
+    }
     h->dflag = reinterpret_cast<int*>(h->dsmall);
     h->dscal = reinterpret_cast<double*>(h->dsmall + 64);
     h->dinvell = h->dscal + 16;
@@ -208,6 +215,8 @@ extern "C" int gpx_destroy(gpx_handle* h) {
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (h->hpin) hipHostFree(h->hpin);
+    if (h->hinv) hipHostFree(h->hinv);
+    if (h->ev_inv) hipEventDestroy(h->ev_inv);
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
     if (h->stream3) { hipStreamSynchronize(h->stream3); hipStreamDestroy(h->stream3); }
     if (h->stream4) { hipStreamSynchronize(h->stream4); hipStreamDestroy(h->stream4); }
@@ -375,11 +384,14 @@ static int fit_core(gpx_handle* h, const double* dX, int64_t N, int64_t d, const
     h->N = N; h->Np = Np; h->d = d; h->kernel_id = kid;
     h->rho = rho; h->sn2 = sn2; h->bias = bias;
     h->ell.assign(ell, ell + d);
-    double inv[DMAX];
-    for (int64_t k = 0; k < d; ++k) inv[k] = 1.0 / ell[k];
+    // 1/ell goes through a pinned buffer of the handle (round 2 synchronised the stream here for a stack buffer);
+    // the previous fit's copy has long completed -- the event wait returns at once
+    if (h->inv_inflight) { HIPCHK(h, hipEventSynchronize(h->ev_inv)); h->inv_inflight = false; }
+    for (int64_t k = 0; k < d; ++k) h->hinv[k] = 1.0 / ell[k];
     hipStream_t s = h->stream;
-    HIPCHK(h, hipMemcpyAsync(h->dinvell, inv, (size_t)d * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipStreamSynchronize(s));  // inv[] is a stack buffer
+    HIPCHK(h, hipMemcpyAsync(h->dinvell, h->hinv, (size_t)d * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipEventRecord(h->ev_inv, s));
+    h->inv_inflight = true;
     HIPCHK(h, hipMemcpyAsync(h->dXraw, dX, (size_t)N * d * 8, hipMemcpyDeviceToDevice, s));
     HIPCHK(h, hipMemsetAsync(h->dy, 0, (size_t)Np * 8, s));
     HIPCHK(h, hipMemcpyAsync(h->dy, dy, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
@@ -601,6 +613,31 @@ extern "C" int gpx_mean_at_obs(gpx_handle* h, double* mu_host, double* mu_max) {
         return GPX_OK;
     });
 }
+
+extern "C" int gpx_var_at_obs(gpx_handle* h, double* s2_host) {
+    return guarded(h, [&]() -> int {
+        if (!h) return GPX_EARG;
+        if (!s2_host) return fail(h, GPX_EARG, "var_at_obs: NULL output");
+        if (!h->fitted) return fail(h, GPX_ESTATE, "var_at_obs: model is not fitted");
+        HIPCHK(h, hipSetDevice(h->device));
+        int rc;
+        if ((rc = ensure_inverse(h))) return rc;
+        const int64_t N = h->N;
+        if ((rc = ensure(h, h->dout, h->cap_out, N))) return rc;
+        launch_kinv_diag(h, h->dout);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipMemcpyAsync(s2_host, h->dout, (size_t)N * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        // s2_i = sn2 - sn2^2 [K^-1]_ii  (latent variance at observed input i), clipped like the sweep's
+        for (int64_t i = 0; i < N; ++i) {
+            const double v = h->sn2 * (1.0 - h->sn2 * s2_host[i]);
+            s2_host[i] = v > 1e-100 ? v : 1e-100;
+        }
+        return GPX_OK;
+    });
+}
+
+extern "C" int64_t gpx_capacity(const gpx_handle* h) { return h ? h->cap_np : 0; }
 
 // ---- sweep ------------------------------------------------------------------------------------
 // top-k of a device vector (value descending, index ascending, NaN last) -> host buffers; synchronises.
@@ -1187,6 +1224,7 @@ static int grid_create_impl(int device, int kind, const double* bounds, int64_t 
     *out = nullptr;
     if (!bounds || M < 1 || d < 1 || d > DMAX) { g_create_err = "grid_create: bad sizes or NULL bounds"; return GPX_EARG; }
     if (kind != GPX_GRID_UNIFORM && kind != GPX_GRID_SOBOL) { g_create_err = "grid_create: unknown grid kind"; return GPX_EARG; }
+    if (first < 0) { g_create_err = "grid_create: first must be >= 0"; return GPX_EARG; }
     if (kind == GPX_GRID_SOBOL && (!sv || bits < 1 || bits > 32 || first < 0 ||
                                    (bits < 63 && (uint64_t)(first + M) > (1ull << bits)))) {
         g_create_err = "grid_create: Sobol needs direction numbers (d, bits), 1 <= bits <= 32, first + M <= 2^bits";
@@ -1215,7 +1253,7 @@ static int grid_create_impl(int device, int kind, const double* bounds, int64_t 
         GRIDTRY(hipMemcpy(dsv, sv, (size_t)d * bits * 4, hipMemcpyHostToDevice));
         launch_grid_sobol(nullptr, dsv, bits, first, M, (int)d, dB, g->dX);
     } else {
-        launch_grid_uniform(nullptr, seed, M, (int)d, dB, g->dX);
+        launch_grid_uniform(nullptr, seed, first, M, (int)d, dB, g->dX);
     }
     GRIDTRY(hipGetLastError());
     GRIDTRY(hipDeviceSynchronize());
@@ -1247,8 +1285,12 @@ extern "C" int gpx_grid_rows(gpx_grid* g, const int64_t* idx, int64_t k, double*
         if (k < 1) return GPX_OK;
         for (int64_t i = 0; i < k; ++i)
             if (idx[i] < 0 || idx[i] >= g->M) { g_create_err = "grid_rows: index out of range"; return GPX_EARG; }
-        for (int64_t i = 0; i < k; ++i)
-            GRIDCHK(hipMemcpy(out + i * g->d, g->dX + idx[i] * g->d, (size_t)g->d * 8, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < k;) {                 // one copy per run of consecutive rows
+            int64_t j = i + 1;
+            while (j < k && idx[j] == idx[j - 1] + 1) ++j;
+            GRIDCHK(hipMemcpy(out + i * g->d, g->dX + idx[i] * g->d, (size_t)(j - i) * g->d * 8, hipMemcpyDeviceToHost));
+            i = j;
+        }
         return GPX_OK;
     } catch (...) {
         return GPX_EOOM;

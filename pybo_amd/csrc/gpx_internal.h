@@ -61,6 +61,9 @@ struct gpx_handle {
     double* da = nullptr;     // (Np,) a = T (y - bias)
     double* dalpha = nullptr; // (Np,) alpha = U a
     double* dinvell = nullptr;// (DMAX,) 1/ell
+    double* hinv = nullptr;   // pinned host staging of 1/ell (DMAX doubles): its H2D copy needs no host synchronisation
+    hipEvent_t ev_inv = nullptr;     // completion of that copy (waited for before the buffer is rewritten)
+    bool inv_inflight = false;
     double* hpin = nullptr;   // pinned host staging of predict-with-gradients (GB points)
     int64_t cap_hpin = 0;
     char* dsmall = nullptr;   // ONE allocation behind dflag / dscal / dinvell
@@ -134,6 +137,7 @@ int ensure_side_streams(gpx_handle* h);   // api.hip: streams 2 / 3 + events, on
 void launch_cholesky(gpx_handle* h);   // S -> R, diag blocks of T/U; sets dflag
 void launch_trtri(gpx_handle* h);      // R, diag blocks -> T, U (uses S as workspace)
 void launch_alpha(gpx_handle* h);      // a = T (y - bias); alpha = U a
+void launch_kinv_diag(gpx_handle* h, double* out);   // out[i] = [K^-1]_ii = sum_m U[i][m]^2
 void launch_transpose_lower(hipStream_t s, const double* R, int64_t Np, double* out, int64_t N);
 
 // launchers (kernels_sweep.hip)
@@ -196,6 +200,7 @@ void launch_ens_finish(hipStream_t s, const double* acc0, const double* acc1, in
                        double beta, double* out, double* mu_out, double* s2_out);
 void launch_grid_sobol(hipStream_t s, const uint32_t* sv, int bits, int64_t first, int64_t M, int d,
                        const double* bounds, double* X);
-void launch_grid_uniform(hipStream_t s, uint64_t seed, int64_t M, int d, const double* bounds, double* X);
+void launch_grid_uniform(hipStream_t s, uint64_t seed, int64_t first, int64_t M, int d, const double* bounds,
+                         double* X);
 
 }  // namespace gpx

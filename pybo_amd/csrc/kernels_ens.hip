@@ -124,10 +124,13 @@ __device__ inline void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) 
 __global__ __launch_bounds__(256) void k_grid_uniform(uint64_t seed, int64_t first_elem, int64_t total, int d,
                                                       const double* __restrict__ bounds,
                                                       double* __restrict__ X) {
-    const int64_t pairs = (total + 1) / 2;
+    // rows first .. first+M-1 of the stream: GLOBAL element E = first_elem + e lives in output E >> 1, half E & 1,
+    // so a shard generated with an offset holds exactly the numbers the whole grid holds at those rows
+    const int64_t gp0 = first_elem >> 1;
+    const int64_t pairs = ((first_elem + total + 1) >> 1) - gp0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < pairs; p += stride) {
-        const uint64_t ctr = (uint64_t)(p + first_elem / 2);
+        const uint64_t ctr = (uint64_t)(p + gp0);
         uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
         uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
@@ -141,8 +144,8 @@ __global__ __launch_bounds__(256) void k_grid_uniform(uint64_t seed, int64_t fir
             (double)((((uint64_t)c[2] << 32) | c[3]) >> 11) * (1.0 / 9007199254740992.0)};
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int64_t e = 2 * p + t;
-            if (e < total) {
+            const int64_t e = 2 * (p + gp0) + t - first_elem;
+            if (e >= 0 && e < total) {
                 const int j = (int)(e % d);
                 const double lo = bounds[2 * j], hi = bounds[2 * j + 1];
                 const double w = hi - lo;
@@ -163,8 +166,9 @@ void launch_grid_sobol(hipStream_t s, const uint32_t* sv, int bits, int64_t firs
     hipLaunchKernelGGL(k_grid_sobol, dim3(ew_blocks(M * d)), dim3(256), 0, s, sv, bits, first, M, d, bounds, X);
 }
 
-void launch_grid_uniform(hipStream_t s, uint64_t seed, int64_t M, int d, const double* bounds, double* X) {
-    hipLaunchKernelGGL(k_grid_uniform, dim3(ew_blocks((M * d + 1) / 2)), dim3(256), 0, s, seed, (int64_t)0,
+void launch_grid_uniform(hipStream_t s, uint64_t seed, int64_t first, int64_t M, int d, const double* bounds,
+                         double* X) {
+    hipLaunchKernelGGL(k_grid_uniform, dim3(ew_blocks((M * d + 1) / 2 + 1)), dim3(256), 0, s, seed, first * d,
                        M * d, d, bounds, X);
 }
 

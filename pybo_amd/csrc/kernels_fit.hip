@@ -977,6 +977,27 @@ void launch_alpha(gpx_handle* h) {
                        1, h->dalpha);
 }
 
+// diag(K^-1) = row sums of squares of U = R^-1 (K^-1 = U U^T): the posterior variance AT the observed inputs has the
+// closed form  s2_i = sn2 - sn2^2 [K^-1]_ii  (k_i = K e_i - sn2 e_i  =>  k_i^T K^-1 k_i = k_ii - sn2 + sn2^2 [K^-1]_ii),
+// one HBM-read pass over U instead of the N x N x N triangular product a sweep over X_obs costs.
+__global__ __launch_bounds__(256) void k_row_sumsq_upper(const double* __restrict__ U, int64_t Np, int64_t N,
+                                                         double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= N) return;
+    const double* ur = U + row * Np;
+    double acc = 0.0;
+    for (int64_t j = row + lane; j < N; j += 64) acc = fma(ur[j], ur[j], acc);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) out[row] = acc;
+}
+
+void launch_kinv_diag(gpx_handle* h, double* out) {
+    hipLaunchKernelGGL(k_row_sumsq_upper, dim3((unsigned)((h->N + 3) / 4)), dim3(256), 0, h->stream, h->dU, h->Np, h->N,
+                       out);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Batched log marginal likelihoods: B hyper-parameter vectors on the handle's resident data, ONE launch chain
 // (batch element = blockIdx.z of the Gram / Cholesky kernels above) and ONE host synchronisation -- what a

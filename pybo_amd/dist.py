@@ -14,7 +14,8 @@ Two transports for that exchange:
 """
 import numpy as np
 
-__all__ = ['shard_bounds', 'merge_topk', 'gather_topk', 'gather_pairs', 'sharded_topk', 'ShardedIndex']
+__all__ = ['shard_bounds', 'merge_topk', 'gather_topk', 'gather_pairs', 'sharded_topk', 'ShardedIndex', 'world_size',
+           'spmd_objective']
 
 
 def shard_bounds(M, rank, world):
@@ -105,18 +106,30 @@ def sharded_topk(index, xgrid, k, group=None, comm=None):
     else:
         rank = dist.get_rank(group) if dist else 0
         world = dist.get_world_size(group) if dist else 1
+    from ._lib import DeviceGrid
     M = len(xgrid)
     lo, hi = shard_bounds(M, rank, world)
+    # this rank's rows: a host array is sliced; a DeviceGrid (the whole grid resident on this rank's GPU) is
+    # viewed in place -- the same view object every call, so a device model's warm sweep cache keeps working
+    if isinstance(xgrid, DeviceGrid):
+        mine = xgrid.view(lo, hi)
+    else:
+        if not isinstance(xgrid, np.ndarray):
+            xgrid = np.asarray(xgrid, dtype=float)
+        mine = xgrid[lo:hi]
     if comm is not None:
+        # every precondition is checked BEFORE the local sweep and depends on arguments all ranks share (M, k, world)
+        # or on this rank's own objects, so a violation raises on every rank alike instead of leaving the others
+        # blocked in the collective
         if M // world < k:
             raise ValueError('device exchange needs at least k candidates on every rank')
-        index.topk(xgrid[lo:hi], k)
         owner = getattr(index, 'topk_engine', None)
         if owner is None or owner() is not comm._engine:
-            raise ValueError('the communicator is bound to another engine than the one that ran the sweep')
+            raise ValueError('the communicator is bound to another engine than the one that runs the sweep')
+        index.topk(mine, k)
         return comm.topk_allgather(k, lo, k)
     if hi > lo:
-        vals, idx = index.topk(xgrid[lo:hi], min(k, hi - lo))
+        vals, idx = index.topk(mine, min(k, hi - lo))
         idx = np.asarray(idx, dtype=np.int64)
         good = idx >= 0
         vals, idx = np.asarray(vals)[good], idx[good] + lo
@@ -137,3 +150,40 @@ class ShardedIndex(object):
 
     def topk(self, xgrid, k):
         return sharded_topk(self._index, xgrid, k, self._group, self._comm)
+
+
+# ---- SPMD runs of the whole loop: ONE objective evaluation per iteration ---------------------------------------
+def world_size(group=None):
+    dist = _dist()
+    return dist.get_world_size(group) if dist else 1
+
+
+def spmd_objective(objective, group=None, src=0):
+    """pybo evaluates the black box ONCE per iteration in one process (pybo/bayesopt.py:268).  When the whole loop
+    runs SPMD (one rank per GPU under torch.distributed, every rank executing solve_bayesopt), only rank `src`
+    calls `objective`; the query point it used and the value it got are broadcast, so that every rank feeds its
+    replicated model the SAME observation -- with a noisy or expensive objective, P independent evaluations would
+    give P different models whose shard-local top-k lists cannot be merged.  Without a process group (or with one
+    rank) the objective is returned unchanged."""
+    dist = _dist()
+    if dist is None or dist.get_world_size(group) == 1:
+        return objective
+    rank = dist.get_rank(group)
+
+    def evaluate(x):
+        box = [None]
+        if rank == src:
+            try:
+                box[0] = ('ok', objective(x))
+            except BaseException as exc:          # noqa: every rank must leave the collective, then re-raise
+                box[0] = ('error', repr(exc))
+                dist.broadcast_object_list(box, src=src, group=group)
+                raise
+        dist.broadcast_object_list(box, src=src, group=group)
+        status, value = box[0]
+        if status != 'ok':
+            raise RuntimeError('objective failed on rank %d: %s' % (src, value))
+        return value
+
+    evaluate.spmd = True
+    return evaluate

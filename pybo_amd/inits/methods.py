@@ -62,20 +62,24 @@ def init_sobol(bounds, n=None, rng=None):
 def init_sobol_device(bounds, n=None, rng=None, device=0):
     """The points of `init_sobol(bounds, n, rng)` -- same `skip` draw, bit-identical coordinates -- generated
     on the GPU and left there: returns a `DeviceGrid` for `solve_lbfgs(..., xgrid=...)`."""
-    from .._lib import DeviceGrid
+    from .._lib import DeviceGrid, ShardedDeviceGrid
     rng = rstate(rng)
     d = len(np.array(bounds, dtype=float, ndmin=2))
     n = 3 * d if n is None else n
     skip = rng.randint(100, 200)
+    if isinstance(device, (list, tuple)):          # one shard per listed device (pybo_amd.models.ShardedGP)
+        return ShardedDeviceGrid('sobol', bounds, n, device, first=skip)
     return DeviceGrid('sobol', bounds, n, first=skip, device=device)
 
 
 def init_uniform_device(bounds, n=None, rng=None, device=0):
     """n i.i.d. uniform points generated on the GPU (Philox4x32-10 keyed by one 62-bit draw from `rng`) -- the
     device counterpart of `init_uniform`; a different stream of numbers than numpy's MT19937."""
-    from .._lib import DeviceGrid
+    from .._lib import DeviceGrid, ShardedDeviceGrid
     rng = rstate(rng)
     d = len(np.array(bounds, dtype=float, ndmin=2))
     n = 3 * d if n is None else n
     seed = (int(rng.randint(0, 2 ** 31 - 1)) << 31) | int(rng.randint(0, 2 ** 31 - 1))
+    if isinstance(device, (list, tuple)):
+        return ShardedDeviceGrid('uniform', bounds, n, device, seed=seed)
     return DeviceGrid('uniform', bounds, n, seed=seed, device=device)

@@ -26,7 +26,13 @@ __all__ = ['GP', 'make_gp']
 
 _KERNELS = ('se', 'matern5', 'matern3', 'matern1')
 _ENGINE_POOL = []      # engines whose last owner died; reused so steady-state BO never re-allocates
-_POOL_SMALL_N = 1024   # handles that last held at most this many observations count as small (<= ~35 MB)
+_POOL_SMALL_N = 1024   # handles whose factor buffers are ALLOCATED for at most ~this many rows count as small (<= ~40 MB)
+
+
+def _is_small(engine):
+    """Pool class of a handle by what it keeps allocated (gpx_capacity), not by its last fit: buffers never shrink,
+    so a handle that once held a large model stays large however small its current one is."""
+    return engine.capacity() <= _POOL_SMALL_N + 256
 
 
 class _DeviceState(object):
@@ -36,10 +42,14 @@ class _DeviceState(object):
         self.engine = None
         self.key = None            # hyper-parameters of the fit the engine holds
         self.cache_grid = None     # the DeviceGrid whose sweep sums the engine keeps (warm BO step)
-        while _ENGINE_POOL and self.engine is None:
-            cand = _ENGINE_POOL.pop()
-            if cand._h and cand.device == device:      # never hand out a closed handle
+        for i in range(len(_ENGINE_POOL) - 1, -1, -1):
+            cand = _ENGINE_POOL[i]
+            if not cand._h:                            # never hand out a closed handle
+                del _ENGINE_POOL[i]
+            elif cand.device == device:                # handles of other devices wait for their own models
+                del _ENGINE_POOL[i]
                 self.engine = cand
+                break
         if self.engine is None:
             self.engine = _lib.Engine(device)
         self.nrefs = 1
@@ -51,10 +61,12 @@ class _DeviceState(object):
             # allocations), which was 80 % of a default solve_bayesopt run -- the hyper-parameter sampler turns over
             # ~30 member / proposal models per iteration.  Handles of small models are cheap to keep (a few MB);
             # at most 4 large ones (their factor and sweep buffers stay allocated) wait in the pool.
-            small = self.engine.N <= _POOL_SMALL_N
-            room = (sum(1 for e in _ENGINE_POOL if e.N <= _POOL_SMALL_N) < 64) if small \
-                else (sum(1 for e in _ENGINE_POOL if e.N > _POOL_SMALL_N) < 4)
-            if self.engine._h and room:
+            room = False
+            if self.engine._h:
+                small = _is_small(self.engine)
+                room = (sum(1 for e in _ENGINE_POOL if _is_small(e)) < 64) if small \
+                    else (sum(1 for e in _ENGINE_POOL if not _is_small(e)) < 4)
+            if room:
                 try:
                     self.engine.set_option('sweep_cache', -1)       # the next owner starts without a cache
                 except Exception:
@@ -168,6 +180,14 @@ class GP(object):
         new._X, new._Y = self._X, self._Y          # arrays are replaced, never mutated in place
         for k, p in self.params.items():
             new.params[k].prior = p.prior
+        if self.ndata > 0 and (not self._fitted or self._stale()):
+            # a model that has data but no current fit (just unpickled, or its hyper-parameters were assigned) is
+            # fitted HERE, so that the copy shares the fit instead of paying for its own and leaving this model
+            # unfitted (every policy call starts with model.copy(), pybo/policies/simple.py:20,34,57)
+            try:
+                self._engine()
+            except np.linalg.LinAlgError:
+                pass                               # surfaces where the copy is first used
         if self._state is not None and self._fitted:
             self._state.nrefs += 1
             new._state, new._fitted = self._state, True
@@ -251,13 +271,57 @@ class GP(object):
             mu, s2 = np.full(M, self.bias), np.full(M, self.rho)
             return (mu, s2, np.zeros((M, d)), np.zeros((M, d))) if grad else (mu, s2)
         eng = self._engine()
-        if not grad and X.shape == self._X.shape and np.array_equal(X, self._X):
-            # posterior mean at the training inputs has the closed form y - sn2*alpha (no N^3 solve);
-            # the variance still needs the sweep.  Used by EI/PI for their target (simple.py:21,35).
-            mu, _ = eng.mean_at_obs()
-            s2 = eng.sweep('mean', None, X, k=0, want_all=False, want_moments=True)['s2']
-            return mu, s2
+        if not grad:
+            rows = self._data_rows(X)
+            if rows is not None:
+                # posterior moments AT the training inputs have closed forms: mu = y - sn2*alpha,
+                # s2 = sn2 - sn2^2 [K^-1]_ii (two O(N^2) passes) -- a sweep over X_obs would be an N x N x N
+                # product, 3x the Cholesky.  EI / PI ask for it once per policy call (simple.py:21,35), the
+                # recommenders once per iteration (recommenders.py:22-34).
+                return eng.mean_at_obs()[0][rows], eng.var_at_obs()[rows]
         return eng.predict(X, grad=grad)
+
+    def _data_rows(self, X):
+        """Row range of `X` in the model's data when X is a contiguous run of the data rows, else None.  The trace of
+        a BO run is one: pybo/bayesopt.py:243-259 puts the initial design in the model but not in the trace, and the
+        recommender sees the trace BEFORE the newest point is appended to it (:270-271) -- so X is the data, the data
+        without its head, or without its last row."""
+        n, N = len(X), len(self._X)
+        if not 0 < n <= N or X.shape[1] != self._X.shape[1]:
+            return None
+        for o in (N - n, max(N - n - 1, 0), 0):              # the usual offsets first
+            if np.array_equal(X, self._X[o:o + n]):
+                return slice(o, o + n)
+        for o in np.flatnonzero(np.all(self._X[:N - n + 1] == X[0], axis=1)):
+            if np.array_equal(X, self._X[o:o + n]):
+                return slice(int(o), int(o) + n)
+        return None
+
+    def predict_mean(self, X):
+        """Posterior mean only: `model.predict(X)[0]` without the variance nobody reads (EI / PI targets, the
+        incumbent recommender).  Closed form at the model's own data, one device call otherwise."""
+        X = np.array(X, ndmin=2, dtype=float)
+        if X.shape[0] == 0:
+            return np.zeros(0)
+        if self.ndata == 0:
+            return np.full(len(X), self.bias)
+        rows = self._data_rows(X)
+        if rows is not None:
+            return self._engine().mean_at_obs()[0][rows]
+        return self._engine().predict(X)[0]
+
+    def mean_topk(self, xgrid, k):
+        """(values, indices) of the k largest posterior means over `xgrid` -- the grid stage of the latent
+        recommender (pybo/recommenders.py:22-27 runs solve_lbfgs with xgrid = X_obs): closed form + host ranking
+        when the grid is the model's data, the device sweep otherwise."""
+        if not isinstance(xgrid, DeviceGrid):
+            xgrid = np.array(xgrid, ndmin=2, dtype=float)
+            if self.ndata and self._data_rows(xgrid) is not None:
+                mu = self.predict_mean(xgrid)
+                v = np.where(np.isnan(mu), -np.inf, mu)
+                order = np.lexsort((np.arange(len(v)), -v))[:int(k)]
+                return mu[order], order
+        return self.acq_topk('mean', None, xgrid, k)
 
     # -- hyper-parameter access (used by the MCMC meta-model) ---------------------------------------------
     def hyper_vector(self):
@@ -284,7 +348,14 @@ class GP(object):
         thetas = np.array(thetas, dtype=float, ndmin=2)
         d = len(self.ell)
         hyp = np.column_stack([np.exp(thetas[:, 0]), np.exp(thetas[:, 1]), np.exp(thetas[:, 2:2 + d]), thetas[:, 2 + d]])
-        return self._engine().loglik_batch(hyp)
+        eng = self._engine()
+        # gpx_loglik_batch takes B <= 64 vectors and at most 16e9 bytes of batch buffers (2 B Np^2 doubles):
+        # larger requests go in sub-batches (down to one vector at a time; the values do not depend on the grouping)
+        Np = -(-self.ndata // 128) * 128
+        per = int(max(1, min(64, 16e9 // (16.0 * Np * Np))))
+        if len(hyp) <= per:
+            return eng.loglik_batch(hyp)
+        return np.concatenate([eng.loglik_batch(hyp[i:i + per]) for i in range(0, len(hyp), per)])
 
     def acq_values(self, kind, param, xgrid):
         """Acquisition values over a whole grid (device sweep, values copied back)."""
@@ -362,10 +433,10 @@ class GP(object):
         sc = np.sqrt(2.0 * self.rho / n)
         if self.ndata == 0:
             return RFFSampleDevice(self, W, b, sc * z)
-        if n < 128:      # feature Gram AND the n x n weight posterior on the device (gpx_rff_posterior)
+        if n < 128 and self.sn2 > 0.0:      # feature Gram AND the n x n weight posterior on the device (gpx_rff_posterior)
             theta = self._engine().rff_posterior(W[None], b[None], z[None], sc)[0]
             return RFFSampleDevice(self, W, b, theta)
-        A, v = self._engine().rff_gram(W, b)           # wide feature maps: the n x n solve on the host
+        A, v = self._engine().rff_gram(W, b)           # wide feature maps / a noise-free model: the n x n solve on the host
         Am = (sc * sc) * A + self.sn2 * np.eye(n)
         L = np.linalg.cholesky(Am)
         mean = np.linalg.solve(L.T, np.linalg.solve(L, sc * v))
@@ -373,6 +444,11 @@ class GP(object):
         return RFFSampleDevice(self, W, b, sc * (mean + noise))
 
 
-def make_gp(sn2, rho, ell, bias=0.0, kernel='se', device=0):
-    """`reggie.make_gp(sn2, rho, ell, bias)` (pybo/bayesopt.py:105) plus kernel family and device."""
+def make_gp(sn2, rho, ell, bias=0.0, kernel='se', device=0, devices=None):
+    """`reggie.make_gp(sn2, rho, ell, bias)` (pybo/bayesopt.py:105) plus kernel family and device.
+    `devices=[0, 1, ...]`: one process, several GPUs -- a `ShardedGP` with one handle per listed device (the fit
+    replicated, every grid-sized call sharded over them; models/sharded.py)."""
+    if devices is not None and len(devices) > 0:
+        from .sharded import ShardedGP
+        return ShardedGP(sn2, rho, ell, bias, kernel, devices)
     return GP(sn2, rho, ell, bias, kernel, device)

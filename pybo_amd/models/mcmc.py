@@ -184,18 +184,44 @@ class MCMC(object):
     # collector instead of going back to the handle pool at once.
     @property
     def acq_topk(self):
-        if not hasattr(self._proto, 'acq_values'):
+        if not hasattr(self._proto, '_engine'):      # single-handle device members only (gpx_ensemble_sweep)
             raise AttributeError('acq_topk')
         return self._acq_topk
 
     @property
     def topk_engine(self):
-        if not hasattr(self._proto, 'acq_values'):
+        if not hasattr(self._proto, '_engine'):
             raise AttributeError('topk_engine')
         return self._lead_engine
 
     def _lead_engine(self):
         return self._engines()[0]                # the ensemble's lead handle ranks the average
+
+    @property
+    def mean_topk(self):
+        if not hasattr(self._proto, '_engine'):
+            raise AttributeError('mean_topk')
+        return self._mean_topk
+
+    def predict_mean(self, X):
+        """Mixture mean only (= predict(X)[0]): the members' closed forms at the data where they have one
+        (EI / PI targets and the recommenders ask for the mean at the observed points, pybo/policies/simple.py:21,35,
+        pybo/recommenders.py:22-34 -- as a sweep that is n members x an N x N x N product)."""
+        members = self._need()
+        if all(hasattr(m, 'predict_mean') for m in members):
+            return np.mean([m.predict_mean(X) for m in members], axis=0)
+        return self.predict(X)[0]
+
+    def _mean_topk(self, xgrid, k):
+        from .._lib import DeviceGrid
+        if not isinstance(xgrid, DeviceGrid):
+            xgrid = np.array(xgrid, ndmin=2, dtype=float)
+            if self._members and self._members[0]._data_rows(xgrid) is not None:
+                mu = self.predict_mean(xgrid)
+                v = np.where(np.isnan(mu), -np.inf, mu)
+                order = np.lexsort((np.arange(len(v)), -v))[:int(k)]
+                return mu[order], order
+        return self._acq_topk('mean', None, xgrid, k)
 
     # -- sampling ----------------------------------------------------------------------------------
     def _advance(self, nsteps, keep):

@@ -33,7 +33,9 @@ def _attach_topk(index, model, kind, param):
 def _incumbent_target(model, X, xi):
     """Copy the model (the caller's must stay untouched) and compute best-posterior-mean-at-the-data + xi."""
     snapshot = model.copy()
-    return snapshot, snapshot.predict(X)[0].max() + xi
+    mean_only = getattr(snapshot, 'predict_mean', None)      # device models: no variance sweep nobody reads
+    mu = mean_only(X) if mean_only is not None else snapshot.predict(X)[0]
+    return snapshot, mu.max() + xi
 
 
 def EI(model, _, X, xi=0.0):

@@ -17,13 +17,14 @@ def best_latent(model, bounds, X):
             return post[0], post[2]
         return model.predict(X)[0]
 
-    fast = getattr(model, 'acq_topk', None)
+    fast = getattr(model, 'mean_topk', None)        # device models: closed form at the data, else the device sweep
     if fast is not None:
-        mean.topk = lambda xgrid, k: fast('mean', None, xgrid, k)
+        mean.topk = fast
     xbest, _ = solvers.solve_lbfgs(mean, bounds, xgrid=X)
     return xbest
 
 
 def best_incumbent(model, _, X):
-    mu, _ = model.predict(X)
+    mean_only = getattr(model, 'predict_mean', None)
+    mu = mean_only(X) if mean_only is not None else model.predict(X)[0]
     return np.asarray(X)[int(np.argmax(mu))]

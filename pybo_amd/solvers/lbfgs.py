@@ -26,7 +26,9 @@ import numpy as np
 import scipy.optimize
 
 from ..inits import init_uniform
-from .._lib import DeviceGrid, TOPK_MAX
+from .._lib import DeviceGrid, ShardedDeviceGrid, TOPK_MAX
+
+_DEVICE_GRIDS = (DeviceGrid, ShardedDeviceGrid)
 
 __all__ = ['solve_lbfgs']
 
@@ -100,13 +102,26 @@ def _refine_lockstep(f, seeds, bounds):
     return out
 
 
-def solve_lbfgs(f, bounds, nbest=10, ngrid=10000, xgrid=None, rng=None, select='first', batched=True):
-    """Maximise f over the box; returns (xmax, fmax)."""
+def solve_lbfgs(f, bounds, nbest=10, ngrid=10000, xgrid=None, rng=None, select='first', batched=True,
+                shard='auto'):
+    """Maximise f over the box; returns (xmax, fmax).
+
+    shard: 'auto' (default) -- when the process runs as one rank of an initialised torch.distributed group and the
+    index has a device `.topk`, the grid stage is sharded over the ranks (pybo_amd.dist.ShardedIndex: contiguous
+    slices, one all-gather of the (value, index) pairs, identical merged seeds on every rank); True forces it,
+    False keeps the whole grid on this rank.  Selectable through the plugin API: solver=('lbfgs', {'shard': ...})."""
     bounds = np.array(bounds, dtype=float, ndmin=2)
     topk = getattr(f, 'topk', None)
+    if shard not in ('auto', True, False):
+        raise ValueError("shard must be 'auto', True or False")
+    if topk is not None and shard is not False:
+        from .. import dist as pdist
+        if not isinstance(f, pdist.ShardedIndex) and (shard is True or pdist.world_size() > 1):
+            f = pdist.ShardedIndex(f)
+            topk = f.topk
     if xgrid is None:
         xgrid = init_uniform(bounds, ngrid, rng)
-    elif isinstance(xgrid, DeviceGrid):
+    elif isinstance(xgrid, _DEVICE_GRIDS):
         if topk is None:                      # host-side index: it needs the coordinates
             xgrid = np.asarray(xgrid)
     else:
@@ -117,7 +132,7 @@ def solve_lbfgs(f, bounds, nbest=10, ngrid=10000, xgrid=None, rng=None, select='
         # the device top-k keeps at most TOPK_MAX entries; the reference accepts any nbest
         # (pybo/solvers/lbfgs.py:51 is a full argsort), so larger requests rank the values on the host
         topk = None
-        if isinstance(xgrid, DeviceGrid):
+        if isinstance(xgrid, _DEVICE_GRIDS):
             xgrid = np.asarray(xgrid)
     if topk is not None:
         _, best = topk(xgrid, k)

@@ -133,3 +133,60 @@ def test_lockstep_refinement_surfaces_index_errors():
         solvers.solve_lbfgs(broken, [[0, 1], [0, 1]], nbest=3, xgrid=np.random.RandomState(0).rand(20, 2),
                             select='best')
 
+
+
+def test_trace_rows_behave_like_the_reference_lists_and_convert_in_one_copy():
+    """The trace columns are lists of points (pybo/bayesopt.py:271 appends to them) that also hand numpy one array."""
+    from pybo_amd.bayesopt import _Rows
+    import pickle
+    rows = _Rows()
+    assert len(rows) == 0 and not rows and np.array(rows).size == 0
+    pts = np.random.RandomState(0).rand(40, 3)
+    for p in pts[:20]:
+        rows.append(p)
+    rows.extend(pts[20:])
+    assert len(rows) == 40 and rows[-1].shape == (3,) and np.array_equal(rows[17], pts[17])
+    np.testing.assert_array_equal(np.array(rows, ndmin=2, dtype=float), pts)
+    np.testing.assert_array_equal(np.array(list(rows)), pts)
+    back = pickle.loads(pickle.dumps(rows))
+    assert isinstance(back, _Rows) and np.array_equal(np.array(back), pts)
+    with pytest.raises(ValueError):
+        rows.append(np.zeros(4))
+
+
+def test_checkpoint_stores_the_trace_as_arrays_and_loads_lists(tmp_path):
+    from pybo_amd.bayesopt import safe_dump, safe_load, Info
+    log = str(tmp_path / 'c.pkl')
+    X = np.random.RandomState(1).rand(7, 2)
+    safe_dump({'m': 1}, Info(list(X), list(X[:, 0]), list(X[:5])), log)
+    model, info = safe_load(log)
+    assert model == {'m': 1} and isinstance(info.x, list) and len(info.x) == 7 and len(info.xbest) == 5
+    np.testing.assert_array_equal(np.array(info.x), X)
+    assert info.y == list(X[:, 0])
+
+
+def test_solver_shard_option_resolves_through_the_plugin_api():
+    from pybo_amd.bayesopt import get_component
+    from pybo_amd import solvers
+    from helpers import analytic_index
+    solver = get_component(('lbfgs', {'shard': False, 'ngrid': 500}), solvers, np.random.RandomState(0), lstrip='solve_')
+    f, bounds = analytic_index('bimodal2')
+    x, fx = solver(f, bounds)
+    assert abs(fx - 2.0) < 0.1
+    with pytest.raises(ValueError):
+        solvers.solve_lbfgs(f, bounds, shard='maybe')
+
+
+def test_bench_self_launch_builds_the_driver_shaped_command(monkeypatch):
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run."""
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+    monkeypatch.setattr(subprocess, 'call', lambda cmd, **kw: seen.update(cmd=cmd, kw=kw) or 0)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '2'])
+    assert bench.self_launch(4) == 0
+    cmd = seen['cmd']
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '4'
+    assert '--master-addr' in cmd and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[-4:] == ['--gpus', '4', '--steps', '2'] and cmd[-5].endswith('bench.py')

@@ -156,3 +156,51 @@ def test_device_exchange_branch_checks_its_preconditions():
     del index.topk_engine
     with pytest.raises(ValueError):
         pdist.sharded_topk(index, grid, 5, comm=comm)                  # a host index has no device pairs
+
+
+# ---- SPMD runs of the whole loop: the objective is evaluated ONCE per iteration (pybo/bayesopt.py:268) -------------
+def _spmd_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import pybo_amd
+        from helpers import SmootherModel
+        calls = []
+        noise = np.random.RandomState(1000 + rank)           # a NOISY objective: every rank would see other values
+
+        def objective(x):
+            calls.append(np.array(x))
+            return float(-np.sum((np.ravel(x) - 0.3) ** 2) + 0.3 * noise.randn())
+
+        bounds = [[0.0, 1.0], [0.0, 1.0]]
+        xbest, model, info = pybo_amd.solve_bayesopt(objective, bounds, model=SmootherModel(), niter=5, policy='ei',
+                                                     solver=('lbfgs', {'ngrid': 200}), recommender='incumbent', rng=3)
+        q.put((rank, len(calls), info.x, info.y, model.X, model.Y, xbest))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_spmd_loop_evaluates_the_objective_on_one_rank_and_keeps_the_models_equal():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_spmd_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict((g[0], g[1:]) for g in (q.get(timeout=300) for _ in range(world)))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][0] == 6 and got[1][0] == 0            # box centre + 5 iterations, all on rank 0
+    for a, b in zip(got[0][1:], got[1][1:]):            # traces, model data and recommendation: bitwise equal
+        np.testing.assert_array_equal(a, b)
+    assert len(got[0][2]) == 6
+
+
+def test_spmd_objective_is_the_identity_without_a_process_group():
+    f = lambda x: 1.0                                    # noqa: E731
+    assert pdist.spmd_objective(f) is f and pdist.world_size() == 1

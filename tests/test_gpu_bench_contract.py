@@ -58,3 +58,25 @@ def test_two_ranks_through_torch_distributed_run_select_the_same_candidate():
     assert two['n_gpus'] == 2 and two['scaling'] == 'strong'
     assert two['selected'] == one['selected']          # bit-identical merged top-1 (value and global index)
     assert two['warm_step']['selected'] == one['warm_step']['selected']
+
+
+def test_gpus_2_without_a_launcher_starts_its_own_ranks():
+    """The driver's command shape is literally `python3 bench.py --gpus N` (BENCH_r02.json.cmd): bench.py must start
+    the N ranks itself.  Dry run on the one GPU of the box: gloo + --share-device 0.  One JSON line, n_gpus = 2, the
+    single-rank selection, and the N > 1 line carries roofline, cpu_baseline and parity too."""
+    one = _line([sys.executable, 'bench.py'] + COMMON + ['--no-cpu-baseline', '--no-refine', '--plugin-steps', '0'])
+    two = _line([sys.executable, 'bench.py', '--gpus', '2', '--backend', 'gloo', '--share-device', '0'] + COMMON +
+                ['--no-refine', '--cpu-candidates', '8192'])
+    assert two['n_gpus'] == 2 and two['selected'] == one['selected']
+    assert two['warm_step']['selected'] == one['warm_step']['selected']
+    assert two['roofline']['frac'] > 0.05 and two['cpu_baseline']['value'] > 0
+    assert two['parity']['selected_index_matches'] and two['parity']['moments_within_stated_tolerance']
+
+
+def test_single_rank_line_reports_parity_and_the_plugin_level_step():
+    o = _line([sys.executable, 'bench.py'] + COMMON + ['--cpu-candidates', '8192', '--no-refine', '--plugin-steps', '3'])
+    p = o['parity']
+    assert p['n_compared'] == 8192 and p['selected_index_matches'] and p['moments_within_stated_tolerance']
+    assert p['max_rel_mu'] < 1e-6 and p['max_rel_s2'] < 1e-6 and p['max_rel_acq'] < 1e-6
+    s = o['plugin_step']
+    assert s['iterations'] == 3 and s['cold_ms'] > 0 and len(s['warm_ms_each']) == 2 and s['warm_ms'] > 0
