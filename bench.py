@@ -109,13 +109,9 @@ def cpu_baseline(w, budget_candidates):
     the fit in full, the sweep on `budget_candidates` of the M candidates, extrapolated linearly.
     Returns (the cpu_baseline record, the oracle's values on the sample for the parity record)."""
     from oracle import gp_ref
-    threads, limiter = len(os.sched_getaffinity(0)), None
+    threads = len(os.sched_getaffinity(0))
     try:
-        from threadpoolctl import threadpool_info, threadpool_limits
-        if os.environ.get('OMP_NUM_THREADS') == '1' and int(os.environ.get('WORLD_SIZE', '1')) > 1:
-            # torch.distributed.run pins OMP_NUM_THREADS=1 for multi-rank launches; the baseline (rank 0 only, the
-            # other ranks idle in a barrier) gets the host's cores back
-            limiter = threadpool_limits(limits=threads)
+        from threadpoolctl import threadpool_info
         threads = max([p.get('num_threads', 1) for p in threadpool_info()] or [1])
     except Exception:
         pass
@@ -142,8 +138,6 @@ def cpu_baseline(w, budget_candidates):
         v = smp.get(Z)
     vals.update(acq=v, best=int(np.argmax(v)))
     t_sw = time.perf_counter() - t0
-    if limiter is not None:
-        limiter.restore_original_limits()
     step = t_fit + t_sw * (w['M'] / float(len(Z)))
     how = 'in full' if len(Z) == w['M'] else 'extrapolated linearly to M'
     rec = dict(value=1.0 / step, unit='steps/s', cores=int(threads), kind='port',
@@ -153,6 +147,26 @@ def cpu_baseline(w, budget_candidates):
                          len(os.sched_getaffinity(0))),
                extrapolated=len(Z) != w['M'], seconds_per_step=step)
     return rec, vals
+
+
+def cpu_baseline_unpinned(workload, M, nc):
+    """torch.distributed.run pins OMP_NUM_THREADS=1 in every rank of a multi-rank launch, and a BLAS that was
+    initialised with one thread cannot safely be widened afterwards: rank 0 therefore times the baseline in a child
+    process of its own with the pin removed (the other ranks wait in the closing barrier), and reads the record and
+    the oracle's values back from a scratch file."""
+    import pickle
+    import subprocess
+    import tempfile
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('OMP_NUM_THREADS', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR',
+                        'MASTER_PORT', 'GROUP_RANK', 'ROLE_RANK', 'ROLE_WORLD_SIZE', 'TORCHELASTIC_RUN_ID')}
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'cpu.pkl')
+        subprocess.check_call([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', path, '--workload',
+                               workload, '--candidates', str(M), '--cpu-candidates', str(nc)], env=env,
+                              stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL)
+        with open(path, 'rb') as fh:
+            return pickle.load(fh)
 
 
 def parity_record(w, ref_vals, dev_vals):
@@ -280,7 +294,15 @@ def main():
     ap.add_argument('--plugin-steps', type=int, default=4,
                     help='also time this many iterations of pybo_amd.solve_bayesopt THROUGH THE PLUGIN API at the '
                          'workload size (cold + warm; reported separately as plugin_step); 0 = skip')
+    ap.add_argument('--cpu-baseline-worker', default='', help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.cpu_baseline_worker:                      # child of cpu_baseline_unpinned: no GPU, no process group
+        import pickle
+        res = cpu_baseline(make_workload(args.workload, args.candidates), args.cpu_candidates)
+        with open(args.cpu_baseline_worker, 'wb') as fh:
+            pickle.dump(res, fh)
+        return
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         # invoked as `python bench.py --gpus N`: start the N ranks ourselves
@@ -558,7 +580,10 @@ def main():
             # --cpu-candidates 131072 gives SURVEY 8(d)'s 2^17 sample (~1.5 min).  With N > 1 ranks rank 0 times it
             # (on the candidates at the head of its own shard) while the others wait in the closing barrier.
             nc = min(args.cpu_candidates or (M if N <= 2048 else 32768), Ml if w['acq'] != 'thompson' else M)
-            out['cpu_baseline'], ref_vals = cpu_baseline(w, nc)
+            if world > 1 and os.environ.get('OMP_NUM_THREADS') == '1':
+                out['cpu_baseline'], ref_vals = cpu_baseline_unpinned(w['name'], M, nc)
+            else:
+                out['cpu_baseline'], ref_vals = cpu_baseline(w, nc)
             # the same candidates on the device, outside any timed region: every bench line is also a parity check
             eng.fit_dev(dX.data_ptr(), N, d, dy.data_ptr(), w['kernel'], w['ell'], w['rho'], w['sn2'], w['bias'])
             dev_vals = {}

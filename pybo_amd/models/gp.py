@@ -13,6 +13,7 @@ logic only: data bookkeeping, copy-on-write sharing of the device state between 
 gradient chain rule on top of device-computed (mu, s2, dmu, ds2).
 There is NO CPU fallback: without the library / a GPU, the first device call raises.
 """
+import threading
 import weakref
 
 import numpy as np
@@ -26,6 +27,7 @@ __all__ = ['GP', 'make_gp']
 
 _KERNELS = ('se', 'matern5', 'matern3', 'matern1')
 _ENGINE_POOL = []      # engines whose last owner died; reused so steady-state BO never re-allocates
+_POOL_LOCK = threading.RLock()      # models are created and dropped from several host threads (models/sharded.py)
 _POOL_SMALL_N = 1024   # handles whose factor buffers are ALLOCATED for at most ~this many rows count as small (<= ~40 MB)
 
 
@@ -38,18 +40,20 @@ def _is_small(engine):
 class _DeviceState(object):
     """A fitted engine shared by a model and its copies (copy-on-write in GP._own_state)."""
 
-    def __init__(self, device):
+    def __init__(self, device, ndata=0):
         self.engine = None
         self.key = None            # hyper-parameters of the fit the engine holds
         self.cache_grid = None     # the DeviceGrid whose sweep sums the engine keeps (warm BO step)
-        for i in range(len(_ENGINE_POOL) - 1, -1, -1):
-            cand = _ENGINE_POOL[i]
-            if not cand._h:                            # never hand out a closed handle
-                del _ENGINE_POOL[i]
-            elif cand.device == device:                # handles of other devices wait for their own models
-                del _ENGINE_POOL[i]
-                self.engine = cand
-                break
+        # a pooled handle of this device, preferably of the model's size class (a small model that borrows a
+        # multi-GB handle keeps it out of reach of the next large model, which then allocates afresh)
+        with _POOL_LOCK:
+            _ENGINE_POOL[:] = [e for e in _ENGINE_POOL if e._h]          # never hand out a closed handle
+            want_small = ndata <= _POOL_SMALL_N
+            mine = [e for e in _ENGINE_POOL if e.device == device]       # other devices' handles wait for their models
+            pick = next((e for e in reversed(mine) if _is_small(e) == want_small), mine[-1] if mine else None)
+            if pick is not None:
+                _ENGINE_POOL.remove(pick)
+                self.engine = pick
         if self.engine is None:
             self.engine = _lib.Engine(device)
         self.nrefs = 1
@@ -61,19 +65,20 @@ class _DeviceState(object):
             # allocations), which was 80 % of a default solve_bayesopt run -- the hyper-parameter sampler turns over
             # ~30 member / proposal models per iteration.  Handles of small models are cheap to keep (a few MB);
             # at most 4 large ones (their factor and sweep buffers stay allocated) wait in the pool.
-            room = False
-            if self.engine._h:
-                small = _is_small(self.engine)
-                room = (sum(1 for e in _ENGINE_POOL if _is_small(e)) < 64) if small \
-                    else (sum(1 for e in _ENGINE_POOL if not _is_small(e)) < 4)
-            if room:
-                try:
-                    self.engine.set_option('sweep_cache', -1)       # the next owner starts without a cache
-                except Exception:
-                    pass
-                _ENGINE_POOL.append(self.engine)
-            self.engine = None
-            self.cache_grid = None
+            with _POOL_LOCK:
+                room = False
+                if self.engine._h:
+                    small = _is_small(self.engine)
+                    room = (sum(1 for e in _ENGINE_POOL if _is_small(e)) < 64) if small \
+                        else (sum(1 for e in _ENGINE_POOL if not _is_small(e)) < 4)
+                if room:
+                    try:
+                        self.engine.set_option('sweep_cache', -1)       # the next owner starts without a cache
+                    except Exception:
+                        pass
+                    _ENGINE_POOL.append(self.engine)
+                self.engine = None
+                self.cache_grid = None
 
 
 class Param(object):
@@ -199,7 +204,7 @@ class GP(object):
             self._state.release()
             self._state = None
         if self._state is None:
-            self._state = _DeviceState(self.device)
+            self._state = _DeviceState(self.device, self.ndata)
         return self._state
 
     def _hyper_key(self):

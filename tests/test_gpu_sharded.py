@@ -211,6 +211,9 @@ def test_a_warm_plugin_iteration_launches_no_sweep():
 def test_pool_classifies_handles_by_what_they_keep_allocated():
     """a handle that once held a large model is pooled as LARGE even if its last fit was small."""
     from pybo_amd.models import gp as gpmod
+    for e in gpmod._ENGINE_POOL:                                  # start from an empty pool
+        e.close()
+    del gpmod._ENGINE_POOL[:]
     X, y, ell = synth_problem(1500, 2, seed=2)
     g = models.make_gp(1e-3, 1.0, ell, 0.0)
     g.add_data(X, y)
@@ -221,6 +224,12 @@ def test_pool_classifies_handles_by_what_they_keep_allocated():
     assert gpmod._is_small(g2._engine()) and g2._engine().capacity() <= 256 + 128
     eng.fit(X[:20], y[:20], 'se', ell, 1.0, 1e-3, 0.0)       # the big handle now holds a small model ...
     assert eng.N == 20 and not gpmod._is_small(eng)          # ... and still counts as large
+    # a released large handle goes to the next LARGE model, a small model gets a small one
+    del g, g2
+    assert sorted(gpmod._is_small(e) for e in gpmod._ENGINE_POOL) == [False, True]
+    g3 = models.make_gp(1e-3, 1.0, ell, 0.0)
+    g3.add_data(X[:30], y[:30])
+    assert gpmod._is_small(g3._engine()) and [gpmod._is_small(e) for e in gpmod._ENGINE_POOL] == [False]
 
 
 def test_loglik_at_chunks_beyond_the_batch_limit():
@@ -237,8 +246,8 @@ def test_loglik_at_chunks_beyond_the_batch_limit():
 
 def test_noise_free_model_can_still_draw_thompson_samples():
     """sn2 = 0 is a valid fit; the weight posterior then runs on the host path."""
-    X, y, ell = synth_problem(40, 2, seed=8)
-    g = models.make_gp(0.0, 1.0, 3 * ell, 0.0)
-    g.add_data(X[:12], y[:12])
-    f = g.sample_f(30, 3)
+    X, y, ell = synth_problem(16, 2, seed=8)
+    g = models.make_gp(0.0, 1.0, 0.25 * ell, 0.0)     # short length-scales: K itself is well conditioned without noise
+    g.add_data(X, y)                                  # 16 observations, 10 features: the feature Gram is positive definite
+    f = g.sample_f(10, 3)
     assert np.all(np.isfinite(f.get(X[:5])))
