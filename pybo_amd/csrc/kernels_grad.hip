@@ -88,11 +88,44 @@ __global__ __launch_bounds__(256) void k_tri_matvec_multi(const double* __restri
         const int64_t lo = (mode == 0) ? 0 : row;
         const int64_t hi = (mode == 0) ? row + 1 : N;
         const double* mr = Mx + row * Np;
-        for (int64_t j = lo + lane; j < hi; j += 64) {
-            const double t = mr[j];
+        {
+            // The pass is a pure HBM stream of the matrix row: 16-byte loads over the aligned pairs that cover
+            // [lo, hi); elements outside [lo, hi) are dropped by select, never multiplied.  With few right-hand sides
+            // (one L-BFGS instance, gpx_append) four loads are in flight per lane (2 KB per wave and step).  Every
+            // variant adds a lane's pairs in the same order (p0 + lane, + 64, ...; x before y), so a row's result does
+            // not depend on the batch it is evaluated in (the lock-step refinement relies on that, tested).
+            const int64_t p0 = lo >> 1, p1 = (hi + 1) >> 1;          // pairs [p0, p1)
+            const double2* mr2 = reinterpret_cast<const double2*>(mr);
+            int64_t p = p0 + lane;
+            for (; MBT <= 4 && p + 192 < p1; p += 256) {
+                double2 t[4];
 #pragma unroll
-            for (int m = 0; m < MBT; ++m)
-                if (m < mb) acc[m] = fma(t, in[(int64_t)m * Np + j], acc[m]);
+                for (int u = 0; u < 4; ++u) t[u] = mr2[p + 64 * u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t j = 2 * (p + 64 * u);
+                    const double tx = (j >= lo) ? t[u].x : 0.0;       // (j + 1 < hi and j < hi hold inside the main loop
+                    const double ty = (j + 1 < hi) ? t[u].y : 0.0;    //  except at the two ragged ends)
+#pragma unroll
+                    for (int m = 0; m < MBT; ++m)
+                        if (m < mb) {
+                            const double2 v = *reinterpret_cast<const double2*>(in + (int64_t)m * Np + j);
+                            acc[m] = fma(tx, v.x, fma(ty, v.y, acc[m]));
+                        }
+                }
+            }
+            for (; p < p1; p += 64) {
+                const double2 t = mr2[p];
+                const int64_t j = 2 * p;
+                const double tx = (j >= lo && j < hi) ? t.x : 0.0;
+                const double ty = (j + 1 >= lo && j + 1 < hi) ? t.y : 0.0;
+#pragma unroll
+                for (int m = 0; m < MBT; ++m)
+                    if (m < mb) {
+                        const double2 v = *reinterpret_cast<const double2*>(in + (int64_t)m * Np + j);
+                        acc[m] = fma(tx, v.x, fma(ty, v.y, acc[m]));
+                    }
+            }
         }
     }
 #pragma unroll
