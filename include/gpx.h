@@ -75,6 +75,11 @@ int gpx_version(void);
  *              0 (default): full sweeps leave an existing cache alone (it stays valid and is still kept current
  *              by gpx_append); -1: drop the cache.
  *          "chol_w" = outer panel width of the blocked factorisation in 128-blocks (2..8; 0 = by size, default).
+ *          "chol_rl" = 1 (default): inside an outer panel the rows still to come receive each factored row's contribution
+ *              at once (right-looking, K = 128 per launch); 0: left-looking row updates (K = 128..(w-1)*128), round 2's
+ *              order.  Bit-identical results either way.
+ *          "x_bg", "x_bg_lds", "x_bg_iters" = DIAGNOSTIC (scripts/chol_bg.py): a synthetic register-only fp64-MFMA kernel of
+ *              x_bg workgroups (x_bg_lds KB of LDS each, x_bg_iters rounds) runs beside the factorisation.
  *          "x_skip" = DIAGNOSTIC (scripts/chol_parts.py): leave out the far updates (bit 0), the chain kernels
  *              (bit 1) or the near updates (bit 2) of the factorisation to time its parts alone -- the result is
  *              then NOT a factorisation; 0 (default) = everything. */

@@ -217,6 +217,7 @@ extern "C" int gpx_destroy(gpx_handle* h) {
     if (h->hpin) hipHostFree(h->hpin);
     if (h->hinv) hipHostFree(h->hinv);
     if (h->ev_inv) hipEventDestroy(h->ev_inv);
+    if (h->stream_bg) { hipStreamSynchronize(h->stream_bg); hipStreamDestroy(h->stream_bg); }
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
     if (h->stream3) { hipStreamSynchronize(h->stream3); hipStreamDestroy(h->stream3); }
     if (h->stream4) { hipStreamSynchronize(h->stream4); hipStreamDestroy(h->stream4); }
@@ -261,9 +262,19 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             h->chol_w = (int)value;
             return GPX_OK;
         }
+        if (!strcmp(name, "chol_rl")) {
+            if (value != 0 && value != 1) return fail(h, GPX_EARG, "chol_rl must be 0 or 1");
+            h->chol_rl = (int)value;
+            return GPX_OK;
+        }
         if (!strcmp(name, "x_skip")) {       // diagnostic only: see launch_cholesky
             if (value < 0 || value > 7) return fail(h, GPX_EARG, "x_skip: bits 0..2");
             h->x_skip = (int)value;
+            return GPX_OK;
+        }
+        if (!strcmp(name, "x_bg") || !strcmp(name, "x_bg_lds") || !strcmp(name, "x_bg_iters")) {   // diagnostic only
+            if (value < 0 || value > 10000000) return fail(h, GPX_EARG, "x_bg*: out of range");
+            (name[4] == 0 ? h->x_bg : (name[5] == 'l' ? h->x_bg_lds : h->x_bg_iters)) = (int)value;
             return GPX_OK;
         }
         if (!strcmp(name, "eager_inverse")) {

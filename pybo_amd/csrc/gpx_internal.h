@@ -35,6 +35,9 @@ struct gpx_handle {
     hipEvent_t ev_chain = nullptr, ev_far = nullptr, ev_rest = nullptr;
     hipEvent_t ev_row[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int x_skip = 0;               // diagnostic: time parts of the factorisation alone (see launch_cholesky)
+    int x_bg = 0, x_bg_lds = 72, x_bg_iters = 10000;   // diagnostic: synthetic MFMA background load (k_bg_mfma)
+    hipStream_t stream_bg = nullptr;
+    int chol_rl = 1;              // in-panel updates right-looking (1, default) or left-looking (0)
     int chol_w = 0;               // outer panel width of the factorisation in 128-blocks (2..8; 0 = by size)
     std::string err;
 

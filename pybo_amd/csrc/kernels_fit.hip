@@ -708,6 +708,32 @@ __global__ __launch_bounds__(GEMM64_THREADS) void k_row_update64(const double* _
 
 constexpr int CHOL_W = 4;   // outer panel width in 128-blocks
 
+// DIAGNOSTIC (option "x_bg", scripts/chol_bg.py): a synthetic background load for the chain kernels -- `G` workgroups
+// that do nothing but fp64 MFMAs on registers for `iters` rounds (16 MFMAs = 1024 matrix-pipe cycles per round and
+// wave), at the far updates' wave priority, holding LDSKB kilobytes of LDS so that 2 (72) or 1 (100) of them fit on a
+// compute unit.  Separates the two ways the trailing updates can slow the chain down: taking its CU SLOTS (not with
+// this kernel: G <= the slots it leaves free) and sharing the DOUBLE-PRECISION PIPE of the SIMDs it runs on.
+template <int LDSKB>
+__global__ __launch_bounds__(256) void k_bg_mfma(int iters, double* __restrict__ sink) {
+    __shared__ double pad[LDSKB * 128];
+    d4 acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = (d4){0.0, 0.0, 0.0, 0.0};
+    const double a = 1e-9 * threadIdx.x, b = 1.0 + 1e-9 * blockIdx.x;
+    for (int it = 0; it < iters; ++it) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    }
+    double t = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += acc[j][0] + acc[j][3];
+    if (threadIdx.x == 0) pad[blockIdx.x & 127] = t;
+    __syncthreads();
+    if (t == 123456.789 && pad[threadIdx.x & 127] == 1.0) sink[0] = t;     // never true: keeps the work alive
+}
+
 // Two-level blocked right-looking factorisation with lookahead.  U(Q, P) = update of panel Q's block rows
 // with the factored rows of panel P (K = W*128); chain(Q) needs every U(Q, P < Q).
 //   chain(P)   rows P0..P1-1 one by one: row update (left-looking inside the panel, 64x64 tiles) -> k_potrf16 ->
@@ -733,13 +759,23 @@ void launch_cholesky(gpx_handle* h) {
     const bool far = !(h->x_skip & 1), chain = !(h->x_skip & 2), near = !(h->x_skip & 4);
     bool mid_pending = false, side_used = false, rest_used = false;
     hipStream_t s4 = h->stream4;
+    if (h->x_bg > 0) {            // diagnostic background load on a stream of its own (see k_bg_mfma)
+        if (!h->stream_bg) hipStreamCreateWithFlags(&h->stream_bg, hipStreamNonBlocking);
+        hipStreamSynchronize(h->stream_bg);                  // (diagnostic: the previous run's load has ended,
+        hipStreamSynchronize(s);                             //  both start from an idle device)
+        if (h->x_bg_lds >= 100)
+            hipLaunchKernelGGL(k_bg_mfma<100>, dim3((unsigned)h->x_bg), dim3(256), 0, h->stream_bg, h->x_bg_iters, h->dscal + 8);
+        else
+            hipLaunchKernelGGL(k_bg_mfma<72>, dim3((unsigned)h->x_bg), dim3(256), 0, h->stream_bg, h->x_bg_iters, h->dscal + 8);
+    }
     int near_rows = 0;            // rows P0+1.. of the CURRENT panel whose near update runs on the third stream
     for (int P0 = 0; P0 < nP; P0 += CW) {
         const int P1 = (P0 + CW < nP) ? P0 + CW : nP;
         for (int I = P0; I < P1; ++I) {
-            if (I == P0 + 1 && near_rows > 0)      // rows P0+1.. got the previous panel's update on stream 3
+            const bool rl = h->chol_rl != 0;     // in-panel updates right-looking (K = 128 per step) instead of left-looking
+            if (!rl && I == P0 + 1 && near_rows > 0)      // rows P0+1.. got the previous panel's update on stream 3
                 hipStreamWaitEvent(s, h->ev_row[0], 0);
-            if (I > P0 && chain)   // block row I <- contributions of rows P0..I-1 of this panel
+            if (!rl && I > P0 && chain)   // block row I <- contributions of rows P0..I-1 of this panel
                 hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - I)), 2), dim3(GEMM64_THREADS), 0, s,
                                    h->dR, h->dS, Np, P0, I, I, (int64_t)0, nP, 3);
             if (chain)
@@ -749,6 +785,16 @@ void launch_cholesky(gpx_handle* h) {
             if (rem > 0 && chain)
                 hipLaunchKernelGGL(k_panel_solve16, dim3((unsigned)(2 * rem)), dim3(256), 0, s, h->dU, h->dS, h->dR, Np,
                                    I, h->dflag, (int64_t)0);
+            if (rl && I + 1 < P1) {
+                // RIGHT-LOOKING inside the panel: the rows of this panel that are still to come receive row I's
+                // contribution now (K = 128 per launch: the latency of a K = 128 tile, ~12 us, instead of the
+                // K = 128 .. 384 of the left-looking row update, 12 .. 24 us, in front of every diagonal block).
+                // The same FMAs in the same order per element (accumulators start from S): bit-identical.
+                if (I == P0 && near_rows > 0) hipStreamWaitEvent(s, h->ev_row[0], 0);
+                if (chain)
+                    hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - I - 1)), (unsigned)(2 * (P1 - I - 1))),
+                                       dim3(GEMM64_THREADS), 0, s, h->dR, h->dS, Np, I, I + 1, I + 1, (int64_t)0, nP, 3);
+            }
         }
         near_rows = 0;
         if (P1 >= nP) break;
