@@ -86,8 +86,8 @@ int gpx_version(void);
 int gpx_set_option(gpx_handle *h, const char *name, int64_t value);
 
 /* ---- GP fit = model.add_data(X, Y)            [pybo/bayesopt.py:114,258,269] ------------- */
-/* Limits: 1 <= d <= 1024 for the exact-GP entry points (fit, sweep, predict, append, loglik, grids); the Thompson /
- * RFF entry points take d <= 64 (their feature tiles live in LDS); top-k requests k <= 64.
+/* Limits: 1 <= d <= 1024 for every entry point (the Thompson / RFF kernels keep a whole feature tile in LDS up to
+ * d = 64 and walk the coordinates 32 at a time beyond); top-k requests k <= 64.
  * Gram build K = k(X,X) + sn2 I and Cholesky K = R^T R.  The triangular inverse T = R^-T, a = T (y - bias)
  * and alpha follow on FIRST USE (sweep, predict, mean_at_obs, loglik, append, introspection): the Thompson
  * entry points never read them.  X is (N,d), y is (N,), ell is (d,) on the HOST in both variants. */

@@ -874,7 +874,7 @@ static int rff_core(gpx_handle* h, const double* W, const double* b, const doubl
                     double* top_val, int64_t* top_idx, double* d_vals) {
     if (!W || !b || !theta || !dXc) return fail(h, GPX_EARG, "rff_sweep: NULL pointer");
     if (S < 1 || n < 1 || d < 1 || M < 1) return fail(h, GPX_EARG, "rff_sweep: bad sizes");
-    if (d > DMAX_RFF) return fail(h, GPX_EARG, "rff_sweep: the Thompson kernels take d <= 64 (feature tiles in LDS)");
+    if (d > DMAX_RFF) return fail(h, GPX_EARG, "rff_sweep: d must be <= 1024");
     if (k < 0 || k > TOPK_MAX) return fail(h, GPX_EARG, "rff_sweep: k must be in [0, 64]");
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
@@ -1019,7 +1019,6 @@ extern "C" int gpx_rff_gram_batch(gpx_handle* h, const double* W, const double* 
         if (!h) return GPX_EARG;
         if (h->stage < 1) return fail(h, GPX_ESTATE, "rff_gram: no data on the device (fit first)");
         if (!W || !b || !A || !v || n < 1 || S < 1) return fail(h, GPX_EARG, "rff_gram: bad arguments");
-        if (h->d > DMAX_RFF) return fail(h, GPX_EARG, "rff_gram: the Thompson kernels take d <= 64 (feature tiles in LDS)");
         HIPCHK(h, hipSetDevice(h->device));
         hipStream_t s = h->stream;
         const int64_t d = h->d, Np = h->Np, N = h->N;
@@ -1066,7 +1065,6 @@ extern "C" int gpx_rff_posterior(gpx_handle* h, const double* W, const double* b
         if (!W || !b || !z || !theta || n < 1 || S < 1) return fail(h, GPX_EARG, "rff_posterior: bad arguments");
         if (n >= TBH) return fail(h, GPX_EARG, "rff_posterior: n <= 127 features (the weight posterior lives in LDS)");
         if (!(sc > 0.0) || !(h->sn2 > 0.0)) return fail(h, GPX_EARG, "rff_posterior: needs sc > 0 and a noise variance > 0");
-        if (h->d > DMAX_RFF) return fail(h, GPX_EARG, "rff_posterior: the Thompson kernels take d <= 64");
         HIPCHK(h, hipSetDevice(h->device));
         hipStream_t s = h->stream;
         int rc;

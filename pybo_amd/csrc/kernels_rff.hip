@@ -57,28 +57,35 @@ __device__ __forceinline__ double cos_cw(double z) {
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_rff_mfma(const double* __restrict__ Wt,
                                                               const double* __restrict__ bt,
                                                               const double* __restrict__ tt, int S, int nfb, int n,
-                                                              int d, int dp, double bias,
+                                                              int d, int dp, int dk, double bias,
                                                               const double* __restrict__ Xc, int64_t M,
                                                               double* __restrict__ vals) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];   // At[dp][LDT] | Bt[dp][LDT]
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // At[dk][LDT] | Bt[dk][LDT]
     // (single-buffered feature tile: 2*dp*144*8 B = 74 KB at d = 32, so TWO workgroups share a CU and hide
     //  each other's tile loads and cosine chains; a double-buffered tile would leave one workgroup per CU)
+    // dk = rows of the k-range held in LDS at a time.  dk == dp (d <= 64): the candidate tile is transposed into LDS
+    // once and stays for the workgroup's life, only feature tiles stream through.  dk < dp (d > 64, round 3: the
+    // Thompson entry points used to stop at d = 64): the projection walks the coordinates dk at a time, candidate and
+    // feature chunks both streaming -- the accumulators carry over, the k order is the same ascending one.
     double* At = lds;
-    double* Bt = lds + dp * LDT;
+    double* Bt = lds + dk * LDT;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int64_t m0 = (int64_t)blockIdx.x * TB;
-    // candidate tile, transposed into k-major once (lane <-> candidate: conflict-free LDS stores)
-    for (int e = t; e < TB * dp; e += GEMM_THREADS) {
-        const int k = e >> 7, m = e & 127;
-        const int64_t gm = m0 + m;
-        At[k * LDT + m] = (k < d && gm < M) ? Xc[gm * d + k] : 0.0;
-    }
+    const bool resident = (dk == dp);
+    auto load_a = [&](int k0, int kc) {   // candidate chunk, transposed into k-major (lane <-> candidate: conflict-free LDS stores)
+        for (int e = t; e < TB * kc; e += GEMM_THREADS) {
+            const int k = e >> 7, m = e & 127;
+            const int64_t gm = m0 + m;
+            At[k * LDT + m] = (k0 + k < d && gm < M) ? Xc[gm * d + k0 + k] : 0.0;
+        }
+    };
+    if (resident) load_a(0, dp);
     const int fr = lane & 15, fk = lane >> 4;
     const int ntile = S * nfb;
-    auto load_b = [&](int tile) {   // 16-byte pieces, coalesced rows of 1 KiB
-        const double* Wtile = Wt + (int64_t)tile * dp * TB;
+    auto load_b = [&](int tile, int k0, int kc) {   // 16-byte pieces, coalesced rows of 1 KiB
+        const double* Wtile = Wt + ((int64_t)tile * dp + k0) * TB;
         double* dst = Bt;
-        for (int e = t; e < (TB / 2) * dp; e += GEMM_THREADS) {
+        for (int e = t; e < (TB / 2) * kc; e += GEMM_THREADS) {
             const int k = e >> 6, c = (e & 63) * 2;
             *reinterpret_cast<d2*>(dst + k * LDT + c) = *reinterpret_cast<const d2*>(Wtile + (int64_t)k * TB + c);
         }
@@ -88,8 +95,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_rff_mfma(const double* __re
         const int fb = tile % nfb, s = tile / nfb;
         const int nv = min(TB, n - fb * TB);          // features of this tile that exist
         const int jt = (nv + 15) >> 4;                // ... in 16-column groups (uniform)
-        load_b(tile);
-        __syncthreads();   // feature tile (and, first time, the candidate tile) complete
         if (fb == 0) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -103,17 +108,24 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_rff_mfma(const double* __re
             for (int j = 0; j < 8; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
         const double* as = At + w * 32 + fr;
         const double* bs = Bt + fr;
-        for (int kk = 0; kk < dp / 4; ++kk) {
-            const int kr = kk * 4 + fk;
-            const double a0 = as[kr * LDT], a1 = as[kr * LDT + 16];
+        for (int k0 = 0; k0 < dp; k0 += dk) {
+            const int kc = min(dk, dp - k0);
+            if (!resident) load_a(k0, kc);
+            load_b(tile, k0, kc);
+            __syncthreads();   // this k-range of the feature tile (and of the candidate tile) is complete
+            for (int kk = 0; kk < kc / 4; ++kk) {
+                const int kr = kk * 4 + fk;
+                const double a0 = as[kr * LDT], a1 = as[kr * LDT + 16];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if (j < jt) {
-                    const double b = bs[kr * LDT + j * 16];
-                    acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1][j], 0, 0, 0);
+                for (int j = 0; j < 8; ++j) {
+                    if (j < jt) {
+                        const double b = bs[kr * LDT + j * 16];
+                        acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][j], 0, 0, 0);
+                        acc[1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1][j], 0, 0, 0);
+                    }
                 }
             }
+            if (k0 + dk < dp) __syncthreads();   // everyone has read this k-range: the next one may overwrite it
         }
         const double* bb = bt + (int64_t)tile * TB + fr;
         const double* th = tt + (int64_t)tile * TB + fr;
@@ -147,13 +159,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_rff_mfma(const double* __re
 }
 
 // device staging layout for the MFMA path: [Wt S*nfb*dp*128][bt S*nfb*128][tt S*nfb*128]
+// rows of the k-range the RFF kernels keep in LDS: the whole (padded) input dimension up to 64 coordinates (147 KB),
+// 32 at a time beyond (74 KB: two workgroups per CU)
+static int rff_k_chunk(int dp) { return dp <= DMAX_RFF_RESIDENT ? dp : 32; }
+
 void launch_rff_mfma(hipStream_t s, const double* Wt, const double* bt, const double* tt, int S, int nfb, int n, int d,
                      int dp, double bias, const double* Xc, int64_t M, double* vals) {
     dim3 grid((unsigned)((M + TB - 1) / TB));
-    const size_t ldsb = (size_t)(2 * dp * LDT) * sizeof(double);
+    const int dk = rff_k_chunk(dp);
+    const size_t ldsb = (size_t)(2 * dk * LDT) * sizeof(double);
     if (ldsb > 64 * 1024)
         hipFuncSetAttribute((const void*)k_rff_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    hipLaunchKernelGGL(k_rff_mfma, grid, dim3(GEMM_THREADS), ldsb, s, Wt, bt, tt, S, nfb, n, d, dp, bias, Xc, M,
+    hipLaunchKernelGGL(k_rff_mfma, grid, dim3(GEMM_THREADS), ldsb, s, Wt, bt, tt, S, nfb, n, d, dp, dk, bias, Xc, M,
                        vals);
 }
 
@@ -169,45 +186,54 @@ void launch_rff_mfma(hipStream_t s, const double* Wt, const double* bt, const do
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_rff_phi(const double* __restrict__ Wt,
                                                              const double* __restrict__ bt, int S, int n, int d,
-                                                             int dp, const double* __restrict__ X, int64_t N,
+                                                             int dp, int dk, const double* __restrict__ X, int64_t N,
                                                              int64_t Np, const double* __restrict__ y,
                                                              double bias, double* __restrict__ Phi) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];   // At[dp][LDT] | Bt[dp][LDT]
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // At[dk][LDT] | Bt[dk][LDT]  (dk: see k_rff_mfma)
     double* At = lds;
-    double* Bt = lds + dp * LDT;
+    double* Bt = lds + dk * LDT;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int wm = w >> 1, wn = w & 1;
     const int64_t m0 = (int64_t)blockIdx.x * TB;
-    for (int e = t; e < TB * dp; e += GEMM_THREADS) {
-        const int k = e >> 7, m = e & 127;
-        const int64_t gm = m0 + m;
-        At[k * LDT + m] = (k < d && gm < N) ? X[gm * d + k] : 0.0;
-    }
+    const bool resident = (dk == dp);
+    auto load_a = [&](int k0, int kc) {
+        for (int e = t; e < TB * kc; e += GEMM_THREADS) {
+            const int k = e >> 7, m = e & 127;
+            const int64_t gm = m0 + m;
+            At[k * LDT + m] = (k0 + k < d && gm < N) ? X[gm * d + k0 + k] : 0.0;
+        }
+    };
+    if (resident) load_a(0, dp);
     const int fr = lane & 15, fk = lane >> 4;
     for (int s = 0; s < S; ++s) {
-        const double* Wtile = Wt + (int64_t)s * dp * TB;
-        for (int e = t; e < (TB / 2) * dp; e += GEMM_THREADS) {
-            const int k = e >> 6, c = (e & 63) * 2;
-            *reinterpret_cast<d2*>(Bt + k * LDT + c) = *reinterpret_cast<const d2*>(Wtile + (int64_t)k * TB + c);
-        }
-        __syncthreads();
         d4 acc[4][4];
         acc_zero(acc);
         const double* as = At + wm * 64 + fr;
         const double* bs = Bt + wn * 64 + fr;
-        for (int kk = 0; kk < dp / 4; ++kk) {
-            const int kr = kk * 4 + fk;
-            double a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = as[kr * LDT + i * 16];
-                b[i] = bs[kr * LDT + i * 16];
+        for (int k0 = 0; k0 < dp; k0 += dk) {
+            const int kc = min(dk, dp - k0);
+            if (!resident) load_a(k0, kc);
+            const double* Wtile = Wt + ((int64_t)s * dp + k0) * TB;
+            for (int e = t; e < (TB / 2) * kc; e += GEMM_THREADS) {
+                const int k = e >> 6, c = (e & 63) * 2;
+                *reinterpret_cast<d2*>(Bt + k * LDT + c) = *reinterpret_cast<const d2*>(Wtile + (int64_t)k * TB + c);
             }
+            __syncthreads();
+            for (int kk = 0; kk < kc / 4; ++kk) {
+                const int kr = kk * 4 + fk;
+                double a[4], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i) {
+                    a[i] = as[kr * LDT + i * 16];
+                    b[i] = bs[kr * LDT + i * 16];
+                }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            if (k0 + dk < dp) __syncthreads();
         }
         double* out = Phi + (int64_t)s * Np * TB;
 #pragma unroll
@@ -281,7 +307,6 @@ __global__ __launch_bounds__(256) void k_rff_posterior(const double* __restrict_
                                                        const double* __restrict__ z, int n, double sc, double sn2,
                                                        double* __restrict__ theta, int* __restrict__ flag) {
     __shared__ double Bm[(RFP_NMAX + 1) * (RFP_NMAX + 2)];
-    __shared__ int bad;
     const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
     const int ld = (n + 1) | 1;
     const int64_t q = blockIdx.x;
@@ -294,12 +319,13 @@ __global__ __launch_bounds__(256) void k_rff_posterior(const double* __restrict_
         if (j <= i) Bm[i * ld + j] = sc * sc * A[e] + ((i == j) ? sn2 : 0.0);
     }
     for (int j = t; j < n; j += 256) Bm[n * ld + j] = sc * v[j];
-    if (t == 0) bad = 0;
+    bool failed = false;
     __syncthreads();
     for (int j = 0; j < n; ++j) {
         const double piv = Bm[j * ld + j];
-        if (!(piv > 0.0) || !(piv < 1.0e300)) {          // uniform: every thread reads the same value
-            if (t == 0) { bad = 1; atomicCAS(flag, 0, j + 1); }
+        if (!(piv > 0.0) || !(piv < 1.0e300)) {          // uniform: every thread reads the same value ...
+            if (t == 0) atomicCAS(flag, 0, j + 1);
+            failed = true;                               // ... and leaves on its own copy of the verdict
             break;
         }
         const double rinv = 1.0 / sqrt(piv);
@@ -313,7 +339,7 @@ __global__ __launch_bounds__(256) void k_rff_posterior(const double* __restrict_
         }
         __syncthreads();
     }
-    if (bad) return;
+    if (failed) return;
     // w = L^-1 (sc v) + sqrt(sn2) z, in place in the augmented row; then theta = sc L^-T w
     const double sn = sqrt(sn2);
     for (int j = t; j < n; j += 256) Bm[n * ld + j] = fma(sn, z[j], Bm[n * ld + j]);
@@ -337,10 +363,11 @@ void launch_rff_gram_batch(hipStream_t s, const double* Xraw, int64_t N, int64_t
                            double* scratch, double* A, double* v) {
     double* Phi = scratch;
     double* part = scratch + (int64_t)S * Np * TB;
-    const size_t ldsb = (size_t)(2 * dp * LDT) * sizeof(double);
+    const int dk = rff_k_chunk(dp);
+    const size_t ldsb = (size_t)(2 * dk * LDT) * sizeof(double);
     if (ldsb > 64 * 1024)
         hipFuncSetAttribute((const void*)k_rff_phi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    hipLaunchKernelGGL(k_rff_phi, dim3((unsigned)(Np / TB)), dim3(GEMM_THREADS), ldsb, s, Wt, bt, S, n, d, dp,
+    hipLaunchKernelGGL(k_rff_phi, dim3((unsigned)(Np / TB)), dim3(GEMM_THREADS), ldsb, s, Wt, bt, S, n, d, dp, dk,
                        Xraw, N, Np, y, bias, Phi);
     hipLaunchKernelGGL(k_rff_gram_sk, dim3(RFF_SPLIT, (unsigned)S), dim3(GEMM_THREADS), 0, s, Phi, Np, part);
     const int64_t outs = (int64_t)S * n * (n + 1);

@@ -256,8 +256,8 @@ def test_topk_edge_cases():
 
 
 def test_nan_candidates_rank_last_and_max_dimension():
-    # d = 64 is the largest input dimension of the Thompson kernels; the exact-GP path goes on to 1024
-    # (test_high_dimensional_inputs) and refuses 1025
+    # every entry point takes d <= 1024 (test_high_dimensional_inputs, test_thompson_beyond_64_input_dimensions)
+    # and refuses 1025
     from pybo_amd._lib import GpxError, GPX_EARG
     X, y, ell = synth_problem(130, 64, seed=8)
     ref = gp_ref.make_gp(1e-3, 1.0, ell * 4, 0.0)
@@ -569,3 +569,51 @@ def test_device_model_returns_empty_for_empty_input():
     assert m.get_improvement(0.3, Z).shape == (0,)
     f, g = m.get_tail(0.3, Z, grad=True)
     assert f.shape == (0,) and g.shape == (0, 2)
+
+
+@pytest.mark.parametrize('d,kernel', [(64, 'se'), (65, 'se'), (96, 'matern5'), (200, 'se')])
+def test_thompson_beyond_64_input_dimensions(d, kernel):
+    """Round 2 stopped the Thompson / RFF entry points at d = 64 (the [d][144] feature tile had to fit in LDS).  The
+    projection now walks the coordinates 32 at a time for d > 64 (kernels_rff.hip: k-chunked k_rff_mfma / k_rff_phi):
+    feature Gram, weight posterior, sweep + top-k and gradients against the oracle, through the model protocol too."""
+    from pybo_amd import models
+    N, n = 300, 100
+    X, y, ell = synth_problem(N, d, seed=40 + d)
+    ell = ell * np.sqrt(d)                                   # keep the kernel matrix informative in high dimension
+    rho, sn2, bias = 1.3, 1e-2, 0.2
+    ref = gp_ref.make_gp(sn2, rho, ell, bias, kernel)
+    ref.add_data(X, y)
+    e = _engine()
+    e.fit(X, y, kernel, ell, rho, sn2, bias)
+    S = 2
+    samples = [ref.sample_f(n, rng=300 + s) for s in range(S)]
+    Ws, bs, ths = (np.array([getattr(s, a) for s in samples]) for a in ('W', 'b', 'theta'))
+    Ab, vb = e.rff_gram_batch(Ws, bs)
+    zs = []
+    for q in range(S):
+        C = np.cos(X @ Ws[q].T + bs[q])
+        np.testing.assert_allclose(Ab[q], C.T @ C, rtol=1e-11, atol=1e-10)
+        np.testing.assert_allclose(vb[q], C.T @ (y - bias), rtol=1e-11, atol=1e-10)
+        rng = np.random.RandomState(300 + q)
+        gp_ref.rff_draw_spectral(gp_ref.KERNEL_IDS[kernel], n, d, ell, rng)
+        zs.append(rng.randn(n))
+    th_dev = e.rff_posterior(Ws, bs, np.array(zs), np.sqrt(2.0 * rho / n))
+    for q in range(S):
+        np.testing.assert_allclose(th_dev[q], ths[q], rtol=0, atol=1e-7 * np.abs(ths[q]).max())
+    Z = np.random.RandomState(9).rand(2500, d)
+    r = e.rff_sweep(Ws, bs, ths, bias, Z, k=5)
+    for q in range(S):
+        want = samples[q].get(Z)
+        np.testing.assert_allclose(r['vals'][q], want, rtol=1e-9, atol=1e-10)
+        np.testing.assert_array_equal(r['top_idx'][q], gp_ref.topk_desc(r['vals'][q], 5))
+    f, g = e.rff_eval_grad(Ws[0], bs[0], ths[0], bias, Z[:5])
+    fr, gr = samples[0].get(Z[:5], grad=True)
+    np.testing.assert_allclose(f, fr, rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(g, gr, rtol=1e-9, atol=1e-10)
+    e.close()
+    # the model protocol: model.sample_f(n, rng).get / .topk  (pybo/policies/simple.py:48)
+    gp = models.make_gp(sn2, rho, ell, bias, kernel=kernel)
+    gp.add_data(X, y)
+    smp = gp.sample_f(n, 300)
+    np.testing.assert_allclose(smp.get(Z[:64]), samples[0].get(Z[:64]), rtol=1e-6, atol=1e-7)
+    assert smp.topk(Z, 1)[1][0] == int(np.argmax(samples[0].get(Z)))
