@@ -432,7 +432,7 @@ def test_model_protocol_matches_oracle_and_is_copy_on_write():
 def test_high_dimensional_inputs():
     """the exact-GP path had a d <= 64 limit the reference does not have.  The kernels
     walk coordinates 16 at a time, so only buffer sizes depended on it: d = 100 through fit / sweep / gradients /
-    append / batched likelihood.  (The Thompson kernels keep d <= 64: their feature tiles live in LDS.)"""
+    append / batched likelihood -- and, since round 3, the Thompson entry points (k-chunked projection)."""
     from pybo_amd._lib import GpxError
     d, N = 100, 200
     rng = np.random.RandomState(8)
@@ -460,8 +460,12 @@ def test_high_dimensional_inputs():
     assert np.all(np.abs(mu - mr) <= mu_tol(mr, rho)) and np.all(np.abs(s2 - sr) <= s2_tol(sr, rho))
     hyp = np.concatenate([[sn2, rho], ell, [bias]])
     assert abs(e.loglik_batch(hyp[None])[0] - ref.loglikelihood()) <= 1e-9 * abs(ref.loglikelihood())
-    with pytest.raises(GpxError):
-        e.rff_gram(rng.randn(20, d), rng.rand(20))
+    # the Thompson entry points take the same d now (round 2 refused d > 64 here)
+    Wd, bd = rng.randn(20, d) / np.sqrt(d), rng.rand(20)
+    Xall = np.vstack([X[:N], X[N:]])
+    C = np.cos(Xall @ Wd.T + bd)
+    Ad, vd = e.rff_gram(Wd, bd)
+    np.testing.assert_allclose(Ad, C.T @ C, rtol=1e-10, atol=1e-9)
     with pytest.raises(GpxError):
         e.fit(np.zeros((4, 1025)), np.zeros(4), 'se', np.ones(1025), 1.0, 1e-3, 0.0)
     e.close()
