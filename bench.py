@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X datasheet fp64 matrix (= fp64 vector) peak, dense
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILE = 'r02_pmc_traffic.json'
+PMC_TRAFFIC_FILE = 'r03_pmc_traffic.json'
 
 
 def hartmann6(X):
@@ -325,7 +325,18 @@ def main():
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=dev)      # = RCCL over xGMI on MI355X
         else:
-            dist.init_process_group('gloo')
+            # the gloo transport announces its connections on STDOUT ("[Gloo] Rank 0 is connected to ..."); the contract
+            # is ONE JSON line there, so fd 1 points at stderr while the group comes up
+            sys.stdout.flush()
+            keep = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group('gloo')
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(keep, 1)
+                os.close(keep)
 
     from pybo_amd._lib import Engine
     from pybo_amd import dist as pdist

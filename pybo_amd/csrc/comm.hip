@@ -17,8 +17,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "gpx_internal.h"
 
@@ -41,11 +43,22 @@ struct Rccl {
 
 // One process-wide binding.  Search order: $GPX_RCCL_LIB, then the soname (which resolves to a copy already
 // mapped into the process -- e.g. the one torch.distributed brought -- before touching the library path).
+static std::string g_load_err;     // why the binding failed (written once, under the once-flag; read-only afterwards)
+
+static void rccl_bind(Rccl& r);
+
 Rccl* rccl() {
     static Rccl r;
-    static bool tried = false;
-    if (tried) return r.lib ? &r : nullptr;
-    tried = true;
+    static std::once_flag once;
+    std::call_once(once, [] { rccl_bind(r); });          // thread-safe: handles are driven from several host threads
+    if (!r.lib) {
+        g_comm_err = g_load_err;                         // EVERY failing call reports why, not only the first
+        return nullptr;
+    }
+    return &r;
+}
+
+static void rccl_bind(Rccl& r) {
     const char* names[] = {getenv("GPX_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) {
         if (!n || !*n) continue;
@@ -54,8 +67,8 @@ Rccl* rccl() {
     }
     if (!r.lib) {
         const char* e = dlerror();
-        g_comm_err = std::string("cannot load librccl (set GPX_RCCL_LIB): ") + (e ? e : "unknown error");
-        return nullptr;
+        g_load_err = std::string("cannot load librccl (set GPX_RCCL_LIB): ") + (e ? e : "unknown error");
+        return;
     }
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
@@ -63,12 +76,10 @@ Rccl* rccl() {
     r.AllGather = (decltype(r.AllGather))dlsym(r.lib, "ncclAllGather");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString) {
-        g_comm_err = "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
+        g_load_err = "librccl lacks one of ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
         dlclose(r.lib);
         r.lib = nullptr;
-        return nullptr;
     }
-    return &r;
 }
 
 int nccl_fail(Rccl* r, const char* what, ncclResult_t e) {
@@ -76,23 +87,40 @@ int nccl_fail(Rccl* r, const char* what, ncclResult_t e) {
     return GPX_ERCCL;
 }
 
-// send[i] = (value, index + offset) of pair i; padding entries (index < 0) keep -1
+// A rank's message: n (value, index + offset) pairs, then ONE status pair (status, rank).  status != 0: this rank
+// could not contribute (its last sweep left no n pairs on the device) -- it still takes part in the collective, with
+// padding entries, so that no rank is left blocked in the all-gather and EVERY rank returns the same error.
+// send[2i], send[2i+1] = pair i (padding: index -1); v == NULL: padding only
 __global__ void k_pack_pairs(const double* __restrict__ v, const int64_t* __restrict__ idx, int64_t n, int64_t off,
-                             double* __restrict__ send) {
+                             int64_t status, int64_t rank, double* __restrict__ send) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i > n) return;
+    if (i == n) {
+        send[2 * n] = __longlong_as_double(status);
+        send[2 * n + 1] = __longlong_as_double(rank);
+        return;
+    }
+    if (!v) {
+        send[2 * i] = -HUGE_VAL;
+        send[2 * i + 1] = __longlong_as_double((int64_t)-1);
+        return;
+    }
     const int64_t g = idx[i] < 0 ? (int64_t)-1 : idx[i] + off;
     send[2 * i] = v[i];
     send[2 * i + 1] = __longlong_as_double(g);
 }
 
-// all[2i], all[2i+1] -> vals[i], idx[i]; index < 0 becomes the "no entry" marker of the merge kernel
-__global__ void k_unpack_pairs(const double* __restrict__ all, int64_t n, double* __restrict__ vals,
-                               int64_t* __restrict__ idx, int for_merge) {
+// pair j of rank r (message stride n + 1 pairs) -> vals[r n + j], idx[r n + j]; index < 0 becomes the "no entry" marker
+// of the merge kernel; stat[r] = rank r's status word
+__global__ void k_unpack_pairs(const double* __restrict__ all, int64_t n, int64_t nranks, double* __restrict__ vals,
+                               int64_t* __restrict__ idx, int for_merge, int64_t* __restrict__ stat) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int64_t g = __double_as_longlong(all[2 * i + 1]);
-    vals[i] = all[2 * i];
+    if (i < nranks) stat[i] = __double_as_longlong(all[2 * (i * (n + 1) + n)]);
+    if (i >= n * nranks) return;
+    const int64_t r = i / n, j = i - r * n;
+    const double* src = all + 2 * (r * (n + 1) + j);
+    const int64_t g = __double_as_longlong(src[1]);
+    vals[i] = src[0];
     idx[i] = (g < 0 && for_merge) ? (int64_t)0x7fffffffffffffffLL : g;
 }
 
@@ -172,16 +200,15 @@ extern "C" int gpx_topk_allgather(gpx_comm* c, int64_t n, int64_t index_offset, 
             return GPX_EARG;
         }
         gpx_handle* h = c->h;
-        if (!h->last_topv || !h->last_topi || h->last_topn != n) {
-            g_comm_err = "topk_allgather: the handle's last sweep did not leave n (value, index) pairs on the device";
-            return GPX_ESTATE;
-        }
+        // a rank that cannot contribute still joins the collective (see k_pack_pairs): the verdict is collective too
+        const bool mine_ok = h->last_topv && h->last_topi && h->last_topn == n;
         Rccl* r = rccl();
         if (!r) return GPX_ERCCL;
         if (hipSetDevice(h->device) != hipSuccess) { g_comm_err = "topk_allgather: hipSetDevice failed"; return GPX_EHIP; }
         hipStream_t s = h->stream;
         const int64_t W = c->nranks, tot = n * W;
-        const int64_t need = 2 * n + 2 * tot + 2 * tot + 2 * (k > 0 ? k : 1);
+        // [send 2(n+1)][all 2(n+1)W][vals tot][idx tot][stat W][topv k][topi k]
+        const int64_t need = 2 * (n + 1) + 2 * (n + 1) * W + 2 * tot + W + 2 * (k > 0 ? k : 1);
         if (need > c->cap) {
             if (c->dbuf) hipFree(c->dbuf);
             c->dbuf = nullptr;
@@ -193,31 +220,41 @@ extern "C" int gpx_topk_allgather(gpx_comm* c, int64_t n, int64_t index_offset, 
             c->cap = need;
         }
         double* send = c->dbuf;
-        double* all = send + 2 * n;
-        double* vals = all + 2 * tot;
+        double* all = send + 2 * (n + 1);
+        double* vals = all + 2 * (n + 1) * W;
         int64_t* idx = reinterpret_cast<int64_t*>(vals + tot);
-        double* topv = vals + 2 * tot;
+        int64_t* stat = idx + tot;
+        double* topv = reinterpret_cast<double*>(stat + W);
         int64_t* topi = reinterpret_cast<int64_t*>(topv + (k > 0 ? k : 1));
-        hipLaunchKernelGGL(k_pack_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, h->last_topv,
-                           h->last_topi, n, index_offset, send);
+        hipLaunchKernelGGL(k_pack_pairs, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, s,
+                           mine_ok ? h->last_topv : (const double*)nullptr, h->last_topi, n, index_offset,
+                           (int64_t)(mine_ok ? 0 : 1), (int64_t)c->rank, send);
         // (value, index) pairs travel as raw 64-bit words
-        ncclResult_t e = r->AllGather(send, all, (size_t)(2 * n), ncclUint64, c->comm, s);
+        ncclResult_t e = r->AllGather(send, all, (size_t)(2 * (n + 1)), ncclUint64, c->comm, s);
         if (e != ncclSuccess) return nccl_fail(r, "ncclAllGather", e);
-        hipLaunchKernelGGL(k_unpack_pairs, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, all, tot, vals, idx,
-                           k > 0 ? 1 : 0);
-        bool ok;
+        const int64_t nthreads = tot > W ? tot : W;
+        hipLaunchKernelGGL(k_unpack_pairs, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, all, n, W, vals, idx,
+                           k > 0 ? 1 : 0, stat);
+        std::vector<int64_t> hstat((size_t)W, 0);
+        bool ok = hipMemcpyAsync(hstat.data(), stat, (size_t)W * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
         if (k > 0) {
             launch_topk_merge(s, vals, idx, tot, (int)k, topv, topi);
-            ok = hipMemcpyAsync(out_val, topv, (size_t)k * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+            ok = ok && hipMemcpyAsync(out_val, topv, (size_t)k * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
                  hipMemcpyAsync(out_idx, topi, (size_t)k * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
         } else {
-            ok = hipMemcpyAsync(out_val, vals, (size_t)tot * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
+            ok = ok && hipMemcpyAsync(out_val, vals, (size_t)tot * 8, hipMemcpyDeviceToHost, s) == hipSuccess &&
                  hipMemcpyAsync(out_idx, idx, (size_t)tot * 8, hipMemcpyDeviceToHost, s) == hipSuccess;
         }
         if (!ok || hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) {
             g_comm_err = "topk_allgather: kernel, collective or D2H copy failed";
             return GPX_EHIP;
         }
+        for (int64_t q = 0; q < W; ++q)
+            if (hstat[(size_t)q] != 0) {           // the same verdict on every rank
+                g_comm_err = "topk_allgather: rank " + std::to_string(q) +
+                             "'s last sweep did not leave n (value, index) pairs on the device";
+                return GPX_ESTATE;
+            }
         return GPX_OK;
     } catch (...) {
         return GPX_EOOM;
