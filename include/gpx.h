@@ -78,6 +78,9 @@ int gpx_version(void);
  *          "chol_rl" = 1 (default): inside an outer panel the rows still to come receive each factored row's contribution
  *              at once (right-looking, K = 128 per launch); 0: left-looking row updates (K = 128..(w-1)*128), round 2's
  *              order.  Bit-identical results either way.
+ *          "chol_merge" = n >= 1 (default 1): while at least n block rows lie beyond the next two panels, the far trailing
+ *              update of every other panel is deferred and applied together with the next panel's (one pass, twice the K
+ *              extent); 0: one far update per panel (round 2).  Bit-identical results either way.
  *          "x_bg", "x_bg_lds", "x_bg_iters" = DIAGNOSTIC (scripts/chol_bg.py): a synthetic register-only fp64-MFMA kernel of
  *              x_bg workgroups (x_bg_lds KB of LDS each, x_bg_iters rounds) runs beside the factorisation.
  *          "x_skip" = DIAGNOSTIC (scripts/chol_parts.py): leave out the far updates (bit 0), the chain kernels

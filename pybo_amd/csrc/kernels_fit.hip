@@ -769,6 +769,7 @@ void launch_cholesky(gpx_handle* h) {
             hipLaunchKernelGGL(k_bg_mfma<72>, dim3((unsigned)h->x_bg), dim3(256), 0, h->stream_bg, h->x_bg_iters, h->dscal + 8);
     }
     int near_rows = 0;            // rows P0+1.. of the CURRENT panel whose near update runs on the third stream
+    int pend_k0 = -1;             // first block row of a panel whose rest update was deferred (two-panel accumulation)
     for (int P0 = 0; P0 < nP; P0 += CW) {
         const int P1 = (P0 + CW < nP) ? P0 + CW : nP;
         for (int I = P0; I < P1; ++I) {
@@ -829,19 +830,31 @@ void launch_cholesky(gpx_handle* h) {
             // mid(P) and rest(P) touch disjoint block rows and both follow rest(P-1) (which wrote all of them): they
             // run CONCURRENTLY, mid on a fourth stream -- alone on the side stream its <= 4 x 56 tiles (one workgroup
             // per CU) held the chip for 150-190 us per panel before the big update could start.
+            //
+            // TWO-PANEL ACCUMULATION (option chol_merge = minimum number of rest block rows, 0 = off): while the far
+            // region is large, rest(P) of every other panel is DEFERRED and applied together with the next panel's in one
+            // pass with twice the K extent -- half as many read-modify-write passes over the far tiles, and tiles long
+            // enough to amortise their S-tile load / store and pipeline fill (K = 512: 50 TFLOP/s, K = 640: 61).  The
+            // rows that cannot wait (the next panel's: near, the one after: mid) are updated at once as before; mid of
+            // the FLUSHING panel covers both panels, because its rows were in the deferred rest.  Every element still
+            // receives every panel's contribution once, k ascending: bit-identical.
+            const bool flush = pend_k0 >= 0;
+            const int k0 = flush ? pend_k0 : P0;
+            const bool defer = !flush && h->chol_merge > 0 && nrest >= h->chol_merge;
+            pend_k0 = defer ? P0 : -1;
             hipStreamWaitEvent(s4, h->ev_chain, 0);
             if (rest_used) hipStreamWaitEvent(s4, h->ev_rest, 0);          // rest(P-1) wrote mid(P)'s rows
             if (far)
                 hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)(nP - m0), (unsigned)nmid), dim3(GEMM_THREADS), 0, s4,
-                               h->dR, h->dS, Np, P0, P1, m0, m0, (int64_t)0);
+                               h->dR, h->dS, Np, k0, P1, m0, m0, (int64_t)0);
             hipEventRecord(h->ev_far, s4);
             mid_pending = true;
             side_used = true;
-            if (nrest > 0) {
+            if (nrest > 0 && !defer) {
                 hipStreamWaitEvent(s2, h->ev_chain, 0);
                 if (far)
                     hipLaunchKernelGGL(k_syrk_update_tri, dim3((unsigned)(nrest * (nrest + 1) / 2)), dim3(GEMM_THREADS),
-                                       0, s2, h->dR, h->dS, Np, P0, P1, r0, nrest);
+                                       0, s2, h->dR, h->dS, Np, k0, P1, r0, nrest);
                 hipEventRecord(h->ev_rest, s2);
                 rest_used = true;
             }
