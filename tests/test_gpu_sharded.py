@@ -251,3 +251,33 @@ def test_noise_free_model_can_still_draw_thompson_samples():
     g.add_data(X, y)                                  # 16 observations, 10 features: the feature Gram is positive definite
     f = g.sample_f(10, 3)
     assert np.all(np.isfinite(f.get(X[:5])))
+
+
+def test_default_mcmc_model_and_thompson_run_on_a_sharded_gp():
+    """pybo's default model is MCMC(gp, n=10, burn=100) (pybo/bayesopt.py:115): `init_model(..., devices=[...])` builds
+    it around a ShardedGP.  The sampler's likelihoods come from replica 0 (same numbers => the same chain as on one
+    handle), the ensemble members are ShardedGPs; and the Thompson policy draws ONE sample that every replica evaluates
+    on its shard."""
+    def f(x):
+        return float(-branin(x)[0] / 10.0)
+
+    runs = {}
+    for name, devices in (('one', None), ('two', [0, 0])):
+        calls = []
+        model = pybo_amd.init_model(lambda x: (calls.append(1), f(x))[1], BOUNDS, ninit=8, rng=5, devices=devices)
+        assert len(calls) == 8
+        x1, m1, info = pybo_amd.solve_bayesopt(f, BOUNDS, model=model, niter=3, policy='ei',
+                                               solver=('lbfgs', {'ngrid': 2000}), recommender='incumbent', rng=6)
+        runs[name] = (np.array(m1.samples), info.x, x1)
+    np.testing.assert_array_equal(runs['one'][0], runs['two'][0])          # the hyper-parameter chain: identical
+    np.testing.assert_allclose(runs['one'][1], runs['two'][1], rtol=0, atol=1e-5)   # queries: the same up to summation order
+    # Thompson through the loop, fixed hyper-parameters
+    X, y, ell, rho, sn2, bias = _problem(N=300, seed=9)
+    outs = []
+    for devices in (None, [0, 0, 0]):
+        gp = models.make_gp(sn2, rho, ell, bias, devices=devices)
+        gp.add_data(X, y)
+        xb, _, info = pybo_amd.solve_bayesopt(f, BOUNDS, model=gp, niter=3, policy='thompson',
+                                              solver=('lbfgs', {'ngrid': 30000}), recommender='incumbent', rng=2)
+        outs.append(info.x)
+    np.testing.assert_array_equal(outs[0], outs[1])
