@@ -71,6 +71,10 @@ int gpx_version(void);
  *              Every setting produces bit-identical results.
  *          "super_m" = rows of the XCD super-tile of 64 workgroups (8 -> 8x8 default, 4 -> 4x16, ...).
  *          "eager_inverse" = 1: form the triangular inverse inside gpx_fit instead of on first use.
+ *          "refine_inverse" = 1: one Newton step T <- (2I - T R^T) T on the triangular inverse after it is formed (2 N^3 / 3
+ *              more flop, one more Np^2 buffer): squares the LEFT residual T R^T - I, the one the sweep's error is
+ *              proportional to -- for hyper-parameters with cond(K) >~ 1e9 (sn2 ~ 1e-6 rho), where the plain inverse is
+ *              10-20x less accurate than substitution (still 3.5 orders inside the stated tolerance).  Default 0.
  *          "sweep_cache" = 1: full sweeps keep their candidates and reduced sums for gpx_sweep_update;
  *              0 (default): full sweeps leave an existing cache alone (it stays valid and is still kept current
  *              by gpx_append); -1: drop the cache.

@@ -211,7 +211,7 @@ extern "C" int gpx_destroy(gpx_handle* h) {
     for (auto& p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : h->pool) hipEventDestroy(e);
     void* ptrs[] = {h->dXs, h->dXraw, h->dy, h->dS, h->dR, h->dT, h->dU, h->da, h->dalpha, h->dsmall, h->dKs, h->dQp, h->dXc, h->dout, h->dblkv, h->dblki,
-                    h->dtopv, h->drff, h->drffs, h->dgrad, h->dens, h->dcZ, h->dcq, h->dbatch, h->dpend};  // dPp, dtopi, dcp alias dQp, dtopv, dcq
+                    h->dtopv, h->drff, h->drffs, h->dgrad, h->dens, h->dcZ, h->dcq, h->dbatch, h->dpend, h->drefine};  // dPp, dtopi, dcp alias dQp, dtopv, dcq
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (h->hpin) hipHostFree(h->hpin);
@@ -280,6 +280,11 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
         if (!strcmp(name, "x_bg") || !strcmp(name, "x_bg_lds") || !strcmp(name, "x_bg_iters")) {   // diagnostic only
             if (value < 0 || value > 10000000) return fail(h, GPX_EARG, "x_bg*: out of range");
             (name[4] == 0 ? h->x_bg : (name[5] == 'l' ? h->x_bg_lds : h->x_bg_iters)) = (int)value;
+            return GPX_OK;
+        }
+        if (!strcmp(name, "refine_inverse")) {
+            if (value != 0 && value != 1) return fail(h, GPX_EARG, "refine_inverse must be 0 or 1");
+            h->refine_inverse = (value != 0);
             return GPX_OK;
         }
         if (!strcmp(name, "eager_inverse")) {
@@ -373,6 +378,11 @@ int gpx::ensure_inverse(gpx_handle* h) {
     {
         Span sp(h, T_TRTRI);
         launch_trtri(h);
+        if (h->refine_inverse) {
+            int rc = ensure(h, h->drefine, h->cap_refine, h->cap_np * h->cap_np);
+            if (rc) return rc;
+            launch_refine_inverse(h, h->drefine);
+        }
     }
     {
         Span sp(h, T_ALPHA);

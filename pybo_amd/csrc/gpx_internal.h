@@ -48,6 +48,9 @@ struct gpx_handle {
     int stage = 0;               // 0 none, 1 gram, 2 chol (fitted; T/U/a/alpha not formed yet), 3 + inverse
     bool diag_inv_pending = false;   // the diagonal blocks of T / U hold 16x16 inverses only (k_trtri_diag128 due)
     bool eager_inverse = false;  // option: form the inverse inside the fit (timing experiments)
+    bool refine_inverse = false; // option: one Newton step on the triangular inverse (left residual)
+    double* drefine = nullptr;   // its Np^2 scratch (allocated on first use, capacity cap_np^2)
+    int64_t cap_refine = 0;
     int64_t N = 0, Np = 0, d = 0;
     int kernel_id = 0;
     double rho = 1, sn2 = 0, bias = 0;
@@ -141,6 +144,7 @@ void launch_gram_sym(hipStream_t s, const double* Xs, int64_t N, int64_t Np, int
 int ensure_side_streams(gpx_handle* h);   // api.hip: streams 2 / 3 + events, on first use
 void launch_cholesky(gpx_handle* h);   // S -> R, diag blocks of T/U; sets dflag
 void launch_trtri(gpx_handle* h);      // R, diag blocks -> T, U (uses S as workspace)
+void launch_refine_inverse(gpx_handle* h, double* tmp);   // option refine_inverse: one Newton step on T / U (tmp: Np^2 scratch)
 void launch_alpha(gpx_handle* h);      // a = T (y - bias); alpha = U a
 void launch_kinv_diag(gpx_handle* h, double* out);   // out[i] = [K^-1]_ii = sum_m U[i][m]^2
 void launch_transpose_lower(hipStream_t s, const double* R, int64_t Np, double* out, int64_t N);

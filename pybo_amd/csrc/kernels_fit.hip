@@ -13,6 +13,8 @@
 
 #include <vector>
 
+#include <utility>
+
 #include "gemm_core.h"
 #include "gpx_internal.h"
 #include "gpx_math.h"
@@ -1002,6 +1004,87 @@ void launch_trtri(gpx_handle* h) {
             hipLaunchKernelGGL(k_trtri_gemm2_64, grid, dim3(GEMM64_THREADS), 0, s, h->dS, h->dT, h->dU, Np, nP, hb);
         }
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// OPTION "refine_inverse": one Newton step on the triangular inverse, in the form that serves the sweep.
+//
+// The sweep forms V = T k*; its error is (T L - I) V (L = R^T): the LEFT residual of the computed inverse times a
+// well-scaled vector.  The recursive doubling above computes T21 = -T22 (L21 T11), which keeps the RIGHT residual
+// L T - I small; its rounding error in the left residual carries a factor |T11| |L11| (measured against long double at
+// sn2 = 1e-6 rho: the explicit inverse is 10-20x less accurate than substitution).
+//     E = I - T L                 (left residual, lower triangular, ~cond * eps)
+//     T <- T + E T  = (2I - T L) T
+// squares the left residual down to the rounding error of E itself (~eps |T| |L|, what a row-wise substitution leaves).
+// Both products are lower x lower triangular GEMMs on the tile engine; L as a k-major B operand needs a transposed
+// copy of R (every operand here is k-major: R row-major serves L only as an A operand).  2 N^3 / 3 more flop.
+//   k_transpose_full   Lrm = R^T                                  (Np x Np, 32 x 32 tiles through LDS)
+//   k_tri_lower_prod<1>  Et(J-cols, I-rows) = (delta - sum_K T(I,K) L(K,J))^T        A = U (= T^T, k-major T), B = Lrm
+//   k_tri_lower_prod<2>  T1(I,J) = T(I,J) + sum_K E(I,K) T(K,J), U(J,I) = T1(I,J)^T   A = Et (k-major E), B = T
+// K runs over blocks J..I (both factors lower triangular).  T1 goes to the workspace (T is still being read), U is
+// rewritten in place (not an input of the second product); the caller swaps the T buffer with the workspace.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_transpose_full(const double* __restrict__ A, int64_t Np, double* __restrict__ At) {
+    __shared__ double tile[32][33];
+    const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+    tile[threadIdx.y][threadIdx.x] = A[(r0 + threadIdx.y) * Np + c0 + threadIdx.x];
+    __syncthreads();
+    At[(c0 + threadIdx.y) * Np + r0 + threadIdx.x] = tile[threadIdx.x][threadIdx.y];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_tri_lower_prod(const double* __restrict__ Ak,
+                                                                    const double* __restrict__ Bk,
+                                                                    const double* __restrict__ T0,
+                                                                    double* __restrict__ out,
+                                                                    double* __restrict__ outT, int64_t Np, int nP) {
+    // tiles (I, J), I >= J, heaviest (largest I - J) first: linear index over diagonals d = nP-1 .. 0
+    int idx = blockIdx.x, dgl = nP - 1;
+    while (idx >= nP - dgl) { idx -= nP - dgl; --dgl; }       // diagonal dgl holds nP - dgl tiles
+    const int J = idx, I = idx + dgl;
+    __shared__ __attribute__((aligned(16))) double smem[GEMM_LDS_F64];
+    const int64_t i0 = (int64_t)I * NB, j0 = (int64_t)J * NB;
+    d4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = acc_row(i, r), n = acc_col(j);
+                acc[i][j][r] = (MODE == 1) ? ((I == J && m == n) ? 1.0 : 0.0) : T0[(i0 + m) * Np + j0 + n];
+            }
+    if (MODE == 1) gemm_tile_128_g<true, true>(acc, Ak + i0, Np, Bk + j0, Np, J * NB, (I + 1) * NB, smem);
+    else gemm_tile_128_g<true, false>(acc, Ak + i0, Np, Bk + j0, Np, J * NB, (I + 1) * NB, smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gm = i0 + acc_row(i, r), gn = j0 + acc_col(j);
+                if (MODE == 1) {
+                    outT[gn * Np + gm] = acc[i][j][r];                   // E^T: the k-major A operand of the second product
+                } else {
+                    const double v = (gn <= gm) ? acc[i][j][r] : 0.0;    // exact zeros above the diagonal
+                    out[gm * Np + gn] = v;
+                    outT[gn * Np + gm] = v;
+                }
+            }
+}
+
+// T, U <- refined (see above).  `tmp` (Np x Np) is the caller's scratch for E^T; S is the workspace (free after launch_trtri).
+void launch_refine_inverse(gpx_handle* h, double* tmp) {
+    const int64_t Np = h->Np;
+    const int nP = (int)(Np / NB);
+    hipStream_t s = h->stream;
+    const unsigned ntiles = (unsigned)(nP * (nP + 1) / 2);
+    hipLaunchKernelGGL(k_transpose_full, dim3((unsigned)(Np / 32), (unsigned)(Np / 32)), dim3(32, 32), 0, s, h->dR, Np, h->dS);
+    hipLaunchKernelGGL(k_tri_lower_prod<1>, dim3(ntiles), dim3(GEMM_THREADS), 0, s, h->dU, h->dS, (const double*)nullptr,
+                       (double*)nullptr, tmp, Np, nP);
+    hipLaunchKernelGGL(k_tri_lower_prod<2>, dim3(ntiles), dim3(GEMM_THREADS), 0, s, tmp, h->dT, h->dT, h->dS, h->dU, Np, nP);
+    std::swap(h->dT, h->dS);          // the refined T lives in the old workspace; the old T buffer is the workspace now
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -95,3 +95,33 @@ def test_config_b_default_noise_full_grid_properties():
     eir = ref.get_improvement(ref.mean_at_obs().max(), w['Xc'][pick])
     assert np.all(np.abs(r['acq'][pick] - eir) <= ei_tol(mr, sr, mx, rho))
     e.close()
+
+
+def test_refine_inverse_option_squares_the_left_residual():
+    """Option "refine_inverse" (include/gpx.h): one Newton step T <- (2I - T L) T on the explicit inverse.  The sweep's
+    error is (T L - I) V, so the LEFT residual is what counts; the recursive doubling keeps the right one small.
+    Measured against the long-double truth (profiles/r03_illcond_refined.txt): the posterior MEAN gets up to 6x closer
+    (config B, sn2 = 1e-6: 1.8e-9 -> 3.1e-10 sqrt(rho)); the variance does not move -- its 1e-14 rho is the fp64
+    accumulation of the N-term sums q = sum V^2, not the inverse -- which is why the option is off by default."""
+    from pybo_amd._lib import Engine
+    w = bench.make_workload('b', 1 << 12)
+    rho, sn2 = w['rho'], 1e-6 * w['rho']
+    Z = FX['Z_b']
+    res, mom = [], []
+    for refine in (0, 1):
+        e = Engine(0)
+        e.set_option('refine_inverse', refine)
+        e.fit(w['X'], w['y'], 'se', w['ell'], rho, sn2, w['bias'])
+        L, T = e.get_matrix('L'), e.get_matrix('T')
+        res.append((np.abs(T @ L - np.eye(len(L))).max(), np.abs(L @ T - np.eye(len(L))).max()))
+        assert np.all(np.triu(T, 1) == 0)
+        mom.append(e.predict(Z))
+        a, alpha = e.get_vectors()
+        np.testing.assert_allclose(T @ (w['y'] - w['bias']), a, rtol=0, atol=1e-9 * np.abs(a).max())
+        e.close()
+    print('\nleft / right residual of the explicit inverse: plain %.2e / %.2e, refined %.2e / %.2e' % (res[0] + res[1]))
+    assert res[1][0] < 0.2 * res[0][0]                    # the left residual collapses ...
+    assert res[1][1] < 10 * res[0][1] + 1e-9              # ... and the right one does not blow up
+    mt, st = FX['mu_b_rel'], FX['s2_b_rel']
+    for m, s in mom:
+        assert np.all(np.abs(m - mt) <= mu_tol(mt, rho)) and np.all(np.abs(s - st) <= s2_tol(st, rho))
