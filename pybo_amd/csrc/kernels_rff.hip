@@ -20,31 +20,36 @@ namespace gpx {
 //   The candidate tile stays in LDS (k-major) for the workgroup's life; feature tiles stream through.
 //   Epilogue per accumulator element: theta_f * cos(z + b_f), summed over the tile's 128 columns into a
 //   per-row register, reduced across lanes / the two column-waves once at the end.
-// cos: 3-term Cody-Waite reduction by pi/2 + the fdlibm minimax kernels on [-pi/4, pi/4] (both evaluated,
-// selected by quadrant: branch-free, ~25 DP ops).  |z| = |w.x + b| stays far below the 2^20*pi/2 validity
-// range of the reduction.
+// cos: 3-term Cody-Waite reduction by pi + one even polynomial on [-pi/2, pi/2] (see cos_cw).  |z| = |w.x + b| stays
+// far below the 2^20 pi validity range of the reduction.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double cos_cw(double z) {
-    const double n = rint(z * 6.36619772367581382433e-01);
-    double r = fma(-n, 1.57079632673412561417e+00, z);
-    r = fma(-n, 6.07710050630396597660e-11, r);
-    r = fma(-n, 2.02226624879595063154e-21, r);
+    // Round 3: reduction by pi (not pi/2) and ONE even polynomial on [-pi/2, pi/2]: cos z = (-1)^n cos r, r = z - n pi.
+    // The quadrant form evaluated BOTH fdlibm kernels (sine and cosine on [-pi/4, pi/4]) and selected: 37 VALU
+    // instructions per evaluation, and k_rff_mfma is bound by VALU + MFMA issue on the shared double-precision pipe
+    // (profiles/r03_pmc_rff_mfma.txt: 43 % + 37 % of the cycles).  Here: 3-term Cody-Waite (n pi_hi exact for
+    // |n| < 2^20: pi_hi has 33 significant bits), the Taylor series through r^22 / 22! (the next term is 8e-20 at
+    // |r| = pi/2; no minimax fit needed), sign from the parity of n: ~22 instructions.  Absolute error <= 3e-16
+    // (Horner over terms that sum to cosh(pi/2) = 2.5 in magnitude); the features enter sums of ~100 terms of size
+    // theta ~ 0.1, compared with the oracle at 1e-9 relative.
+    const double n = rint(z * 3.18309886183790671538e-01);
+    double r = fma(-n, 3.14159265346825122833e+00, z);
+    r = fma(-n, 1.21542010126079319532e-10, r);
+    r = fma(-n, 4.04453249759190126308e-21, r);
     const double r2 = r * r;
-    double ps = fma(r2, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = fma(r2, ps, 2.75573137070700676789e-06);
-    ps = fma(r2, ps, -1.98412698298579493134e-04);
-    ps = fma(r2, ps, 8.33333333332248946124e-03);
-    ps = fma(r2, ps, -1.66666666666666324348e-01);
-    const double sn = fma(r * r2, ps, r);
-    double pc = fma(r2, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = fma(r2, pc, -2.75573143513906633035e-07);
-    pc = fma(r2, pc, 2.48015872894767294178e-05);
-    pc = fma(r2, pc, -1.38888888888741095749e-03);
-    pc = fma(r2, pc, 4.16666666666666019037e-02);
-    const double cs = fma(r2 * r2, pc, fma(-0.5, r2, 1.0));
-    const int q = ((int)n) & 3;
-    const double v = (q & 1) ? sn : cs;
-    return (q == 1 || q == 2) ? -v : v;
+    double p = -8.89679139245057328675e-22;                 // -1/22!
+    p = fma(r2, p, 4.11031762331216485548e-19);             //  1/20!
+    p = fma(r2, p, -1.56192069685862264622e-16);            // -1/18!
+    p = fma(r2, p, 4.77947733238738529744e-14);             //  1/16!
+    p = fma(r2, p, -1.14707455977297247139e-11);            // -1/14!
+    p = fma(r2, p, 2.08767569878680989792e-09);             //  1/12!
+    p = fma(r2, p, -2.75573192239858906526e-07);            // -1/10!
+    p = fma(r2, p, 2.48015873015873015873e-05);             //  1/8!
+    p = fma(r2, p, -1.38888888888888888889e-03);            // -1/6!
+    p = fma(r2, p, 4.16666666666666666667e-02);             //  1/4!
+    p = fma(r2, p, -0.5);
+    const double cs = fma(r2, p, 1.0);
+    return (((int)n) & 1) ? -cs : cs;
 }
 
 // Wt:  [S][nfb][dp][128]   feature tiles, k-major (zero padded);  bt, tt: [S][nfb][128]
