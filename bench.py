@@ -230,6 +230,20 @@ def plugin_step(w, nsteps, k):
                                                      recommender='latent', log=log)
         t1 = time.perf_counter()
         ckpt_bytes = os.path.getsize(log)
+        # the same loop continued with a black box that takes 40 ms per evaluation (a sleep: the GPU stays free): what
+        # an iteration costs BEYOND its objective call.  The query point is announced to the device before the
+        # objective is called (model.anticipate -> gpx_append_begin), so the cache-correction pass runs meanwhile.
+        slow_ms, nslow, marks = 40.0, min(4, nsteps), []
+
+        def slow_objective(x):
+            marks.append(time.perf_counter())
+            time.sleep(slow_ms * 1e-3)
+            marks.append(time.perf_counter())
+            return float(w['f'](np.array(x, ndmin=2))[0] + 1e-3 * rng.randn())
+
+        pybo_amd.solve_bayesopt(slow_objective, bounds, niter=N + nsteps + nslow, policy=policy,
+                                solver=('lbfgs', {'xgrid': grid, 'nbest': k}), recommender='latent', log=log)
+        between = [(marks[2 * i + 2] - marks[2 * i + 1]) * 1e3 for i in range(nslow - 1)]    # end of call i -> start of call i+1
     spans = np.diff(stamps)
     rec = {'what': 'pybo_amd.solve_bayesopt resumed at N observations, policy %r, solver lbfgs over a DeviceGrid of '
                    '%d Sobol points, recommender latent, checkpoint every iteration; spans between consecutive '
@@ -242,6 +256,11 @@ def plugin_step(w, nsteps, k):
     if len(spans):
         rec['warm_ms'] = float(np.mean(spans) * 1e3)
         rec['warm_ms_each'] = [float(s * 1e3) for s in spans]
+    if between:
+        rec['warm_ms_beside_a_%d_ms_objective' % int(slow_ms)] = float(np.mean(between))
+        rec['beside_what'] = ('time from the return of one objective call to the start of the next (add_data + recommender + '
+                              'checkpoint + policy + solver) when the objective itself takes %d ms: the N*M covariance '
+                              'evaluations of the cache correction ran during the call (announced query point)' % int(slow_ms))
     return rec
 
 

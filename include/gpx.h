@@ -120,6 +120,16 @@ int gpx_loglik_batch(gpx_handle *h, int64_t B, const double *hypers, double *out
  * gpx_fit.  If a sweep cache is live (below) its per-candidate sums are corrected for the new observation in
  * the same call (one N*M pass). */
 int gpx_append(gpx_handle *h, const double *x, double y);
+/* ANNOUNCE the next observation's location before its value exists: between `x, _ = solver(index, bounds)` and
+ * `y = objective(x)` of the BO loop [pybo/bayesopt.py:265-268] the query point is known and the black box is being
+ * evaluated -- the time the reference spends idle.  Everything of the coming gpx_append(h, x, y) that does not depend on
+ * y is enqueued now, without a host synchronisation: k(X, x), the two triangular passes, and -- on a side stream -- the
+ * N*M covariance evaluations of the sweep-cache correction (the new row v of V over the cached candidates).  A following
+ * gpx_append with the bit-identical x then costs the scalars, the scatter and q += v^2, p += v a_new (O(N + M)); with
+ * any other x, or after anything else changed the model, the announcement is ignored.  Results are bit-identical to an
+ * unannounced append.  GPX_ESTATE (nothing started, not an error) without a live sweep cache or when the next append
+ * has to add a 128-block first. */
+int gpx_append_begin(gpx_handle *h, const double *x);
 /* 0-based index of the failing pivot of the last GPX_ENOTPD fit, else -1. */
 int64_t gpx_fail_pivot(const gpx_handle *h);
 

@@ -28,6 +28,7 @@ SYMBOLS = {
     'gpx_loglik': (C.c_int, [_P, _P]),
     'gpx_loglik_batch': (C.c_int, [_P, _i64, _P, _P]),
     'gpx_append': (C.c_int, [_P, _P, _dbl]),
+    'gpx_append_begin': (C.c_int, [_P, _P]),
     'gpx_fail_pivot': (_i64, [_P]),
     'gpx_get_matrix': (C.c_int, [_P, C.c_int, _P]),
     'gpx_get_vectors': (C.c_int, [_P, _P, _P]),
@@ -430,6 +431,18 @@ class Engine(object):
             return False
         self._check(rc)
         self.N += 1
+        return True
+
+    def append_begin(self, x):
+        """Announce the next observation's location (gpx_append_begin): the value-independent work of the coming
+        append runs ahead.  Returns False when there is nothing to run ahead (no live sweep cache, block boundary)."""
+        x = _f64(x).reshape(-1)
+        if len(x) != self.d:
+            raise ValueError('x must have %d coordinates' % self.d)
+        rc = self._lib.gpx_append_begin(self._h, _ptr(x))
+        if rc == GPX_ESTATE:
+            return False
+        self._check(rc)
         return True
 
     def fail_pivot(self):

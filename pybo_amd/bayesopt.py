@@ -232,7 +232,10 @@ def _bo_step(model, trace, objective, bounds, policy, solver, recommender):
     index = policy(model, bounds, trace.x)          # acquisition closure over a model copy
     x, _ = solver(index, bounds)                    # grid sweep + top-k + refinement
     del index                                       # drop the policy's model copy: add_data below may then
-    y = objective(x)                                # extend the factorisation in place instead of refitting
+    announce = getattr(model, 'anticipate', None)   # extend the factorisation in place instead of refitting;
+    if announce is not None:                        # device models start the value-independent part of that
+        announce(x)                                 # update now, while the black box is being evaluated
+    y = objective(x)
     model.add_data(x, y)                            # refit
     xbest = recommender(model, bounds, trace.x)     # NB: trace.x does not contain x yet (as in the reference)
     trace.x.append(x)

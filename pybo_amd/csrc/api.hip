@@ -107,6 +107,7 @@ struct Span {
 };
 static void harvest(gpx_handle* h) {
     hipStreamSynchronize(h->stream);
+    if (h->spec_launched && h->stream3) hipStreamSynchronize(h->stream3);   // its timing events live on that stream
     for (auto& p : h->pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) h->tacc[p.slot] += ms;
@@ -211,12 +212,14 @@ extern "C" int gpx_destroy(gpx_handle* h) {
     for (auto& p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : h->pool) hipEventDestroy(e);
     void* ptrs[] = {h->dXs, h->dXraw, h->dy, h->dS, h->dR, h->dT, h->dU, h->da, h->dalpha, h->dsmall, h->dKs, h->dQp, h->dXc, h->dout, h->dblkv, h->dblki,
-                    h->dtopv, h->drff, h->drffs, h->dgrad, h->dens, h->dcZ, h->dcq, h->dbatch, h->dpend, h->drefine};  // dPp, dtopi, dcp alias dQp, dtopv, dcq
+                    h->dtopv, h->drff, h->drffs, h->dgrad, h->dens, h->dcZ, h->dcq, h->dbatch, h->dpend, h->drefine, h->dspec};  // dPp, dtopi, dcp alias dQp, dtopv, dcq
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (h->hpin) hipHostFree(h->hpin);
     if (h->hinv) hipHostFree(h->hinv);
     if (h->ev_inv) hipEventDestroy(h->ev_inv);
+    if (h->ev_spec_go) hipEventDestroy(h->ev_spec_go);
+    if (h->ev_spec_done) hipEventDestroy(h->ev_spec_done);
     if (h->stream_bg) { hipStreamSynchronize(h->stream_bg); hipStreamDestroy(h->stream_bg); }
     if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
     if (h->stream3) { hipStreamSynchronize(h->stream3); hipStreamDestroy(h->stream3); }
@@ -317,6 +320,15 @@ extern "C" int gpx_timers(gpx_handle* h, double* out, int n, int reset) {
     });
 }
 
+// An announcement's correction pass may still be reading Xs / the cached candidates on the third stream: whoever is
+// about to rewrite those (a refit, a new full sweep with the cache on, the next announcement) orders itself after it.
+static void spec_cancel(gpx_handle* h) {
+    if (h->spec_launched && h->ev_spec_done) hipStreamWaitEvent(h->stream, h->ev_spec_done, 0);
+    h->spec_active = false;
+    h->spec_launched = false;
+    h->apply_pending = false;        // (callers either flushed first or are discarding the cache)
+}
+
 // ---- fit --------------------------------------------------------------------------------------
 static int check_fit_args(gpx_handle* h, const void* X, int64_t N, int64_t d, const void* y, int kid,
                           const double* ell, double rho, double sn2) {
@@ -399,6 +411,8 @@ static int fit_core(gpx_handle* h, const double* dX, int64_t N, int64_t d, const
                     const double* ell, double rho, double sn2, double bias, int stage) {
     HIPCHK(h, hipSetDevice(h->device));
     const int64_t Np = (N + NB - 1) / NB * NB;
+    spec_cancel(h);              // an announced observation belongs to the model that is being replaced
+    ++h->gen;
     h->fitted = false;
     h->stage = 0;
     h->fail_pivot = -1;
@@ -502,6 +516,19 @@ extern "C" int gpx_loglik(gpx_handle* h, double* out) {
 // Apply the cache corrections of the observations appended since the last flush: ONE pass over the candidates
 // (kernels_sweep.hip: k_sweep_rankq).
 static int flush_pending(gpx_handle* h) {
+    if (h->apply_pending) {
+        // an announced observation was appended: its row of V over the cached candidates was computed on the third
+        // stream; fold it into the sums now that somebody needs them (not earlier: the caller's stream stays free for
+        // the recommender's gradient calls while the pass finishes)
+        h->apply_pending = false;
+        if (h->cache_valid && h->spec_M == h->cache_M) {
+            const SpecBuf sb = spec_layout(h);
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_spec_done, 0));
+            h->spec_launched = false;
+            Span sp(h, T_RANK1);
+            launch_cache_apply(h->stream, sb.v, sb.scal, h->cache_M, h->dcq, h->dcp);
+        }
+    }
     if (h->npend == 0) return GPX_OK;
     if (h->cache_valid) {
         Span sp(h, T_RANK1);
@@ -521,6 +548,62 @@ extern "C" int gpx_loglik_batch(gpx_handle* h, int64_t B, const double* hypers, 
     });
 }
 
+extern "C" int gpx_append_begin(gpx_handle* h, const double* x) {
+    return guarded(h, [&]() -> int {
+        if (!h) return GPX_EARG;
+        if (!x) return fail(h, GPX_EARG, "append_begin: NULL point");
+        if (!h->fitted) return fail(h, GPX_ESTATE, "append_begin: model is not fitted");
+        if (!h->cache_valid) return fail(h, GPX_ESTATE, "append_begin: no live sweep cache (nothing to run ahead)");
+        HIPCHK(h, hipSetDevice(h->device));
+        int rc;
+        if ((rc = ensure_inverse(h))) return rc;
+        if (h->N >= h->Np) return fail(h, GPX_ESTATE, "append_begin: the next append adds a block first");
+        if ((rc = flush_pending(h))) return rc;                 // earlier appends' corrections: apply them now
+        if ((rc = ensure_side_streams(h))) return rc;
+        if (!h->ev_spec_go &&
+            (hipEventCreateWithFlags(&h->ev_spec_go, hipEventDisableTiming) != hipSuccess ||
+             hipEventCreateWithFlags(&h->ev_spec_done, hipEventDisableTiming) != hipSuccess))
+            return fail(h, GPX_EHIP, "append_begin: event creation failed");
+        spec_cancel(h);                                          // a previous announcement's pass has ended
+        if (h->ev_spec_go) HIPCHK(h, hipEventSynchronize(h->ev_spec_go));   // ... and its copy of spec_x too
+        const int64_t d = h->d, M = h->cache_M, ld = h->cap_np;
+        const int64_t xpad = (h->cap_d + 63) / 64 * 64;
+        const int64_t need = 2 * xpad + 5 * ld + 64 + M;
+        if ((rc = ensure(h, h->dspec, h->cap_spec, need))) return rc;
+        h->spec_ld = ld;
+        h->spec_M = M;
+        const SpecBuf sb = spec_layout(h);
+        h->spec_x.assign(x, x + d);
+        hipStream_t s = h->stream, s3 = h->stream3;
+        int* flag = h->dflag + 12;                               // its own word; a bad pivot surfaces at gpx_append
+        HIPCHK(h, hipMemsetAsync(flag, 0, sizeof(int), s));
+        HIPCHK(h, hipMemcpyAsync(sb.x, h->spec_x.data(), (size_t)d * 8, hipMemcpyHostToDevice, s));
+        launch_append_prepare(h, s, sb.x, sb.ks, sb.g, sb.r, sb.tu, 0.0, sb.scal, flag);
+        launch_scale_point(s, sb.x, h->dinvell, (int)d, sb.xs);
+        launch_pend_store(s, sb.tu, h->N, ld, sb.scal, sb.row, sb.pscal);
+        HIPCHK(h, hipEventRecord(h->ev_spec_go, s));
+        HIPCHK(h, hipStreamWaitEvent(s3, h->ev_spec_go, 0));
+        {
+            EventPair p;                                          // T_RANK1, timed on the stream the pass runs on
+            if (h->pending.size() >= 256) harvest_finished(h);
+            p.a = ev_get(h);
+            p.b = ev_get(h);
+            p.slot = T_RANK1;
+            hipEventRecord(p.a, s3);
+            launch_sweep_rank1_v(s3, h->dXs, h->N + 1, (int)d, sb.row, ld, sb.pscal, h->dcZ, M, h->dinvell, h->kernel_id,
+                                 h->rho, sb.xs, sb.v);
+            hipEventRecord(p.b, s3);
+            h->pending.push_back(p);
+        }
+        HIPCHK(h, hipEventRecord(h->ev_spec_done, s3));
+        HIPCHK(h, hipGetLastError());
+        h->spec_active = true;
+        h->spec_launched = true;
+        h->spec_gen = h->gen;
+        return GPX_OK;
+    });
+}
+
 extern "C" int gpx_append(gpx_handle* h, const double* x, double y) {
     return guarded(h, [&]() -> int {
         if (!h) return GPX_EARG;
@@ -533,6 +616,17 @@ extern "C" int gpx_append(gpx_handle* h, const double* x, double y) {
         if (rc != GPX_OK) {
             if (rc != GPX_EARG && rc != GPX_ESTATE) { h->cache_valid = false; h->npend = 0; }
             return rc;
+        }
+        ++h->gen;
+        if (h->cache_valid && h->spec_used && h->spec_M == h->cache_M) {
+            // the point was announced: its row of V over the cached candidates is ready (or about to be) on the third
+            // stream; what is left is q += v^2, p += v a_new -- O(M)
+            const SpecBuf sb = spec_layout(h);
+            // keep {d, 1/d, a_new, d^2} beside v (the handle's scalar scratch is rewritten by the next call); the sums
+            // are updated by flush_pending when they are next read
+            HIPCHK(h, hipMemcpyAsync(sb.scal, h->dscal, 4 * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            h->apply_pending = true;
+            return GPX_OK;
         }
         if (h->cache_valid) {
             // keep the cached per-candidate sums current: the correction for this observation (one N*M pass
@@ -714,6 +808,7 @@ static int sweep_core(gpx_handle* h, int acq_id, const double* params, int npara
     double* cq = nullptr;
     double* cp = nullptr;
     if (h->cache_on) {
+        spec_cancel(h);          // (the candidates it reads are about to be replaced)
         h->cache_valid = false;
         h->npend = 0;
         if ((rc = ensure(h, h->dcZ, h->cap_cz, M * h->d))) return rc;

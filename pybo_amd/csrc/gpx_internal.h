@@ -125,6 +125,18 @@ struct gpx_handle {
     int64_t pend_ld = 0;
     int npend = 0;
 
+    // announced observation (gpx_append_begin): the y-independent part of the next append and the correction pass of
+    // the sweep cache run ahead, on the third stream, while the caller evaluates its objective
+    bool spec_active = false;    // an announcement is waiting for its gpx_append
+    bool spec_launched = false;  // the third stream may still be reading the announcement's buffers
+    bool spec_used = false;      // the last append_host consumed the announcement (api.hip finishes the cache update)
+    bool apply_pending = false;  // ... whose q += v^2, p += v a is still due (applied by flush_pending)
+    uint64_t gen = 0, spec_gen = 0;      // model generation (fit / append / grow) now and at the announcement
+    std::vector<double> spec_x;  // the announced point (host copy, compared bit for bit)
+    double* dspec = nullptr;     // [x xpad][xs xpad][ks Np][g Np][r Np][tu Np][row ldw][pscal 2 + scal 16][v M]
+    int64_t cap_spec = 0, spec_ld = 0, spec_M = 0;
+    hipEvent_t ev_spec_go = nullptr, ev_spec_done = nullptr;
+
     double* dbatch = nullptr;    // gpx_loglik_batch: Gram / factor / scaled inputs / a of the batch (one allocation)
     int64_t cap_batch = 0;
 
@@ -164,6 +176,11 @@ void launch_acq(hipStream_t s, const double* Qp, const double* Pp, int64_t ldp, 
 // correction of the cached sums after q <= 8 appended observations in one pass (see kernels_sweep.hip)
 void launch_pend_store(hipStream_t s, const double* w, int64_t Nj, int64_t ldw, const double* scal, double* row,
                        double* pscal_j);
+void launch_cache_apply(hipStream_t s, const double* v, const double* scal, int64_t M, double* qsum, double* psum);
+void launch_scale_point(hipStream_t s, const double* x, const double* invell, int d, double* xs);
+void launch_sweep_rank1_v(hipStream_t s, const double* Xs, int64_t Ntot, int d, const double* Wq, int64_t ldw,
+                          const double* pscal, const double* Z, int64_t M, const double* invell, int kernel_id,
+                          double rho, const double* xlast, double* vout);
 void launch_sweep_rankq(hipStream_t s, const double* Xs, int64_t Ntot, int d, const double* Wq, int64_t ldw, int q,
                         const double* pscal, const double* Z, int64_t M, const double* invell, int kernel_id,
                         double rho, double* qsum, double* psum);
@@ -186,6 +203,13 @@ int ensure_inverse(gpx_handle* h);
 int loglik_host(gpx_handle* h, double* out);
 int loglik_batch_host(gpx_handle* h, int64_t B, const double* hyp, double* out);   // kernels_fit.hip
 int append_host(gpx_handle* h, const double* x, double ynew);
+// the y-independent kernels of an append, enqueued on s: k* = k(X, x), r = T k*, {d, 1/d, (resid - r.a)/d, d^2} -> scal
+// (a non-positive d^2 sets *flag), tu = U r.  dx: the point on the device.
+void launch_append_prepare(gpx_handle* h, hipStream_t s, const double* dx, double* dks, double* dg, double* dr,
+                           double* dtu, double resid, double* scal, int* flag);
+// layout of the announcement scratch (pointers into h->dspec)
+struct SpecBuf { double *x, *xs, *ks, *g, *r, *tu, *row, *pscal, *scal, *v; };
+SpecBuf spec_layout(const gpx_handle* h);
 int rff_grad_host(gpx_handle* h, const double* W, const double* b, const double* theta, int64_t n, int64_t d,
                   double bias, const double* Xc, int64_t M, double* f, double* g);
 

@@ -334,7 +334,12 @@ __global__ __launch_bounds__(256) void k_sweep_rankq(const double* __restrict__ 
                                                      const double* __restrict__ pscal,
                                                      const double* __restrict__ Z, int64_t M,
                                                      const double* __restrict__ invell, int kid, double rho,
-                                                     double* __restrict__ qsum, double* __restrict__ psum) {
+                                                     double* __restrict__ qsum, double* __restrict__ psum,
+                                                     const double* __restrict__ xlast, double* __restrict__ vout) {
+    // xlast (optional): the scaled coordinates of row Ntot - 1 when that row is NOT in Xs yet -- an ANNOUNCED
+    // observation (gpx_append_begin): its location is known, its value is not, the factor is untouched.
+    // vout (optional, q == 1): write v_n instead of updating the sums; gpx_append applies q += v^2, p += v a once the
+    // value has arrived (k_cache_apply: the same two FMAs, the same bits).
     __shared__ double xo[XDC][XK];
     __shared__ double xc[XDC][XN];
     __shared__ double wv[Q][XK];
@@ -365,7 +370,8 @@ __global__ __launch_bounds__(256) void k_sweep_rankq(const double* __restrict__ 
             __syncthreads();
             for (int e = t; e < XK * kc; e += 256) {
                 const int row = e / kc, k = e - row * kc;
-                xo[k][row] = (k0 + row < Ntot) ? Xs[(k0 + row) * d + c0 + k] : 0.0;
+                const int64_t gr = k0 + row;
+                xo[k][row] = (gr < Ntot) ? ((xlast && gr == Ntot - 1) ? xlast[c0 + k] : Xs[gr * d + c0 + k]) : 0.0;
             }
             if (c0 == 0) {
                 for (int e = t; e < Q * XK; e += 256) {
@@ -421,17 +427,55 @@ __global__ __launch_bounds__(256) void k_sweep_rankq(const double* __restrict__ 
 #pragma unroll
             for (int g = 0; g < 8; ++g) dot += red[g][t];
             const double v = -dot * pscal[2 * j];
-            dq = fma(v, v, dq);
-            dp = fma(v, pscal[2 * j + 1], dp);
+            if (vout) {
+                if (n0 + t < M) vout[n0 + t] = v;
+            } else {
+                dq = fma(v, v, dq);
+                dp = fma(v, pscal[2 * j + 1], dp);
+            }
         }
     }
-    if (t < XN) {
+    if (t < XN && !vout) {
         const int64_t gm = n0 + t;
         if (gm < M) {
             qsum[gm] += dq;
             psum[gm] += dp;
         }
     }
+}
+
+// the value of an announced observation has arrived: q_n += v_n^2, p_n += v_n a  (a = scal[2], device-resident)
+__global__ void k_cache_apply(const double* __restrict__ v, const double* __restrict__ scal, int64_t M,
+                              double* __restrict__ qsum, double* __restrict__ psum) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const double vi = v[i];
+    qsum[i] += fma(vi, vi, 0.0);
+    psum[i] += fma(vi, scal[2], 0.0);
+}
+
+void launch_cache_apply(hipStream_t s, const double* v, const double* scal, int64_t M, double* qsum, double* psum) {
+    hipLaunchKernelGGL(k_cache_apply, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, v, scal, M, qsum, psum);
+}
+
+// x scaled by 1/ell (the row an announced observation will occupy in Xs)
+__global__ void k_scale_point(const double* __restrict__ x, const double* __restrict__ invell, int d,
+                              double* __restrict__ xs) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < d) xs[k] = x[k] * invell[k];
+}
+
+void launch_scale_point(hipStream_t s, const double* x, const double* invell, int d, double* xs) {
+    hipLaunchKernelGGL(k_scale_point, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, s, x, invell, d, xs);
+}
+
+// the correction pass of ONE announced observation: v_n for every cached candidate -> vout (sums untouched)
+void launch_sweep_rank1_v(hipStream_t s, const double* Xs, int64_t Ntot, int d, const double* Wq, int64_t ldw,
+                          const double* pscal, const double* Z, int64_t M, const double* invell, int kernel_id,
+                          double rho, const double* xlast, double* vout) {
+    const dim3 grid((unsigned)((M + XN - 1) / XN));
+    hipLaunchKernelGGL(k_sweep_rankq<1>, grid, dim3(256), 0, s, Xs, Ntot, d, Wq, ldw, 1, pscal, Z, M, invell, kernel_id,
+                       rho, (double*)nullptr, (double*)nullptr, xlast, vout);
 }
 
 // row j of the pending-correction table: [w (Nj entries), -1, zeros up to ldw]; pscal_j = {1/d, a_new}
@@ -457,13 +501,13 @@ void launch_sweep_rankq(hipStream_t s, const double* Xs, int64_t Ntot, int d, co
     const dim3 grid((unsigned)((M + XN - 1) / XN));
     if (q == 1)
         hipLaunchKernelGGL(k_sweep_rankq<1>, grid, dim3(256), 0, s, Xs, Ntot, d, Wq, ldw, q, pscal, Z, M, invell,
-                           kernel_id, rho, qsum, psum);
+                           kernel_id, rho, qsum, psum, (const double*)nullptr, (double*)nullptr);
     else if (q <= 4)
         hipLaunchKernelGGL(k_sweep_rankq<4>, grid, dim3(256), 0, s, Xs, Ntot, d, Wq, ldw, q, pscal, Z, M, invell,
-                           kernel_id, rho, qsum, psum);
+                           kernel_id, rho, qsum, psum, (const double*)nullptr, (double*)nullptr);
     else
         hipLaunchKernelGGL(k_sweep_rankq<8>, grid, dim3(256), 0, s, Xs, Ntot, d, Wq, ldw, q, pscal, Z, M, invell,
-                           kernel_id, rho, qsum, psum);
+                           kernel_id, rho, qsum, psum, (const double*)nullptr, (double*)nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------

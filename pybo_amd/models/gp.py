@@ -266,6 +266,20 @@ class GP(object):
         self._fitted = False
         self._engine()              # refit now: a non-PD Gram matrix must surface here (LinAlgError)
 
+    def anticipate(self, x):
+        """The loop knows the next query point before it knows its value (`x, _ = solver(...)`; `y = objective(x)`,
+        pybo/bayesopt.py:265-268): tell the device now.  Everything of the coming `add_data(x, y)` that does not depend
+        on y -- k(X, x), the triangular passes, the N*M covariance evaluations that keep the warm sweep cache current --
+        runs while the objective is being evaluated (gpx_append_begin); `add_data` with the same x then only finishes.
+        Returns True when work was started.  Never required: `add_data` gives bit-identical results without it."""
+        st = self._state
+        if not (self._fitted and st is not None and st.nrefs == 1 and st.cache_grid is not None) or self._stale():
+            return False
+        try:
+            return bool(st.engine.append_begin(np.array(x, dtype=float).reshape(-1)))
+        except Exception:
+            return False
+
     def predict(self, X, grad=False):
         X = np.array(X, ndmin=2, dtype=float)
         if X.shape[0] == 0:                      # empty in, empty out (numpy semantics; no device call)

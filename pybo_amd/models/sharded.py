@@ -167,6 +167,10 @@ class ShardedGP(object):
         every device, no broadcast of factors ('every rank factorises redundantly')."""
         _run([lambda r=r: r.add_data(X, Y) for r in self._reps])
 
+    def anticipate(self, x):
+        """Announce the next query point to every replica (see GP.anticipate)."""
+        return any(_run([lambda r=r: r.anticipate(x) for r in self._reps]))
+
     def _rows(self, call, X):
         """`call(replica, rows)` over contiguous row shards; outputs (arrays or tuples of arrays) concatenated."""
         X = np.array(X, ndmin=2, dtype=float)

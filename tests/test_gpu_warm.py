@@ -118,3 +118,91 @@ def test_bo_loop_over_a_device_grid_runs_warm_and_selects_the_same_points():
     tm = ma._state.engine.timers()
     # 12 iterations: ONE full sweep of the grid (the first), then rank-1 corrections
     assert tm['rank1'] > 0 and tm['append'] > 0
+
+
+# ---- announced observations: the value-independent part of add_data runs during the objective (gpx_append_begin) ---
+def test_announced_append_is_bit_identical_and_survives_every_way_of_not_using_it():
+    from pybo_amd._lib import Engine
+    from helpers import synth_problem
+    X, y, ell = synth_problem(300, 3, seed=12)          # Np = 384: 84 rows of padding left
+    rho, sn2, bias = 1.3, 1e-3, 0.2
+    Z = np.random.RandomState(1).rand(20000, 3)
+    rng = np.random.RandomState(5)
+    new = rng.rand(6, 3)
+    ynew = np.sin(3 * new.sum(1))
+
+    def engine():
+        e = Engine(0)
+        e.fit(X, y, 'matern5', ell, rho, sn2, bias)
+        e.set_option('sweep_cache', 1)
+        e.sweep('ei', 0.4, Z, k=5, want_all=False)
+        e.set_option('sweep_cache', 0)
+        return e
+
+    plain, ahead = engine(), engine()
+    for i in range(6):
+        assert plain.append(new[i], ynew[i])
+        if i == 2:
+            assert ahead.append_begin(new[5])           # announce ONE point, append ANOTHER: the announcement is ignored
+        elif i == 4:
+            assert ahead.append_begin(new[i])
+            mu, s2 = ahead.predict(Z[:50])              # other work between the announcement and the value is fine
+        else:
+            assert ahead.append_begin(new[i])
+        assert ahead.append(new[i], ynew[i])
+        a = plain.sweep_update('ei', 0.4, k=5, want_moments=True)
+        b = ahead.sweep_update('ei', 0.4, k=5, want_moments=True)
+        for key in ('acq', 'mu', 's2', 'top_val', 'top_idx'):
+            np.testing.assert_array_equal(a[key], b[key])      # the same FMAs in the same order: the same bits
+    np.testing.assert_array_equal(plain.get_matrix('L'), ahead.get_matrix('L'))
+    np.testing.assert_array_equal(plain.get_vectors()[1], ahead.get_vectors()[1])
+    # an announcement followed by a refit, and one without a live cache
+    assert ahead.append_begin(new[0])
+    ahead.fit(X, y, 'matern5', ell, rho, sn2, bias)
+    assert not ahead.append_begin(new[0])               # the refit dropped the cache: nothing to run ahead
+    r = ahead.sweep('ei', 0.4, Z[:3000], k=3)
+    ref = engine().sweep('ei', 0.4, Z[:3000], k=3)
+    np.testing.assert_array_equal(r['acq'], ref['acq'])
+    # at a block boundary the next append adds a block first: no announcement
+    Xb, yb, ellb = synth_problem(256, 2, seed=3)
+    e = Engine(0)
+    e.fit(Xb, yb, 'se', ellb, 1.0, 1e-3, 0.0)
+    e.set_option('sweep_cache', 1)
+    e.sweep('ucb', 2.0, Z[:1000, :2], k=1, want_all=False)
+    assert not e.append_begin(np.array([0.3, 0.4]))
+    assert e.append(np.array([0.3, 0.4]), 0.1) and e.append_begin(np.array([0.5, 0.1]))
+    assert e.append(np.array([0.5, 0.1]), -0.2)
+
+
+def test_the_loop_announces_its_query_point_and_results_do_not_change():
+    """pybo_amd.bayesopt._bo_step calls model.anticipate(x) between the solver and the objective; the run is the same
+    bit for bit as without it, and add_data finds the announcement (the correction pass is not repeated)."""
+    import pybo_amd
+    from pybo_amd import models, inits
+    from helpers import branin
+    bounds = np.array([[-5.0, 10.0], [0.0, 15.0]])
+    rng = np.random.RandomState(0)
+    X = bounds[:, 0] + (bounds[:, 1] - bounds[:, 0]) * rng.rand(400, 2)
+    y = -branin(X) / 10.0
+    traces = []
+    for announce in (True, False):
+        gp = models.make_gp(1e-4 * np.var(y), np.var(y), 0.25 * (bounds[:, 1] - bounds[:, 0]), np.mean(y))
+        gp.add_data(X, y)
+        seen = []
+        real = models.GP.anticipate
+
+        def spy(self, x, seen=seen):
+            seen.append(real(self, x))
+            return seen[-1]
+        grid = inits.init_sobol_device(bounds, 30000, rng=3)
+        models.GP.anticipate = spy if announce else (lambda self, x: False)
+        try:
+            xb, m, info = pybo_amd.solve_bayesopt(lambda x: float(-branin(x)[0] / 10.0), bounds, model=gp, niter=5,
+                                                  solver=('lbfgs', {'xgrid': grid}), recommender='latent', rng=1)
+        finally:
+            models.GP.anticipate = real
+        if announce:
+            assert seen[1:] == [True] * 4               # from the second iteration on the cache is live
+        traces.append((info.x, info.xbest, m._engine().get_matrix('L')))
+    for a, b in zip(*traces):
+        np.testing.assert_array_equal(a, b)
