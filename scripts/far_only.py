@@ -1,3 +1,6 @@
+"""Far trailing updates of the factorisation ALONE (x_skip = 6) under option sets -- does a larger K per far tile (two-panel
+accumulation, wider panels) make the far part faster?  (No: 3.49 vs 3.63 ms at N = 8192 with chol_merge; the wider-panel
+rows of the table move work into the near updates, which this mode skips.)  python scripts/far_only.py"""
 import sys, os
 import numpy as np
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
