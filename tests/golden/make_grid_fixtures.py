@@ -64,8 +64,35 @@ def make_c():
                         beta=beta, sha=digest(w, M))
 
 
+def make_full(name):
+    """North-star workload / config C over ALL 2^20 candidates (~10-20 min on 8 vCPU each): the oracle's ranking of the
+    whole grid (top 256) and every 8th value + moments, so that the device's selected candidate is checked against the
+    oracle's argmax over the WHOLE grid, not over a sub-sample.  -> tests/golden/grid_<name>_full.npz (~3 MB)"""
+    M = 1 << 20
+    w = bench.make_workload(name, M)
+    ref = gp_ref.make_gp(w['sn2'], w['rho'], w['ell'], w['bias'], w['kernel'])
+    ref.add_data(w['X'], w['y'])
+    t0 = time.time()
+    mu, s2 = ref.predict(w['Xc'])
+    if w['acq'] == 'ei':
+        param = float(ref.mean_at_obs().max())
+        s = np.sqrt(s2)
+        z = (mu - param) / s
+        val = (mu - param) * gp_ref.norm_cdf(z) + s * gp_ref.norm_pdf(z)
+    else:
+        param = float(bench.ucb_beta(w['N']))
+        val = mu + np.sqrt(param * s2)
+    print('%s: oracle over %d candidates in %.1f s; max %.9g at %d' % (name, M, time.time() - t0, val.max(), int(np.argmax(val))))
+    top = gp_ref.topk_desc(val, 256)
+    np.savez_compressed(os.path.join(HERE, 'grid_%s_full.npz' % name), val8=val[::8], mu8=mu[::8], s28=s2[::8], top=top,
+                        top_val=val[top], param=param, vmax=float(val.max()), sha=digest(w, M))
+
+
 if __name__ == '__main__':
     which = sys.argv[1:] or ['b', 'c']
+    for name in ('ns', 'c'):
+        if name + '_full' in which:
+            make_full(name)
     if 'b' in which:
         make_b()
     if 'c' in which:

@@ -203,3 +203,49 @@ def test_config_c_first_2_16_candidates_against_the_committed_oracle_sweep():
     assert int(np.argmax(r['acq'])) == int(fx['top'][0])
     _check_ranking(r['top_idx'], r['top_val'], fx['ucb'], fx['top'], 1e-6 * scale)
     e.close()
+
+
+@pytest.mark.parametrize('name', ['ns', 'c'])
+def test_whole_grid_selection_against_the_oracle_s_ranking_of_all_2_20_candidates(name):
+    """tests/golden/grid_{ns,c}_full.npz: oracle/gp_ref.py over ALL 2^20 candidates of the north-star workload (EI) and of
+    config C (UCB) -- ~10 min of host time each in the build container (make_grid_fixtures.py ns_full c_full) -- kept as
+    the oracle's top 256 of the whole grid plus every 8th value and moment.  The device's selected candidate is the
+    oracle's argmax over the WHOLE grid, its top 64 are the oracle's in the oracle's order (up to the tolerance), and
+    131 072 values / moments agree to the stated tolerances."""
+    from pybo_amd._lib import Engine
+    M = 1 << 20
+    w = bench.make_workload(name, M)
+    fx = _golden('grid_%s_full.npz' % name)
+    assert _digest(w, M) == str(fx['sha'])
+    rho = w['rho']
+    e = Engine(0)
+    e.fit(w['X'], w['y'], w['kernel'], w['ell'], rho, w['sn2'], w['bias'])
+    if w['acq'] == 'ei':
+        _, param = e.mean_at_obs()
+        assert abs(param - float(fx['param'])) <= 1e-9 * np.sqrt(rho)
+    else:
+        param = bench.ucb_beta(w['N'])
+        assert param == float(fx['param'])
+    r = e.sweep(w['acq'], param, w['Xc'], k=64, want_moments=True)
+    val = r['acq']
+    scale = float(fx['vmax'])
+    # every 8th candidate
+    assert np.all(np.abs(r['mu'][::8] - fx['mu8']) <= mu_tol(fx['mu8'], rho))
+    assert np.all(np.abs(r['s2'][::8] - fx['s28']) <= s2_tol(fx['s28'], rho))
+    live = np.abs(fx['val8']) > 1e-9 * abs(scale)
+    rel = np.abs(val[::8][live] - fx['val8'][live]) / np.abs(fx['val8'][live])
+    print('%s: %d of %d strided values live, max relative error %.2e' % (name, live.sum(), len(live), rel.max()))
+    assert rel.max() <= 1e-6
+    # the ranking of the WHOLE grid
+    top, top_val = fx['top'], fx['top_val']
+    tol = 1e-6 * abs(scale)
+    assert int(np.argmax(val)) == int(r['top_idx'][0])
+    if top_val[0] - top_val[1] > 2 * tol:
+        assert int(r['top_idx'][0]) == int(top[0])                      # the selected candidate
+    rank_of = {int(i): k for k, i in enumerate(top)}
+    assert all(int(i) in rank_of for i in r['top_idx']), 'a device pick is outside the best 256 of 2^20 by the oracle'
+    ov = np.array([top_val[rank_of[int(i)]] for i in r['top_idx']])     # the oracle's values of the device's picks
+    assert np.all(ov[:-1] - ov[1:] >= -2 * tol)                         # in the oracle's order
+    assert np.all(ov >= top_val[63] - 2 * tol)                          # and they ARE its top 64 (up to ties at the cut)
+    np.testing.assert_allclose(r['top_val'], ov, rtol=0, atol=2 * tol)
+    e.close()
