@@ -161,6 +161,11 @@ int64_t gpx_capacity(const gpx_handle *h);
 int gpx_predict(gpx_handle *h, const double *Xc, int64_t M, double *mu, double *s2, double *dmu,
                 double *ds2);
 
+/* The mean alone, mu (M,) and optionally dmu (M,d) (NULL to skip): mu = bias + k(x, X).alpha reads neither the
+ * factor nor its inverse -- what the latent recommender maximises, model.predict(X, True)[0::2]
+ * [pybo/recommenders.py:17-24], without the two triangular passes per point the variance costs. */
+int gpx_predict_mean(gpx_handle *h, const double *Xc, int64_t M, double *mu, double *dmu);
+
 /* ---- acquisition sweep + top-k = the batched index call and argsort of the solver
  *      finit = f(xgrid); idx = argsort(finit)[::-1]       [pybo/solvers/lbfgs.py:50-51] ---- */
 /* Evaluates acq over M candidates, returns the k best (value desc, then index asc) in host

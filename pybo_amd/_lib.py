@@ -37,6 +37,7 @@ SYMBOLS = {
     'gpx_var_at_obs': (C.c_int, [_P, _P]),
     'gpx_capacity': (_i64, [_P]),
     'gpx_predict': (C.c_int, [_P, _P, _i64, _P, _P, _P, _P]),
+    'gpx_predict_mean': (C.c_int, [_P, _P, _i64, _P, _P]),
     'gpx_sweep': (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _i64, _i64, _P, _P, _P, _P, _P]),
     'gpx_sweep_dev': (C.c_int, [_P, C.c_int, _P, C.c_int, _P, _i64, _i64, _P, _P, _P, _P, _P]),
     'gpx_sweep_update': (C.c_int, [_P, C.c_int, _P, C.c_int, _i64, _P, _P, _P, _P, _P]),
@@ -487,6 +488,15 @@ class Engine(object):
             return mu, s2, dmu, ds2
         self._check(self._lib.gpx_predict(self._h, _ptr(Xc), M, _ptr(mu), _ptr(s2), None, None))
         return mu, s2
+
+    def predict_mean(self, Xc, grad=False):
+        """Posterior mean [and its gradient] only, k(x, X).alpha: no pass over the factor's inverse per call."""
+        Xc = _f64(Xc).reshape(-1, self.d)
+        M = len(Xc)
+        mu = np.empty(M)
+        dmu = np.empty((M, self.d)) if grad else None
+        self._check(self._lib.gpx_predict_mean(self._h, _ptr(Xc), M, _ptr(mu), _ptr(dmu) if grad else None))
+        return (mu, dmu) if grad else mu
 
     def sweep(self, acq, param, Xc, k=0, want_all=True, want_moments=False):
         """Host-buffer sweep.  Returns dict(top_val, top_idx, acq, mu, s2)."""

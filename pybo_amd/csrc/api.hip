@@ -978,6 +978,13 @@ extern "C" int gpx_predict(gpx_handle* h, const double* Xc, int64_t M, double* m
     });
 }
 
+extern "C" int gpx_predict_mean(gpx_handle* h, const double* Xc, int64_t M, double* mu, double* dmu) {
+    return guarded(h, [&]() -> int {
+        if (!h) return GPX_EARG;
+        return gpx::predict_mean_host(h, Xc, M, mu, dmu);
+    });
+}
+
 // ---- Thompson / RFF ---------------------------------------------------------------------------
 static int rff_core(gpx_handle* h, const double* W, const double* b, const double* theta, int64_t S,
                     int64_t n, int64_t d, double bias, const double* dXc, int64_t M, int64_t k,

@@ -194,6 +194,7 @@ int64_t topk_blocks(int64_t M);
 // predict with gradients (small M path)
 int ensemble_predict_grad_host(gpx_handle* const* mem, int n, const double* Xc, int64_t M, double* mu, double* s2,
                                double* dmu, double* ds2);
+int predict_mean_host(gpx_handle* h, const double* Xc, int64_t M, double* mu, double* dmu);
 int predict_grad_host(gpx_handle* h, const double* Xc, int64_t M, double* mu, double* s2, double* dmu,
                       double* ds2);
 

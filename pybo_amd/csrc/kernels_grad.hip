@@ -205,10 +205,37 @@ __global__ __launch_bounds__(256) void k_grad_reduce(const double* __restrict__ 
     }
 }
 
+// The mean alone needs neither T nor U: mu = bias + k(x, X).alpha, dmu_j = sum_i alpha_i dk_i/dx_j.  Same grid and
+// output layout as k_grad_reduce (the s2 slots are left untouched).
+__global__ __launch_bounds__(256) void k_mean_reduce(const double* __restrict__ Xs, int64_t N, int64_t Np, int d,
+                                                     const double* __restrict__ Xc,
+                                                     const double* __restrict__ invell,
+                                                     const double* __restrict__ ks, const double* __restrict__ g,
+                                                     const double* __restrict__ alpha, double bias,
+                                                     double* __restrict__ out) {
+    __shared__ double sh[4];
+    const int j = blockIdx.x, m = blockIdx.y;
+    const int64_t base = (int64_t)m * Np;
+    double* o = out + (int64_t)m * (2 + 2 * d);
+    double acc = 0.0;
+    if (j == d) {
+        for (int64_t i = threadIdx.x; i < N; i += 256) acc = fma(ks[base + i], alpha[i], acc);
+        acc = block_sum(acc, sh);
+        if (threadIdx.x == 0) o[0] = bias + acc;
+        return;
+    }
+    const double cj = Xc[(int64_t)m * d + j] * invell[j];
+    const double two_inv = 2.0 * invell[j];
+    for (int64_t i = threadIdx.x; i < N; i += 256)
+        acc = fma(g[base + i] * (two_inv * (cj - Xs[i * d + j])), alpha[i], acc);
+    acc = block_sum(acc, sh);
+    if (threadIdx.x == 0) o[2 + j] = acc;
+}
+
 // One chunk (mb <= GB points) of predict-with-gradients, ENQUEUED on the handle's stream: upload, the four kernels,
 // download into the handle's pinned staging buffer.  No synchronisation: the ensemble entry point enqueues a chunk on
 // every member's stream before it waits for any of them.
-static int predict_grad_enqueue(gpx_handle* h, const double* Xc, int mb) {
+static int predict_grad_enqueue(gpx_handle* h, const double* Xc, int mb, bool mean_only = false) {
     if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return GPX_EHIP; }
     hipStream_t s = h->stream;
     const int64_t Np = h->Np, N = h->N;
@@ -249,10 +276,15 @@ static int predict_grad_enqueue(gpx_handle* h, const double* Xc, int mb) {
     }
     hipLaunchKernelGGL(k_kstar, dim3((unsigned)((Np + 255) / 256), (unsigned)mb), dim3(256), 0, s, h->dXs,
                        N, Np, d, dX, h->dinvell, h->kernel_id, h->rho, dks, dg);
-    launch_tri_matvec_multi(s, rows4, h->dT, Np, N, dks, mb, 0, dV);
-    launch_tri_matvec_multi(s, rows4, h->dU, Np, N, dV, mb, 1, dw);
-    hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)(d + 1), (unsigned)mb), dim3(256), 0, s, h->dXs, N, Np,
-                       d, dX, h->dinvell, dg, dV, dw, h->da, h->dalpha, h->rho, h->bias, dout);
+    if (mean_only) {
+        hipLaunchKernelGGL(k_mean_reduce, dim3((unsigned)(d + 1), (unsigned)mb), dim3(256), 0, s, h->dXs, N, Np, d,
+                           dX, h->dinvell, dks, dg, h->dalpha, h->bias, dout);
+    } else {
+        launch_tri_matvec_multi(s, rows4, h->dT, Np, N, dks, mb, 0, dV);
+        launch_tri_matvec_multi(s, rows4, h->dU, Np, N, dV, mb, 1, dw);
+        hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)(d + 1), (unsigned)mb), dim3(256), 0, s, h->dXs, N, Np,
+                           d, dX, h->dinvell, dg, dV, dw, h->da, h->dalpha, h->rho, h->bias, dout);
+    }
     if (hipMemcpyAsync(h->hpin, dout, (size_t)mb * per * 8, hipMemcpyDeviceToHost, s) != hipSuccess) {
         h->err = "predict: D2H copy failed";
         return GPX_EHIP;
@@ -271,10 +303,10 @@ static int predict_grad_collect(gpx_handle* h, int mb, double* mu, double* s2, d
     for (int m = 0; m < mb; ++m) {
         const double* o = h->hpin + (size_t)m * per;
         mu[m] = o[0];
-        s2[m] = o[1];
+        if (s2) s2[m] = o[1];
         for (int j = 0; j < d; ++j) {
-            dmu[(int64_t)m * d + j] = o[2 + j];
-            ds2[(int64_t)m * d + j] = o[2 + d + j];
+            if (dmu) dmu[(int64_t)m * d + j] = o[2 + j];
+            if (ds2) ds2[(int64_t)m * d + j] = o[2 + d + j];
         }
     }
     return GPX_OK;
@@ -291,6 +323,22 @@ int predict_grad_host(gpx_handle* h, const double* Xc, int64_t M, double* mu, do
         const int mb = (int)std::min<int64_t>(GB, M - m0);
         if (int rc = predict_grad_enqueue(h, Xc + m0 * d, mb)) return rc;
         if (int rc = predict_grad_collect(h, mb, mu + m0, s2 + m0, dmu + m0 * d, ds2 + m0 * d)) return rc;
+    }
+    return GPX_OK;
+}
+
+// Mean (and its gradient) only: k(x, X).alpha -- no pass over T or U per call (alpha itself comes with the lazily built
+// inverse, once per fit).
+int predict_mean_host(gpx_handle* h, const double* Xc, int64_t M, double* mu, double* dmu) {
+    if (!h->fitted) { h->err = "predict_mean: model is not fitted"; return GPX_ESTATE; }
+    if (!Xc || !mu || M < 1) { h->err = "predict_mean: need M >= 1 points and a mu output"; return GPX_EARG; }
+    if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return GPX_EHIP; }
+    if (int rc0 = ensure_inverse(h)) return rc0;
+    const int d = (int)h->d;
+    for (int64_t m0 = 0; m0 < M; m0 += GB) {
+        const int mb = (int)std::min<int64_t>(GB, M - m0);
+        if (int rc = predict_grad_enqueue(h, Xc + m0 * d, mb, true)) return rc;
+        if (int rc = predict_grad_collect(h, mb, mu + m0, nullptr, dmu ? dmu + m0 * d : nullptr, nullptr)) return rc;
     }
     return GPX_OK;
 }

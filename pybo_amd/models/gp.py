@@ -134,6 +134,7 @@ class RFFSampleDevice(object):
 
 class GP(object):
     APPEND_MAX = 16     # add_data with at most this many new rows extends the factorisation in place
+    MEAN_DIRECT_ROWS = 256      # predict_mean of at most this many points: k(x, X).alpha, 16 points per device call
 
     def __init__(self, sn2, rho, ell, bias=0.0, kernel='se', device=0):
         if kernel not in _KERNELS:
@@ -316,17 +317,23 @@ class GP(object):
                 return slice(int(o), int(o) + n)
         return None
 
-    def predict_mean(self, X):
-        """Posterior mean only: `model.predict(X)[0]` without the variance nobody reads (EI / PI targets, the
-        incumbent recommender).  Closed form at the model's own data, one device call otherwise."""
+    def predict_mean(self, X, grad=False):
+        """Posterior mean only: `model.predict(X)[0]` (with grad: `model.predict(X, True)[0::2]`) without the variance
+        nobody reads (EI / PI targets, both recommenders).  Closed form at the model's own data; a few points or a
+        gradient: `k(x, X).alpha` on the device, no pass over the factor's inverse; a large batch: the sweep."""
         X = np.array(X, ndmin=2, dtype=float)
         if X.shape[0] == 0:
-            return np.zeros(0)
+            return (np.zeros(0), np.zeros((0, len(self.ell)))) if grad else np.zeros(0)
         if self.ndata == 0:
-            return np.full(len(X), self.bias)
+            mu = np.full(len(X), self.bias)
+            return (mu, np.zeros(X.shape)) if grad else mu
+        if grad:
+            return self._engine().predict_mean(X, True)
         rows = self._data_rows(X)
         if rows is not None:
             return self._engine().mean_at_obs()[0][rows]
+        if len(X) <= self.MEAN_DIRECT_ROWS:
+            return self._engine().predict_mean(X)
         return self._engine().predict(X)[0]
 
     def mean_topk(self, xgrid, k):

@@ -186,8 +186,8 @@ class ShardedGP(object):
     def predict(self, X, grad=False):
         return self._rows(lambda r, Z: r.predict(Z, grad), X)
 
-    def predict_mean(self, X):
-        return self._reps[0].predict_mean(X)
+    def predict_mean(self, X, grad=False):
+        return self._reps[0].predict_mean(X, grad)
 
     def mean_topk(self, xgrid, k):
         if not isinstance(xgrid, (DeviceGrid, ShardedDeviceGrid)):

@@ -11,7 +11,11 @@ __all__ = ['best_latent', 'best_incumbent']
 
 
 def best_latent(model, bounds, X):
+    mean_only = getattr(model, 'predict_mean', None)     # device models: no variance, no pass over the factor
+
     def mean(X, grad=False):
+        if mean_only is not None:
+            return mean_only(X, grad) if grad else mean_only(X)
         if grad:
             post = model.predict(X, True)
             return post[0], post[2]

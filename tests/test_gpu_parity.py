@@ -293,6 +293,32 @@ def test_predict_with_gradients(kernel):
     assert np.all(np.abs(s2 - sr) <= s2_tol(sr, rho))
     np.testing.assert_allclose(dmu, dmr, rtol=1e-6, atol=1e-8)
     np.testing.assert_allclose(ds2, dsr, rtol=1e-6, atol=1e-8)
+    # the mean alone (gpx_predict_mean: k(x, X).alpha, no pass over T / U): same numbers, with and without gradient
+    m1, dm1 = e.predict_mean(Z, grad=True)
+    assert np.all(np.abs(m1 - mr) <= mu_tol(mr, rho))
+    np.testing.assert_allclose(dm1, dmr, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(m1, mu, rtol=1e-10, atol=1e-12 * np.sqrt(rho))
+    np.testing.assert_array_equal(e.predict_mean(Z), m1)
+    # ... at the training inputs too (where the latent recommender's refinement starts)
+    m2, dm2 = e.predict_mean(X[:5], grad=True)
+    mr2, _, dmr2, _ = ref.predict(X[:5], grad=True)
+    assert np.all(np.abs(m2 - mr2) <= mu_tol(mr2, rho))
+    np.testing.assert_allclose(dm2, dmr2, rtol=1e-6, atol=1e-8)
+    e.close()
+
+
+def test_predict_mean_is_the_first_call_after_a_fit():
+    """gpx_fit leaves the inverse (and with it alpha) to the first call that needs it: the mean-only path is one."""
+    e, ref, (X, y, ell, rho, sn2, bias) = _pair(300, 4, 'se', seed=23)
+    Z = np.random.RandomState(7).rand(5, 4)
+    m, dm = e.predict_mean(Z, grad=True)
+    want = ref.predict(Z, grad=True)
+    assert np.all(np.abs(m - want[0]) <= mu_tol(want[0], rho))
+    np.testing.assert_allclose(dm, want[2], rtol=1e-6, atol=1e-8)
+    e.append(Z[0], 0.3)                               # ... and it follows an append (alpha is updated in place)
+    ref.add_data(Z[:1], np.array([0.3]))
+    m = e.predict_mean(Z)
+    assert np.all(np.abs(m - ref.predict(Z)[0]) <= mu_tol(m, rho))
     e.close()
 
 
