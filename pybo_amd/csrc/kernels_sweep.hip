@@ -24,69 +24,106 @@ namespace gpx {
 // ------------------------------------------------------------------------------------------------
 constexpr int XK = 64, XN = 128, XDC = 16;
 
-__global__ __launch_bounds__(256) void k_cross_gram(const double* __restrict__ Xs, int64_t N, int d,
-                                                    const double* __restrict__ Xc, int64_t m0, int64_t M,
-                                                    const double* __restrict__ invell, int kid,
-                                                    double rho, double* __restrict__ Ks, int64_t ldk) {
-    __shared__ double xo[XDC][XK];
-    __shared__ double xc[XDC][XN];
-    const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
-    const int64_t k0 = (int64_t)blockIdx.y * XK;   // observed row origin
-    const int64_t n0 = (int64_t)blockIdx.x * XN;   // chunk-local candidate origin
-    double r2[8][4];
+// Staging of a (rows x kc) block of row-major coordinates into LDS as [k][row] WITHOUT index divisions: a thread owns
+// one row and every STRIDE-th coordinate of it (counters: the e / kc, e % kc form cost ~13 of 50-58 VALU instructions
+// per covariance evaluation at d = 8 -- these kernels are VALU-issue-bound).
+// Squared scaled distances of an 8 x 4 block per thread, one dimension at a time; the first dimension starts the sums
+// (df * df == fma(df, df, +0): same bits as a zero-initialised accumulator).
+template <bool FIRST>
+__device__ __forceinline__ void dist_step(const double (*xo)[XK], const double (*xc)[XN], int k, int ty, int tx,
+                                          double (&r2)[8][4]) {
+    double a8[8], b4[4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) a8[a] = xo[k][ty * 8 + a];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) b4[b] = xc[k][tx * 4 + b];
 #pragma unroll
     for (int a = 0; a < 8; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) r2[a][b] = 0.0;
-
-    for (int c0 = 0; c0 < d; c0 += XDC) {
-        const int kc = min(XDC, d - c0);
-        __syncthreads();
-        for (int e = t; e < XK * kc; e += 256) {
-            const int row = e / kc, k = e - row * kc;
-            xo[k][row] = Xs[(k0 + row) * d + c0 + k];
-        }
-        for (int e = t; e < XN * kc; e += 256) {
-            const int row = e / kc, k = e - row * kc;
-            const int64_t gm = m0 + n0 + row;
-            xc[k][row] = (gm < M) ? Xc[gm * d + c0 + k] * invell[c0 + k] : 0.0;
-        }
-        __syncthreads();
-        for (int k = 0; k < kc; ++k) {
-            double a8[8], b4[4];
-#pragma unroll
-            for (int a = 0; a < 8; ++a) a8[a] = xo[k][ty * 8 + a];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) b4[b] = xc[k][tx * 4 + b];
-#pragma unroll
-            for (int a = 0; a < 8; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const double df = a8[a] - b4[b];
-                    r2[a][b] = fma(df, df, r2[a][b]);
-                }
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < 8; ++a) {
-        const int64_t gk = k0 + ty * 8 + a;
-        d4 o;
-#pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const int64_t gm = m0 + n0 + tx * 4 + b;
-            o[b] = (gk < N && gm < M) ? kern_eval(kid, r2[a][b], rho) : 0.0;
+            const double df = a8[a] - b4[b];
+            r2[a][b] = FIRST ? df * df : fma(df, df, r2[a][b]);
         }
-        // tile-blocked layout [nt][k][128]: the 64 x 128 outputs of this block are ONE contiguous 64 KB run
-        *reinterpret_cast<d4*>(Ks + ((int64_t)blockIdx.x * ldk + gk) * XN + tx * 4) = o;
+}
+
+// One workgroup: 128 candidates x xrt consecutive 64-row tiles (the candidates' coordinates are staged once when
+// d <= XDC).  grid (ceil(Np / 64 / xrt), cols / 128): consecutive workgroups write consecutive runs of Ks.
+constexpr int XRT = 8;
+
+template <int KID>
+__global__ __launch_bounds__(256, 3) void k_cross_gram(const double* __restrict__ Xs, int64_t N, int64_t Np, int d,
+                                                       const double* __restrict__ Xc, int64_t m0, int64_t M,
+                                                       const double* __restrict__ invell, double rho,
+                                                       double* __restrict__ Ks, int64_t ldk, int xrt) {
+    __shared__ double xo[XDC][XK];
+    __shared__ double xc[XDC][XN];
+    const int t = threadIdx.x, tx = t & 31, ty = t >> 5;
+    const int crow = t & (XN - 1), ckq = t >> 7;      // staging of candidates: row, first coordinate (stride 2)
+    const int orow = t & (XK - 1), okq = t >> 6;      // staging of observed rows: row, first coordinate (stride 4)
+    const int64_t n0 = (int64_t)blockIdx.y * XN;      // chunk-local candidate origin
+    const int64_t gmc = m0 + n0 + crow;
+    const bool onepass = (d <= XDC);
+    if (onepass)
+        for (int k = ckq; k < d; k += 2) xc[k][crow] = (gmc < M) ? Xc[gmc * d + k] * invell[k] : 0.0;
+    for (int rt = 0; rt < xrt; ++rt) {
+        const int64_t k0 = ((int64_t)blockIdx.x * xrt + rt) * XK;   // observed row origin
+        if (k0 >= Np) break;
+        double r2[8][4];
+        auto stage = [&](int c0, int kc) {
+            __syncthreads();
+            for (int k = okq; k < kc; k += 4) xo[k][orow] = Xs[(k0 + orow) * d + c0 + k];
+            if (!onepass)
+                for (int k = ckq; k < kc; k += 2)
+                    xc[k][crow] = (gmc < M) ? Xc[gmc * d + c0 + k] * invell[c0 + k] : 0.0;
+            __syncthreads();
+        };
+        {
+            const int kc = min(XDC, d);
+            stage(0, kc);
+            dist_step<true>(xo, xc, 0, ty, tx, r2);
+#pragma unroll 1
+            for (int k = 1; k < kc; ++k) dist_step<false>(xo, xc, k, ty, tx, r2);
+        }
+        for (int c0 = XDC; c0 < d; c0 += XDC) {
+            const int kc = min(XDC, d - c0);
+            stage(c0, kc);
+#pragma unroll 1
+            for (int k = 0; k < kc; ++k) dist_step<false>(xo, xc, k, ty, tx, r2);
+        }
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const int64_t gk = k0 + ty * 8 + a;
+            d4 o;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int64_t gm = m0 + n0 + tx * 4 + b;
+                o[b] = (gk < N && gm < M) ? kern_eval(KID, r2[a][b], rho) : 0.0;
+            }
+            // tile-blocked layout [nt][k][128]: the 64 x 128 outputs of a row tile are ONE contiguous 64 KB run
+            *reinterpret_cast<d4*>(Ks + ((int64_t)blockIdx.y * ldk + gk) * XN + tx * 4) = o;
+        }
     }
 }
 
 void launch_cross_gram(hipStream_t s, const double* Xs, int64_t Np, int64_t N, int d, const double* Xc,
                        int64_t m0, int64_t M, int64_t cols, const double* invell, int kernel_id,
                        double rho, double* Ks, int64_t ldk) {
-    dim3 grid((unsigned)(cols / XN), (unsigned)(Np / XK));
-    hipLaunchKernelGGL(k_cross_gram, grid, dim3(256), 0, s, Xs, N, d, Xc, m0, M, invell, kernel_id, rho,
-                       Ks, ldk);
+    const int64_t tiles = Np / XK;
+    // row tiles per workgroup: the SE kernel at small d is bound by its 8 B/evaluation of stores (one tile per
+    // workgroup interleaves them best: 3.5 vs 4.3 ms per 2^31 evaluations), the others by their VALU work (the
+    // candidates staged once per 8 tiles: Matern-5/2 4.35 vs 4.85 ms); non-temporal stores change nothing
+    const int XRTa = (kernel_id == GPX_KERN_SE_ARD && d <= XDC) ? 1 : XRT;
+    const int XRTv = XRTa;
+    dim3 grid((unsigned)((tiles + XRTa - 1) / XRTa), (unsigned)(cols / XN));   // x: row groups of one candidate tile = one contiguous run of Ks
+#define GPX_CG(KID) \
+    hipLaunchKernelGGL(k_cross_gram<KID>, grid, dim3(256), 0, s, Xs, N, Np, d, Xc, m0, M, invell, rho, Ks, ldk, XRTv)
+    switch (kernel_id) {
+        case GPX_KERN_SE_ARD: GPX_CG(GPX_KERN_SE_ARD); break;
+        case GPX_KERN_MATERN52: GPX_CG(GPX_KERN_MATERN52); break;
+        case GPX_KERN_MATERN32: GPX_CG(GPX_KERN_MATERN32); break;
+        default: GPX_CG(GPX_KERN_MATERN12); break;
+    }
+#undef GPX_CG
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -328,12 +365,12 @@ void launch_acq(hipStream_t s, const double* Qp, const double* Pp, int64_t ldp, 
 // depend on the launch geometry); thread (ty, tx) accumulates rows ty*8..+7 of each tile for candidates
 // tx*4..+3, the 8 row groups are combined through LDS at the end.
 // ------------------------------------------------------------------------------------------------
-template <int Q>
-__global__ __launch_bounds__(256) void k_sweep_rankq(const double* __restrict__ Xs, int64_t Ntot, int d,
+template <int Q, int KID>
+__global__ __launch_bounds__(256, (Q == 1) ? 3 : 2) void k_sweep_rankq(const double* __restrict__ Xs, int64_t Ntot, int d,
                                                      const double* __restrict__ Wq, int64_t ldw, int q,
                                                      const double* __restrict__ pscal,
                                                      const double* __restrict__ Z, int64_t M,
-                                                     const double* __restrict__ invell, int kid, double rho,
+                                                     const double* __restrict__ invell, double rho,
                                                      double* __restrict__ qsum, double* __restrict__ psum,
                                                      const double* __restrict__ xlast, double* __restrict__ vout) {
     // xlast (optional): the scaled coordinates of row Ntot - 1 when that row is NOT in Xs yet -- an ANNOUNCED
@@ -352,61 +389,47 @@ __global__ __launch_bounds__(256) void k_sweep_rankq(const double* __restrict__ 
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[j][b] = 0.0;
     const bool onepass = (d <= XDC);          // candidates' coordinates stay in LDS across row tiles
-    if (onepass) {
-        for (int e = t; e < XN * d; e += 256) {
-            const int row = e / d, k = e - row * d;
-            const int64_t gm = n0 + row;
-            xc[k][row] = (gm < M) ? Z[gm * d + k] * invell[k] : 0.0;
-        }
-    }
+    const int crow = t & (XN - 1), ckq = t >> 7;      // staging of candidates: row, first coordinate (stride 2)
+    const int orow = t & (XK - 1), okq = t >> 6;      // staging of observed rows: row, first coordinate (stride 4)
+    const int64_t gmc = n0 + crow;
+    if (onepass)
+        for (int k = ckq; k < d; k += 2) xc[k][crow] = (gmc < M) ? Z[gmc * d + k] * invell[k] : 0.0;
     for (int64_t k0 = 0; k0 < Ntot; k0 += XK) {
         double r2[8][4];
-#pragma unroll
-        for (int a = 0; a < 8; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) r2[a][b] = 0.0;
-        for (int c0 = 0; c0 < d; c0 += XDC) {
-            const int kc = min(XDC, d - c0);
+        auto stage = [&](int c0, int kc) {
             __syncthreads();
-            for (int e = t; e < XK * kc; e += 256) {
-                const int row = e / kc, k = e - row * kc;
-                const int64_t gr = k0 + row;
-                xo[k][row] = (gr < Ntot) ? ((xlast && gr == Ntot - 1) ? xlast[c0 + k] : Xs[gr * d + c0 + k]) : 0.0;
-            }
+            const int64_t gr = k0 + orow;
+            const double* src = (xlast && gr == Ntot - 1) ? xlast + c0 : Xs + gr * d + c0;
+            for (int k = okq; k < kc; k += 4) xo[k][orow] = (gr < Ntot) ? src[k] : 0.0;
             if (c0 == 0) {
                 for (int e = t; e < Q * XK; e += 256) {
-                    const int j = e / XK, row = e - j * XK;
+                    const int j = e / XK, row = e - j * XK;      // XK is a compile-time power of two
                     wv[j][row] = (j < q && k0 + row < Ntot) ? Wq[(int64_t)j * ldw + k0 + row] : 0.0;
                 }
             }
-            if (!onepass) {
-                for (int e = t; e < XN * kc; e += 256) {
-                    const int row = e / kc, k = e - row * kc;
-                    const int64_t gm = n0 + row;
-                    xc[k][row] = (gm < M) ? Z[gm * d + c0 + k] * invell[c0 + k] : 0.0;
-                }
-            }
+            if (!onepass)
+                for (int k = ckq; k < kc; k += 2)
+                    xc[k][crow] = (gmc < M) ? Z[gmc * d + c0 + k] * invell[c0 + k] : 0.0;
             __syncthreads();
-            for (int k = 0; k < kc; ++k) {
-                double a8[8], b4[4];
-#pragma unroll
-                for (int a = 0; a < 8; ++a) a8[a] = xo[k][ty * 8 + a];
-#pragma unroll
-                for (int b = 0; b < 4; ++b) b4[b] = xc[k][tx * 4 + b];
-#pragma unroll
-                for (int a = 0; a < 8; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) {
-                        const double df = a8[a] - b4[b];
-                        r2[a][b] = fma(df, df, r2[a][b]);
-                    }
-            }
+        };
+        {
+            const int kc = min(XDC, d);
+            stage(0, kc);
+            dist_step<true>(xo, xc, 0, ty, tx, r2);
+#pragma unroll 1
+            for (int k = 1; k < kc; ++k) dist_step<false>(xo, xc, k, ty, tx, r2);
+        }
+        for (int c0 = XDC; c0 < d; c0 += XDC) {
+            const int kc = min(XDC, d - c0);
+            stage(c0, kc);
+#pragma unroll 1
+            for (int k = 0; k < kc; ++k) dist_step<false>(xo, xc, k, ty, tx, r2);
         }
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
             double kv[4];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) kv[b] = kern_eval(kid, r2[a][b], rho);
+            for (int b = 0; b < 4; ++b) kv[b] = kern_eval(KID, r2[a][b], rho);
 #pragma unroll
             for (int j = 0; j < Q; ++j) {
                 const double wa = wv[j][ty * 8 + a];      // 0 beyond a point's own row: contributes nothing
@@ -469,13 +492,29 @@ void launch_scale_point(hipStream_t s, const double* x, const double* invell, in
     hipLaunchKernelGGL(k_scale_point, dim3((unsigned)((d + 255) / 256)), dim3(256), 0, s, x, invell, d, xs);
 }
 
+template <int Q>
+static void launch_rankq_kid(hipStream_t s, dim3 grid, const double* Xs, int64_t Ntot, int d, const double* Wq,
+                             int64_t ldw, int q, const double* pscal, const double* Z, int64_t M, const double* invell,
+                             int kernel_id, double rho, double* qsum, double* psum, const double* xlast, double* vout) {
+#define GPX_RANKQ(KID)                                                                                              \
+    hipLaunchKernelGGL((k_sweep_rankq<Q, KID>), grid, dim3(256), 0, s, Xs, Ntot, d, Wq, ldw, q, pscal, Z, M, invell, \
+                       rho, qsum, psum, xlast, vout)
+    switch (kernel_id) {
+        case GPX_KERN_SE_ARD: GPX_RANKQ(GPX_KERN_SE_ARD); break;
+        case GPX_KERN_MATERN52: GPX_RANKQ(GPX_KERN_MATERN52); break;
+        case GPX_KERN_MATERN32: GPX_RANKQ(GPX_KERN_MATERN32); break;
+        default: GPX_RANKQ(GPX_KERN_MATERN12); break;
+    }
+#undef GPX_RANKQ
+}
+
 // the correction pass of ONE announced observation: v_n for every cached candidate -> vout (sums untouched)
 void launch_sweep_rank1_v(hipStream_t s, const double* Xs, int64_t Ntot, int d, const double* Wq, int64_t ldw,
                           const double* pscal, const double* Z, int64_t M, const double* invell, int kernel_id,
                           double rho, const double* xlast, double* vout) {
     const dim3 grid((unsigned)((M + XN - 1) / XN));
-    hipLaunchKernelGGL(k_sweep_rankq<1>, grid, dim3(256), 0, s, Xs, Ntot, d, Wq, ldw, 1, pscal, Z, M, invell, kernel_id,
-                       rho, (double*)nullptr, (double*)nullptr, xlast, vout);
+    launch_rankq_kid<1>(s, grid, Xs, Ntot, d, Wq, ldw, 1, pscal, Z, M, invell, kernel_id, rho, nullptr, nullptr, xlast,
+                        vout);
 }
 
 // row j of the pending-correction table: [w (Nj entries), -1, zeros up to ldw]; pscal_j = {1/d, a_new}
@@ -500,14 +539,14 @@ void launch_sweep_rankq(hipStream_t s, const double* Xs, int64_t Ntot, int d, co
                         double rho, double* qsum, double* psum) {
     const dim3 grid((unsigned)((M + XN - 1) / XN));
     if (q == 1)
-        hipLaunchKernelGGL(k_sweep_rankq<1>, grid, dim3(256), 0, s, Xs, Ntot, d, Wq, ldw, q, pscal, Z, M, invell,
-                           kernel_id, rho, qsum, psum, (const double*)nullptr, (double*)nullptr);
+        launch_rankq_kid<1>(s, grid, Xs, Ntot, d, Wq, ldw, q, pscal, Z, M, invell, kernel_id, rho, qsum, psum, nullptr,
+                            nullptr);
     else if (q <= 4)
-        hipLaunchKernelGGL(k_sweep_rankq<4>, grid, dim3(256), 0, s, Xs, Ntot, d, Wq, ldw, q, pscal, Z, M, invell,
-                           kernel_id, rho, qsum, psum, (const double*)nullptr, (double*)nullptr);
+        launch_rankq_kid<4>(s, grid, Xs, Ntot, d, Wq, ldw, q, pscal, Z, M, invell, kernel_id, rho, qsum, psum, nullptr,
+                            nullptr);
     else
-        hipLaunchKernelGGL(k_sweep_rankq<8>, grid, dim3(256), 0, s, Xs, Ntot, d, Wq, ldw, q, pscal, Z, M, invell,
-                           kernel_id, rho, qsum, psum, (const double*)nullptr, (double*)nullptr);
+        launch_rankq_kid<8>(s, grid, Xs, Ntot, d, Wq, ldw, q, pscal, Z, M, invell, kernel_id, rho, qsum, psum, nullptr,
+                            nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
