@@ -265,6 +265,11 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             h->chol_w = (int)value;
             return GPX_OK;
         }
+        if (!strcmp(name, "chol_fuse")) {
+            if (value != 0 && value != 1) return fail(h, GPX_EARG, "chol_fuse must be 0 or 1");
+            h->chol_fuse = (int)value;
+            return GPX_OK;
+        }
         if (!strcmp(name, "chol_merge")) {
             if (value < 0 || value > 100000) return fail(h, GPX_EARG, "chol_merge: 0 (off) or a minimum number of block rows");
             h->chol_merge = (int)value;

@@ -39,6 +39,7 @@ struct gpx_handle {
     int x_bg = 0, x_bg_lds = 72, x_bg_iters = 10000;   // diagnostic: synthetic MFMA background load (k_bg_mfma)
     hipStream_t stream_bg = nullptr;
     int chol_merge = 1;           // two-panel accumulation of the far updates while >= this many rest block rows (0 = off)
+    int chol_fuse = 0;            // diagonal block + panel solve in one launch (k_potrf_solve16)
     int chol_rl = 1;              // in-panel updates right-looking (1, default) or left-looking (0)
     int chol_w = 0;               // outer panel width of the factorisation in 128-blocks (2..8; 0 = by size)
     std::string err;

@@ -346,20 +346,18 @@ __device__ __forceinline__ void pf16_trail(d4 (&accA)[8], d4 (&accB)[8], int cA,
 // DBG (scripts/potrf_bench.hip only): wall-clock stamps of the phases go to `dbg` (thread 0)
 // Batched use (gpx_loglik_batch): blockIdx.z = batch element, S / R / U `bs` elements apart, one flag each;
 // T may be NULL (the batched path needs U_d only and keeps it in the dead diagonal blocks of S).
+// The body of k_potrf16 (one workgroup of 256 threads; Pn / Ud / sflag are the caller's LDS).  sflag != 0 afterwards:
+// a non-positive pivot (recorded in *flag) or an earlier block's failure.
 template <bool DBG>
-__global__ __launch_bounds__(256) void k_potrf16(const double* __restrict__ S, double* __restrict__ R,
-                                                 double* __restrict__ T, double* __restrict__ U, int64_t Np,
-                                                 int p, int* __restrict__ flag, long long* __restrict__ dbg,
-                                                 int64_t bs) {
-    S += (int64_t)blockIdx.z * bs;
-    R += (int64_t)blockIdx.z * bs;
-    U += (int64_t)blockIdx.z * bs;
-    if (T) T += (int64_t)blockIdx.z * bs;
-    flag += blockIdx.z;
-    __shared__ double Pn[2 * 16 * PFP];   // the 16-row panels of the current and the previous step
-    __shared__ double Ud[256];            // the current 16x16 inverse, transposed (k-major A operand)
-    __shared__ int sflag;
-    if (*flag != 0) return;               // an earlier block already failed
+__device__ __forceinline__ void potrf16_body(const double* __restrict__ S, double* __restrict__ R,
+                                             double* __restrict__ T, double* __restrict__ U, int64_t Np, int p,
+                                             int* __restrict__ flag, long long* __restrict__ dbg,
+                                             double* __restrict__ Pn, double* __restrict__ Ud, int& sflag) {
+    if (*flag != 0) {                     // an earlier block already failed (uniform)
+        if (threadIdx.x == 0) sflag = 1;
+        __syncthreads();
+        return;
+    }
     // The chain kernels run at the highest wave priority: they share compute units with the side streams'
     // trailing updates, whose waves raise their own priority to 1 around their MFMA phases -- a chain wave at
     // priority 0 on the same SIMD was measured to run 3x slower (k_potrf16 36 -> 107 us).
@@ -416,6 +414,25 @@ __global__ __launch_bounds__(256) void k_potrf16(const double* __restrict__ S, d
 #undef GPX_PF_STEP
     if (DBG && t == 0) dbg[9] = wall_clock64();
     if (DBG && t == 0) dbg[10] = wall_clock64();
+}
+
+// DBG (scripts/potrf_bench.hip only): wall-clock stamps of the phases go to `dbg` (thread 0)
+// Batched use (gpx_loglik_batch): blockIdx.z = batch element, S / R / U `bs` elements apart, one flag each;
+// T may be NULL (the batched path needs U_d only and keeps it in the dead diagonal blocks of S).
+template <bool DBG>
+__global__ __launch_bounds__(256) void k_potrf16(const double* __restrict__ S, double* __restrict__ R,
+                                                 double* __restrict__ T, double* __restrict__ U, int64_t Np,
+                                                 int p, int* __restrict__ flag, long long* __restrict__ dbg,
+                                                 int64_t bs) {
+    S += (int64_t)blockIdx.z * bs;
+    R += (int64_t)blockIdx.z * bs;
+    U += (int64_t)blockIdx.z * bs;
+    if (T) T += (int64_t)blockIdx.z * bs;
+    flag += blockIdx.z;
+    __shared__ double Pn[2 * 16 * PFP];   // the 16-row panels of the current and the previous step
+    __shared__ double Ud[256];            // the current 16x16 inverse, transposed (k-major A operand)
+    __shared__ int sflag;
+    potrf16_body<DBG>(S, R, T, U, Np, p, flag, dbg, Pn, Ud, sflag);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -556,20 +573,13 @@ __global__ __launch_bounds__(256) void k_trtri_diag128(const double* __restrict_
 // the next MFMAs straight from registers as the B operand,
 //     x_jb = T_d(jb) s_jb        s_i -= R[jb, i]^T x_jb   (i > jb)        144 MFMAs per wave.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_panel_solve16(const double* __restrict__ U, const double* __restrict__ S,
-                                                       double* __restrict__ R, int64_t Np, int p,
-                                                       const int* __restrict__ flag, int64_t bs) {
-    U += (int64_t)blockIdx.z * bs;       // batched use: blockIdx.z = batch element
-    S += (int64_t)blockIdx.z * bs;
-    R += (int64_t)blockIdx.z * bs;
-    flag += blockIdx.z;
+__device__ __forceinline__ void panel_solve16_body(const double* __restrict__ U, const double* __restrict__ S,
+                                                   double* __restrict__ R, int64_t Np, int p) {
     // NO LDS and no barrier: the A fragments (tiles of R_pp, the 16x16 inverses) are read straight from global
     // memory / L2 in the k-major fragment layout (lane (g, n) <- row 4kk + g, column n: four 128-byte segments
     // per instruction), one step ahead of the MFMAs that consume them.  A 155 KB LDS image of R_pp was measured
     // first: alone it ran in 9.5 us, but it needs an EMPTY compute unit, and next to the side stream's trailing
     // updates (2 x 72 KB per CU) its launches waited up to 480 us for one.
-    if (*flag != 0) return;
-    __builtin_amdgcn_s_setprio(3);                // chain kernel: see k_potrf16
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int g = lane >> 4, n = lane & 15;
     const int64_t p0 = (int64_t)p * NB;
@@ -619,6 +629,38 @@ __global__ __launch_bounds__(256) void k_panel_solve16(const double* __restrict_
     for (int r = 0; r < 8; ++r)
 #pragma unroll
         for (int q = 0; q < 4; ++q) R[(p0 + 16 * r + g + 4 * q) * Np + j0 + n] = X[r][q];
+}
+
+__global__ __launch_bounds__(256) void k_panel_solve16(const double* __restrict__ U, const double* __restrict__ S,
+                                                       double* __restrict__ R, int64_t Np, int p,
+                                                       const int* __restrict__ flag, int64_t bs) {
+    U += (int64_t)blockIdx.z * bs;       // batched use: blockIdx.z = batch element
+    S += (int64_t)blockIdx.z * bs;
+    R += (int64_t)blockIdx.z * bs;
+    flag += blockIdx.z;
+    if (*flag != 0) return;
+    __builtin_amdgcn_s_setprio(3);                // chain kernel: see k_potrf16
+    panel_solve16_body(U, S, R, Np, p);
+}
+
+// Diagonal block AND panel solve in ONE launch (option chol_fuse): every workgroup of the panel solve factors the
+// 128 x 128 diagonal block ITSELF (the same instructions on the same inputs: every copy writes the same bits to R_pp
+// and to the 16 x 16 inverses, then reads its own back through L2) and goes on with its 64 columns.  What this buys is
+// one launch-to-start delay per 128-block instead of two: next to the trailing updates k_potrf16 runs in 29.6 us once
+// it has started but takes 133 us per launch at N = 16384 (profiles/r03_chol_parts.txt, section 6), and the panel
+// solve 63 instead of 11.5.  The redundant factorisations are ~30 us of ONE workgroup slot each -- next to a chip
+// full of 175-us trailing tiles.
+__global__ __launch_bounds__(256) void k_potrf_solve16(const double* __restrict__ S, double* __restrict__ R,
+                                                       double* __restrict__ T, double* __restrict__ U, int64_t Np,
+                                                       int p, int* __restrict__ flag) {
+    __shared__ double Pn[2 * 16 * PFP];
+    __shared__ double Ud[256];
+    __shared__ int sflag;
+    potrf16_body<false>(S, R, T, U, Np, p, flag, nullptr, Pn, Ud, sflag);
+    __threadfence();                      // this workgroup's copy of R_pp / U_d is in L2 before it is read back
+    __syncthreads();
+    if (sflag) return;
+    panel_solve16_body(U, S, R, Np, p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -781,13 +823,18 @@ void launch_cholesky(gpx_handle* h) {
             if (!rl && I > P0 && chain)   // block row I <- contributions of rows P0..I-1 of this panel
                 hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - I)), 2), dim3(GEMM64_THREADS), 0, s,
                                    h->dR, h->dS, Np, P0, I, I, (int64_t)0, nP, 3);
-            if (chain)
-                hipLaunchKernelGGL(k_potrf16<false>, dim3(1), dim3(256), 0, s, h->dS, h->dR, h->dT, h->dU, Np, I, h->dflag,
-                               (long long*)nullptr, (int64_t)0);
             const int rem = nP - 1 - I;
-            if (rem > 0 && chain)
-                hipLaunchKernelGGL(k_panel_solve16, dim3((unsigned)(2 * rem)), dim3(256), 0, s, h->dU, h->dS, h->dR, Np,
-                                   I, h->dflag, (int64_t)0);
+            if (chain && h->chol_fuse && rem > 0) {
+                hipLaunchKernelGGL(k_potrf_solve16, dim3((unsigned)(2 * rem)), dim3(256), 0, s, h->dS, h->dR, h->dT, h->dU,
+                                   Np, I, h->dflag);
+            } else {
+                if (chain)
+                    hipLaunchKernelGGL(k_potrf16<false>, dim3(1), dim3(256), 0, s, h->dS, h->dR, h->dT, h->dU, Np, I,
+                                       h->dflag, (long long*)nullptr, (int64_t)0);
+                if (rem > 0 && chain)
+                    hipLaunchKernelGGL(k_panel_solve16, dim3((unsigned)(2 * rem)), dim3(256), 0, s, h->dU, h->dS, h->dR,
+                                       Np, I, h->dflag, (int64_t)0);
+            }
             if (rl && I + 1 < P1) {
                 // RIGHT-LOOKING inside the panel: the rows of this panel that are still to come receive row I's
                 // contribution now (K = 128 per launch: the latency of a K = 128 tile, ~12 us, instead of the
