@@ -20,7 +20,8 @@ def _fresh(X, y, kernel, ell, rho, sn2, bias):
     return e
 
 
-@pytest.mark.parametrize('kernel,N0,d', [('se', 300, 3), ('matern5', 256, 2)])
+@pytest.mark.parametrize('kernel,N0,d', [('se', 300, 3), ('matern5', 256, 2), ('matern3', 200, 20), ('matern1', 130, 5),
+                                         ('se', 140, 40)])
 def test_sweep_update_tracks_a_full_resweep(kernel, N0, d):
     from pybo_amd._lib import GpxError
     X, y, ell = synth_problem(N0 + 200, d, seed=17)
