@@ -207,14 +207,13 @@ class MCMC(object):
         """Mixture mean only (= predict(X)[0]): the members' closed forms at the data where they have one
         (EI / PI targets and the recommenders ask for the mean at the observed points, pybo/policies/simple.py:21,35,
         pybo/recommenders.py:22-34 -- as a sweep that is n members x an N x N x N product)."""
+        if grad:        # all members' moments and gradients come from ONE device call (gpx_ensemble_predict)
+            post = self.predict(X, True)
+            return post[0], post[2]
         members = self._need()
         if all(hasattr(m, 'predict_mean') for m in members):
-            if grad:
-                parts = [m.predict_mean(X, True) for m in members]
-                return np.mean([p[0] for p in parts], axis=0), np.mean([p[1] for p in parts], axis=0)
             return np.mean([m.predict_mean(X) for m in members], axis=0)
-        post = self.predict(X, grad)
-        return (post[0], post[2]) if grad else post[0]
+        return self.predict(X)[0]
 
     def _mean_topk(self, xgrid, k):
         from .._lib import DeviceGrid
