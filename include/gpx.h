@@ -85,6 +85,9 @@ int gpx_version(void);
  *          "chol_merge" = n >= 1 (default 1): while at least n block rows lie beyond the next two panels, the far trailing
  *              update of every other panel is deferred and applied together with the next panel's (one pass, twice the K
  *              extent); 0: one far update per panel (round 2).  Bit-identical results either way.
+ *          "chol_fuse" = 1: the diagonal block is factored by every workgroup of the panel solve (one launch per 128-block
+ *              instead of two); "chol_graph" = 1: the factorisation's launches are replayed from a captured hipGraph.
+ *              Both bit-identical, both measured and off by default ("The fit -- round 3").
  *          "x_bg", "x_bg_lds", "x_bg_iters" = DIAGNOSTIC (scripts/chol_bg.py): a synthetic register-only fp64-MFMA kernel of
  *              x_bg workgroups (x_bg_lds KB of LDS each, x_bg_iters rounds) runs beside the factorisation.
  *          "x_skip" = DIAGNOSTIC (scripts/chol_parts.py): leave out the far updates (bit 0), the chain kernels

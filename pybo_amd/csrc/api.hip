@@ -217,6 +217,7 @@ extern "C" int gpx_destroy(gpx_handle* h) {
         if (p) hipFree(p);
     if (h->hpin) hipHostFree(h->hpin);
     if (h->hinv) hipHostFree(h->hinv);
+    if (h->chol_exec) hipGraphExecDestroy(h->chol_exec);
     if (h->ev_inv) hipEventDestroy(h->ev_inv);
     if (h->ev_spec_go) hipEventDestroy(h->ev_spec_go);
     if (h->ev_spec_done) hipEventDestroy(h->ev_spec_done);
@@ -268,6 +269,11 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
         if (!strcmp(name, "chol_fuse")) {
             if (value != 0 && value != 1) return fail(h, GPX_EARG, "chol_fuse must be 0 or 1");
             h->chol_fuse = (int)value;
+            return GPX_OK;
+        }
+        if (!strcmp(name, "chol_graph")) {
+            if (value != 0 && value != 1) return fail(h, GPX_EARG, "chol_graph must be 0 or 1");
+            h->chol_graph = (int)value;
             return GPX_OK;
         }
         if (!strcmp(name, "chol_merge")) {

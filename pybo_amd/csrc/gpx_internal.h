@@ -26,6 +26,13 @@ struct EventPair { hipEvent_t a, b; int slot; };
 
 }  // namespace gpx
 
+struct CholGraphKey {             // what a captured factorisation depends on (compared bytewise: zero-filled before use)
+    int64_t Np;
+    int w, rl, merge, fuse;
+    const void *S, *R, *T, *U, *flag;
+    hipStream_t s2, s3, s4;
+};
+
 struct gpx_handle {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -40,6 +47,9 @@ struct gpx_handle {
     hipStream_t stream_bg = nullptr;
     int chol_merge = 1;           // two-panel accumulation of the far updates while >= this many rest block rows (0 = off)
     int chol_fuse = 0;            // diagonal block + panel solve in one launch (k_potrf_solve16)
+    int chol_graph = 0;           // replay the factorisation's launches from a captured hipGraph (per size / options / buffers)
+    hipGraphExec_t chol_exec = nullptr;
+    CholGraphKey chol_key;
     int chol_rl = 1;              // in-panel updates right-looking (1, default) or left-looking (0)
     int chol_w = 0;               // outer panel width of the factorisation in 128-blocks (2..8; 0 = by size)
     std::string err;

@@ -15,6 +15,8 @@
 
 #include <utility>
 
+#include <cstring>
+
 #include "gemm_core.h"
 #include "gpx_internal.h"
 #include "gpx_math.h"
@@ -789,7 +791,7 @@ __global__ __launch_bounds__(256) void k_bg_mfma(int iters, double* __restrict__
 //   rest(P)    U(Q >= P+3, P): the bulk, back-to-back on the (low-priority) side stream, concurrently with mid(P)
 //              (disjoint block rows); it only has to be finished before mid(P+1) and rest(P+1).
 // So the critical path never waits for a whole trailing update, only for the W block rows it is about to use.
-void launch_cholesky(gpx_handle* h) {
+static void enqueue_cholesky(gpx_handle* h) {
     const int64_t Np = h->Np;
     const int nP = (int)(Np / NB);
     hipStream_t s = h->stream, s2 = h->stream2, s3 = h->stream3;
@@ -916,6 +918,48 @@ void launch_cholesky(gpx_handle* h) {
     }
     // (stream 3 needs no join: every launch on it is followed by an event the main stream has waited on)
     // only the 16x16 inverses are in the diagonal blocks of T / U so far; launch_trtri completes them
+    h->diag_inv_pending = true;
+}
+
+// The factorisation of one size is the same ~250 launches and ~100 event operations over four streams every time:
+// option chol_graph captures them ONCE per (size, schedule options, buffers) into a hipGraph and replays it.  The
+// cross-stream waits become edges of the graph (every side stream forks from and joins the handle's stream inside
+// enqueue_cholesky), the kernels and their arguments are the captured ones -- the result is bit-identical.
+void launch_cholesky(gpx_handle* h) {
+    const bool plain = h->x_skip == 0 && h->x_bg <= 0;
+    if (!h->chol_graph || !plain) {
+        enqueue_cholesky(h);
+        return;
+    }
+    CholGraphKey key;
+    std::memset(&key, 0, sizeof key);
+    key.Np = h->Np; key.w = h->chol_w; key.rl = h->chol_rl; key.merge = h->chol_merge; key.fuse = h->chol_fuse;
+    key.S = h->dS; key.R = h->dR; key.T = h->dT; key.U = h->dU; key.flag = h->dflag;
+    key.s2 = h->stream2; key.s3 = h->stream3; key.s4 = h->stream4;
+    if (!h->chol_exec || std::memcmp(&key, &h->chol_key, sizeof key) != 0) {
+        if (h->chol_exec) { hipGraphExecDestroy(h->chol_exec); h->chol_exec = nullptr; }
+        hipGraph_t g = nullptr;
+        bool ok = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            enqueue_cholesky(h);
+            ok = hipStreamEndCapture(h->stream, &g) == hipSuccess && g != nullptr;
+        }
+        if (ok) ok = hipGraphInstantiate(&h->chol_exec, g, nullptr, nullptr, 0) == hipSuccess;
+        if (g) hipGraphDestroy(g);
+        if (!ok) {                      // capture is an optimisation: without it the launches go out one by one
+            (void)hipGetLastError();
+            h->chol_exec = nullptr;
+            h->chol_graph = 0;
+            enqueue_cholesky(h);
+            return;
+        }
+        h->chol_key = key;
+    }
+    if (hipGraphLaunch(h->chol_exec, h->stream) != hipSuccess) {
+        (void)hipGetLastError();
+        enqueue_cholesky(h);
+        return;
+    }
     h->diag_inv_pending = true;
 }
 
