@@ -80,6 +80,33 @@ def test_refit_with_different_sizes_reuses_the_handle():
     e.close()
 
 
+@pytest.mark.parametrize('N', [700, 2304])
+def test_factor_does_not_depend_on_the_schedule(N):
+    """The factorisation's schedule options (panel width, left- / right-looking in-panel updates, two-panel accumulation
+    of the far updates, diagonal block fused into the panel solve, replay from a captured hipGraph) reorder LAUNCHES,
+    never the additions into an element (accumulators start from S, k ascending): the factor is the same bit for bit,
+    and a second fit through a cached graph too."""
+    X, y, ell = synth_problem(N, 4, seed=N)
+    base = None
+    for opts in [{}, {'chol_w': 3}, {'chol_w': 6}, {'chol_rl': 0}, {'chol_merge': 0}, {'chol_fuse': 1},
+                 {'chol_graph': 1}, {'chol_graph': 1, 'chol_fuse': 1, 'chol_w': 2}]:
+        e = _engine(**opts)
+        for rep in range(2 if 'chol_graph' in opts else 1):
+            e.fit(X, y, 'matern5', ell, 1.3, 1e-4, 0.1, stage=2)
+            L = e.get_matrix('L')
+            if base is None:
+                base = L
+            assert np.array_equal(L, base), (opts, rep)
+        e.close()
+    # a failing pivot is reported from the fused kernel as well
+    Xd = np.vstack([X[:200], X[:3]])
+    e = _engine(chol_fuse=1)
+    with pytest.raises(np.linalg.LinAlgError):
+        e.fit(Xd, np.hstack([y[:200], y[:3]]), 'se', ell, 1.0, 0.0, 0.0)
+    assert 200 <= e.fail_pivot() < 203
+    e.close()
+
+
 def test_not_positive_definite_reports_pivot():
     from pybo_amd._lib import GpxError
     X, y, ell = synth_problem(40, 2, seed=3)
