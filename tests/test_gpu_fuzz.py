@@ -1,0 +1,61 @@
+"""Seeded random shapes through the engine's main entry points against the oracle: odd N, d and M (nothing a multiple of
+the 16 / 64 / 128 tile edges), every covariance family, cold sweep, warm step (appends + cached re-score), mean-only and
+gradient calls.  The fixed-shape parity tests cover the BASELINE configurations; this one looks for indexing mistakes in
+the staging / tail code of the kernels."""
+import numpy as np
+import pytest
+
+from oracle import gp_ref
+from helpers import synth_problem, s2_tol, mu_tol
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = ['se', 'matern5', 'matern3', 'matern1']
+
+
+@pytest.mark.parametrize('seed', range(64))
+def test_random_shapes_against_the_oracle(seed):
+    from pybo_amd._lib import Engine
+    rng = np.random.RandomState(1000 + seed)
+    N = int(rng.choice([1, 2, 3, 17, 63, 64, 65, 127, 128, 129, 200, 257, 300, 511, 640]))
+    d = int(rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 31, 33, 40]))
+    M = int(rng.choice([1, 2, 63, 127, 128, 129, 255, 1000, 1025, 4097]))
+    kernel = KERNELS[seed % 4]
+    nadd = int(rng.choice([0, 1, 3, 9]))
+    X, y, ell = synth_problem(N + nadd, d, seed=seed)
+    rho, sn2, bias = 1.0 + rng.rand(), 10.0 ** rng.uniform(-4, -2), rng.randn() * 0.3
+    Z = rng.rand(M, d)
+    ref = gp_ref.make_gp(sn2, rho, ell, bias, kernel)
+    ref.add_data(X[:N], y[:N])
+    e = Engine(0)
+    e.set_option('sweep_cache', 1)
+    e.fit(X[:N], y[:N], kernel, ell, rho, sn2, bias)
+    k = min(8, M)
+    out = e.sweep('ucb', 2.0, Z, k=k, want_moments=True)
+    mr, sr = ref.predict(Z)
+    assert np.all(np.abs(out['mu'] - mr) <= mu_tol(mr, rho)), (N, d, M, kernel)
+    assert np.all(np.abs(out['s2'] - sr) <= s2_tol(sr, rho)), (N, d, M, kernel)
+    ucb = mr + np.sqrt(2.0 * sr)
+    assert abs(out['top_val'][0] - ucb.max()) <= 1e-6 * max(1.0, abs(ucb.max()))
+    # warm step: nadd appended observations, cached sums corrected, grid re-scored
+    for i in range(N, N + nadd):
+        e.append(X[i], y[i])
+        ref.add_data(X[i:i + 1], y[i:i + 1])
+    if nadd:
+        warm = e.sweep_update('ucb', 2.0, k=k, want_moments=True)
+        mr, sr = ref.predict(Z)
+        assert np.all(np.abs(warm['mu'] - mr) <= mu_tol(mr, rho)), (N, d, M, kernel, nadd)
+        assert np.all(np.abs(warm['s2'] - sr) <= s2_tol(sr, rho)), (N, d, M, kernel, nadd)
+    # point calls: moments + gradients, the mean alone
+    P = Z[:min(M, 19)]
+    got = e.predict(P, grad=True)
+    want = ref.predict(P, grad=True)
+    assert np.all(np.abs(got[0] - want[0]) <= mu_tol(want[0], rho))
+    assert np.all(np.abs(got[1] - want[1]) <= s2_tol(want[1], rho))
+    if kernel != 'matern1':          # (the exponential kernel's gradient has its kink at r = 0; covered in test_gpu_parity)
+        np.testing.assert_allclose(got[2], want[2], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(got[3], want[3], rtol=1e-6, atol=1e-7)
+        m1, dm1 = e.predict_mean(P, grad=True)
+        np.testing.assert_allclose(dm1, want[2], rtol=1e-6, atol=1e-7)
+        assert np.all(np.abs(m1 - want[0]) <= mu_tol(want[0], rho))
+    e.close()
