@@ -59,3 +59,37 @@ def test_random_shapes_against_the_oracle(seed):
         np.testing.assert_allclose(dm1, want[2], rtol=1e-6, atol=1e-7)
         assert np.all(np.abs(m1 - want[0]) <= mu_tol(want[0], rho))
     e.close()
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_random_thompson_shapes_against_numpy(seed):
+    """gpx_rff_sweep / gpx_rff_gram on odd shapes: draws S, features n (not a multiple of 16, beyond 128), d beyond the
+    resident 64 (k-chunked projection), candidates not a multiple of 128 -- against the closed form in numpy."""
+    from pybo_amd._lib import Engine
+    rng = np.random.RandomState(5000 + seed)
+    N = int(rng.choice([5, 64, 130, 300]))
+    d = int(rng.choice([1, 3, 8, 31, 64, 65, 100]))
+    n = int(rng.choice([1, 7, 16, 100, 127, 129, 200]))
+    S = int(rng.choice([1, 2, 5]))
+    M = int(rng.choice([1, 127, 129, 1000, 2049]))
+    X = rng.rand(N, d)
+    y = np.sin(X.sum(axis=1))
+    W = rng.randn(S, n, d) * 2.0
+    b = rng.rand(S, n) * 2.0 * np.pi
+    th = rng.randn(S, n) * 0.1
+    Z = rng.rand(M, d) * 2.0 - 1.0
+    bias = 0.25
+    e = Engine(0)
+    e.fit(X, y, 'se', np.full(d, 0.7 * np.sqrt(d)), 1.0, 1e-3, bias)
+    k = min(4, M)
+    r = e.rff_sweep(W, b, th, bias, Z, k=k)
+    for s in range(S):
+        want = bias + np.cos(Z @ W[s].T + b[s]) @ th[s]
+        scale = np.abs(th[s]).sum() + abs(bias)
+        np.testing.assert_allclose(r['vals'][s], want, rtol=0, atol=1e-12 * max(scale, 1.0)), (N, d, n, S, M)
+        np.testing.assert_array_equal(r['top_idx'][s], gp_ref.topk_desc(r['vals'][s], k))
+    C = np.cos(X @ W[0].T + b[0])
+    A, v = e.rff_gram(W[0], b[0])
+    np.testing.assert_allclose(A, C.T @ C, rtol=1e-11, atol=1e-10)
+    np.testing.assert_allclose(v, C.T @ (y - bias), rtol=1e-11, atol=1e-10)
+    e.close()
