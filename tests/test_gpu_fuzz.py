@@ -93,3 +93,26 @@ def test_random_thompson_shapes_against_numpy(seed):
     np.testing.assert_allclose(A, C.T @ C, rtol=1e-11, atol=1e-10)
     np.testing.assert_allclose(v, C.T @ (y - bias), rtol=1e-11, atol=1e-10)
     e.close()
+
+
+@pytest.mark.parametrize('N', [641, 1153, 2500, 4099])
+def test_odd_sizes_through_the_multi_panel_factorisation(N):
+    """Sizes that are no multiple of the 128-block (identity padding inside the last block) and span several outer panels
+    with all four streams active: residual of the factor, the explicit inverse, and the posterior against numpy."""
+    from pybo_amd._lib import Engine
+    X, y, ell = synth_problem(N, 5, seed=N)
+    rho, sn2, bias = 1.2, 1e-3, 0.1
+    ref = gp_ref.make_gp(sn2, rho, ell, bias, 'matern5')
+    ref.add_data(X, y)
+    K = ref.gram()
+    e = Engine(0)
+    e.fit(X, y, 'matern5', ell, rho, sn2, bias)
+    L = e.get_matrix('L')
+    assert np.linalg.norm(L @ L.T - K) / np.linalg.norm(K) <= 1e-13
+    T = e.get_matrix('T')
+    assert np.max(np.abs(T @ L - np.eye(N))) < 1e-9
+    Z = np.random.RandomState(N).rand(777, 5)
+    mu, s2 = e.predict(Z)
+    mr, sr = ref.predict(Z)
+    assert np.all(np.abs(mu - mr) <= mu_tol(mr, rho)) and np.all(np.abs(s2 - sr) <= s2_tol(sr, rho))
+    e.close()
