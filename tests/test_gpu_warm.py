@@ -207,3 +207,51 @@ def test_the_loop_announces_its_query_point_and_results_do_not_change():
         traces.append((info.x, info.xbest, m._engine().get_matrix('L')))
     for a, b in zip(*traces):
         np.testing.assert_array_equal(a, b)
+
+
+def test_long_warm_run_across_block_boundaries_ends_where_a_fresh_fit_does():
+    """300 iterations of solve_bayesopt over a resident grid of 2^17 Sobol points, started at N = 900: the factor grows
+    across three 128-block boundaries, every acquisition sweep after the first is a correction of the cached sums
+    (announced query points, noisy objective, checkpoint on).  At the end the warm model must agree with the oracle
+    fitted from scratch on the final data, and its cached re-score with a cold sweep of a fresh handle."""
+    from pybo_amd import solve_bayesopt, models, inits
+    from pybo_amd._lib import Engine
+    import bench
+    d = 6
+    bounds = np.stack([np.zeros(d), np.ones(d)], axis=1)
+    noise = np.random.RandomState(3)
+    calls = []
+
+    def f(x):
+        calls.append(np.array(x, dtype=float))
+        return float(bench.hartmann6(np.array(x, ndmin=2))[0] + 1e-3 * noise.randn())
+
+    X0 = np.random.RandomState(2).rand(900, d)
+    y0 = np.array([float(bench.hartmann6(x[None])[0]) for x in X0])
+    sn2, rho, ell, bias = 1e-5, float(np.var(y0)), np.full(d, 0.35), float(y0.mean())
+    gp = models.make_gp(sn2, rho, ell, bias, kernel='matern5')
+    gp.add_data(X0, y0)
+    grid = inits.init_sobol_device(bounds, 1 << 17)
+    _, model, info = solve_bayesopt(f, bounds, model=gp, niter=300, policy='ei', recommender='incumbent',
+                                    solver=('lbfgs', {'xgrid': grid, 'nbest': 2}), rng=0)
+    eng = model._state.engine
+    # (solve_bayesopt feeds a user model the box centre first: 900 + 1 + 300 observations)
+    assert eng.N == 1201 and len(calls) == 301
+    tm = eng.timers()
+    assert tm['sweep_trmm_launches'] <= 4          # ONE full sweep (2 chunks of 65536), everything after it warm
+    Xall, yall = model.data
+    ref = gp_ref.make_gp(sn2, rho, ell, bias, 'matern5')
+    ref.add_data(Xall, yall)
+    Z = np.random.RandomState(9).rand(4000, d)
+    mu, s2 = model.predict(Z)
+    mr, sr = ref.predict(Z)
+    assert np.all(np.abs(mu - mr) <= mu_tol(mr, rho)) and np.all(np.abs(s2 - sr) <= s2_tol(sr, rho))
+    target = float(eng.mean_at_obs()[1])
+    warm = eng.sweep_update('ei', target, k=8, want_moments=True)
+    cold_e = Engine(0)
+    cold_e.fit(Xall, yall, 'matern5', ell, rho, sn2, bias)
+    cold = cold_e.sweep('ei', target, np.asarray(grid), k=8, want_moments=True)
+    cold_e.close()
+    mg, sg = cold['mu'], cold['s2']
+    assert np.all(np.abs(warm['mu'] - mg) <= mu_tol(mg, rho)) and np.all(np.abs(warm['s2'] - sg) <= s2_tol(sg, rho))
+    assert warm['top_idx'][0] == cold['top_idx'][0]
