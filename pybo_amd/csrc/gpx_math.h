@@ -23,10 +23,15 @@ __constant__ double kExpC[16] = {
     -6.93147180369123816490e-01,      // [13] -ln2_hi (21 trailing zero bits)
     -1.90821492927058770002e-10,      // [14] -ln2_lo
     -746.0};                          // [15] below this exp() is 0 in fp64
+// 1.5 * 2^52: fma(x, 1/ln2, kExpMagic) is that constant plus the integer nearest x / ln2 (one rounding), the integer
+// itself sits in the low mantissa bits -- the low dword IS k in two's complement for |k| < 2^31 -- and subtracting the
+// constant again returns it as a double: v_rndne_f64 and v_cvt_i32_f64 (0.7 of an FMA's issue rate) are not needed.
+__constant__ double kExpMagic = 6755399441055744.0;
 
 __device__ __forceinline__ double exp_nonpos(double x) {
     x = (x < kExpC[15]) ? kExpC[15] : x;                        // NaN passes through
-    const double k = __builtin_rint(x * kExpC[12]);
+    const double t = fma(x, kExpC[12], kExpMagic);
+    const double k = t - kExpMagic;
     double r = fma(k, kExpC[13], x);
     r = fma(k, kExpC[14], r);
     double p = kExpC[0];
@@ -34,7 +39,23 @@ __device__ __forceinline__ double exp_nonpos(double x) {
     for (int i = 1; i < 12; ++i) p = fma(p, r, kExpC[i]);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    return ldexp(p, (int)k);
+    return ldexp(p, __double2loint(t));                         // (t NaN: p is NaN too)
+}
+
+// sqrt of a squared distance: x >= 0 (a sum of squares) or NaN.  v_rsq_f64 seed (5e-8) + one coupled Goldschmidt step +
+// two residual corrections -- the library's own iteration without its range scaling (4 instructions shorter): arguments
+// below 1e-280 (distances below 1e-140 length scales) give 0, which is what their covariance rounds to anyway.
+__device__ __forceinline__ double sqrt_r2(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    double e = fma(-g, g, x);
+    g = fma(e, h, g);
+    e = fma(-g, g, x);
+    g = fma(e, h, g);
+    return (x > 1.0e-280) ? g : x * 0.0;                        // 0 -> 0, NaN -> NaN
 }
 
 // covariance as a function of the squared scaled distance r2 = sum_k ((x_k - z_k)/ell_k)^2
@@ -43,15 +64,15 @@ __device__ __forceinline__ double kern_eval(int kid, double r2, double rho) {
         case GPX_KERN_SE_ARD:
             return rho * exp_nonpos(-0.5 * r2);
         case GPX_KERN_MATERN52: {
-            const double s = 2.23606797749978969641 * sqrt(r2);
+            const double s = 2.23606797749978969641 * sqrt_r2(r2);
             return rho * (1.0 + s + (5.0 / 3.0) * r2) * exp_nonpos(-s);
         }
         case GPX_KERN_MATERN32: {
-            const double s = 1.73205080756887729353 * sqrt(r2);
+            const double s = 1.73205080756887729353 * sqrt_r2(r2);
             return rho * (1.0 + s) * exp_nonpos(-s);
         }
         default:
-            return rho * exp_nonpos(-sqrt(r2));
+            return rho * exp_nonpos(-sqrt_r2(r2));
     }
 }
 

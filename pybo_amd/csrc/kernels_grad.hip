@@ -29,21 +29,21 @@ __device__ __forceinline__ void kern_and_grad(int kid, double r2, double rho, do
             break;
         }
         case GPX_KERN_MATERN52: {
-            const double s = 2.23606797749978969641 * sqrt(r2);
+            const double s = 2.23606797749978969641 * sqrt_r2(r2);
             const double e = rho * exp_nonpos(-s);
             k = (1.0 + s + (5.0 / 3.0) * r2) * e;
             g = -(5.0 / 6.0) * (1.0 + s) * e;
             break;
         }
         case GPX_KERN_MATERN32: {
-            const double s = 1.73205080756887729353 * sqrt(r2);
+            const double s = 1.73205080756887729353 * sqrt_r2(r2);
             const double e = rho * exp_nonpos(-s);
             k = (1.0 + s) * e;
             g = -1.5 * e;
             break;
         }
         default: {
-            const double r = sqrt(r2);
+            const double r = sqrt_r2(r2);
             k = rho * exp_nonpos(-r);
             // exp(-r) has a kink at r = 0 (a candidate on top of an observation: the L-BFGS seeds of the
             // recommender ARE observations): dk/dx is +-1 from either side, take the symmetric value 0

@@ -216,7 +216,11 @@ def test_long_warm_run_across_block_boundaries_ends_where_a_fresh_fit_does():
     fitted from scratch on the final data, and its cached re-score with a cold sweep of a fresh handle."""
     from pybo_amd import solve_bayesopt, models, inits
     from pybo_amd._lib import Engine
+    from pybo_amd.models import gp as gpmod
     import bench
+    for pooled in gpmod._ENGINE_POOL:              # fresh handles: the launch counter below is a handle's lifetime total
+        pooled.close()
+    del gpmod._ENGINE_POOL[:]
     d = 6
     bounds = np.stack([np.zeros(d), np.ones(d)], axis=1)
     noise = np.random.RandomState(3)
