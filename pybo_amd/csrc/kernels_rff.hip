@@ -59,6 +59,10 @@ __device__ __forceinline__ double cos_cw(double z) {
 // n = 100 (the Thompson default) uses 7 of 8 groups: 12.5 % fewer MFMAs and cosines than the padded tile; with the
 // 2 x 2 layout of the GEMM engine only the waves of the right half could have skipped, and the workgroup would
 // have waited for the others.  A row's sum over the features then lives in ONE wave (16-lane reduction, no LDS).
+// PF (dp <= 32, candidate tile resident): the NEXT feature tile's 32 KB are loaded into registers (8 x 16 B per thread)
+// before the matrix phase and written to LDS between the matrix phase and the cosine epilogue -- the global-load latency
+// of a tile no longer sits between two barriers (counters: 31 % of the wave time was spent parked there).
+template <bool PF>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_rff_mfma(const double* __restrict__ Wt,
                                                               const double* __restrict__ bt,
                                                               const double* __restrict__ tt, int S, int nfb, int n,
@@ -96,6 +100,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_rff_mfma(const double* __re
         }
     };
     double rowsum[2][4];
+    if (PF) {
+        load_b(0, 0, dp);
+        __syncthreads();
+    }
     for (int tile = 0; tile < ntile; ++tile) {
         const int fb = tile % nfb, s = tile / nfb;
         const int nv = min(TB, n - fb * TB);          // features of this tile that exist
@@ -113,6 +121,38 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_rff_mfma(const double* __re
             for (int j = 0; j < 8; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
         const double* as = At + w * 32 + fr;
         const double* bs = Bt + fr;
+        d2 pre[8];
+        if (PF) {
+            // Bt already holds this tile (loaded before the loop / written below from `pre`); fetch the next one
+            if (tile + 1 < ntile) {
+                const double* Wnext = Wt + (int64_t)(tile + 1) * dp * TB;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = t + u * GEMM_THREADS;
+                    if (e < (TB / 2) * dp) pre[u] = *reinterpret_cast<const d2*>(Wnext + (int64_t)(e >> 6) * TB + (e & 63) * 2);
+                }
+            }
+            for (int kk = 0; kk < dp / 4; ++kk) {
+                const int kr = kk * 4 + fk;
+                const double a0 = as[kr * LDT], a1 = as[kr * LDT + 16];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (j < jt) {
+                        const double b = bs[kr * LDT + j * 16];
+                        acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc[0][j], 0, 0, 0);
+                        acc[1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc[1][j], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();   // everyone has read this feature tile
+            if (tile + 1 < ntile) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = t + u * GEMM_THREADS;
+                    if (e < (TB / 2) * dp) *reinterpret_cast<d2*>(Bt + (e >> 6) * LDT + (e & 63) * 2) = pre[u];
+                }
+            }
+        } else
         for (int k0 = 0; k0 < dp; k0 += dk) {
             const int kc = min(dk, dp - k0);
             if (!resident) load_a(k0, kc);
@@ -173,9 +213,14 @@ void launch_rff_mfma(hipStream_t s, const double* Wt, const double* bt, const do
     dim3 grid((unsigned)((M + TB - 1) / TB));
     const int dk = rff_k_chunk(dp);
     const size_t ldsb = (size_t)(2 * dk * LDT) * sizeof(double);
+    if (dk == dp && dp <= 32) {
+        hipLaunchKernelGGL(k_rff_mfma<true>, grid, dim3(GEMM_THREADS), ldsb, s, Wt, bt, tt, S, nfb, n, d, dp, dk, bias, Xc,
+                           M, vals);
+        return;
+    }
     if (ldsb > 64 * 1024)
-        hipFuncSetAttribute((const void*)k_rff_mfma, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    hipLaunchKernelGGL(k_rff_mfma, grid, dim3(GEMM_THREADS), ldsb, s, Wt, bt, tt, S, nfb, n, d, dp, dk, bias, Xc, M,
+        hipFuncSetAttribute((const void*)k_rff_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+    hipLaunchKernelGGL(k_rff_mfma<false>, grid, dim3(GEMM_THREADS), ldsb, s, Wt, bt, tt, S, nfb, n, d, dp, dk, bias, Xc, M,
                        vals);
 }
 
