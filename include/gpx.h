@@ -88,6 +88,15 @@ int gpx_version(void);
  *          "chol_fuse" = 1: the diagonal block is factored by every workgroup of the panel solve (one launch per 128-block
  *              instead of two); "chol_graph" = 1: the factorisation's launches are replayed from a captured hipGraph.
  *              Both bit-identical, both measured and off by default ("The fit -- round 3").
+ *          "chol_tg" = 1 (default): the factorisation runs as ONE persistent kernel that walks its task graph (dedicated
+ *              workgroups for the diagonal blocks and the two tiles between consecutive ones, everything else as
+ *              throughput work from dependency-checked queues; kernels_chol_tg.hip) for fits of >= "chol_tg_min" (default 2)
+ *              128-blocks; 0: the stream schedule above.  Bit-identical factors either way.  Tuning / diagnostics:
+ *              "chol_tg_chunks" (k-chunk sizes counted back from the pivot as decimal digits, default 1124 = 1, 1, 2, 4, 4, ..),
+ *              "chol_tg_split" (chunks ending within this many blocks of the pivot are urgent, default 0), "chol_tg_side"
+ *              (workgroups reserved for the critical tiles, default 4), "chol_tg_grid" (workgroups launched, 0 = by size),
+ *              "chol_tg_tmo_ms" (bound of every spin, default 2000: on expiry the fit re-runs on the stream schedule and
+ *              says so on stderr), "chol_tg_trace" = 1 (stamp the critical path, read with gpx_chol_trace).
  *          "x_bg", "x_bg_lds", "x_bg_iters" = DIAGNOSTIC (scripts/chol_bg.py): a synthetic register-only fp64-MFMA kernel of
  *              x_bg workgroups (x_bg_lds KB of LDS each, x_bg_iters rounds) runs beside the factorisation.
  *          "x_skip" = DIAGNOSTIC (scripts/chol_parts.py): leave out the far updates (bit 0), the chain kernels
@@ -300,6 +309,20 @@ int gpx_topk_allgather(gpx_comm *c, int64_t n, int64_t index_offset, int64_t k, 
  * [11] append (rank-1 extension of the fit) [12] correction passes over the sweep cache.
  * Synchronises the stream.  Returns the number of slots written (<= n). */
 int gpx_timers(gpx_handle *h, double *out, int n, int reset);
+/* DIAGNOSTIC (option "chol_tg_trace" = 1): wall-clock stamps (100 MHz ticks) the task-graph factorisation of the last fit
+ * took with its own clock: out[4 p + {0, 1, 2}] = the diagonal workgroup started waiting for / started / finished block
+ * p (nP = N/128 rounded up blocks), then out[4 nP + 2 (5 p + i) + {0, 1}] = start / end of the critical tasks that follow
+ * block p (i = 0, 1: the two halves of the panel solve of tile (p, p+1); 2..4: the quadrants of the update of tile
+ * (p+1, p+1)).  Returns the number of words written (<= n; 14 nP when complete, followed by up to 1024 x 8 per-workgroup counters: tasks, ticks spent taking / updating / solving /
+ * publishing, block updates applied, role, exit stamp), 0 without a trace. */
+int64_t gpx_chol_trace(gpx_handle *h, int64_t *out, int64_t n);
+/* The task lists the task-graph factorisation of an nblocks x nblocks block matrix walks (host only, no device needed:
+ * what the CPU tests replay to prove that every tile receives every block row once, in order, and that the lists never
+ * dead-lock): counts[3] = tasks in the critical / urgent / far queue, out (total, 8) int16 = {type (1 panel solve,
+ * 2 tile update, 3 diagonal-tile quadrant update), I, J, k0, k1, ordinal, aux, urgent}, queues back to back.  chunks /
+ * split as the options "chol_tg_chunks" / "chol_tg_split" (<= 0 / < 0: defaults).  Returns the total number of tasks
+ * (written only when cap >= total), -1 on bad arguments. */
+int64_t gpx_chol_tasks(int nblocks, int chunks, int split, int16_t *out, int64_t cap, int64_t *counts);
 int gpx_sync(gpx_handle *h);
 
 #ifdef __cplusplus

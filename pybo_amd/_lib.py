@@ -63,6 +63,8 @@ SYMBOLS = {
     'gpx_comm_last_error': (C.c_char_p, []),
     'gpx_topk_allgather': (C.c_int, [_P, _i64, _i64, _i64, _P, _P]),
     'gpx_timers': (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    'gpx_chol_trace': (_i64, [_P, _P, _i64]),
+    'gpx_chol_tasks': (_i64, [C.c_int, C.c_int, C.c_int, _P, _i64, _P]),
     'gpx_sync': (C.c_int, [_P]),
 }
 
@@ -75,6 +77,20 @@ TIMER_NAMES = ['gram', 'cholesky', 'trtri', 'alpha', 'cross_gram', 'sweep_trmm',
 TOPK_MAX = 64
 
 _lib = None
+
+
+def chol_tasks(nblocks, chunks=0, split=-1):
+    """The task lists of the task-graph factorisation (host only): three (n, 8) int16 arrays
+    {type, I, J, k0, k1, ordinal, aux, urgent} -- critical, urgent and far queue (include/gpx.h: gpx_chol_tasks)."""
+    lib = load()
+    counts = np.zeros(3, dtype=np.int64)
+    tot = lib.gpx_chol_tasks(nblocks, chunks, split, None, 0, _ptr(counts))
+    if tot < 0:
+        raise ValueError('gpx_chol_tasks: bad arguments')
+    out = np.zeros((max(int(tot), 1), 8), dtype=np.int16)
+    lib.gpx_chol_tasks(nblocks, chunks, split, _ptr(out), int(tot), _ptr(counts))
+    o = np.cumsum(np.r_[0, counts])
+    return [out[o[q]:o[q + 1]] for q in range(3)]
 
 
 class GpxError(RuntimeError):
@@ -654,6 +670,22 @@ class Engine(object):
         out = np.zeros(len(TIMER_NAMES))
         self._lib.gpx_timers(self._h, _ptr(out), len(out), 1 if reset else 0)
         return dict(zip(TIMER_NAMES, out.tolist()))
+
+    def chol_trace(self, nblocks):
+        """Diagnostic (option chol_tg_trace = 1): the task-graph factorisation's own stamps of the last fit, microseconds
+        from the first one: (diag (nblocks, 3) = wait / start / end per diagonal block, crit (nblocks, 5, 2) = start / end
+        of the two panel-solve halves and three quadrant updates that follow each block); None without a trace."""
+        out = np.zeros(14 * nblocks + 8 * 1024, dtype=np.int64)
+        n = self._lib.gpx_chol_trace(self._h, _ptr(out), out.size)
+        if n < 14 * nblocks:
+            return None
+        self.last_chol_profile = out[14 * nblocks:].reshape(1024, 8).copy()   # per workgroup (role index): see tg_trace.py
+        out = out[:14 * nblocks]
+        t0 = out[0]
+        diag = (out[:4 * nblocks].reshape(nblocks, 4)[:, :3] - t0) / 100.0
+        crit = out[4 * nblocks:].reshape(nblocks, 5, 2).astype(np.float64)
+        crit = np.where(crit > 0, (crit - t0) / 100.0, np.nan)
+        return diag, crit
 
     def sync(self):
         self._check(self._lib.gpx_sync(self._h))

@@ -209,6 +209,7 @@ extern "C" int gpx_destroy(gpx_handle* h) {
     if (!h) return GPX_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
+    tg_free(h);
     for (auto& p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : h->pool) hipEventDestroy(e);
     void* ptrs[] = {h->dXs, h->dXraw, h->dy, h->dS, h->dR, h->dT, h->dU, h->da, h->dalpha, h->dsmall, h->dKs, h->dQp, h->dXc, h->dout, h->dblkv, h->dblki,
@@ -266,6 +267,22 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             h->chol_w = (int)value;
             return GPX_OK;
         }
+        if (!strcmp(name, "chol_tg") || !strcmp(name, "chol_tg_chunks") || !strcmp(name, "chol_tg_split") ||
+            !strcmp(name, "chol_tg_side") || !strcmp(name, "chol_tg_grid") || !strcmp(name, "chol_tg_trace") ||
+            !strcmp(name, "chol_tg_tmo_ms") || !strcmp(name, "chol_tg_min") || !strcmp(name, "chol_tg_isolate")) {
+            if (value < -1 || value > 100000000) return fail(h, GPX_EARG, "chol_tg*: out of range");
+            const char* sub = name + 7;
+            if (*sub == 0) { if (value != 0 && value != 1) return fail(h, GPX_EARG, "chol_tg must be 0 or 1"); h->chol_tg = (int)value; }
+            else if (!strcmp(sub, "_chunks")) h->tg_chunks = (int)value;
+            else if (!strcmp(sub, "_split")) h->tg_split = (int)value;
+            else if (!strcmp(sub, "_side")) h->tg_side = (int)value;
+            else if (!strcmp(sub, "_grid")) h->tg_grid = (int)value;
+            else if (!strcmp(sub, "_trace")) h->tg_trace = (int)value;
+            else if (!strcmp(sub, "_tmo_ms")) h->tg_tmo_ms = (int)value;
+            else if (!strcmp(sub, "_isolate")) h->tg_isolate = (int)value;
+            else h->tg_min = (int)std::max<int64_t>(1, value);
+            return GPX_OK;
+        }
         if (!strcmp(name, "chol_fuse")) {
             if (value != 0 && value != 1) return fail(h, GPX_EARG, "chol_fuse must be 0 or 1");
             h->chol_fuse = (int)value;
@@ -316,6 +333,22 @@ extern "C" int gpx_sync(gpx_handle* h) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         return GPX_OK;
     });
+}
+
+extern "C" int64_t gpx_chol_tasks(int nblocks, int chunks, int split, int16_t* out, int64_t cap, int64_t* counts) {
+    if (!counts) return -1;
+    try {
+        return gpx::tg_tasks_copy(nblocks, chunks, split, out, cap, counts);
+    } catch (...) {
+        return -1;
+    }
+}
+
+extern "C" int64_t gpx_chol_trace(gpx_handle* h, int64_t* out, int64_t n) {
+    if (!h || !out || n <= 0) return 0;
+    if (hipSetDevice(h->device) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) return 0;
+    static_assert(sizeof(long long) == sizeof(int64_t), "trace words");
+    return tg_trace_copy(h, reinterpret_cast<long long*>(out), n);
 }
 
 extern "C" int gpx_timers(gpx_handle* h, double* out, int n, int reset) {
@@ -455,13 +488,31 @@ static int fit_core(gpx_handle* h, const double* dX, int64_t N, int64_t d, const
     if (stage >= 2) {
         {
             Span sp(h, T_CHOL);
-            // more than one outer panel: the lookahead needs its streams (see launch_cholesky)
-            if (h->Np / NB > (h->chol_w ? h->chol_w : 4) && (rc = ensure_side_streams(h))) return rc;
-            launch_cholesky(h);
+            // the persistent task-graph kernel (kernels_chol_tg.hip) unless switched off, diagnosed in parts, or too small
+            h->tg_launched = false;
+            const bool tg = h->chol_tg && h->x_skip == 0 && h->x_bg <= 0 && h->Np / NB >= h->tg_min && launch_cholesky_tg(h);
+            if (!tg) {
+                // more than one outer panel: the lookahead needs its streams (see launch_cholesky)
+                if (h->Np / NB > (h->chol_w ? h->chol_w : 4) && (rc = ensure_side_streams(h))) return rc;
+                launch_cholesky(h);
+            }
         }
         int flag = 0;
         HIPCHK(h, hipMemcpyAsync(&flag, h->dflag, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipStreamSynchronize(s));
+        if (h->tg_launched && flag == 0 && tg_abort_code(h) == 2) {
+            // a spin of the persistent kernel gave up (the device is shared with something that kept its workgroups from
+            // becoming resident): S is half-consumed -- rebuild it and run the stream schedule.  Loud, and counted.
+            ++h->tg_fallbacks;
+            fprintf(stderr, "libgpx: the task-graph factorisation gave up waiting (N = %lld); re-running the stream schedule\n",
+                    (long long)N);
+            h->tg_launched = false;
+            launch_gram_sym(s, h->dXs, N, Np, (int)d, kid, rho, sn2, h->dS);
+            if (h->Np / NB > (h->chol_w ? h->chol_w : 4) && (rc = ensure_side_streams(h))) return rc;
+            launch_cholesky(h);
+            HIPCHK(h, hipMemcpyAsync(&flag, h->dflag, sizeof(int), hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipStreamSynchronize(s));
+        }
         if (flag != 0) {
             h->fail_pivot = (int64_t)flag - 1;
             char buf[160];

@@ -127,10 +127,12 @@ __device__ __forceinline__ void gemm_tile_128_b(d4 (&acc)[4][4], const double* _
 // workgroup to keep the matrix pipe busy meanwhile.
 constexpr int BK32 = 32;
 
+// PRIO: wave priority during the matrix phase (0 = leave it alone; 1 for throughput tiles, 2 for the task-graph
+// kernel's urgent tiles; PRIO - 1 outside the phase).
 // NEGA: the A operand is negated on its way into LDS, i.e. acc += -(A^T-panel) * B: the symmetric updates start
 // their accumulators from the S tile they update (loaded while the first k-steps are in flight) and store
 // S - sum A B directly, instead of a dependent read-modify-write round trip after the k-loop.
-template <bool PRIO, bool NEGA = false>
+template <int PRIO, bool NEGA = false>
 __device__ __forceinline__ void gemm_tile_128_g(d4 (&acc)[4][4], const double* __restrict__ A, int64_t lda,
                                                 const double* __restrict__ B, int64_t ldb, int k_lo,
                                                 int k_hi, double* smem) {
@@ -172,7 +174,7 @@ __device__ __forceinline__ void gemm_tile_128_g(d4 (&acc)[4][4], const double* _
         if (kt + 1 < nk) gload();
         const double* as = As + wm * 64 + fr;
         const double* bs = Bs + wn * 64 + fr;
-        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
 #pragma unroll
         for (int kk = 0; kk < BK32 / 4; ++kk) {
             const int kr = kk * 4 + fk;
@@ -188,7 +190,7 @@ __device__ __forceinline__ void gemm_tile_128_g(d4 (&acc)[4][4], const double* _
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(PRIO - 1);
         __syncthreads();               // everyone has finished reading the buffer
         if (kt + 1 < nk) {
             swrite();

@@ -52,6 +52,19 @@ struct gpx_handle {
     CholGraphKey chol_key;
     int chol_rl = 1;              // in-panel updates right-looking (1, default) or left-looking (0)
     int chol_w = 0;               // outer panel width of the factorisation in 128-blocks (2..8; 0 = by size)
+    // the factorisation as ONE persistent task-graph kernel (kernels_chol_tg.hip)
+    int chol_tg = 1;              // 1 (default): task-graph kernel for fits of >= tg_min blocks; 0: the stream schedule
+    int tg_min = 2;               // smallest number of 128-blocks the task-graph kernel is used for
+    int tg_chunks = 0;            // chunk sizes counted back from the pivot, as decimal digits (0 = default 1124: 1, 1, 2, 4, 4, ..)
+    int tg_split = -1;            // chunks ending within this many blocks of the pivot go to the urgent queue (-1 = default 0)
+    int tg_side = 0;              // workgroups reserved for the two critical tiles per block (0 = default 4)
+    int tg_grid = 0;              // workgroups launched (0 = by size, bounded by residency)
+    int tg_isolate = 1;           // the critical workgroups keep their compute units to themselves (full grids only)
+    int tg_trace = 0;             // diagnostic: stamp the critical path with the kernel's own clock (gpx_chol_trace)
+    int tg_tmo_ms = 0;            // bound of every spin in milliseconds (0 = default 2000)
+    bool tg_launched = false;     // the last factorisation ran on the task-graph kernel
+    int tg_fallbacks = 0;         // launches that gave up (spin bound) and were re-run on the stream schedule
+    void* tg = nullptr;           // its cached tables / control block (gpx::TgCache)
     std::string err;
 
     // model state
@@ -166,6 +179,11 @@ void launch_gram_sym(hipStream_t s, const double* Xs, int64_t N, int64_t Np, int
                      double rho, double sn2, double* S);
 int ensure_side_streams(gpx_handle* h);   // api.hip: streams 2 / 3 + events, on first use
 void launch_cholesky(gpx_handle* h);   // S -> R, diag blocks of T/U; sets dflag
+bool launch_cholesky_tg(gpx_handle* h);    // the same by the persistent task-graph kernel (kernels_chol_tg.hip); false: not launched
+int tg_abort_code(gpx_handle* h);          // after the stream has drained: 0 ok, 1 not PD, 2 a spin gave up
+int64_t tg_trace_copy(gpx_handle* h, long long* out, int64_t n);
+void tg_free(gpx_handle* h);
+int64_t tg_tasks_copy(int nP, int chunks, int split, int16_t* out, int64_t cap, int64_t* counts);
 void launch_trtri(gpx_handle* h);      // R, diag blocks -> T, U (uses S as workspace)
 void launch_refine_inverse(gpx_handle* h, double* tmp);   // option refine_inverse: one Newton step on T / U (tmp: Np^2 scratch)
 void launch_alpha(gpx_handle* h);      // a = T (y - bias); alpha = U a

@@ -1,0 +1,678 @@
+// kernels_chol_tg.hip -- the blocked Cholesky as ONE persistent kernel that walks the factorisation's task graph
+// (option "chol_tg"; serves `model.add_data(X, Y)`, pybo/bayesopt.py:114,258,269 -- the fit behind every BO step).
+//
+// Why: the stream-scheduled factorisation in kernels_fit.hip launches ~250 kernels over four streams; its serial chain
+// (diagonal block -> panel solve -> row update, per 128-block) is latency-bound, and every chain launch waits ~100 us
+// to START behind the trailing updates' resident tiles (profiles/r03_chol_parts.txt).  Here nothing is launched after
+// the first instruction: the workgroups stay resident, take roles, and hand tiles to each other through agent-scope
+// flags in device memory.
+//
+//   role C (1 workgroup)    POTRF(p), p = 0 .. nP-1: the 16-wide MFMA-blocked diagonal factorisation (potrf16_body).
+//   role S (a few)          the two tiles on the critical path between POTRF(p) and POTRF(p+1): the panel solve of tile
+//                           (p, p+1) in two 64-column halves, then the update of the diagonal tile (p+1, p+1) with block
+//                           row p in three 64 x 64 quadrants, operands straight from global memory (no LDS staging).
+//   role W (everyone else)  the throughput work, from two queues (urgent first): panel solves TRSM(p, J), J >= p+2, and the
+//                           tile updates  S_IJ -= sum_{k in [k0,k1)} R_kI^T R_kJ  on the 128 x 128 fp64-MFMA tile engine.
+//
+// Tile (I, J) receives its I block updates in CHUNKS of consecutive k, graded by distance from the pivot (default 1, 1, 2,
+// 4, 4, ... blocks counted back from k = I): far from the pivot a chunk is long (arithmetic intensity), next to it the
+// chunks are single blocks (latency: the final chunk of row I becomes available when block row I-1 is solved and is
+// needed one diagonal block later).  Accumulators start from the S tile and k ascends within and across chunks, so every
+// element sees the same sequence of FMAs as in the stream-scheduled kernels: the factor is BIT-IDENTICAL.
+//
+// Scheduling: task lists are built on the host in the order the tasks become available (a valid topological order);
+// a worker takes the head of a queue ONLY when its dependencies are already met (compare-and-swap on the head), so no
+// workgroup ever waits while holding a task -- progress needs nothing but the role-C / role-S workgroups and one worker
+// being resident, and roles are handed out in order of arrival.  Every spin is bounded (abort code 2 -> the launcher's
+// caller re-runs the stream schedule).  Dependencies are counters: seq[I][J] = chunks applied to tile (I, J),
+// solved[2J + h] = block rows solved in the 64-column half h of block column J, diag[p], and quad[p] = quadrants of the
+// diagonal tile p that have received block row p-1.
+//
+// Hand-offs follow MI355X_MICROARCH.md ("inter-workgroup visibility"): payloads are stored write-through at agent scope
+// (fit_tiles.h, AG = true), every storing wave drains (s_waitcnt vmcnt(0)), barrier, ONE lane stores the flag; consumers
+// poll relaxed from one wave, read tiles with sc1 loads (8-byte fragments) or after ONE agent acquire (the tile engine's
+// 16-byte operand loads).
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "fit_tiles.h"
+
+namespace gpx {
+
+enum { TG_TRSM = 1, TG_UPD = 2, TG_UPDQ = 3 };
+struct TgTask { int16_t type, I, J, k0, k1, ord, aux, rsv; };     // 16 bytes; aux = column half (TRSM) / quadrant (UPDQ)
+
+struct TgArgs {
+    double *S, *R, *T, *U;
+    int64_t Np;
+    int nP;
+    int* dflag;                  // [0] = failing pivot + 1
+    int* ctl;                    // control block (zeroed before every launch), layout below
+    const TgTask* q[3];          // 0: critical (role S), 1: urgent, 2: far
+    int n[3];
+    int nside;
+    int isolate;                 // the critical workgroups keep their compute units to themselves
+    long long* trace;            // optional: [p][4] critical-path stamps, then [crit task][2]
+    long long tmo;               // spin bound in wall-clock ticks (100 MHz)
+};
+
+// control block (ints): [0] arrivals, [32] abort (1 = not positive definite, 2 = a spin gave up), [64 + 32 q] queue heads,
+// then diag[nPad], quad[nPad], solved[2 nPad], seq[nP * nP], and per compute unit (key = xcc | se | sh | cu, 12 bits)
+// the number of workgroups that have started there and the role of the first one
+constexpr int TG_CTL_ABORT = 32, TG_CTL_HEAD = 64, TG_CTL_BASE = 192, TG_CU_KEYS = 4096;
+__host__ __device__ inline int tg_npad(int nP) { return (nP + 31) / 32 * 32; }
+__host__ __device__ inline int tg_ctl_ints(int nP) { return TG_CTL_BASE + 4 * tg_npad(nP) + nP * nP + 2 * TG_CU_KEYS; }
+
+__device__ __forceinline__ int ldi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sti(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Find the next task for this workgroup in the queues QB .. QB+NQ-1 (lowest index = highest priority).  Called by ONE
+// full wave; lane l < NQ looks after queue QB + l.  Returns 1 (task in `out`, the same in every lane), 0 (every queue is
+// exhausted and nothing is held) or -1 (abort).
+//
+// Tickets are drawn with ONE fetch-and-add per task.  (The first version claimed a head with compare-and-swap after
+// checking its dependencies: every claim had to observe the previous one -- 1.3 us per task chip-wide with 123 workers,
+// 5.9 us with 507, and the workers spent 90 % of the factorisation inside this function.)  A lane first PEEKS: the task at
+// the head it reads, if its dependencies are met, is worth a ticket; the ticket it then draws may be a later one (others
+// drew at the same moment), and if that task is not ready yet the workgroup HOLDS it (one per queue, in `held`) and keeps
+// looking: a held task is run as soon as it is ready, a higher-priority queue is served meanwhile.  No workgroup ever
+// sleeps on a task: the earliest incomplete task of the whole graph is either held by a workgroup that polls it or at the
+// head of its queue where every workgroup without a held ticket for that queue peeks -- the lists cannot dead-lock.
+struct TgHeld { TgTask t[3]; int have[3]; int pad; };       // in LDS, one per workgroup (indexed by queue)
+
+__device__ __forceinline__ bool tg_deps_met(const TgTask& t, const int* dd, const int* sv, const int* sq, int nP) {
+    const int I = t.I, J = t.J;
+    const int s = ldi(sq + I * nP + J);
+    if (t.type == TG_TRSM) return (ldi(dd + I) != 0) && (s == t.ord);
+    const int s0 = ldi(sv + 2 * I), s1 = ldi(sv + 2 * I + 1), s2 = ldi(sv + 2 * J), s3 = ldi(sv + 2 * J + 1);
+    return (s == t.ord) && (min(min(s0, s1), min(s2, s3)) >= t.k1);
+}
+
+template <int QB, int NQ>
+__device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, TgHeld* held) {
+    const int nP = a.nP, npad = tg_npad(nP);
+    int* ctl = a.ctl;
+    const int* dd = ctl + TG_CTL_BASE;
+    const int* sv = dd + 2 * npad;
+    const int* sq = sv + 2 * npad;
+    const long long t0 = wall_clock64();
+    int nap = 0;                                   // polls since the last find: the pauses grow (QB == 0: stay alert)
+    const int q = QB + (lane < NQ ? lane : 0);
+    int* head = ctl + TG_CTL_HEAD + 32 * q;
+    const int nq = (q == 0) ? a.n[0] : ((q == 1) ? a.n[1] : a.n[2]);
+    const TgTask* tq = (q == 0) ? a.q[0] : ((q == 1) ? a.q[1] : a.q[2]);
+    for (unsigned spins = 0;; ++spins) {
+        if (ldi(ctl + TG_CTL_ABORT) != 0) return -1;
+        bool live = false, ready = false, mine = false;
+        union { TgTask t; int4 v; } u;
+        u.v = make_int4(0, 0, 0, 0);
+        if (lane < NQ) {
+            mine = held->have[q] != 0;
+            if (mine) {
+                u.t = held->t[q];
+                live = true;
+            } else {
+                const int h = ldi(head);
+                live = h < nq;
+                if (live) u.v = *reinterpret_cast<const int4*>(tq + h);
+            }
+            if (live) ready = tg_deps_met(u.t, dd, sv, sq, nP);
+        }
+        if (__ballot(live) == 0) return 0;
+        // a held urgent ticket that is not ready yet is about to be: do not start a long task of a lower queue under it
+        const bool hold_back = NQ > 1 && nap < 12 && __shfl((mine && !ready) ? 1 : 0, 0) != 0;
+        const unsigned long long mr = __ballot(ready && !(hold_back && lane > 0));
+        if (mr != 0) {
+            const int pick = __ffsll((long long)mr) - 1;
+            int got = 0;                            // 1: u.t is ours and ready
+            if (lane == pick) {
+                if (mine) {
+                    held->have[q] = 0;
+                    got = 1;
+                } else {
+                    const int k = atomicAdd(head, 1);
+                    if (k < nq) {
+                        u.v = *reinterpret_cast<const int4*>(tq + k);
+                        if (tg_deps_met(u.t, dd, sv, sq, nP)) {
+                            got = 1;
+                        } else {
+                            held->t[q] = u.t;
+                            held->have[q] = 1;
+                        }
+                    }
+                }
+            }
+            got = __shfl(got, pick);
+            if (got) {
+                u.v.x = __shfl(u.v.x, pick); u.v.y = __shfl(u.v.y, pick);
+                u.v.z = __shfl(u.v.z, pick); u.v.w = __shfl(u.v.w, pick);
+                out = u.t;
+                return 1;
+            }
+            nap = 0;
+            continue;                              // drew a ticket that has to wait (or the queue ran out): look again
+        }
+        if (QB == 0 || nap < 4) __builtin_amdgcn_s_sleep(4);
+        else if (nap < 16) __builtin_amdgcn_s_sleep(32);
+        else __builtin_amdgcn_s_sleep(127);
+        ++nap;
+        if ((spins & 63) == 63 && wall_clock64() - t0 > a.tmo) {
+            if (lane == 0) sti(ctl + TG_CTL_ABORT, 2);
+            return -1;
+        }
+    }
+}
+
+// Quadrant q of the diagonal tile (I, I) <- block rows [k0, k1):  q = 0: rows 0-63 x columns 0-63, 1: rows 0-63 x
+// columns 64-127, 2: rows 64-127 x columns 64-127 (the lower-left quadrant is never read).  One wave = 16 rows x 64
+// columns = 4 accumulators; fragments straight from global memory in the k-major layout (lane (g, n) <- row 4 kk + g,
+// column n), 16 k-steps (80 loads per lane) in flight per round trip; no LDS, no barrier.  The same FMAs per element as
+// the tile engines: the accumulators start from S, A enters negated, k ascends 4 at a time.
+template <bool AG>
+__device__ __forceinline__ void updq_body(const double* __restrict__ R, double* __restrict__ S, int64_t Np, int k0, int k1,
+                                          int I, int q) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, n = lane & 15;
+    const int64_t i0 = (int64_t)I * NB;
+    const int r0 = (q == 2) ? 64 : 0, c0 = (q == 0) ? 0 : 64;
+    d4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j][r] = ldg<AG>(S + (i0 + r0 + 16 * w + g + 4 * r) * Np + i0 + c0 + 16 * j + n);
+    const double* Ra = R + i0 + r0 + 16 * w + n;
+    const double* Rb = R + i0 + c0 + n;
+    for (int kb = k0 * NB; kb < k1 * NB; kb += 64) {
+        double av[16], bv[16][4];
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int64_t row = (int64_t)(kb + 4 * kk + g) * Np;
+            av[kk] = ldg<AG>(Ra + row);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[kk][j] = ldg<AG>(Rb + row + 16 * j);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[kk], bv[kk][j], acc[j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stg<AG>(S + (i0 + r0 + 16 * w + g + 4 * r) * Np + i0 + c0 + 16 * j + n, acc[j][r]);
+}
+
+// The panel solve of fit_tiles.h with the factor's diagonal block staged in LDS.  panel_solve16_body reads its A fragments
+// from global memory one step ahead: eight dependent round trips, ~1.4 us each through L1 -- but ~3 us each past it (the
+// agent-scope loads this kernel needs), 25 us per solve on the critical path.  Here the 36 upper 16-tiles of R_pp (72 KB =
+// the tile engine's LDS buffer, exactly) arrive with 18 16-byte loads per thread in flight at once, together with the
+// right-hand sides and the eight 16 x 16 inverses (registers): ONE round trip, then the substitution runs from LDS.
+// Tile (r, c), r <= c, sits at 256 * (8 r - r (r - 1) / 2 + c - r), row-major 16 x 16: a fragment read (lane (g, n) <-
+// row 4 kk + g, column n) is 64 consecutive doubles.  Same MFMAs in the same order as panel_solve16_body.
+__device__ __forceinline__ int tri_index(int r, int c) { return 8 * r - r * (r - 1) / 2 + c - r; }
+
+__device__ __forceinline__ void panel_solve16_lds(const double* __restrict__ U, const double* __restrict__ S,
+                                                  double* __restrict__ R, int64_t Np, int p, int cb, double* lds) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int g = lane >> 4, n = lane & 15;
+    const int64_t p0 = (int64_t)p * NB;
+    const int64_t j0 = (int64_t)(p + 1) * NB + (int64_t)cb * 64 + 16 * w;
+    const double* Rd = R + p0 * Np + p0;          // R_pp
+    const double* Ud = U + p0 * Np + p0;          // diagonal 16-tiles hold T_d^T
+    // (1) everything this workgroup reads, issued back to back
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Rd), 0, (int)(128 * Np * 8), 0x00020000);
+    u4v stage[18];
+    int dst[18];
+#pragma unroll
+    for (int q = 0; q < 18; ++q) {
+        const int e = t + 256 * q;                 // 36 tiles x 128 16-byte pieces
+        int tile = e >> 7, r = 0;
+        const int piece = e & 127, row = piece >> 3, c2 = piece & 7;
+        int idx = tile;
+        while (idx >= 8 - r) { idx -= 8 - r; ++r; }
+        const int c = r + idx;
+        stage[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((16 * r + row) * Np + 16 * c + 2 * c2) * 8), 0, 16);
+        dst[q] = tile * 256 + row * 16 + 2 * c2;
+    }
+    d4 X[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) X[r][q] = ldg<true>(S + (p0 + 16 * r + g + 4 * q) * Np + j0 + n);
+    double ti[8][4];                               // A fragments of the eight T_d
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) ti[jb][kk] = ldg<true>(Ud + (int64_t)(16 * jb + 4 * kk + g) * Np + 16 * jb + n);
+#pragma unroll
+    for (int q = 0; q < 18; ++q) *reinterpret_cast<u4v*>(lds + dst[q]) = stage[q];
+    __syncthreads();
+    // (2) the substitution
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) {
+        d4 x = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(ti[jb][kk], X[jb][kk], x, 0, 0, 0);
+        X[jb] = x;
+        const d4 xn = -x;
+#pragma unroll
+        for (int i = jb + 1; i < 8; ++i) {
+            const double* tl = lds + 256 * tri_index(jb, i) + g * 16 + n;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) X[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(tl[kk * 64], xn[kk], X[i], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) stg<true>(R + (p0 + 16 * r + g + 4 * q) * Np + j0 + n, X[r][q]);
+    __syncthreads();                               // the LDS image is free again
+}
+
+// the strictly-lower 16-tiles of R's diagonal blocks are zero (potrf16_body writes them itself in the stream schedule)
+__global__ __launch_bounds__(256) void k_zero_diag_lower(double* __restrict__ R, int64_t Np) {
+    const int64_t p0 = (int64_t)blockIdx.x * NB;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int idx4 = t + 256 * q;
+        const int r = idx4 >> 5, c = (idx4 & 31) * 4;
+        if ((c >> 4) < (r >> 4)) *reinterpret_cast<d4*>(R + (p0 + r) * Np + p0 + c) = (d4){0.0, 0.0, 0.0, 0.0};
+    }
+}
+
+constexpr int TG_LDS_F64 = GEMM_LDS_F64 + 16;       // + the task in hand (2), flags (2), held tickets (8)
+
+// a wave-uniform 64-bit value the compiler cannot prove uniform (fields of the argument block reached through a reference)
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <class T>
+__device__ __forceinline__ T* uni(T* p) { return reinterpret_cast<T*>(uni64(reinterpret_cast<unsigned long long>(p))); }
+
+__device__ __forceinline__ void tg_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// The workgroup's LDS: the tile engine's buffer (the diagonal kernel's panels fit inside) + a slot for the task in hand.
+// File scope, so that the role bodies below can be separate (non-inlined) functions with their own register allocation
+// and still address it with ds_* instructions: inlined into one kernel body the roles spilled 319 VGPRs.
+__shared__ __attribute__((aligned(16))) double tg_smem[TG_LDS_F64];
+
+__device__ __noinline__ void tg_role_diag(const TgArgs& a) {
+    double* Pn = tg_smem;                          // 2 x 16 x PFP
+    double* Ud = tg_smem + 2 * 16 * PFP;           // 256
+    int* code = reinterpret_cast<int*>(tg_smem + GEMM_LDS_F64 + 2);
+    int& sflag = code[1];
+    const int t = threadIdx.x;
+    const int nP = a.nP, npad = tg_npad(nP);
+    int* ctl = a.ctl;
+    int* dd = ctl + TG_CTL_BASE;
+    int* qd = dd + npad;
+    for (int p = 0; p < nP; ++p) {
+        if (t == 0) {
+            int c = 1;
+            if (a.trace) a.trace[4 * p] = wall_clock64();
+            if (p > 0) {
+                const long long t0 = wall_clock64();
+                for (unsigned spins = 0; ldi(qd + p) != 3; ++spins) {
+                    if (ldi(ctl + TG_CTL_ABORT) != 0) { c = -1; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                    if ((spins & 255) == 255 && wall_clock64() - t0 > a.tmo) { sti(ctl + TG_CTL_ABORT, 2); c = -1; break; }
+                }
+            }
+            code[0] = c;
+            if (a.trace) a.trace[4 * p + 1] = wall_clock64();
+        }
+        __syncthreads();
+        if (code[0] != 1) break;
+        potrf16_body<false, true>(a.S, a.R, a.T, a.U, a.Np, p, a.dflag, nullptr, Pn, Ud, sflag);
+        tg_drain();
+        __syncthreads();
+        if (sflag) {
+            if (t == 0) sti(ctl + TG_CTL_ABORT, 1);
+            break;
+        }
+        if (t == 0) {
+            sti(dd + p, 1);
+            if (a.trace) a.trace[4 * p + 2] = wall_clock64();
+        }
+    }
+}
+
+template <int PRIO>
+__device__ __noinline__ void tg_do_upd(const TgArgs& a, int k0, int k1, int I, int J) {
+    // (arguments of a non-inlined function travel in VGPRs: tell the compiler they are wave-uniform)
+    k0 = __builtin_amdgcn_readfirstlane(k0); k1 = __builtin_amdgcn_readfirstlane(k1);
+    I = __builtin_amdgcn_readfirstlane(I); J = __builtin_amdgcn_readfirstlane(J);
+    syrk_tile<true, PRIO>(uni(a.R), uni(a.S), (int64_t)uni64((unsigned long long)a.Np), k0, k1, I, J, tg_smem);
+}
+__device__ __noinline__ void tg_do_trsm(const TgArgs& a, int p, int cb) {
+    p = __builtin_amdgcn_readfirstlane(p); cb = __builtin_amdgcn_readfirstlane(cb);
+    __builtin_amdgcn_s_setprio(3);
+    panel_solve16_lds(uni(a.U), uni(a.S), uni(a.R), (int64_t)uni64((unsigned long long)a.Np), p, cb, tg_smem);
+}
+__device__ __noinline__ void tg_do_updq(const TgArgs& a, int k0, int k1, int I, int q) {
+    k0 = __builtin_amdgcn_readfirstlane(k0); k1 = __builtin_amdgcn_readfirstlane(k1);
+    I = __builtin_amdgcn_readfirstlane(I); q = __builtin_amdgcn_readfirstlane(q);
+    __builtin_amdgcn_s_setprio(3);
+    updq_body<true>(uni(a.R), uni(a.S), (int64_t)uni64((unsigned long long)a.Np), k0, k1, I, q);
+}
+template <int QB, int NQ>
+__device__ __noinline__ int tg_take_call(const TgArgs& a, TgTask& out, int lane) {
+    return tg_take<QB, NQ>(a, out, lane, reinterpret_cast<TgHeld*>(tg_smem + GEMM_LDS_F64 + 4));
+}
+
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
+    TgTask* cur = reinterpret_cast<TgTask*>(tg_smem + GEMM_LDS_F64);           // 16 bytes
+    int* code = reinterpret_cast<int*>(tg_smem + GEMM_LDS_F64 + 2);             // [0] take result / role, [1] potrf's sflag
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int nP = a.nP, npad = tg_npad(nP);
+    int* ctl = a.ctl;
+    int* dd = ctl + TG_CTL_BASE;
+    int* qd = dd + npad;
+    int* sv = qd + npad;
+    int* sq = sv + 2 * npad;
+    if (t == 0) {
+        // Roles in order of arrival.  The critical workgroups (role C and the role-S side-kicks) keep their compute unit
+        // to themselves: next to a worker's matrix phases the diagonal block took 60-80 us instead of 26 and the
+        // critical solves twice their time (profiles/r04_chol_taskgraph.txt).  The second workgroup to start on a CU
+        // looks up what the first one became and leaves at once if that is a critical role (a grid of two workgroups
+        // per CU has no third one waiting to take the slot).
+        TgHeld* hd = reinterpret_cast<TgHeld*>(tg_smem + GEMM_LDS_F64 + 4);
+        hd->have[0] = hd->have[1] = hd->have[2] = 0;
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf;
+        const int key = (int)((xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf));
+        int* cu_cnt = sq + nP * nP;
+        int* cu_role = cu_cnt + TG_CU_KEYS;
+        int r = -1;
+        if (a.isolate && atomicAdd(cu_cnt + key, 1) > 0) {
+            int first = 0;
+            for (unsigned spins = 0; (first = ldi(cu_role + key)) == 0 && spins < 100000; ++spins) __builtin_amdgcn_s_sleep(1);
+            if (first != 0 && first - 1 <= a.nside) r = -2;          // leave
+        }
+        if (r != -2) {
+            r = atomicAdd(ctl, 1);
+            if (a.isolate) atomicCAS(cu_role + key, 0, r + 1);
+        }
+        code[0] = r;
+    }
+    __syncthreads();
+    const int role = code[0];
+    __syncthreads();
+    if (role < 0) return;
+    if (role == 0) {            // role C: the diagonal blocks, one after the other
+        tg_role_diag(a);
+        return;
+    }
+    const bool side = role <= a.nside;
+    long long prof[6] = {0, 0, 0, 0, 0, 0};
+    long long tprev = a.trace ? wall_clock64() : 0;
+    for (;;) {
+        if (w == 0) {
+            TgTask tk;
+            tk.type = 0;
+            __builtin_amdgcn_s_setprio(0);
+            const int c = side ? tg_take_call<0, 1>(a, tk, lane) : tg_take_call<1, 2>(a, tk, lane);
+            if (lane == 0) {
+                *cur = tk;
+                code[0] = c;
+                // the tile engine reads its operand panels with plain 16-byte loads: drop this CU's stale L1 lines
+                if (c == 1 && tk.type == TG_UPD) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+        }
+        __syncthreads();
+        if (code[0] != 1) break;
+        const TgTask tk = *cur;
+        long long ts = 0;
+        if (a.trace && t == 0) { ts = wall_clock64(); prof[1] += ts - tprev; }
+        if (tk.type == TG_UPD) {
+            if (tk.rsv) tg_do_upd<2>(a, tk.k0, tk.k1, tk.I, tk.J);
+            else tg_do_upd<1>(a, tk.k0, tk.k1, tk.I, tk.J);
+        } else if (tk.type == TG_TRSM) {
+            tg_do_trsm(a, tk.I, 2 * (tk.J - tk.I - 1) + tk.aux);
+        } else {
+            tg_do_updq(a, tk.k0, tk.k1, tk.I, tk.aux);
+        }
+        tg_drain();
+        __syncthreads();
+        if (t == 0) {
+            long long te = 0;
+            if (a.trace) {
+                te = wall_clock64();
+                prof[0] += 1;
+                prof[tk.type == TG_UPD ? 2 : 3] += te - ts;
+                if (tk.type == TG_UPD) prof[5] += tk.k1 - tk.k0;
+            }
+            if (tk.type == TG_UPD) sti(sq + tk.I * nP + tk.J, tk.ord + 1);
+            else if (tk.type == TG_TRSM) sti(sv + 2 * tk.J + tk.aux, tk.I + 1);
+            else atomicAdd(qd + tk.I, 1);
+            if (side && a.trace) {
+                const int slot = (tk.type == TG_TRSM) ? (5 * tk.I + tk.aux) : (5 * (tk.I - 1) + 2 + tk.aux);
+                a.trace[4 * nP + 2 * slot] = ts;
+                a.trace[4 * nP + 2 * slot + 1] = wall_clock64();
+            }
+            if (a.trace) { tprev = wall_clock64(); prof[4] += tprev - te; }
+        }
+    }
+    if (a.trace && t == 0 && role < 1024) {
+        long long* o = a.trace + 14 * (long long)nP + 8 * role;
+        for (int i = 0; i < 6; ++i) o[i] = prof[i];
+        o[6] = side ? 1 : 2;
+        o[7] = wall_clock64();
+    }
+}
+
+// ---- host: the task lists -----------------------------------------------------------------------------------------
+
+// chunk boundaries of block row I: k = I - d for the distances d = 0, c1, c1 + c2, ... (chunk sizes counted back from
+// the pivot, the last size repeated), plus 0; a first chunk shorter than 2 blocks is merged into the next one
+static std::vector<int> tg_boundaries(int I, const std::vector<int>& sizes) {
+    std::vector<int> b;
+    int d = 0;
+    size_t i = 0;
+    b.push_back(I);
+    while (true) {
+        d += sizes[std::min(i, sizes.size() - 1)];
+        ++i;
+        if (I - d <= 0) break;
+        b.push_back(I - d);
+    }
+    b.push_back(0);
+    std::reverse(b.begin(), b.end());                 // ascending: 0 = b[0] < ... < b[nb] = I
+    b.erase(std::unique(b.begin(), b.end()), b.end());
+    while (b.size() > 2 && b[1] - b[0] < 2) b.erase(b.begin() + 1);
+    return b;
+}
+
+struct TgTables { std::vector<TgTask> q[3]; };
+
+static void tg_build(int nP, int chunk_code, int split, TgTables& out) {
+    std::vector<int> sizes;
+    {
+        std::vector<int> dg;
+        for (int c = chunk_code; c > 0; c /= 10) dg.push_back(c % 10);
+        std::reverse(dg.begin(), dg.end());
+        for (int v : dg) if (v > 0) sizes.push_back(v);
+        if (sizes.empty() || sizes[0] != 1) sizes.insert(sizes.begin(), 1);      // the final chunk is one block
+    }
+    std::vector<std::vector<int>> bnd(nP);
+    std::vector<std::vector<int>> ends(nP + 1);        // ends[b] = rows with a chunk ending at boundary b
+    for (int I = 0; I < nP; ++I) {
+        bnd[I] = tg_boundaries(I, sizes);
+        for (size_t j = 1; j < bnd[I].size(); ++j) ends[bnd[I][j]].push_back(I);
+    }
+    auto push = [&](int q, int type, int I, int J, int k0, int k1, int ord, int aux, int rsv) {
+        TgTask t;
+        t.type = (int16_t)type; t.I = (int16_t)I; t.J = (int16_t)J; t.k0 = (int16_t)k0; t.k1 = (int16_t)k1;
+        t.ord = (int16_t)ord; t.aux = (int16_t)aux; t.rsv = (int16_t)rsv;
+        out.q[q].push_back(t);
+    };
+    for (int q = 0; q < 3; ++q) out.q[q].clear();
+    for (int p = 0; p < nP; ++p) {
+        const int nch = (int)bnd[p].size() - 1;        // chunks of every tile of row p (0 for row 0)
+        for (int J = p + 1; J < nP; ++J)
+            for (int h = 0; h < 2; ++h) push(J == p + 1 ? 0 : 1, TG_TRSM, p, J, 0, 0, (p == 0) ? 0 : nch, h, 0);
+        for (int I : ends[p + 1]) {                    // rows ascending: nearest the pivot first
+            if (I == 0) continue;
+            size_t j = 1;
+            while (bnd[I][j] != p + 1) ++j;
+            const int k0 = bnd[I][j - 1], k1 = p + 1, ord = (int)j - 1, d = I - k1;
+            const int q = (d <= split) ? 1 : 2;
+            for (int J = I; J < nP; ++J) {
+                if (d == 0 && J == I) {
+                    for (int qu = 0; qu < 3; ++qu) push(0, TG_UPDQ, I, I, k0, k1, ord, qu, 0);
+                } else {
+                    push(q, TG_UPD, I, J, k0, k1, ord, 0, q == 1 ? 1 : 0);
+                }
+            }
+        }
+    }
+}
+
+// host-only view of the lists for the CPU tests (gpx_chol_tasks): 8 int16 per task, queues back to back
+int64_t tg_tasks_copy(int nP, int chunks, int split, int16_t* out, int64_t cap, int64_t* counts) {
+    if (nP < 1 || nP > 2047) return -1;
+    TgTables tb;
+    tg_build(nP, chunks > 0 ? chunks : 1124, split >= 0 ? split : 0, tb);
+    int64_t tot = 0;
+    for (int q = 0; q < 3; ++q) { counts[q] = (int64_t)tb.q[q].size(); tot += counts[q]; }
+    if (out && cap >= tot) {
+        int64_t o = 0;
+        for (int q = 0; q < 3; ++q) {
+            if (!tb.q[q].empty()) std::memcpy(out + 8 * o, tb.q[q].data(), tb.q[q].size() * sizeof(TgTask));
+            o += counts[q];
+        }
+    }
+    return tot;
+}
+
+struct TgCache {                 // per handle (gpx_handle::tg): device copies of the tables and the control block
+    int nP = 0, chunks = 0, split = 0;
+    TgTask* dq = nullptr;
+    int64_t cap_q = 0;
+    int n[3] = {0, 0, 0};
+    int64_t off[3] = {0, 0, 0};
+    int* dctl = nullptr;
+    int64_t cap_ctl = 0;
+    long long* dtrace = nullptr;
+    int64_t cap_trace = 0;
+    int max_resident = 0;
+};
+
+void tg_free(gpx_handle* h) {
+    TgCache* c = static_cast<TgCache*>(h->tg);
+    if (!c) return;
+    if (c->dq) (void)hipFree(c->dq);
+    if (c->dctl) (void)hipFree(c->dctl);
+    if (c->dtrace) (void)hipFree(c->dtrace);
+    delete c;
+    h->tg = nullptr;
+}
+
+// S -> R (and the 16 x 16 inverses in the diagonal tiles of T / U) by the persistent kernel.  Returns false when the
+// launch could not be prepared (the caller runs the stream schedule instead).  After the stream has drained,
+// tg_abort_code() tells whether a spin gave up (2): the caller then rebuilds the Gram matrix and re-runs the stream schedule.
+bool launch_cholesky_tg(gpx_handle* h) {
+    const int64_t Np = h->Np;
+    const int nP = (int)(Np / NB);
+    if (nP > 2047) return false;                       // int16 task fields
+    if (!h->tg) h->tg = new TgCache();
+    TgCache* c = static_cast<TgCache*>(h->tg);
+    hipStream_t s = h->stream;
+    const int chunks = h->tg_chunks > 0 ? h->tg_chunks : 1124;
+    const int split = h->tg_split >= 0 ? h->tg_split : 0;
+    if (c->nP != nP || c->chunks != chunks || c->split != split || !c->dq) {
+        TgTables tb;
+        tg_build(nP, chunks, split, tb);
+        const int64_t tot = (int64_t)tb.q[0].size() + (int64_t)tb.q[1].size() + (int64_t)tb.q[2].size() + 3;
+        if (tot > c->cap_q) {
+            if (c->dq) (void)hipFree(c->dq);
+            c->dq = nullptr; c->cap_q = 0;
+            if (hipMalloc((void**)&c->dq, (size_t)tot * sizeof(TgTask)) != hipSuccess) { (void)hipGetLastError(); return false; }
+            c->cap_q = tot;
+        }
+        int64_t o = 0;
+        (void)hipStreamSynchronize(s);                 // (an earlier launch may still be reading the old tables)
+        for (int q = 0; q < 3; ++q) {
+            c->off[q] = o;
+            c->n[q] = (int)tb.q[q].size();
+            if (c->n[q] > 0 &&
+                hipMemcpy(c->dq + o, tb.q[q].data(), tb.q[q].size() * sizeof(TgTask), hipMemcpyHostToDevice) != hipSuccess) {
+                (void)hipGetLastError();
+                c->nP = 0;
+                return false;
+            }
+            o += c->n[q] + 1;
+        }
+        c->nP = nP; c->chunks = chunks; c->split = split;
+    }
+    const int64_t nctl = tg_ctl_ints(nP);
+    if (nctl > c->cap_ctl) {
+        if (c->dctl) (void)hipFree(c->dctl);
+        c->dctl = nullptr; c->cap_ctl = 0;
+        if (hipMalloc((void**)&c->dctl, (size_t)nctl * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return false; }
+        c->cap_ctl = nctl;
+    }
+    const int nside = std::max(1, std::min(h->tg_side > 0 ? h->tg_side : 4, 16));
+    const int64_t ntrace = 14 * (int64_t)nP + 8 * 1024 + 16;
+    if (h->tg_trace && ntrace > c->cap_trace) {
+        if (c->dtrace) (void)hipFree(c->dtrace);
+        c->dtrace = nullptr; c->cap_trace = 0;
+        if (hipMalloc((void**)&c->dtrace, (size_t)ntrace * 8) != hipSuccess) { (void)hipGetLastError(); return false; }
+        c->cap_trace = ntrace;
+    }
+    if (c->max_resident == 0) {
+        int nb = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_chol_tg, GEMM_THREADS, 0) != hipSuccess || nb < 1 ||
+            hipGetDeviceProperties(&prop, h->device) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        c->max_resident = nb * prop.multiProcessorCount;
+    }
+    (void)hipMemsetAsync(h->dflag, 0, sizeof(int), s);
+    (void)hipMemsetAsync(c->dctl, 0, (size_t)nctl * sizeof(int), s);
+    if (h->tg_trace) (void)hipMemsetAsync(c->dtrace, 0, (size_t)ntrace * 8, s);
+    hipLaunchKernelGGL(k_zero_diag_lower, dim3((unsigned)nP), dim3(256), 0, s, h->dR, Np);
+    // one worker per tile of the matrix can be busy at most (plus the solves of a block row)
+    int64_t want = 1 + nside + (int64_t)nP * (nP + 1) / 2 + 2 * nP;
+    if (h->tg_grid > 0) want = h->tg_grid;
+    const int grid = (int)std::max<int64_t>(2 + nside, std::min<int64_t>(want, c->max_resident));
+    const bool grid_is_full = grid >= c->max_resident;      // two workgroups per CU everywhere: isolation has a meaning
+    TgArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.S = h->dS; a.R = h->dR; a.T = h->dT; a.U = h->dU;
+    a.Np = Np; a.nP = nP; a.dflag = h->dflag; a.ctl = c->dctl;
+    for (int q = 0; q < 3; ++q) { a.q[q] = c->dq + c->off[q]; a.n[q] = c->n[q]; }
+    a.nside = nside;
+    a.isolate = (h->tg_isolate != 0 && grid_is_full) ? 1 : 0;
+    a.trace = h->tg_trace ? c->dtrace : nullptr;
+    a.tmo = (long long)(h->tg_tmo_ms > 0 ? h->tg_tmo_ms : 2000) * 100000LL;
+    hipLaunchKernelGGL(k_chol_tg, dim3((unsigned)grid), dim3(GEMM_THREADS), 0, s, a);
+    h->diag_inv_pending = true;
+    h->tg_launched = true;
+    return true;
+}
+
+// the abort word of the last launch (valid once the stream has drained): 0 ok, 1 not positive definite, 2 a spin gave up
+int tg_abort_code(gpx_handle* h) {
+    TgCache* c = static_cast<TgCache*>(h->tg);
+    if (!c || !c->dctl) return 0;
+    int v = 0;
+    if (hipMemcpy(&v, c->dctl + TG_CTL_ABORT, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 2; }
+    return v;
+}
+
+// diagnostic (option "chol_tg_trace"): the stamps of the last launch, 100 MHz ticks: out[4 p + {0, 1, 2}] = role C started
+// waiting for / started / finished diagonal block p; then per critical task (5 per block row) start / end
+int64_t tg_trace_copy(gpx_handle* h, long long* out, int64_t n) {
+    TgCache* c = static_cast<TgCache*>(h->tg);
+    if (!c || !c->dtrace || !h->tg_trace) return 0;
+    const int64_t have = std::min<int64_t>(n, 14 * (int64_t)c->nP + 8 * 1024);
+    if (have <= 0) return 0;
+    if (hipMemcpy(out, c->dtrace, (size_t)have * 8, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return have;
+}
+
+}  // namespace gpx

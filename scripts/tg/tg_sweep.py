@@ -1,0 +1,21 @@
+"""Option sweep of the task-graph Cholesky: python scripts/tg/tg_sweep.py N "opt=v,opt=v" "..." ; prints median / min ms."""
+import sys, os
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from pybo_amd._lib import Engine
+N = int(sys.argv[1])
+rng = np.random.RandomState(N)
+X = rng.rand(N, 8); y = -((X - 0.5) ** 2).sum(1) + 1e-3 * rng.randn(N)
+ell = 0.25 * np.ones(8); rho = float(np.var(y)); bias = float(y.mean()); sn2 = 1e-4 * rho
+for opts in sys.argv[2:]:
+    e = Engine(0)
+    e.set_option('chol_tg_tmo_ms', 500)
+    for kv in filter(None, opts.split(',')):
+        k, v = kv.split('='); e.set_option(k, int(v))
+    ts = []
+    for r in range(6):
+        e.timers(reset=True)
+        e.fit(X, y, 'se', ell, rho, sn2, bias, stage=2); e.sync()
+        ts.append(e.timers(reset=True)['cholesky'])
+    print('N=%d %-60s median %.3f min %.3f ms' % (N, opts, np.median(ts[1:]), min(ts[1:])), flush=True)
+    e.close()

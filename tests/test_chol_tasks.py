@@ -1,0 +1,173 @@
+"""CPU tests of the task-graph factorisation's task lists (pybo_amd/csrc/kernels_chol_tg.hip, host part; exported as
+gpx_chol_tasks): replayed under the device's own protocol -- a queue head is taken only when its dependencies are met,
+tasks complete in any order -- the lists must (1) never dead-lock, (2) apply every block row to every tile exactly once and
+in ascending order (what makes the factor bit-identical to the stream schedule's), (3) BE a Cholesky factorisation when the
+tasks are executed with numpy on a small block size.  Serves `model.add_data` (pybo/bayesopt.py:114,258,269)."""
+import numpy as np
+import pytest
+
+from pybo_amd import _lib
+
+TRSM, UPD, UPDQ = 1, 2, 3
+
+
+class Replay(object):
+    """The control block of k_chol_tg and, optionally, the matrix it works on (block size nb instead of 128)."""
+
+    def __init__(self, nP, queues, nb=0, seed=0):
+        self.nP, self.q = nP, queues
+        self.head = [0, 0, 0]
+        self.seq = np.zeros((nP, nP), dtype=int)        # chunks applied per tile
+        self.applied = np.zeros((nP, nP), dtype=int)    # block rows applied per tile
+        self.solved = np.zeros((nP, 2), dtype=int)
+        self.diag = np.zeros(nP, dtype=bool)
+        self.quad = np.zeros(nP, dtype=int)
+        self.next_potrf = 0
+        self.nb = nb
+        self.rng = np.random.RandomState(seed)
+        if nb:
+            n = nP * nb
+            A = self.rng.randn(n, n)
+            self.K = A @ A.T + n * np.eye(n)
+            self.S = np.triu(self.K).copy()
+            self.R = np.zeros((n, n))
+
+    def ready(self, t):
+        typ, I, J, k0, k1, ordn = (int(v) for v in t[:6])
+        if typ == TRSM:
+            return bool(self.diag[I]) and self.seq[I, J] == ordn
+        return self.seq[I, J] == ordn and min(self.solved[I].min(), self.solved[J].min()) >= k1
+
+    def blk(self, M, I, J):
+        nb = self.nb
+        return M[I * nb:(I + 1) * nb, J * nb:(J + 1) * nb]
+
+    def run_task(self, t):
+        typ, I, J, k0, k1, ordn, aux = (int(v) for v in t[:7])
+        nb, h = self.nb, self.nb // 2
+        if typ == TRSM:
+            assert self.applied[I, J] == I, 'panel solve of an incomplete tile'
+            if nb:
+                Rpp = self.blk(self.R, I, I)
+                cols = slice(J * nb + aux * h, J * nb + (aux + 1) * h)
+                self.R[I * nb:(I + 1) * nb, cols] = np.linalg.solve(Rpp.T, self.S[I * nb:(I + 1) * nb, cols])
+        else:
+            if typ == UPD:
+                assert self.applied[I, J] == k0, 'chunks out of order: tile (%d, %d) has %d, task starts at %d' % (I, J, self.applied[I, J], k0)
+            else:
+                assert I == J and self.applied[I, I] == k0
+            assert 0 <= k0 < k1 <= I
+            if nb:
+                A = self.R[k0 * nb:k1 * nb, I * nb:(I + 1) * nb]
+                B = self.R[k0 * nb:k1 * nb, J * nb:(J + 1) * nb]
+                D = A.T @ B
+                if typ == UPD:
+                    self.blk(self.S, I, J)[...] -= D
+                else:
+                    r = slice(h, nb) if aux == 2 else slice(0, h)
+                    c = slice(0, h) if aux == 0 else slice(h, nb)
+                    self.blk(self.S, I, I)[r, c] -= D[r, c]
+
+    def finish(self, t):
+        typ, I, J, k0, k1, ordn, aux = (int(v) for v in t[:7])
+        if typ == TRSM:
+            assert self.solved[J, aux] == I
+            self.solved[J, aux] = I + 1
+        elif typ == UPD:
+            self.applied[I, J] = k1
+            self.seq[I, J] = ordn + 1
+        else:
+            self.quad[I] += 1
+            if self.quad[I] == 3:
+                self.applied[I, I] = k1
+
+    def potrf(self, p):
+        assert self.applied[p, p] == p or (p > 0 and self.quad[p] == 3)
+        if self.nb:
+            D = self.blk(self.S, p, p)
+            D = np.triu(D) + np.triu(D, 1).T
+            self.blk(self.R, p, p)[...] = np.linalg.cholesky(D).T
+
+    def run(self, max_inflight=7):
+        inflight = []          # tasks taken, not yet published
+        steps = 0
+        total = sum(len(q) for q in self.q) + self.nP
+        done = 0
+        while done < total:
+            steps += 1
+            assert steps < 50 * total + 1000, 'no progress: dead-lock in the task lists'
+            moves = []
+            if len(inflight) < max_inflight:
+                for qi in range(3):
+                    if self.head[qi] < len(self.q[qi]) and self.ready(self.q[qi][self.head[qi]]):
+                        moves.append(('take', qi))
+                p = self.next_potrf
+                if p < self.nP and not any(t[0] == 'potrf' for t in inflight) and (p == 0 or self.quad[p] == 3):
+                    moves.append(('potrf', p))
+            for i in range(len(inflight)):
+                moves.append(('finish', i))
+            assert moves, 'dead-lock: nothing ready, nothing in flight (heads %s, next diagonal block %d)' % (self.head, self.next_potrf)
+            m = moves[self.rng.randint(len(moves))]
+            if m[0] == 'take':
+                t = self.q[m[1]][self.head[m[1]]]
+                self.head[m[1]] += 1
+                self.run_task(t)           # (results become visible at 'finish'; nobody may read them before)
+                inflight.append(('task', t))
+            elif m[0] == 'potrf':
+                self.potrf(m[1])
+                inflight.append(('potrf', m[1]))
+            else:
+                kind, t = inflight.pop(m[1])
+                if kind == 'potrf':
+                    self.diag[t] = True
+                    self.next_potrf = t + 1
+                else:
+                    self.finish(t)
+                done += 1
+        for I in range(self.nP):
+            for J in range(I, self.nP):
+                assert self.applied[I, J] == I, (I, J, self.applied[I, J])
+        assert self.diag.all() and (self.solved[1:] == np.arange(1, self.nP)[:, None]).all()
+
+
+@pytest.mark.parametrize('nP', [1, 2, 3, 5, 8, 17, 40])
+@pytest.mark.parametrize('chunks,split', [(0, -1), (1124, 2), (14, 0), (1128, 0), (11, 0), (1224, 4)])
+def test_lists_complete_in_order_without_deadlock(nP, chunks, split):
+    q = _lib.chol_tasks(nP, chunks, split)
+    n_upd_tiles = nP * (nP + 1) // 2
+    assert len(q[0]) == 5 * (nP - 1)
+    assert sum(int((a[:, 0] == TRSM).sum()) for a in q) == nP * (nP - 1)       # two halves per off-diagonal tile
+    for seed in range(3):
+        Replay(nP, q, seed=seed).run(max_inflight=1 + 3 * seed)
+    assert n_upd_tiles >= 1
+
+
+@pytest.mark.parametrize('nP,chunks,split', [(2, 0, -1), (7, 0, -1), (12, 1124, 0), (12, 13, 2), (9, 1128, 8)])
+def test_lists_are_a_cholesky_factorisation(nP, chunks, split):
+    q = _lib.chol_tasks(nP, chunks, split)
+    r = Replay(nP, q, nb=4, seed=nP)
+    r.run(max_inflight=5)
+    R = np.triu(r.R)
+    np.testing.assert_allclose(R.T @ R, r.K, rtol=1e-12, atol=1e-10)
+    np.testing.assert_allclose(R, np.linalg.cholesky(r.K).T, rtol=1e-10, atol=1e-10)
+
+
+def test_chunks_are_graded_towards_the_pivot():
+    """Default lists: every tile's last chunk is one block (the update the next diagonal block waits for is short), chunks
+    never grow towards the pivot, and the far queue holds the long ones."""
+    nP = 24
+    q = _lib.chol_tasks(nP)
+    upd = np.vstack([a[a[:, 0] == UPD] for a in q[1:]])
+    for I in range(3, nP - 1):
+        mine = upd[(upd[:, 1] == I) & (upd[:, 2] == nP - 1)]
+        sizes = (mine[:, 4] - mine[:, 3])[np.argsort(mine[:, 3])]
+        assert sizes[-1] == 1 and sizes.sum() == I
+        assert np.all(np.diff(sizes[1:]) <= 0)              # (the first chunk absorbs a short remainder)
+    assert np.all(q[1][q[1][:, 0] == UPD][:, 7] == 1) and np.all(q[2][:, 7] == 0)
+    far_sizes = q[2][:, 4] - q[2][:, 3]
+    assert far_sizes.max() <= 5 and far_sizes.min() >= 1
+
+
+def test_bad_arguments():
+    assert _lib.load().gpx_chol_tasks(0, 0, -1, None, 0, _lib._ptr(np.zeros(3, dtype=np.int64))) == -1
+    assert _lib.load().gpx_chol_tasks(4, 0, -1, None, 0, None) == -1
