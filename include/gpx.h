@@ -90,11 +90,13 @@ int gpx_version(void);
  *              Both bit-identical, both measured and off by default ("The fit -- round 3").
  *          "chol_tg" = 1 (default): the factorisation runs as ONE persistent kernel that walks its task graph (dedicated
  *              workgroups for the diagonal blocks and the two tiles between consecutive ones, everything else as
- *              throughput work from dependency-checked queues; kernels_chol_tg.hip) for fits of >= "chol_tg_min" (default 2)
+ *              throughput work from dependency-checked queues; kernels_chol_tg.hip) for fits of >= "chol_tg_min" (default 16)
  *              128-blocks; 0: the stream schedule above.  Bit-identical factors either way.  Tuning / diagnostics:
- *              "chol_tg_chunks" (k-chunk sizes counted back from the pivot as decimal digits, default 1124 = 1, 1, 2, 4, 4, ..),
- *              "chol_tg_split" (chunks ending within this many blocks of the pivot are urgent, default 0), "chol_tg_side"
- *              (workgroups reserved for the critical tiles, default 4), "chol_tg_grid" (workgroups launched, 0 = by size),
+ *              "chol_tg_chunks" (k-chunk sizes counted back from the pivot as decimal digits, default 1248 = 1, 2, 4, 8, 8, ..),
+ *              "chol_tg_split" (s + 1000 b: chunks ending within s blocks of the pivot, and every chunk of the tiles within b
+ *              blocks of the diagonal, go to a queue of their own that is served first; default 200 = one queue),
+ *              "chol_tg_side" (workgroups reserved for the critical tiles, default 8), "chol_tg_grid" (workgroups launched,
+ *              0 = by size), "chol_tg_isolate" (1, default: the critical workgroups keep their compute units to themselves),
  *              "chol_tg_tmo_ms" (bound of every spin, default 2000: on expiry the fit re-runs on the stream schedule and
  *              says so on stderr), "chol_tg_trace" = 1 (stamp the critical path, read with gpx_chol_trace).
  *          "x_bg", "x_bg_lds", "x_bg_iters" = DIAGNOSTIC (scripts/chol_bg.py): a synthetic register-only fp64-MFMA kernel of
@@ -311,9 +313,9 @@ int gpx_topk_allgather(gpx_comm *c, int64_t n, int64_t index_offset, int64_t k, 
 int gpx_timers(gpx_handle *h, double *out, int n, int reset);
 /* DIAGNOSTIC (option "chol_tg_trace" = 1): wall-clock stamps (100 MHz ticks) the task-graph factorisation of the last fit
  * took with its own clock: out[4 p + {0, 1, 2}] = the diagonal workgroup started waiting for / started / finished block
- * p (nP = N/128 rounded up blocks), then out[4 nP + 2 (5 p + i) + {0, 1}] = start / end of the critical tasks that follow
- * block p (i = 0, 1: the two halves of the panel solve of tile (p, p+1); 2..4: the quadrants of the update of tile
- * (p+1, p+1)).  Returns the number of words written (<= n; 14 nP when complete, followed by up to 1024 x 8 per-workgroup counters: tasks, ticks spent taking / updating / solving /
+ * p (nP = N/128 rounded up blocks), then out[4 nP + 2 (8 p + i) + {0, 1}] = start / end of the critical tasks that follow
+ * block p (i = 0, 1: the two halves of the panel solve of tile (p, p+1); 2..7: the pieces of the update of tile
+ * (p+1, p+1)).  Returns the number of words written (<= n; 20 nP when complete, followed by up to 1024 x 8 per-workgroup counters: tasks, ticks spent taking / updating / solving /
  * publishing, block updates applied, role, exit stamp), 0 without a trace. */
 int64_t gpx_chol_trace(gpx_handle *h, int64_t *out, int64_t n);
 /* The task lists the task-graph factorisation of an nblocks x nblocks block matrix walks (host only, no device needed:

@@ -671,19 +671,22 @@ class Engine(object):
         self._lib.gpx_timers(self._h, _ptr(out), len(out), 1 if reset else 0)
         return dict(zip(TIMER_NAMES, out.tolist()))
 
-    def chol_trace(self, nblocks):
+    def chol_trace(self, nblocks, full_log=False):
         """Diagnostic (option chol_tg_trace = 1): the task-graph factorisation's own stamps of the last fit, microseconds
-        from the first one: (diag (nblocks, 3) = wait / start / end per diagonal block, crit (nblocks, 5, 2) = start / end
-        of the two panel-solve halves and three quadrant updates that follow each block); None without a trace."""
-        out = np.zeros(14 * nblocks + 8 * 1024, dtype=np.int64)
+        from the first one: (diag (nblocks, 3) = wait / start / end per diagonal block, crit (nblocks, 8, 2) = start / end
+        of the two panel-solve halves and the six pieces of the diagonal-tile update that follow each block); None without a trace."""
+        out = np.zeros(20 * nblocks + 8 * 1024 + 16 + (4 << 20 if full_log else 0), dtype=np.int64)
         n = self._lib.gpx_chol_trace(self._h, _ptr(out), out.size)
-        if n < 14 * nblocks:
+        if n < 20 * nblocks:
             return None
-        self.last_chol_profile = out[14 * nblocks:].reshape(1024, 8).copy()   # per workgroup (role index): see tg_trace.py
-        out = out[:14 * nblocks]
+        self.last_chol_profile = out[20 * nblocks:20 * nblocks + 8192].reshape(1024, 8).copy()   # per workgroup (role index): see tg_trace.py
+        self.last_chol_tasklog = None
+        if full_log and n >= out.size:     # (option chol_tg_trace = 2) per workgroup 1024 records {task as 8 int16, start, end}
+            self.last_chol_tasklog = out[20 * nblocks + 8192 + 16:].reshape(1024, 1024, 4).copy()
+        out = out[:20 * nblocks]
         t0 = out[0]
         diag = (out[:4 * nblocks].reshape(nblocks, 4)[:, :3] - t0) / 100.0
-        crit = out[4 * nblocks:].reshape(nblocks, 5, 2).astype(np.float64)
+        crit = out[4 * nblocks:].reshape(nblocks, 8, 2).astype(np.float64)
         crit = np.where(crit > 0, (crit - t0) / 100.0, np.nan)
         return diag, crit
 

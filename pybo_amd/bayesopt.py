@@ -52,7 +52,7 @@ def safe_dump(model, info, filename=None):
     """Persist (model, trace); a None filename disables checkpointing."""
     if filename is None:
         return
-    if _spmd_rank() != 0:                # SPMD runs: the ranks hold the same state, one of them writes it
+    if _SPMD['on'] and _spmd_rank() != 0:    # SPMD runs: the ranks hold the same state, one of them writes it
         return
     # the trace goes to disk as three arrays, not as lists of thousands of small ones (pickling a list of 8192
     # (d,) arrays costs ~25 ms per iteration, more than a warm BO step); safe_load turns them back into lists
@@ -113,11 +113,51 @@ class _Rows(list):
     def __reduce__(self):
         return (_Rows, (list(np.array(self)),))
 
+    # every OTHER way a list can change (the loop itself only appends): apply it, then rebuild the mirror from the
+    # list's contents, so that np.array(trace.x) -- what the policies and recommenders read -- never goes stale
+    def _rebuild(self):
+        rows = [np.array(r, dtype=float) for r in list.__iter__(self)]
+        list.clear(self)
+        self._buf, self._n = None, 0
+        for r in rows:
+            self.append(r)
+
+    def _mutator(name):                      # noqa: N805 (class-body helper)
+        plain = getattr(list, name)
+
+        def method(self, *args, **kwargs):
+            out = plain(self, *args, **kwargs)
+            self._rebuild()
+            return self if name in ('__iadd__', '__imul__') else out
+        method.__name__ = name
+        return method
+
+    for _name in ('__setitem__', '__delitem__', 'insert', 'pop', 'remove', 'clear', 'sort', 'reverse', '__iadd__',
+                  '__imul__'):
+        locals()[_name] = _mutator(_name)
+    del _name, _mutator
+
+
+# SPMD is OPT-IN (solve_bayesopt(..., spmd=True) / init_model(..., spmd=True)): a process that merely has
+# torch.distributed initialised -- e.g. tuning something inside a data-parallel training job, a different objective per
+# rank -- runs its own, independent loop and is never pulled into a collective.
+_SPMD = {'on': False, 'group': None}
+
 
 def _spmd_rank():
     from . import dist as pdist
     d = pdist._dist()
-    return d.get_rank() if d is not None else 0
+    return d.get_rank(_SPMD['group']) if d is not None else 0
+
+
+def _spmd_group(spmd):
+    """None / False -> (False, None); True -> the default process group; a ProcessGroup -> that group."""
+    if spmd is None or spmd is False:
+        return False, None
+    from . import dist as pdist
+    if pdist._dist() is None:
+        raise RuntimeError('spmd=%r needs an initialised torch.distributed process group' % (spmd,))
+    return True, (None if spmd is True else spmd)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -132,12 +172,26 @@ def _heuristic_hypers(y, bounds):
                 bias=float(np.mean(y)) if len(y) else 0.0)
 
 
-def init_model(f, bounds, ninit=None, design='latin', log=None, rng=None, kernel='se', devices=None):
+def init_model(f, bounds, ninit=None, design='latin', log=None, rng=None, kernel='se', devices=None, spmd=None):
     """Evaluate an initial design (resumable through `log`) and return a GP fitted to it.  `devices`: a list of
-    GPUs for a one-process multi-device model (models.ShardedGP)."""
+    GPUs for a one-process multi-device model (models.ShardedGP).  `spmd`: see solve_bayesopt."""
     from . import models
-    from .dist import spmd_objective
-    f = f if getattr(f, 'spmd', False) else spmd_objective(f)      # SPMD runs: rank 0 evaluates, everyone receives
+    from .dist import spmd_objective, broadcast_seed
+    on, group = _spmd_group(spmd)
+    if on and not getattr(f, 'spmd', False):
+        rng = broadcast_seed(rng, group)
+        f = spmd_objective(f, group)             # SPMD runs: rank 0 evaluates, everyone receives (x, y)
+    saved = dict(_SPMD)
+    if on:
+        _SPMD.update(on=True, group=group)
+    try:
+        return _init_model(f, bounds, ninit, design, log, rng, kernel, devices)
+    finally:
+        _SPMD.update(saved)
+
+
+def _init_model(f, bounds, ninit, design, log, rng, kernel, devices):
+    from . import models
     rng = rstate(rng)
     bounds = np.array(bounds, dtype=float, ndmin=2)
     stored_model, trace = safe_load(log)
@@ -148,9 +202,13 @@ def init_model(f, bounds, ninit=None, design='latin', log=None, rng=None, kernel
         npts = 3 * len(bounds) if ninit is None else ninit
         trace.x.extend(getattr(inits, 'init_' + design)(bounds, npts, rng))
         trace.y.extend([np.nan] * npts)
+    exchange = getattr(f, 'exchange', None)
     for k, point in enumerate(trace.x):  # (re)evaluate whatever is still missing, saving as we go
         if np.isnan(trace.y[k]):
-            trace.y[k] = f(point)
+            if exchange is not None:     # SPMD: the point rank 0 evaluated is the point every rank records
+                trace.x[k], trace.y[k] = exchange(point)
+            else:
+                trace.y[k] = f(point)
         safe_dump(None, trace, filename=log)
 
     hyp = _heuristic_hypers(trace.y, bounds)
@@ -230,12 +288,20 @@ def _report(i, x, y, xbest):
 def _bo_step(model, trace, objective, bounds, policy, solver, recommender):
     """One iteration: choose, evaluate, absorb, recommend.  Mutates `model` and `trace`."""
     index = policy(model, bounds, trace.x)          # acquisition closure over a model copy
+    if _SPMD['on'] and hasattr(index, 'topk'):      # SPMD: every rank sweeps its slice of the grid, ONE all-gather
+        from .dist import ShardedIndex
+        if not isinstance(index, ShardedIndex):
+            index = ShardedIndex(index, _SPMD['group'])
     x, _ = solver(index, bounds)                    # grid sweep + top-k + refinement
     del index                                       # drop the policy's model copy: add_data below may then
     announce = getattr(model, 'anticipate', None)   # extend the factorisation in place instead of refitting;
     if announce is not None:                        # device models start the value-independent part of that
         announce(x)                                 # update now, while the black box is being evaluated
-    y = objective(x)
+    exchange = getattr(objective, 'exchange', None)
+    if exchange is not None:                        # SPMD: rank 0's query point and value, on every rank
+        x, y = exchange(x)
+    else:
+        y = objective(x)
     model.add_data(x, y)                            # refit
     xbest = recommender(model, bounds, trace.x)     # NB: trace.x does not contain x yet (as in the reference)
     trace.x.append(x)
@@ -245,22 +311,40 @@ def _bo_step(model, trace, objective, bounds, policy, solver, recommender):
 
 
 def solve_bayesopt(objective, bounds, model=None, niter=100, policy='ei', solver='lbfgs',
-                   recommender='latent', ninit=None, verbose=False, log=None, rng=None):
+                   recommender='latent', ninit=None, verbose=False, log=None, rng=None, spmd=None):
     """
     Maximise `objective` over the box `bounds` ((d,2) array-like) by Bayesian optimisation.
 
     `policy`, `solver`, `recommender`: a name, a callable, or (name-or-callable, kwargs); see
     `get_component`.  `model`: any object with the model protocol (copy / add_data / predict /
     get_improvement / get_tail / sample_f); default: a `pybo_amd.models.GP` from `init_model`.
-    Returns (xbest, model, Info(x, y, xbest)) with the Info fields as arrays.
+    Returns (xbest, model, Info(x, y, xbest)) with the Info fields as arrays (np.array of the trace columns; inside the
+    loop the columns x / xbest are `_Rows`: lists that mirror their rows in one array).
+
+    `spmd` (not in the reference, which is single-process): None / False (default) -- this process runs its own loop,
+    whatever torch.distributed state it lives in.  True, or a torch.distributed ProcessGroup: EVERY rank of the group
+    calls solve_bayesopt with the same arguments (one rank per GPU); rank 0 evaluates the objective and broadcasts the
+    query point and the value (the reference evaluates once per iteration, bayesopt.py:268), `rng=None` is replaced by
+    one broadcast seed, the solver's grid stage is sharded over the ranks (pybo_amd.dist.ShardedIndex), and rank 0
+    writes the checkpoints: the replicated models stay bitwise equal.
     """
-    from .dist import spmd_objective
+    on, group = _spmd_group(spmd)
+    saved = dict(_SPMD)
+    if on:
+        from .dist import spmd_objective, broadcast_seed
+        rng = broadcast_seed(rng, group)
+        objective = spmd_objective(objective, group)
+        _SPMD.update(on=True, group=group)
+    try:
+        return _solve_bayesopt(objective, bounds, model, niter, policy, solver, recommender, ninit, verbose, log, rng,
+                               spmd if on else None)
+    finally:
+        _SPMD.update(saved)
+
+
+def _solve_bayesopt(objective, bounds, model, niter, policy, solver, recommender, ninit, verbose, log, rng, spmd):
     rng = rstate(rng)
     bounds = np.array(bounds, dtype=float, ndmin=2)
-    # the reference evaluates the objective once per iteration in one process (bayesopt.py:268).  Under an
-    # initialised torch.distributed group (one rank per GPU, every rank running this loop) rank 0 evaluates and
-    # broadcasts, so every rank absorbs the same observation and the replicated models stay bitwise equal.
-    objective = spmd_objective(objective)
     policy = get_component(policy, policies, rng)
     solver = get_component(solver, solvers, rng, lstrip='solve_')
     recommender = get_component(recommender, recommenders, rng, lstrip='best_')
@@ -269,14 +353,14 @@ def solve_bayesopt(objective, bounds, model=None, niter=100, policy='ei', solver
     if resumed is not None:
         model = resumed
     elif model is None:
-        model = init_model(objective, bounds, ninit, log=log, rng=rng)   # trace stays as loaded above
+        model = init_model(objective, bounds, ninit, log=log, rng=rng, spmd=spmd)   # trace stays as loaded above
     else:
         model = model.copy()             # never mutate the caller's model
     trace = Info(_Rows(trace.x), list(trace.y), _Rows(trace.xbest))
 
     if not trace.x:                      # seed the trace with the centre of the box
         x0 = inits.init_middle(bounds)[0]
-        y0 = objective(x0)
+        y0 = objective(x0)               # (the box centre is the same point on every rank)
         trace.x.append(x0)
         trace.y.append(y0)
         model.add_data(x0, y0)

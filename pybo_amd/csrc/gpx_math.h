@@ -55,7 +55,9 @@ __device__ __forceinline__ double sqrt_r2(double x) {
     g = fma(e, h, g);
     e = fma(-g, g, x);
     g = fma(e, h, g);
-    return (x > 1.0e-280) ? g : x * 0.0;                        // 0 -> 0, NaN -> NaN
+    // 0 -> 0, NaN -> NaN; +inf (an overflowed scaled distance: very small length scales) -> +inf like the library's sqrt
+    // -- rsq(inf) = 0 makes g = inf * 0 = NaN, which would put NaN instead of 0 into every Matern covariance
+    return (x > 1.0e-280) ? ((x < 1.0e300) ? g : x) : x * 0.0;
 }
 
 // covariance as a function of the squared scaled distance r2 = sum_k ((x_k - z_k)/ell_k)^2

@@ -55,11 +55,19 @@ struct TgArgs {
     int isolate;                 // the critical workgroups keep their compute units to themselves
     long long* trace;            // optional: [p][4] critical-path stamps, then [crit task][2]
     long long tmo;               // spin bound in wall-clock ticks (100 MHz)
+    long long* tasklog;          // optional (trace level 2): per workgroup TG_LOG_CAP records {task (2 words), start, end}
 };
 
 // control block (ints): [0] arrivals, [32] abort (1 = not positive definite, 2 = a spin gave up), [64 + 32 q] queue heads,
 // then diag[nPad], quad[nPad], solved[2 nPad], seq[nP * nP], and per compute unit (key = xcc | se | sh | cu, 12 bits)
 // the number of workgroups that have started there and the role of the first one
+// Defaults, from the sweeps in profiles/r04_chol_taskgraph.txt: chunks of 1, 2, 4, 8, 8, .. blocks counted back from the pivot,
+// and ONE worker queue (split >= the matrix: everything is "urgent", i.e. plain generation order).  Two queues with the
+// near-pivot chunks first were measured 15-25 % slower at every size: a near chunk waits for its tile's previous chunk,
+// which then sits in the LOWER-priority queue behind a backlog -- priority inversion.
+constexpr int TG_DEFAULT_CHUNKS = 1248, TG_DEFAULT_SPLIT = 200;
+constexpr int TG_LOG_CAP = 1024, TG_LOG_WGS = 1024;
+constexpr int TG_NPIECE = 6;          // pieces of the critical update of a diagonal tile
 constexpr int TG_CTL_ABORT = 32, TG_CTL_HEAD = 64, TG_CTL_BASE = 192, TG_CU_KEYS = 4096;
 __host__ __device__ inline int tg_npad(int nP) { return (nP + 31) / 32 * 32; }
 __host__ __device__ inline int tg_ctl_ints(int nP) { return TG_CTL_BASE + 4 * tg_npad(nP) + nP * nP + 2 * TG_CU_KEYS; }
@@ -81,9 +89,14 @@ __device__ __forceinline__ void sti(int* p, int v) { __hip_atomic_store(p, v, __
 // head of its queue where every workgroup without a held ticket for that queue peeks -- the lists cannot dead-lock.
 struct TgHeld { TgTask t[3]; int have[3]; int pad; };       // in LDS, one per workgroup (indexed by queue)
 
+// PRE (the critical queue): only the dependency on the tile's earlier chunks -- a side-kick takes its task as soon as the
+// tile it will read first is final, starts loading it, and waits for the last dependency (the diagonal block / the two
+// solves) inside the task body: the loads of the S tile are off the critical path.
+template <bool PRE>
 __device__ __forceinline__ bool tg_deps_met(const TgTask& t, const int* dd, const int* sv, const int* sq, int nP) {
     const int I = t.I, J = t.J;
     const int s = ldi(sq + I * nP + J);
+    if (PRE) return s == t.ord;
     if (t.type == TG_TRSM) return (ldi(dd + I) != 0) && (s == t.ord);
     const int s0 = ldi(sv + 2 * I), s1 = ldi(sv + 2 * I + 1), s2 = ldi(sv + 2 * J), s3 = ldi(sv + 2 * J + 1);
     return (s == t.ord) && (min(min(s0, s1), min(s2, s3)) >= t.k1);
@@ -117,7 +130,7 @@ __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, T
                 live = h < nq;
                 if (live) u.v = *reinterpret_cast<const int4*>(tq + h);
             }
-            if (live) ready = tg_deps_met(u.t, dd, sv, sq, nP);
+            if (live) ready = tg_deps_met<QB == 0>(u.t, dd, sv, sq, nP);
         }
         if (__ballot(live) == 0) return 0;
         // a held urgent ticket that is not ready yet is about to be: do not start a long task of a lower queue under it
@@ -134,7 +147,7 @@ __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, T
                     const int k = atomicAdd(head, 1);
                     if (k < nq) {
                         u.v = *reinterpret_cast<const int4*>(tq + k);
-                        if (tg_deps_met(u.t, dd, sv, sq, nP)) {
+                        if (tg_deps_met<QB == 0>(u.t, dd, sv, sq, nP)) {
                             got = 1;
                         } else {
                             held->t[q] = u.t;
@@ -164,42 +177,74 @@ __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, T
     }
 }
 
-// Quadrant q of the diagonal tile (I, I) <- block rows [k0, k1):  q = 0: rows 0-63 x columns 0-63, 1: rows 0-63 x
-// columns 64-127, 2: rows 64-127 x columns 64-127 (the lower-left quadrant is never read).  One wave = 16 rows x 64
-// columns = 4 accumulators; fragments straight from global memory in the k-major layout (lane (g, n) <- row 4 kk + g,
-// column n), 16 k-steps (80 loads per lane) in flight per round trip; no LDS, no barrier.  The same FMAs per element as
-// the tile engines: the accumulators start from S, A enters negated, k ascends 4 at a time.
-template <bool AG>
-__device__ __forceinline__ void updq_body(const double* __restrict__ R, double* __restrict__ S, int64_t Np, int k0, int k1,
-                                          int I, int q) {
+constexpr int TG_LDS_F64 = GEMM_LDS_F64 + 16;       // + the task in hand (2), flags (2), held tickets (8)
+// The workgroup's LDS: the tile engine's buffer (the diagonal kernel's panels fit inside) + a slot for the task in hand.
+// File scope, so that the role bodies below can be separate (non-inlined) functions with their own register allocation
+// and still address it with ds_* instructions: inlined into one kernel body the roles spilled 319 VGPRs.
+__shared__ __attribute__((aligned(16))) double tg_smem[TG_LDS_F64];
+
+// The last dependency of a task in hand (every thread calls; thread 0 polls): both flags >= need.  false: abort.
+__device__ __forceinline__ bool tg_wait_flags(const TgArgs& a, const int* f0, const int* f1, int need) {
+    int* code = reinterpret_cast<int*>(tg_smem + GEMM_LDS_F64 + 2);
+    if (threadIdx.x == 0) {
+        int ok = 1;
+        const long long t0 = wall_clock64();
+        for (unsigned spins = 0; min(ldi(f0), ldi(f1)) < need; ++spins) {
+            if (ldi(a.ctl + TG_CTL_ABORT) != 0) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(1);
+            if ((spins & 255) == 255 && wall_clock64() - t0 > a.tmo) { sti(a.ctl + TG_CTL_ABORT, 2); ok = 0; break; }
+        }
+        code[2] = ok;
+    }
+    __syncthreads();
+    return code[2] != 0;
+}
+
+// Piece `aux` (0..5) of the update of the diagonal tile (I, I) with block rows [k0, k1): quadrant q = aux >> 1 (0: rows
+// 0-63 x columns 0-63, 1: rows 0-63 x columns 64-127, 2: rows 64-127 x columns 64-127; the lower-left quadrant is never
+// read), column half aux & 1 (32 columns).  One wave = 16 rows x 32 columns = 2 accumulators; fragments straight from
+// global memory in the k-major layout (lane (g, n) <- row 4 kk + g, column n), a whole block row of k (96 loads per
+// lane) in flight at once: ONE round trip per block; no LDS.  The accumulators are loaded BEFORE the task's last
+// dependency (the two solves of tile (I-1, I)) is awaited.  The same FMAs per element as the tile engines: the accumulators
+// start from S, A enters negated, k ascends 4 at a time.  Waves whose two 16-tiles lie below the diagonal do nothing.
+__device__ __forceinline__ bool updq_body(const TgArgs& a, const double* __restrict__ R, double* __restrict__ S, int64_t Np,
+                                          int k0, int k1, int I, int aux, const int* solved) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, n = lane & 15;
     const int64_t i0 = (int64_t)I * NB;
-    const int r0 = (q == 2) ? 64 : 0, c0 = (q == 0) ? 0 : 64;
-    d4 acc[4];
+    const int q = aux >> 1;
+    const int r0 = (q == 2) ? 64 : 0, c0 = ((q == 0) ? 0 : 64) + 32 * (aux & 1);
+    const bool live = (r0 + 16 * w) <= (c0 + 16);           // tile row <= the piece's last tile column
+    d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}};
+    if (live) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[j][r] = ldg<AG>(S + (i0 + r0 + 16 * w + g + 4 * r) * Np + i0 + c0 + 16 * j + n);
-    const double* Ra = R + i0 + r0 + 16 * w + n;
-    const double* Rb = R + i0 + c0 + n;
-    for (int kb = k0 * NB; kb < k1 * NB; kb += 64) {
-        double av[16], bv[16][4];
+            for (int r = 0; r < 4; ++r) acc[j][r] = ldg<true>(S + (i0 + r0 + 16 * w + g + 4 * r) * Np + i0 + c0 + 16 * j + n);
+    }
+    if (!tg_wait_flags(a, solved + 2 * I, solved + 2 * I + 1, k1)) return false;
+    if (live) {
+        const double* Ra = R + i0 + r0 + 16 * w + n;
+        const double* Rb = R + i0 + c0 + n;
+        for (int kb = k0 * NB; kb < k1 * NB; kb += NB) {
+            double av[32], bv[32][2];
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            const int64_t row = (int64_t)(kb + 4 * kk + g) * Np;
-            av[kk] = ldg<AG>(Ra + row);
+            for (int kk = 0; kk < 32; ++kk) {
+                const int64_t row = (int64_t)(kb + 4 * kk + g) * Np;
+                av[kk] = ldg<true>(Ra + row);
+                bv[kk][0] = ldg<true>(Rb + row);
+                bv[kk][1] = ldg<true>(Rb + row + 16);
+            }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[kk][j] = ldg<AG>(Rb + row + 16 * j);
+            for (int kk = 0; kk < 32; ++kk)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[kk], bv[kk][j], acc[j], 0, 0, 0);
         }
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[kk], bv[kk][j], acc[j], 0, 0, 0);
+            for (int r = 0; r < 4; ++r) stg<true>(S + (i0 + r0 + 16 * w + g + 4 * r) * Np + i0 + c0 + 16 * j + n, acc[j][r]);
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) stg<AG>(S + (i0 + r0 + 16 * w + g + 4 * r) * Np + i0 + c0 + 16 * j + n, acc[j][r]);
+    return true;
 }
 
 // The panel solve of fit_tiles.h with the factor's diagonal block staged in LDS.  panel_solve16_body reads its A fragments
@@ -211,15 +256,23 @@ __device__ __forceinline__ void updq_body(const double* __restrict__ R, double* 
 // row 4 kk + g, column n) is 64 consecutive doubles.  Same MFMAs in the same order as panel_solve16_body.
 __device__ __forceinline__ int tri_index(int r, int c) { return 8 * r - r * (r - 1) / 2 + c - r; }
 
-__device__ __forceinline__ void panel_solve16_lds(const double* __restrict__ U, const double* __restrict__ S,
-                                                  double* __restrict__ R, int64_t Np, int p, int cb, double* lds) {
+__device__ __forceinline__ bool panel_solve16_lds(const TgArgs& a, const double* __restrict__ U, const double* __restrict__ S,
+                                                  double* __restrict__ R, int64_t Np, int p, int cb, double* lds,
+                                                  const int* diag) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int g = lane >> 4, n = lane & 15;
     const int64_t p0 = (int64_t)p * NB;
     const int64_t j0 = (int64_t)(p + 1) * NB + (int64_t)cb * 64 + 16 * w;
     const double* Rd = R + p0 * Np + p0;          // R_pp
     const double* Ud = U + p0 * Np + p0;          // diagonal 16-tiles hold T_d^T
-    // (1) everything this workgroup reads, issued back to back
+    // (0) the right-hand sides are final before the diagonal block is: their loads travel while it is awaited
+    d4 X[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) X[r][q] = ldg<true>(S + (p0 + 16 * r + g + 4 * q) * Np + j0 + n);
+    if (!tg_wait_flags(a, diag + p, diag + p, 1)) return false;
+    // (1) everything else this workgroup reads, issued back to back
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Rd), 0, (int)(128 * Np * 8), 0x00020000);
     u4v stage[18];
     int dst[18];
@@ -234,11 +287,6 @@ __device__ __forceinline__ void panel_solve16_lds(const double* __restrict__ U, 
         stage[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((16 * r + row) * Np + 16 * c + 2 * c2) * 8), 0, 16);
         dst[q] = tile * 256 + row * 16 + 2 * c2;
     }
-    d4 X[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) X[r][q] = ldg<true>(S + (p0 + 16 * r + g + 4 * q) * Np + j0 + n);
     double ti[8][4];                               // A fragments of the eight T_d
 #pragma unroll
     for (int jb = 0; jb < 8; ++jb)
@@ -267,6 +315,7 @@ __device__ __forceinline__ void panel_solve16_lds(const double* __restrict__ U, 
 #pragma unroll
         for (int q = 0; q < 4; ++q) stg<true>(R + (p0 + 16 * r + g + 4 * q) * Np + j0 + n, X[r][q]);
     __syncthreads();                               // the LDS image is free again
+    return true;
 }
 
 // the strictly-lower 16-tiles of R's diagonal blocks are zero (potrf16_body writes them itself in the stream schedule)
@@ -281,7 +330,6 @@ __global__ __launch_bounds__(256) void k_zero_diag_lower(double* __restrict__ R,
     }
 }
 
-constexpr int TG_LDS_F64 = GEMM_LDS_F64 + 16;       // + the task in hand (2), flags (2), held tickets (8)
 
 // a wave-uniform 64-bit value the compiler cannot prove uniform (fields of the argument block reached through a reference)
 __device__ __forceinline__ unsigned long long uni64(unsigned long long v) {
@@ -292,11 +340,6 @@ template <class T>
 __device__ __forceinline__ T* uni(T* p) { return reinterpret_cast<T*>(uni64(reinterpret_cast<unsigned long long>(p))); }
 
 __device__ __forceinline__ void tg_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-// The workgroup's LDS: the tile engine's buffer (the diagonal kernel's panels fit inside) + a slot for the task in hand.
-// File scope, so that the role bodies below can be separate (non-inlined) functions with their own register allocation
-// and still address it with ds_* instructions: inlined into one kernel body the roles spilled 319 VGPRs.
-__shared__ __attribute__((aligned(16))) double tg_smem[TG_LDS_F64];
 
 __device__ __noinline__ void tg_role_diag(const TgArgs& a) {
     double* Pn = tg_smem;                          // 2 x 16 x PFP
@@ -314,7 +357,7 @@ __device__ __noinline__ void tg_role_diag(const TgArgs& a) {
             if (a.trace) a.trace[4 * p] = wall_clock64();
             if (p > 0) {
                 const long long t0 = wall_clock64();
-                for (unsigned spins = 0; ldi(qd + p) != 3; ++spins) {
+                for (unsigned spins = 0; ldi(qd + p) != TG_NPIECE; ++spins) {
                     if (ldi(ctl + TG_CTL_ABORT) != 0) { c = -1; break; }
                     __builtin_amdgcn_s_sleep(2);
                     if ((spins & 255) == 255 && wall_clock64() - t0 > a.tmo) { sti(ctl + TG_CTL_ABORT, 2); c = -1; break; }
@@ -346,16 +389,18 @@ __device__ __noinline__ void tg_do_upd(const TgArgs& a, int k0, int k1, int I, i
     I = __builtin_amdgcn_readfirstlane(I); J = __builtin_amdgcn_readfirstlane(J);
     syrk_tile<true, PRIO>(uni(a.R), uni(a.S), (int64_t)uni64((unsigned long long)a.Np), k0, k1, I, J, tg_smem);
 }
-__device__ __noinline__ void tg_do_trsm(const TgArgs& a, int p, int cb) {
+__device__ __noinline__ bool tg_do_trsm(const TgArgs& a, int p, int cb) {
     p = __builtin_amdgcn_readfirstlane(p); cb = __builtin_amdgcn_readfirstlane(cb);
     __builtin_amdgcn_s_setprio(3);
-    panel_solve16_lds(uni(a.U), uni(a.S), uni(a.R), (int64_t)uni64((unsigned long long)a.Np), p, cb, tg_smem);
+    const int* diag = uni(a.ctl) + TG_CTL_BASE;
+    return panel_solve16_lds(a, uni(a.U), uni(a.S), uni(a.R), (int64_t)uni64((unsigned long long)a.Np), p, cb, tg_smem, diag);
 }
-__device__ __noinline__ void tg_do_updq(const TgArgs& a, int k0, int k1, int I, int q) {
+__device__ __noinline__ bool tg_do_updq(const TgArgs& a, int k0, int k1, int I, int q) {
     k0 = __builtin_amdgcn_readfirstlane(k0); k1 = __builtin_amdgcn_readfirstlane(k1);
     I = __builtin_amdgcn_readfirstlane(I); q = __builtin_amdgcn_readfirstlane(q);
     __builtin_amdgcn_s_setprio(3);
-    updq_body<true>(uni(a.R), uni(a.S), (int64_t)uni64((unsigned long long)a.Np), k0, k1, I, q);
+    const int* solved = uni(a.ctl) + TG_CTL_BASE + 2 * tg_npad(__builtin_amdgcn_readfirstlane(a.nP));
+    return updq_body(a, uni(a.R), uni(a.S), (int64_t)uni64((unsigned long long)a.Np), k0, k1, I, q, solved);
 }
 template <int QB, int NQ>
 __device__ __noinline__ int tg_take_call(const TgArgs& a, TgTask& out, int lane) {
@@ -429,9 +474,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
             if (tk.rsv) tg_do_upd<2>(a, tk.k0, tk.k1, tk.I, tk.J);
             else tg_do_upd<1>(a, tk.k0, tk.k1, tk.I, tk.J);
         } else if (tk.type == TG_TRSM) {
-            tg_do_trsm(a, tk.I, 2 * (tk.J - tk.I - 1) + tk.aux);
+            if (!tg_do_trsm(a, tk.I, 2 * (tk.J - tk.I - 1) + tk.aux)) break;
         } else {
-            tg_do_updq(a, tk.k0, tk.k1, tk.I, tk.aux);
+            if (!tg_do_updq(a, tk.k0, tk.k1, tk.I, tk.aux)) break;
         }
         tg_drain();
         __syncthreads();
@@ -439,6 +484,12 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
             long long te = 0;
             if (a.trace) {
                 te = wall_clock64();
+                if (a.tasklog && role < TG_LOG_WGS && prof[0] < TG_LOG_CAP) {
+                    long long* rec = a.tasklog + ((long long)role * TG_LOG_CAP + prof[0]) * 4;
+                    union { TgTask t; long long w[2]; } u;
+                    u.t = tk;
+                    rec[0] = u.w[0]; rec[1] = u.w[1]; rec[2] = ts; rec[3] = te;
+                }
                 prof[0] += 1;
                 prof[tk.type == TG_UPD ? 2 : 3] += te - ts;
                 if (tk.type == TG_UPD) prof[5] += tk.k1 - tk.k0;
@@ -447,7 +498,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
             else if (tk.type == TG_TRSM) sti(sv + 2 * tk.J + tk.aux, tk.I + 1);
             else atomicAdd(qd + tk.I, 1);
             if (side && a.trace) {
-                const int slot = (tk.type == TG_TRSM) ? (5 * tk.I + tk.aux) : (5 * (tk.I - 1) + 2 + tk.aux);
+                const int slot = (tk.type == TG_TRSM) ? (8 * tk.I + tk.aux) : (8 * (tk.I - 1) + 2 + tk.aux);
                 a.trace[4 * nP + 2 * slot] = ts;
                 a.trace[4 * nP + 2 * slot + 1] = wall_clock64();
             }
@@ -455,7 +506,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
         }
     }
     if (a.trace && t == 0 && role < 1024) {
-        long long* o = a.trace + 14 * (long long)nP + 8 * role;
+        long long* o = a.trace + 20 * (long long)nP + 8 * role;
         for (int i = 0; i < 6; ++i) o[i] = prof[i];
         o[6] = side ? 1 : 2;
         o[7] = wall_clock64();
@@ -486,7 +537,7 @@ static std::vector<int> tg_boundaries(int I, const std::vector<int>& sizes) {
 
 struct TgTables { std::vector<TgTask> q[3]; };
 
-static void tg_build(int nP, int chunk_code, int split, TgTables& out) {
+static void tg_build(int nP, int chunk_code, int split, int band, TgTables& out) {
     std::vector<int> sizes;
     {
         std::vector<int> dg;
@@ -517,10 +568,11 @@ static void tg_build(int nP, int chunk_code, int split, TgTables& out) {
             size_t j = 1;
             while (bnd[I][j] != p + 1) ++j;
             const int k0 = bnd[I][j - 1], k1 = p + 1, ord = (int)j - 1, d = I - k1;
-            const int q = (d <= split) ? 1 : 2;
             for (int J = I; J < nP; ++J) {
+                // urgent: the chunks next to the pivot (of every tile) and every chunk of the tiles next to the diagonal
+                const int q = (d <= split || J - I <= band) ? 1 : 2;
                 if (d == 0 && J == I) {
-                    for (int qu = 0; qu < 3; ++qu) push(0, TG_UPDQ, I, I, k0, k1, ord, qu, 0);
+                    for (int qu = 0; qu < TG_NPIECE; ++qu) push(0, TG_UPDQ, I, I, k0, k1, ord, qu, 0);
                 } else {
                     push(q, TG_UPD, I, J, k0, k1, ord, 0, q == 1 ? 1 : 0);
                 }
@@ -533,7 +585,9 @@ static void tg_build(int nP, int chunk_code, int split, TgTables& out) {
 int64_t tg_tasks_copy(int nP, int chunks, int split, int16_t* out, int64_t cap, int64_t* counts) {
     if (nP < 1 || nP > 2047) return -1;
     TgTables tb;
-    tg_build(nP, chunks > 0 ? chunks : 1124, split >= 0 ? split : 0, tb);
+    if (chunks <= 0) chunks = TG_DEFAULT_CHUNKS;
+    if (split < 0) split = TG_DEFAULT_SPLIT;
+    tg_build(nP, chunks, split % 1000, split / 1000, tb);
     int64_t tot = 0;
     for (int q = 0; q < 3; ++q) { counts[q] = (int64_t)tb.q[q].size(); tot += counts[q]; }
     if (out && cap >= tot) {
@@ -579,11 +633,11 @@ bool launch_cholesky_tg(gpx_handle* h) {
     if (!h->tg) h->tg = new TgCache();
     TgCache* c = static_cast<TgCache*>(h->tg);
     hipStream_t s = h->stream;
-    const int chunks = h->tg_chunks > 0 ? h->tg_chunks : 1124;
-    const int split = h->tg_split >= 0 ? h->tg_split : 0;
+    const int chunks = h->tg_chunks > 0 ? h->tg_chunks : TG_DEFAULT_CHUNKS;
+    const int split = h->tg_split >= 0 ? h->tg_split : TG_DEFAULT_SPLIT;
     if (c->nP != nP || c->chunks != chunks || c->split != split || !c->dq) {
         TgTables tb;
-        tg_build(nP, chunks, split, tb);
+        tg_build(nP, chunks, split % 1000, split / 1000, tb);
         const int64_t tot = (int64_t)tb.q[0].size() + (int64_t)tb.q[1].size() + (int64_t)tb.q[2].size() + 3;
         if (tot > c->cap_q) {
             if (c->dq) (void)hipFree(c->dq);
@@ -613,8 +667,9 @@ bool launch_cholesky_tg(gpx_handle* h) {
         if (hipMalloc((void**)&c->dctl, (size_t)nctl * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return false; }
         c->cap_ctl = nctl;
     }
-    const int nside = std::max(1, std::min(h->tg_side > 0 ? h->tg_side : 4, 16));
-    const int64_t ntrace = 14 * (int64_t)nP + 8 * 1024 + 16;
+    const int nside = std::max(1, std::min(h->tg_side > 0 ? h->tg_side : 8, 16));
+    const int64_t nlog = (h->tg_trace >= 2) ? (int64_t)TG_LOG_WGS * TG_LOG_CAP * 4 : 0;
+    const int64_t ntrace = 20 * (int64_t)nP + 8 * 1024 + 16 + nlog;
     if (h->tg_trace && ntrace > c->cap_trace) {
         if (c->dtrace) (void)hipFree(c->dtrace);
         c->dtrace = nullptr; c->cap_trace = 0;
@@ -637,6 +692,10 @@ bool launch_cholesky_tg(gpx_handle* h) {
     hipLaunchKernelGGL(k_zero_diag_lower, dim3((unsigned)nP), dim3(256), 0, s, h->dR, Np);
     // one worker per tile of the matrix can be busy at most (plus the solves of a block row)
     int64_t want = 1 + nside + (int64_t)nP * (nP + 1) / 2 + 2 * nP;
+    // up to ~72 blocks the factorisation is bound by the latency of its dependent tasks, not by throughput: ONE workgroup
+    // per compute unit runs every task ~1.6x faster (N = 4096: 1.91 against 2.23 ms, N = 8192: 5.40 against 5.98; from
+    // N = 12288 on two per CU win: 13.6 against 14.4 ms)
+    if (nP <= 72) want = std::min<int64_t>(want, c->max_resident / 2 + 8);
     if (h->tg_grid > 0) want = h->tg_grid;
     const int grid = (int)std::max<int64_t>(2 + nside, std::min<int64_t>(want, c->max_resident));
     const bool grid_is_full = grid >= c->max_resident;      // two workgroups per CU everywhere: isolation has a meaning
@@ -648,6 +707,7 @@ bool launch_cholesky_tg(gpx_handle* h) {
     a.nside = nside;
     a.isolate = (h->tg_isolate != 0 && grid_is_full) ? 1 : 0;
     a.trace = h->tg_trace ? c->dtrace : nullptr;
+    a.tasklog = nlog ? c->dtrace + 20 * (int64_t)nP + 8 * 1024 + 16 : nullptr;
     a.tmo = (long long)(h->tg_tmo_ms > 0 ? h->tg_tmo_ms : 2000) * 100000LL;
     hipLaunchKernelGGL(k_chol_tg, dim3((unsigned)grid), dim3(GEMM_THREADS), 0, s, a);
     h->diag_inv_pending = true;
@@ -669,7 +729,7 @@ int tg_abort_code(gpx_handle* h) {
 int64_t tg_trace_copy(gpx_handle* h, long long* out, int64_t n) {
     TgCache* c = static_cast<TgCache*>(h->tg);
     if (!c || !c->dtrace || !h->tg_trace) return 0;
-    const int64_t have = std::min<int64_t>(n, 14 * (int64_t)c->nP + 8 * 1024);
+    const int64_t have = std::min<int64_t>(n, std::min<int64_t>(c->cap_trace, 20 * (int64_t)c->nP + 8 * 1024 + 16 + (h->tg_trace >= 2 ? (int64_t)TG_LOG_WGS * TG_LOG_CAP * 4 : 0)));
     if (have <= 0) return 0;
     if (hipMemcpy(out, c->dtrace, (size_t)have * 8, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return have;

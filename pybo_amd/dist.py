@@ -15,7 +15,7 @@ Two transports for that exchange:
 import numpy as np
 
 __all__ = ['shard_bounds', 'merge_topk', 'gather_topk', 'gather_pairs', 'sharded_topk', 'ShardedIndex', 'world_size',
-           'spmd_objective']
+           'spmd_objective', 'broadcast_seed']
 
 
 def shard_bounds(M, rank, world):
@@ -160,30 +160,56 @@ def world_size(group=None):
 
 def spmd_objective(objective, group=None, src=0):
     """pybo evaluates the black box ONCE per iteration in one process (pybo/bayesopt.py:268).  When the whole loop
-    runs SPMD (one rank per GPU under torch.distributed, every rank executing solve_bayesopt), only rank `src`
-    calls `objective`; the query point it used and the value it got are broadcast, so that every rank feeds its
-    replicated model the SAME observation -- with a noisy or expensive objective, P independent evaluations would
-    give P different models whose shard-local top-k lists cannot be merged.  Without a process group (or with one
-    rank) the objective is returned unchanged."""
+    runs SPMD (one rank per GPU under torch.distributed, every rank executing solve_bayesopt(..., spmd=True)), only
+    rank `src` calls `objective`; the query point it used AND the value it got are broadcast, and every rank feeds its
+    replicated model that SAME observation -- with a noisy or expensive objective, P independent evaluations would
+    give P different models whose shard-local top-k lists cannot be merged.
+
+    The wrapper is called like the objective, `y = f(x)`; `f.exchange(x)` returns `(x_src, y)`, the pair every rank
+    must absorb (the loop uses this form).  A rank whose own x differs from rank src's is counted in `f.mismatches`
+    (replicated models are bitwise equal, so this stays 0 unless the ranks were seeded differently) -- the src's point
+    wins either way, so the models cannot drift apart silently.  Without a process group (or with one rank) the
+    objective is returned unchanged."""
     dist = _dist()
     if dist is None or dist.get_world_size(group) == 1:
         return objective
     rank = dist.get_rank(group)
 
-    def evaluate(x):
+    def exchange(x):
         box = [None]
         if rank == src:
             try:
-                box[0] = ('ok', objective(x))
+                box[0] = ('ok', np.array(x, dtype=float), objective(x))
             except BaseException as exc:          # noqa: every rank must leave the collective, then re-raise
-                box[0] = ('error', repr(exc))
+                box[0] = ('error', None, repr(exc))
                 dist.broadcast_object_list(box, src=src, group=group)
                 raise
         dist.broadcast_object_list(box, src=src, group=group)
-        status, value = box[0]
+        status, x_src, value = box[0]
         if status != 'ok':
             raise RuntimeError('objective failed on rank %d: %s' % (src, value))
-        return value
+        mine = np.asarray(x, dtype=float)
+        if mine.shape != x_src.shape or not np.array_equal(mine, x_src):
+            evaluate.mismatches += 1
+        return x_src.reshape(mine.shape) if mine.size == x_src.size else x_src, value
 
+    def evaluate(x):
+        return exchange(x)[1]
+
+    evaluate.exchange = exchange
+    evaluate.mismatches = 0
     evaluate.spmd = True
+    evaluate.group = group
     return evaluate
+
+
+def broadcast_seed(rng, group=None, src=0):
+    """SPMD runs: every rank must draw the SAME initial design, candidate grids and posterior samples.  An integer seed
+    or a RandomState the caller seeded identically on every rank passes through; `None` (OS entropy: a different
+    stream per rank) is replaced by one seed drawn on rank `src` and broadcast."""
+    dist = _dist()
+    if rng is not None or dist is None or dist.get_world_size(group) == 1:
+        return rng
+    box = [int(np.random.RandomState().randint(0, 2 ** 31 - 1))] if dist.get_rank(group) == src else [None]
+    dist.broadcast_object_list(box, src=src, group=group)
+    return box[0]

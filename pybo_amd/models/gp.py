@@ -121,6 +121,8 @@ class RFFSampleDevice(object):
 
     def topk(self, xgrid, k):
         eng = self._eng()
+        if isinstance(xgrid, DeviceGrid) and int(xgrid.device) != int(eng.device):
+            xgrid = np.asarray(xgrid)                # resident on ANOTHER GPU: its pointer means nothing here
         if isinstance(xgrid, DeviceGrid):            # grid already resident in HBM
             tv, ti = eng.rff_sweep_dev(self.W[None], self.b[None], self.theta[None], self.bias,
                                        xgrid.ptr, len(xgrid), int(k))
@@ -418,6 +420,8 @@ class GP(object):
     def acq_topk(self, kind, param, xgrid, k):
         """Whole-grid acquisition + top-k on the device: (values (k,), grid indices (k,)).  `xgrid` is a
         host array (uploaded) or a `DeviceGrid` (already in HBM)."""
+        if isinstance(xgrid, DeviceGrid) and int(xgrid.device) != int(self._engine().device):
+            xgrid = np.asarray(xgrid)                # resident on ANOTHER GPU: through the host, never its pointer
         if isinstance(xgrid, DeviceGrid):
             # Warm BO step: a grid resident in HBM that this device state has swept before is only RE-SCORED --
             # the per-candidate sums were kept current by every add_data since (gpx_append's rank-1 correction),

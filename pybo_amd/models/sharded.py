@@ -54,11 +54,16 @@ def _run(jobs):
     return out
 
 
-def _sharded_topk(calls, grid, k):
-    """calls[p](sub_grid, k) -> (values, local indices) on shard p of `grid`; returns the merged global top-k."""
+def _sharded_topk(calls, grid, k, devices=None):
+    """calls[p](sub_grid, k) -> (values, local indices) on shard p of `grid`; returns the merged global top-k.
+    `devices[p]`: the GPU replica p computes on.  A ShardedDeviceGrid is used in place only when shard p LIVES on
+    devices[p] (a grid built for [0, 1] under a model on [1, 0] or [2, 3] would hand a replica a pointer into another
+    GPU's memory); any other layout goes through the host."""
     P = len(calls)
     M = len(grid)
-    if isinstance(grid, ShardedDeviceGrid) and len(grid.shards) == P:
+    in_place = isinstance(grid, ShardedDeviceGrid) and len(grid.shards) == P and devices is not None and \
+        all(g is None or int(g.device) == int(dv) for (_, _, g), dv in zip(grid.shards, devices))
+    if in_place:
         parts = [(lo, hi, g) for lo, hi, g in grid.shards]
     else:
         if isinstance(grid, (DeviceGrid, ShardedDeviceGrid)):
@@ -81,14 +86,15 @@ def _sharded_topk(calls, grid, k):
 class ShardedRFFSample(object):
     """One Thompson draw (pybo/policies/simple.py:48) evaluated by every replica on its shard of the grid."""
 
-    def __init__(self, samples):
+    def __init__(self, samples, devices=None):
         self._samples = samples
+        self._devices = devices
 
     def get(self, X, grad=False):
         return self._samples[0].get(X, grad)
 
     def topk(self, xgrid, k):
-        return _sharded_topk([s.topk for s in self._samples], xgrid, k)
+        return _sharded_topk([s.topk for s in self._samples], xgrid, k, self._devices)
 
     __call__ = get
 
@@ -212,7 +218,8 @@ class ShardedGP(object):
         """The solver's grid stage (pybo/solvers/lbfgs.py:50-51) over all devices: replica p sweeps shard p of the grid
         (a `ShardedDeviceGrid` built for the same device list is already laid out that way and stays in HBM; a host
         grid is sliced and uploaded per shard), the P x k (value, global index) pairs are merged on the host."""
-        return _sharded_topk([lambda g, kk, r=r: r.acq_topk(kind, param, g, kk) for r in self._reps], xgrid, k)
+        return _sharded_topk([lambda g, kk, r=r: r.acq_topk(kind, param, g, kk) for r in self._reps], xgrid, k,
+                             self.devices)
 
     def sample_f(self, n, rng=None):
         """ONE posterior function sample (the host draws and the weight posterior come from replica 0), evaluated by
@@ -221,4 +228,4 @@ class ShardedGP(object):
         rest = [RFFSampleDevice(r, first.W, first.b, first.theta) for r in self._reps[1:]]
         for s in rest:
             s.bias = first.bias
-        return ShardedRFFSample([first] + rest)
+        return ShardedRFFSample([first] + rest, self.devices)

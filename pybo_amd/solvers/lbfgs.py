@@ -103,13 +103,15 @@ def _refine_lockstep(f, seeds, bounds):
 
 
 def solve_lbfgs(f, bounds, nbest=10, ngrid=10000, xgrid=None, rng=None, select='first', batched=True,
-                shard='auto'):
+                shard=False):
     """Maximise f over the box; returns (xmax, fmax).
 
-    shard: 'auto' (default) -- when the process runs as one rank of an initialised torch.distributed group and the
-    index has a device `.topk`, the grid stage is sharded over the ranks (pybo_amd.dist.ShardedIndex: contiguous
-    slices, one all-gather of the (value, index) pairs, identical merged seeds on every rank); True forces it,
-    False keeps the whole grid on this rank.  Selectable through the plugin API: solver=('lbfgs', {'shard': ...})."""
+    shard: False (default) -- the whole grid is swept by this process, whatever torch.distributed state it lives in (a
+    process that merely has a process group initialised is never pulled into a collective).  True, or 'auto' (= True
+    when the default group has more than one rank): the grid stage is sharded over the ranks (pybo_amd.dist.ShardedIndex:
+    contiguous slices, one all-gather of the (value, index) pairs, identical merged seeds on every rank) -- EVERY rank
+    must then make the same call.  solve_bayesopt(..., spmd=True) wraps the index itself; here the switch is for callers
+    of the solver: solver=('lbfgs', {'shard': True})."""
     bounds = np.array(bounds, dtype=float, ndmin=2)
     topk = getattr(f, 'topk', None)
     if shard not in ('auto', True, False):

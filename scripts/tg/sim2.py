@@ -2,8 +2,10 @@
 Design aid for kernels_chol_tg.hip (not product code).  Costs in microseconds."""
 import heapq, argparse
 
+LAZY = [0.0, 0]
 def boundaries(I, D, minfirst):
-    b = sorted({I - d for d in D if I - d > 0} | {0, I})
+    lim = max(LAZY[1], LAZY[0] * I) if LAZY[0] > 0 else 1e9
+    b = sorted({I - d for d in D if I - d > 0 and d <= lim} | {0, I})
     # drop a short first chunk (merge into the next one)
     while len(b) > 2 and b[1] - b[0] < minfirst:
         del b[1]
@@ -86,7 +88,7 @@ class Sim:
 
     def start(s, qn, i):
         t = s.q[qn][i]; c = s.c
-        if t[0] == 'trsm': dur = c['trsm']
+        if t[0] == 'trsm': dur = c['trsm'] if qn == 'c' else c['trsm_w']
         elif t[0] == 'updq': dur = c['updq']
         else:
             _, I, J, k1 = t
@@ -94,8 +96,7 @@ class Sim:
             assert K > 0
             fast = qn != 'c' and qn <= c['fast_levels']
             u = 1.0 - s.idle / s.nw
-            base = c['kblk'] / 2
-            dur = c['ovh'] + base * (1 + (c['share_u'] if fast else 1.0) * u) * K
+            dur = c['ovh'] + c['kalone'] * (1 + (c['share_u'] if fast else c['share']) * u) * K
             s.work += c['kblk'] * K
             s.traffic += 0.262 + 0.262 * K      # MB: S tile r+w, two operand panels
         heapq.heappush(s.ev, (s.t + dur + c['hop'], s.n, t, qn)); s.n += 1
@@ -161,11 +162,20 @@ if __name__ == '__main__':
     ap.add_argument('--potrf', type=float, default=30)
     ap.add_argument('--hop', type=float, default=2.5)
     ap.add_argument('--kblk', type=float, default=32)
+    ap.add_argument('--kalone', type=float, default=21)
+    ap.add_argument('--share', type=float, default=0.5)
+    ap.add_argument('--ovh', type=float, default=6)
+    ap.add_argument('--trsm', type=float, default=18)
+    ap.add_argument('--trsm_w', type=float, default=22)
+    ap.add_argument('--updq', type=float, default=10)
     ap.add_argument('--share_u', type=float, default=0.25)
     ap.add_argument('--reserve', default='')
     ap.add_argument('--trace', type=int, default=0)
+    ap.add_argument('--lazy', type=float, default=0)
+    ap.add_argument('--lazymin', type=int, default=4)
     a = ap.parse_args()
-    c = dict(potrf=a.potrf, hop=a.hop, trsm=5, updq=5, ovh=4, kblk=a.kblk, share_u=a.share_u, fast_levels=a.fast)
+    LAZY[0] = a.lazy; LAZY[1] = a.lazymin
+    c = dict(potrf=a.potrf, hop=a.hop, trsm=a.trsm, trsm_w=a.trsm_w, updq=a.updq, ovh=a.ovh, kalone=a.kalone, share=a.share, kblk=a.kblk, share_u=a.share_u, fast_levels=a.fast)
     D = parse_D(a.chunks, a.nP)
     lv = [int(x) for x in a.levels.split(',')]
     res = [int(x) for x in a.reserve.split(',')] if a.reserve else None

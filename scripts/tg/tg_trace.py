@@ -31,7 +31,7 @@ for p in rows:
     ts = crit[p]
     print('p=%3d potrf %6.1f..%6.1f (%.1f)  trsm start +%.1f/+%.1f end +%.1f/+%.1f  updq start +%s end +%s  next potrf start +%.1f' % (
         p, diag[p, 1], diag[p, 2], diag[p, 2] - diag[p, 1], ts[0, 0] - e0, ts[1, 0] - e0, ts[0, 1] - e0, ts[1, 1] - e0,
-        '/'.join('%.1f' % (v - e0) for v in ts[2:, 0]), '/'.join('%.1f' % (v - e0) for v in ts[2:, 1]), diag[p + 1, 1] - e0))
+        '%.1f..%.1f' % (np.nanmin(ts[2:, 0]) - e0, np.nanmax(ts[2:, 0]) - e0), '%.1f..%.1f' % (np.nanmin(ts[2:, 1]) - e0, np.nanmax(ts[2:, 1]) - e0), diag[p + 1, 1] - e0))
 prof = e.last_chol_profile
 w = prof[prof[:, 6] == 2]
 if len(w):

@@ -190,3 +190,29 @@ def test_bench_self_launch_builds_the_driver_shaped_command(monkeypatch):
     assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in cmd and cmd[cmd.index('--nproc-per-node') + 1] == '4'
     assert '--master-addr' in cmd and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
     assert cmd[-4:] == ['--gpus', '4', '--steps', '2'] and cmd[-5].endswith('bench.py')
+
+
+def test_trace_rows_mirror_follows_every_list_mutation():
+    """_Rows mirrored only append / extend; np.array(trace.x) -- what the policies and recommenders
+    read (pybo/policies/simple.py:20, pybo/recommenders.py:22) -- must follow the other list mutators as well."""
+    import pickle
+    from pybo_amd.bayesopt import _Rows
+    r = _Rows([[1., 2.], [3., 4.], [5., 6.]])
+    r.pop(0)
+    np.testing.assert_array_equal(np.array(r), [[3, 4], [5, 6]])
+    r.insert(0, [9., 9.])
+    r[1] = [0., 0.]
+    np.testing.assert_array_equal(np.array(r), [[9, 9], [0, 0], [5, 6]])
+    r += [[7., 7.]]
+    assert isinstance(r, _Rows) and np.array(r).shape == (4, 2)
+    del r[0]
+    r.reverse()
+    np.testing.assert_array_equal(np.array(r), [[7, 7], [5, 6], [0, 0]])
+    r.sort(key=lambda v: v[0])
+    np.testing.assert_array_equal(np.array(r)[:, 0], [0, 5, 7])
+    np.testing.assert_array_equal(np.array(pickle.loads(pickle.dumps(r))), np.array(r))
+    r.remove(r[0])
+    r.clear()
+    assert len(r) == 0 and np.array(r).size == 0
+    r.append([1., 1.])
+    assert np.array(r).shape == (1, 2)

@@ -64,8 +64,10 @@ class Replay(object):
                 if typ == UPD:
                     self.blk(self.S, I, J)[...] -= D
                 else:
-                    r = slice(h, nb) if aux == 2 else slice(0, h)
-                    c = slice(0, h) if aux == 0 else slice(h, nb)
+                    qd, half, h2 = aux >> 1, aux & 1, h // 2
+                    r = slice(h, nb) if qd == 2 else slice(0, h)
+                    c0 = (0 if qd == 0 else h) + h2 * half
+                    c = slice(c0, c0 + h2)
                     self.blk(self.S, I, I)[r, c] -= D[r, c]
 
     def finish(self, t):
@@ -78,11 +80,11 @@ class Replay(object):
             self.seq[I, J] = ordn + 1
         else:
             self.quad[I] += 1
-            if self.quad[I] == 3:
+            if self.quad[I] == 6:
                 self.applied[I, I] = k1
 
     def potrf(self, p):
-        assert self.applied[p, p] == p or (p > 0 and self.quad[p] == 3)
+        assert self.applied[p, p] == p or (p > 0 and self.quad[p] == 6)
         if self.nb:
             D = self.blk(self.S, p, p)
             D = np.triu(D) + np.triu(D, 1).T
@@ -102,7 +104,7 @@ class Replay(object):
                     if self.head[qi] < len(self.q[qi]) and self.ready(self.q[qi][self.head[qi]]):
                         moves.append(('take', qi))
                 p = self.next_potrf
-                if p < self.nP and not any(t[0] == 'potrf' for t in inflight) and (p == 0 or self.quad[p] == 3):
+                if p < self.nP and not any(t[0] == 'potrf' for t in inflight) and (p == 0 or self.quad[p] == 6):
                     moves.append(('potrf', p))
             for i in range(len(inflight)):
                 moves.append(('finish', i))
@@ -135,7 +137,7 @@ class Replay(object):
 def test_lists_complete_in_order_without_deadlock(nP, chunks, split):
     q = _lib.chol_tasks(nP, chunks, split)
     n_upd_tiles = nP * (nP + 1) // 2
-    assert len(q[0]) == 5 * (nP - 1)
+    assert len(q[0]) == 8 * (nP - 1)
     assert sum(int((a[:, 0] == TRSM).sum()) for a in q) == nP * (nP - 1)       # two halves per off-diagonal tile
     for seed in range(3):
         Replay(nP, q, seed=seed).run(max_inflight=1 + 3 * seed)
@@ -163,9 +165,13 @@ def test_chunks_are_graded_towards_the_pivot():
         sizes = (mine[:, 4] - mine[:, 3])[np.argsort(mine[:, 3])]
         assert sizes[-1] == 1 and sizes.sum() == I
         assert np.all(np.diff(sizes[1:]) <= 0)              # (the first chunk absorbs a short remainder)
-    assert np.all(q[1][q[1][:, 0] == UPD][:, 7] == 1) and np.all(q[2][:, 7] == 0)
-    far_sizes = q[2][:, 4] - q[2][:, 3]
+    assert len(q[2]) == 0                                    # default: ONE worker queue in generation order
+    q2 = _lib.chol_tasks(nP, 1124, 0)                        # two queues: the final chunks (and the solves) first
+    assert np.all(q2[1][q2[1][:, 0] == UPD][:, 7] == 1) and np.all(q2[2][:, 7] == 0)
+    far_sizes = q2[2][:, 4] - q2[2][:, 3]
     assert far_sizes.max() <= 5 and far_sizes.min() >= 1
+    off = q2[1][(q2[1][:, 0] == UPD) & (q2[1][:, 2] > q2[1][:, 1])]      # (every chunk of a DIAGONAL tile is urgent)
+    assert np.all(off[:, 1] == off[:, 4])                                # off the diagonal: final chunks only
 
 
 def test_bad_arguments():

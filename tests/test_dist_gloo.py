@@ -159,7 +159,7 @@ def test_device_exchange_branch_checks_its_preconditions():
 
 
 # ---- SPMD runs of the whole loop: the objective is evaluated ONCE per iteration (pybo/bayesopt.py:268) -------------
-def _spmd_worker(rank, world, port, q):
+def _spmd_worker(rank, world, port, q, mode):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -176,29 +176,86 @@ def _spmd_worker(rank, world, port, q):
             return float(-np.sum((np.ravel(x) - 0.3) ** 2) + 0.3 * noise.randn())
 
         bounds = [[0.0, 1.0], [0.0, 1.0]]
-        xbest, model, info = pybo_amd.solve_bayesopt(objective, bounds, model=SmootherModel(), niter=5, policy='ei',
-                                                     solver=('lbfgs', {'ngrid': 200}), recommender='incumbent', rng=3)
+        kw = dict(model=SmootherModel(), niter=5, policy='ei', solver=('lbfgs', {'ngrid': 200}), recommender='incumbent')
+        if mode == 'seeded':
+            kw.update(rng=3, spmd=True)
+        elif mode == 'unseeded':          # rng=None: OS entropy per rank unless the loop broadcasts one seed
+            kw.update(rng=None, spmd=True)
+        else:                             # 'independent': a process group exists, the loop was NOT asked to use it
+            kw.update(rng=10 + rank)
+        xbest, model, info = pybo_amd.solve_bayesopt(objective, bounds, **kw)
         q.put((rank, len(calls), info.x, info.y, model.X, model.Y, xbest))
     finally:
         dist.destroy_process_group()
 
 
-def test_world2_spmd_loop_evaluates_the_objective_on_one_rank_and_keeps_the_models_equal():
-    world = 2
+def _run_spmd(mode, world=2):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_spmd_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_spmd_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict((g[0], g[1:]) for g in (q.get(timeout=300) for _ in range(world)))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    return got
+
+
+@pytest.mark.parametrize('mode', ['seeded', 'unseeded'])
+def test_world2_spmd_loop_evaluates_the_objective_on_one_rank_and_keeps_the_models_equal(mode):
+    """with rng=None every rank used to draw its own grids (OS entropy), refine different seeds and
+    absorb (its own x, rank 0's y).  Now the seed is broadcast once and the pair (x, y) rank 0 evaluated is what every
+    rank absorbs."""
+    got = _run_spmd(mode)
     assert got[0][0] == 6 and got[1][0] == 0            # box centre + 5 iterations, all on rank 0
     for a, b in zip(got[0][1:], got[1][1:]):            # traces, model data and recommendation: bitwise equal
         np.testing.assert_array_equal(a, b)
     assert len(got[0][2]) == 6
+
+
+def test_a_process_group_alone_does_not_make_the_loop_collective():
+    """SPMD is opt-in.  Two ranks with an initialised group and DIFFERENT seeds run two
+    independent optimisations: each evaluates its own objective, nothing is exchanged, nothing hangs."""
+    got = _run_spmd('independent')
+    assert got[0][0] == 6 and got[1][0] == 6
+    assert not np.array_equal(got[0][1], got[1][1])
+
+
+def test_spmd_objective_broadcasts_the_query_point():
+    """The wrapper's exchange() returns rank 0's (x, y) on every rank and counts ranks that asked about another point."""
+    got = _run_pairs()
+    assert got[0] == (0, [0.25, 0.5], 7.0) and got[1] == (1, [0.25, 0.5], 7.0)
+
+
+def _pair_worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        f = pdist.spmd_objective(lambda x: 7.0)
+        x, y = f.exchange(np.array([0.25, 0.5]) + rank)      # rank 1 proposes another point
+        assert pdist.broadcast_seed(5) == 5
+        seed = pdist.broadcast_seed(None)
+        q.put((rank, (f.mismatches, list(map(float, x)), float(y), int(seed))))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_pairs(world=2):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pair_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got[0][3] == got[1][3]                        # one seed for everybody
+    return {r: (got[r][0], got[r][1], got[r][2]) for r in got}
 
 
 def test_spmd_objective_is_the_identity_without_a_process_group():

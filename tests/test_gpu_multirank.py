@@ -206,14 +206,14 @@ def _spmd_loop(rank):
 
     grid = inits.init_sobol_device(bounds, 40000, rng=9)          # every rank holds the grid, sweeps its view of it
     xbest, fitted, info = pybo_amd.solve_bayesopt(objective, bounds, model=model, niter=5, policy='ei',
-                                                  solver=('lbfgs', {'xgrid': grid}), recommender='latent', rng=1)
+                                                  solver=('lbfgs', {'xgrid': grid}), recommender='latent', rng=1, spmd=True)
     return len(calls), info.x, info.y, info.xbest, _digest(fitted._engine().get_matrix('L'))
 
 
 def test_spmd_loop_with_a_noisy_objective_keeps_every_rank_s_model_bitwise_equal():
     """VERDICT round 2, missing #2: under torch.distributed every rank ran the loop AND called objective(x) itself.
     Now rank 0 evaluates and broadcasts (pybo_amd.dist.spmd_objective, wired into solve_bayesopt), and the solver
-    shards the grid stage by itself (shard='auto'): after 5 iterations with a noisy objective the ranks hold bitwise
+    shards the grid stage (solve_bayesopt(..., spmd=True) wraps the index in dist.ShardedIndex): after 5 iterations with a noisy objective the ranks hold bitwise
     equal factors, identical traces, and the objective ran 6 times in total (box centre + 5), all on rank 0."""
     world = 2
     ctx = mp.get_context('spawn')

@@ -88,22 +88,54 @@ def test_factor_does_not_depend_on_the_schedule(N):
     and a second fit through a cached graph too."""
     X, y, ell = synth_problem(N, 4, seed=N)
     base = None
-    for opts in [{}, {'chol_w': 3}, {'chol_w': 6}, {'chol_rl': 0}, {'chol_merge': 0}, {'chol_fuse': 1},
-                 {'chol_graph': 1}, {'chol_graph': 1, 'chol_fuse': 1, 'chol_w': 2}]:
+    tg = {'chol_tg': 1, 'chol_tg_min': 2}          # the persistent task-graph kernel, also below its default size
+    for opts in [{'chol_tg': 0}, {'chol_tg': 0, 'chol_w': 3}, {'chol_tg': 0, 'chol_w': 6}, {'chol_tg': 0, 'chol_rl': 0},
+                 {'chol_tg': 0, 'chol_merge': 0}, {'chol_tg': 0, 'chol_fuse': 1},
+                 {'chol_tg': 0, 'chol_graph': 1}, {'chol_tg': 0, 'chol_graph': 1, 'chol_fuse': 1, 'chol_w': 2},
+                 tg, dict(tg, chol_tg_chunks=1124, chol_tg_split=0), dict(tg, chol_tg_chunks=14, chol_tg_split=2002),
+                 dict(tg, chol_tg_chunks=11, chol_tg_grid=40), dict(tg, chol_tg_side=2, chol_tg_isolate=0),
+                 dict(tg, chol_tg_grid=512, chol_tg_chunks=1128)]:
         e = _engine(**opts)
-        for rep in range(2 if 'chol_graph' in opts else 1):
+        for rep in range(2 if ('chol_graph' in opts or opts.get('chol_tg')) else 1):
             e.fit(X, y, 'matern5', ell, 1.3, 1e-4, 0.1, stage=2)
             L = e.get_matrix('L')
             if base is None:
                 base = L
             assert np.array_equal(L, base), (opts, rep)
         e.close()
-    # a failing pivot is reported from the fused kernel as well
+    # a failing pivot is reported from the fused kernel and from the task-graph kernel as well
     Xd = np.vstack([X[:200], X[:3]])
-    e = _engine(chol_fuse=1)
-    with pytest.raises(np.linalg.LinAlgError):
-        e.fit(Xd, np.hstack([y[:200], y[:3]]), 'se', ell, 1.0, 0.0, 0.0)
-    assert 200 <= e.fail_pivot() < 203
+    for opts in ({'chol_tg': 0, 'chol_fuse': 1}, tg):
+        e = _engine(**opts)
+        with pytest.raises(np.linalg.LinAlgError):
+            e.fit(Xd, np.hstack([y[:200], y[:3]]), 'se', ell, 1.0, 0.0, 0.0)
+        assert 200 <= e.fail_pivot() < 203
+        e.fit(X, y, 'matern5', ell, 1.3, 1e-4, 0.1, stage=2)       # the handle recovers
+        assert np.array_equal(e.get_matrix('L'), base)
+        e.close()
+
+
+def test_task_graph_factorisation_at_the_bench_sizes_and_when_it_gives_up(capfd):
+    """The persistent kernel (default from 16 blocks) against the stream schedule at N = 2048 and 8192, bit for bit, over
+    repeated fits (hand-offs between workgroups of one launch: a stale read would show as a different bit somewhere); and
+    its exit: with a spin bound no run can meet, the fit says so on stderr, re-runs on the stream schedule and returns the
+    same factor."""
+    for N in (2048, 8192):
+        X, y, ell = synth_problem(N, 5, seed=N)
+        e0 = _engine(chol_tg=0)
+        e0.fit(X, y, 'se', ell, 1.1, 1e-4, 0.0, stage=2)
+        base = e0.get_matrix('L')
+        e0.close()
+        e = _engine()
+        for rep in range(4):
+            e.fit(X, y, 'se', ell, 1.1, 1e-4, 0.0, stage=2)
+            assert np.array_equal(e.get_matrix('L'), base), (N, rep)
+        e.close()
+    capfd.readouterr()
+    e = _engine(chol_tg_tmo_ms=1, chol_tg_grid=24)      # 8192 on two dozen workgroups: milliseconds between dependencies
+    e.fit(X, y, 'se', ell, 1.1, 1e-4, 0.0, stage=2)
+    assert np.array_equal(e.get_matrix('L'), base)
+    assert 're-running the stream schedule' in capfd.readouterr().err
     e.close()
 
 
