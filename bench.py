@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X datasheet fp64 matrix (= fp64 vector) peak, dense
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILE = 'r03_pmc_traffic.json'
+PMC_TRAFFIC_FILE = 'r04_pmc_traffic.json'
 
 
 def hartmann6(X):
@@ -104,9 +104,30 @@ def ucb_beta(nobs, delta=0.1, xi=0.2):
     return xi * 2 * np.log(np.pi ** 2 / 3 / delta) + xi * (4 + nobs) * np.log(nobs + 1)
 
 
-def cpu_baseline(w, budget_candidates):
-    """Time the CPU restatement (oracle/, numpy+scipy on the host's BLAS threads) on a bounded sample:
-    the fit in full, the sweep on `budget_candidates` of the M candidates, extrapolated linearly.
+def sample_indices(nc, span):
+    """The candidates the CPU baseline is timed on: TWO disjoint runs of nc/2 candidates, at the head and at the tail
+    of the first `span` candidates (rank 0's shard) -- timed separately, so that the bench line shows how linear the
+    extrapolation to the whole grid is."""
+    half = max(nc // 2, 1)
+    a = np.arange(0, min(half, span))
+    b = np.arange(max(span - half, len(a)), span) if nc > 1 else np.arange(0)
+    return a, b
+
+
+def thompson_draw(w, s):
+    """Host draws of Thompson sample s (order fixed: randn(n, d), [chisquare], rand(n), randn(n) -- GP.sample_f)."""
+    nu = {'matern5': 2.5, 'matern3': 1.5, 'matern1': 0.5}.get(w['kernel'])
+    rng = np.random.RandomState(100 + s)
+    Wd = rng.randn(100, w['d'])
+    if nu is not None:                        # Matern spectral density = scale mixture of normals
+        Wd = Wd * np.sqrt(2.0 * nu / rng.chisquare(2.0 * nu, size=100))[:, None]
+    return Wd / w['ell'], rng.rand(100) * 2 * np.pi, rng.randn(100)
+
+
+def cpu_baseline(w, budget_candidates, span, draws):
+    """Time the CPU restatement (oracle/, numpy+scipy on the host's BLAS threads) on a bounded sample: the fit in full,
+    the sweep on `budget_candidates` of the M candidates in two disjoint halves (sample_indices), extrapolated linearly.
+    Thompson workloads: every one of the step's `draws` posterior samples (sample_f + its values on the sample).
     Returns (the cpu_baseline record, the oracle's values on the sample for the parity record)."""
     from oracle import gp_ref
     threads = len(os.sched_getaffinity(0))
@@ -119,37 +140,55 @@ def cpu_baseline(w, budget_candidates):
     ref = gp_ref.make_gp(w['sn2'], w['rho'], w['ell'], w['bias'], w['kernel'])
     ref.add_data(w['X'], w['y'])
     t_fit = time.perf_counter() - t0
-    Z = w['Xc'][:budget_candidates]
-    vals = {}
-    t0 = time.perf_counter()
-    if w['acq'] in ('ei', 'ucb'):
-        mu, s2 = ref.predict(Z)
-        if w['acq'] == 'ei':                    # the arithmetic of GPRef.get_improvement on the moments just formed
-            target = ref.mean_at_obs().max()
-            s = np.sqrt(s2)
-            z = (mu - target) / s
-            v = (mu - target) * gp_ref.norm_cdf(z) + s * gp_ref.norm_pdf(z)
-            vals['target'] = float(target)
+    ia, ib = sample_indices(budget_candidates, span)
+    vals = {'index': np.concatenate([ia, ib])}
+    parts, times, t_draws = [], [], 0.0
+    samples = None
+    if w['acq'] == 'thompson':
+        t0 = time.perf_counter()
+        samples = [ref.sample_f(100, rng=100 + s) for s in draws]
+        t_draws = time.perf_counter() - t0
+    for idx in (ia, ib):
+        if len(idx) == 0:
+            continue
+        Z = w['Xc'][idx]
+        t0 = time.perf_counter()
+        if w['acq'] in ('ei', 'ucb'):
+            mu, s2 = ref.predict(Z)
+            if w['acq'] == 'ei':                # the arithmetic of GPRef.get_improvement on the moments just formed
+                target = ref.mean_at_obs().max()
+                s = np.sqrt(s2)
+                z = (mu - target) / s
+                v = (mu - target) * gp_ref.norm_cdf(z) + s * gp_ref.norm_pdf(z)
+                vals['target'] = float(target)
+            else:
+                v = mu + np.sqrt(ucb_beta(w['N']) * s2)
+            parts.append(dict(mu=mu, s2=s2, acq=v))
         else:
-            v = mu + np.sqrt(ucb_beta(w['N']) * s2)
-        vals.update(mu=mu, s2=s2)
-    else:
-        smp = ref.sample_f(100, rng=100)
-        v = smp.get(Z)
-    vals.update(acq=v, best=int(np.argmax(v)))
-    t_sw = time.perf_counter() - t0
-    step = t_fit + t_sw * (w['M'] / float(len(Z)))
-    how = 'in full' if len(Z) == w['M'] else 'extrapolated linearly to M'
+            parts.append(dict(acq=np.array([smp.get(Z) for smp in samples])))       # (draws, len(Z))
+        times.append(time.perf_counter() - t0)
+    for key in parts[0]:
+        vals[key] = np.concatenate([p_[key] for p_ in parts], axis=-1)
+    vals['best'] = np.argmax(vals['acq'], axis=-1)
+    nsamp = len(vals['index'])
+    t_sw = float(sum(times))
+    step = t_fit + t_draws + t_sw * (w['M'] / float(nsamp))
+    how = 'in full' if nsamp == w['M'] else 'extrapolated linearly to M'
+    per_cand = [t / max(len(i), 1) for t, i in zip(times, (ia, ib))]
+    spread = (max(per_cand) - min(per_cand)) / (sum(per_cand) / len(per_cand)) if len(per_cand) > 1 else 0.0
     rec = dict(value=1.0 / step, unit='steps/s', cores=int(threads), kind='port',
-               sample='fit in full (N=%d: %.2f s) + sweep on %d of %d candidates (%.2f s), sweep %s; '
+               sample='fit in full (N=%d: %.2f s)%s + sweep on %d of %d candidates in two disjoint runs (%s s), sweep %s; '
                       'numpy/scipy on %d BLAS threads; host has %d logical cpus, %d in affinity'
-                      % (w['N'], t_fit, len(Z), w['M'], t_sw, how, threads, os.cpu_count(),
+                      % (w['N'], t_fit, (' + %d posterior samples (%.2f s)' % (len(draws), t_draws)) if samples else '',
+                         nsamp, w['M'], ' + '.join('%.2f' % t for t in times), how, threads, os.cpu_count(),
                          len(os.sched_getaffinity(0))),
-               extrapolated=len(Z) != w['M'], seconds_per_step=step)
+               sample_frac=nsamp / float(w['M']), sample_candidates=int(nsamp),
+               seconds_per_candidate_run=[float(v) for v in per_cand], linearity_spread=float(spread),
+               extrapolated=nsamp != w['M'], seconds_per_step=step)
     return rec, vals
 
 
-def cpu_baseline_unpinned(workload, M, nc):
+def cpu_baseline_unpinned(workload, M, nc, span, draws):
     """torch.distributed.run pins OMP_NUM_THREADS=1 in every rank of a multi-rank launch, and a BLAS that was
     initialised with one thread cannot safely be widened afterwards: rank 0 therefore times the baseline in a child
     process of its own with the pin removed (the other ranks wait in the closing barrier), and reads the record and
@@ -163,7 +202,8 @@ def cpu_baseline_unpinned(workload, M, nc):
     with tempfile.TemporaryDirectory() as tmp:
         path = os.path.join(tmp, 'cpu.pkl')
         subprocess.check_call([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', path, '--workload',
-                               workload, '--candidates', str(M), '--cpu-candidates', str(nc)], env=env,
+                               workload, '--candidates', str(M), '--cpu-candidates', str(nc), '--cpu-span', str(span),
+                               '--cpu-draws', ','.join(str(v) for v in draws)], env=env,
                               stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL)
         with open(path, 'rb') as fh:
             return pickle.load(fh)
@@ -184,11 +224,26 @@ def parity_record(w, ref_vals, dev_vals):
             np.all(np.abs(dev_vals['mu'] - mr) <= 1e-6 * np.abs(mr) + 1e-9 * np.sqrt(rho)) and
             np.all(np.abs(dev_vals['s2'] - sr) <= 1e-6 * sr + 1e-10 * rho))
     ar, ad = ref_vals['acq'], dev_vals['acq']
+    if ar.ndim == 2:
+        # Thompson: every local draw; f = bias + (random-feature term): the error is measured against the TERM (size
+        # ~0.1 sqrt(rho)), not against |bias| -- a 1e-16 relative to a bias of 10 says nothing about a term of 0.2
+        term = ar - w['bias']
+        scale = np.sqrt(np.mean(term ** 2, axis=1, keepdims=True))
+        out['draws_compared'] = int(ar.shape[0])
+        out['max_rel_acq'] = float(np.max(np.abs(ad - ar) / (np.abs(term) + 1e-3 * scale)))
+        out['max_abs_err_over_rms_term'] = float(np.max(np.abs(ad - ar) / scale))
+        out['rms_term'] = float(np.sqrt(np.mean(term ** 2)))
+        out['n_acq_compared'] = int(ar.size)
+        bd = np.argmax(ad, axis=1)
+        out['selected_index_matches'] = bool(np.all(bd == ref_vals['best']))
+        out['selected_index'] = {'oracle': [int(v) for v in ref_vals['best'][:8]], 'device': [int(v) for v in bd[:8]],
+                                 'draws_agreeing': int(np.sum(bd == ref_vals['best']))}
+        return out
     live = np.abs(ar) > 1e-9 * np.max(np.abs(ar))
     out['max_rel_acq'] = float(np.max(np.abs(ad[live] - ar[live]) / np.abs(ar[live])))
     out['n_acq_compared'] = int(live.sum())
-    out['selected_index_matches'] = bool(int(np.argmax(ad)) == ref_vals['best'])
-    out['selected_index'] = {'oracle': ref_vals['best'], 'device': int(np.argmax(ad))}
+    out['selected_index_matches'] = bool(int(np.argmax(ad)) == int(ref_vals['best']))
+    out['selected_index'] = {'oracle': int(ref_vals['best']), 'device': int(np.argmax(ad))}
     if 'target' in ref_vals:
         out['abs_err_target'] = float(abs(dev_vals['target'] - ref_vals['target']))
     return out
@@ -281,6 +336,82 @@ def self_launch(ngpus):
     return subprocess.call(cmd, env=env, stdin=subprocess.DEVNULL)
 
 
+def main_sharded(args):
+    """`--mode sharded`: ONE process drives --gpus devices through pybo_amd.models.ShardedGP (one gpx handle per device,
+    host threads) and a ShardedDeviceGrid -- the multi-GPU drop-in under solve_bayesopt() (the objective is evaluated once,
+    in this process; no torch.distributed, no RCCL: the exchange is a host merge of P x k pairs).  Same step as the SPMD
+    mode: every replica refits (replicated, bitwise equal), sweeps its shard of the grid, top-k merged."""
+    import torch
+    from pybo_amd import models
+    from pybo_amd.models import sharded as msh
+    from pybo_amd._lib import ShardedDeviceGrid
+    P = args.gpus
+    ndev = torch.cuda.device_count()
+    if args.share_device < 0 and P > ndev:
+        sys.stderr.write('bench.py: FATAL: --mode sharded --gpus %d but only %d GPU(s) visible\n' % (P, ndev))
+        raise SystemExit(3)
+    devices = list(range(P)) if args.share_device < 0 else [args.share_device] * P
+    w = make_workload(args.workload, args.candidates)
+    if w['acq'] == 'thompson':
+        raise SystemExit('--mode sharded times the EI / UCB workloads (ns, b, c); the Thompson workloads shard DRAWS, '
+                         'which the SPMD mode measures')
+    N, d, M, k = w['N'], w['d'], w['M'], args.topk
+    bounds = np.stack([w['lo'], w['hi']], axis=1)
+    gp = models.make_gp(w['sn2'], w['rho'], w['ell'], w['bias'], kernel=w['kernel'], devices=devices)
+    gp.add_data(w['X'], w['y'])
+    grid = ShardedDeviceGrid('sobol', bounds, M, devices)      # the points of w['Xc'], laid out over the devices
+    for r in gp.replicas:
+        for kv in args.opt:
+            name, val = kv.split('=')
+            r._engine().set_option(name, int(val))
+
+    def step():
+        def refit(r):
+            r._fitted = False
+            return r._engine()
+        msh._run([lambda r=r: refit(r) for r in gp.replicas])
+        param = float(np.max(gp.posterior_mean_at_data())) if w['acq'] == 'ei' else ucb_beta(N)
+        return gp.acq_topk(w['acq'], param, grid, k)
+
+    def sync():
+        for r in gp.replicas:
+            r._engine().sync()
+    for _ in range(args.warmup):
+        best = step()
+    for r in gp.replicas:
+        r._engine().timers(reset=True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        best = step()
+    sync()
+    sec = (time.perf_counter() - t0) / args.steps
+    tms = [r._engine().timers(reset=True) for r in gp.replicas]
+    stages = ('gram', 'cholesky', 'trtri', 'alpha', 'cross_gram', 'sweep_trmm', 'acq_topk')
+    per = {kk: {'min': min(t[kk] for t in tms) / args.steps, 'mean': float(np.mean([t[kk] for t in tms])) / args.steps,
+                'max': max(t[kk] for t in tms) / args.steps} for kk in stages if tms[0][kk] > 0}
+    tm = tms[0]
+    ach = tm['sweep_trmm_flop'] / (tm['sweep_trmm'] * 1e-3) / 1e12
+    out = {'metric': 'BO-step wall-clock (GP fit + 1e6-candidate acq sweep) at N obs; steps/sec',
+           'value': 1.0 / sec, 'unit': 'steps/s', 'n_gpus': P, 'steps': args.steps, 'warmup': args.warmup,
+           'ms_per_step': sec * 1e3, 'seconds_per_step': sec, 'higher_is_better': True, 'scaling': 'strong',
+           'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic', 'mode': 'sharded',
+           'config': {'workload': w['desc'], 'N': N, 'd': d, 'candidates': M, 'kernel': w['kernel'], 'acquisition': w['acq'],
+                      'topk': k, 'devices': devices,
+                      'parallelism': 'ONE process, %d device handles (pybo_amd.models.ShardedGP): fit replicated, grid resident '
+                                     'and sharded contiguously (ShardedDeviceGrid), host merge of the top-k' % P},
+           'selected': {'index': int(best[1][0]), 'value': float(best[0][0])},
+           'stage_ms_per_step_all_replicas': per,
+           'roofline': {'kernel': 'k_sweep_trmm', 'bound': 'mfma', 'achieved': ach, 'peak': FP64_MFMA_PEAK_TFLOPS,
+                        'unit': 'TFLOP/s', 'frac': ach / FP64_MFMA_PEAK_TFLOPS, 'traffic': None,
+                        'launches': int(tm['sweep_trmm_launches']), 'of': 'replica 0'}}
+    if not args.no_cpu_baseline:
+        span = M // P
+        nc = min(args.cpu_candidates or (M if N <= 2048 else (1 << 17)), span)
+        out['cpu_baseline'], _ = cpu_baseline(w, nc, span, [])
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -314,15 +445,25 @@ def main():
                     help='also time this many iterations of pybo_amd.solve_bayesopt THROUGH THE PLUGIN API at the '
                          'workload size (cold + warm; reported separately as plugin_step); 0 = skip')
     ap.add_argument('--cpu-baseline-worker', default='', help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-span', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-draws', default='', help=argparse.SUPPRESS)
+    ap.add_argument('--mode', default='spmd', choices=['spmd', 'sharded'],
+                    help="spmd (default): one process per GPU under torch.distributed, RCCL all-gather of the top-k; "
+                         "sharded: ONE process drives --gpus devices through pybo_amd.models.ShardedGP + "
+                         "ShardedDeviceGrid -- the drop-in under solve_bayesopt(), no process group")
+    ap.add_argument('--init-timeout', type=int, default=180, help='seconds to wait for the process group / RCCL to come up')
     args = ap.parse_args()
 
     if args.cpu_baseline_worker:                      # child of cpu_baseline_unpinned: no GPU, no process group
         import pickle
-        res = cpu_baseline(make_workload(args.workload, args.candidates), args.cpu_candidates)
+        res = cpu_baseline(make_workload(args.workload, args.candidates), args.cpu_candidates, args.cpu_span,
+                           [int(v) for v in args.cpu_draws.split(',') if v != ''])
         with open(args.cpu_baseline_worker, 'wb') as fh:
             pickle.dump(res, fh)
         return
 
+    if args.mode == 'sharded':
+        return main_sharded(args)
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         # invoked as `python bench.py --gpus N`: start the N ranks ourselves
         raise SystemExit(self_launch(args.gpus))
@@ -336,26 +477,58 @@ def main():
                          % (args.gpus, world, args.gpus))
     if args.share_device >= 0:
         local = args.share_device
+    ndev = torch.cuda.device_count()
+    if args.share_device < 0 and world > ndev:
+        # one rank per GPU is the layout: more ranks than visible devices would put two ranks on one GPU and RCCL refuses
+        # that ("invalid usage") only after a long rendezvous -- fail at once, and loudly
+        sys.stderr.write('bench.py: FATAL: WORLD_SIZE=%d but only %d GPU(s) visible to rank %d\n' % (world, ndev, rank))
+        raise SystemExit(3)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
+    rccl_info = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
-        if args.backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)      # = RCCL over xGMI on MI355X
-        else:
-            # the gloo transport announces its connections on STDOUT ("[Gloo] Rank 0 is connected to ..."); the contract
-            # is ONE JSON line there, so fd 1 points at stderr while the group comes up
-            sys.stdout.flush()
-            keep = os.dup(1)
-            os.dup2(2, 1)
-            try:
-                dist.init_process_group('gloo')
-                dist.barrier()
-            finally:
+        tmo = datetime.timedelta(seconds=args.init_timeout)
+        try:
+            if args.backend == 'nccl':
+                dist.init_process_group('nccl', device_id=dev, timeout=tmo)      # = RCCL over xGMI on MI355X
+            else:
+                # the gloo transport announces its connections on STDOUT ("[Gloo] Rank 0 is connected to ..."); the contract
+                # is ONE JSON line there, so fd 1 points at stderr while the group comes up
                 sys.stdout.flush()
-                os.dup2(keep, 1)
-                os.close(keep)
+                keep = os.dup(1)
+                os.dup2(2, 1)
+                try:
+                    dist.init_process_group('gloo', timeout=tmo)
+                    dist.barrier()
+                finally:
+                    sys.stdout.flush()
+                    os.dup2(keep, 1)
+                    os.close(keep)
+            # prove the communicator with one all-reduce before anything is timed: every rank contributes its rank + 1
+            probe = torch.tensor([float(rank + 1)], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
+            t0p = time.perf_counter()
+            dist.all_reduce(probe)
+            if args.backend == 'nccl':
+                torch.cuda.synchronize(dev)
+            first_ms = (time.perf_counter() - t0p) * 1e3
+            if abs(float(probe.item()) - world * (world + 1) / 2.0) > 1e-9:
+                raise RuntimeError('all-reduce over %d ranks returned %r' % (world, float(probe.item())))
+            ver = None
+            if args.backend == 'nccl':
+                try:
+                    ver = '.'.join(str(v) for v in torch.cuda.nccl.version())
+                except Exception:
+                    ver = None
+            rccl_info = {'backend': args.backend, 'ranks': world, 'devices_visible': ndev, 'rccl_version': ver,
+                         'first_allreduce_ms': first_ms, 'init_timeout_s': args.init_timeout}
+        except BaseException as exc:      # noqa: NEVER fall back to another backend on our own: say what failed, exit non-zero
+            sys.stderr.write('bench.py: FATAL: rank %d could not bring up the %s process group over %d ranks: %r\n'
+                             % (rank, args.backend, world, exc))
+            sys.stderr.flush()
+            os._exit(4)
 
     from pybo_amd._lib import Engine
     from pybo_amd import dist as pdist
@@ -387,21 +560,20 @@ def main():
     if w['acq'] == 'thompson':
         S = args.draws or (8 if w['name'] == 'e' else 64)
         mine = [s for s in range(S) if s % world == rank]      # draws are the sharded unit here
-        nu = {'matern5': 2.5, 'matern3': 1.5, 'matern1': 0.5}.get(w['kernel'])
+
+    split = {'local': [], 'exchange': []}      # per step, this rank: seconds before / inside the exchange
 
     def step():
+        t_a = time.perf_counter()
         eng.fit_dev(dX.data_ptr(), N, d, dy.data_ptr(), w['kernel'], w['ell'], w['rho'], w['sn2'], w['bias'])
         if w['acq'] == 'thompson':
             # each rank owns S/world posterior draws and sweeps ALL candidates for them
             Ws, bs, zs = [], [], []
             for s in mine:
-                rng = np.random.RandomState(100 + s)     # same draw order as GP.sample_f / the oracle
-                Wd = rng.randn(100, d)
-                if nu is not None:                        # Matern spectral density = scale mixture of normals
-                    Wd = Wd * np.sqrt(2.0 * nu / rng.chisquare(2.0 * nu, size=100))[:, None]
-                Ws.append(Wd / w['ell'])
-                bs.append(rng.rand(100) * 2 * np.pi)
-                zs.append(rng.randn(100))
+                Wd, bd_, zd_ = thompson_draw(w, s)       # same draw order as GP.sample_f / the oracle
+                Ws.append(Wd)
+                bs.append(bd_)
+                zs.append(zd_)
             Ws, bs = np.array(Ws), np.array(bs)
             sc = np.sqrt(2.0 * w['rho'] / 100)
             # feature Grams and the 100 x 100 weight posteriors of all local draws: one device call
@@ -417,17 +589,21 @@ def main():
                 param = ucb_beta(N)
             tv, ti = eng.sweep_dev(w['acq'], param, dXc.data_ptr(), Ml, k)
             ti = np.where(ti >= 0, ti + lo_i, ti)
+        t_b = time.perf_counter()                   # (the top-k came back to the host: the local work is complete)
         if world > 1:
             if w['acq'] == 'thompson':
                 # one (value, index) pair per draw, draws sharded over ranks: ONE all-gather, no merge
                 # (the q recommendations are w['Xc'][indices])
-                if comm is not None:
-                    return comm.topk_allgather(len(tv), 0, 0)
-                return pdist.gather_pairs(tv, ti)
-            if comm is not None:                     # libgpx's own RCCL binding: device -> xGMI -> device merge
-                return comm.topk_allgather(k, lo_i, k)
-            return pdist.gather_topk(tv, ti, k)      # RCCL all-gather + deterministic merge
-        return tv, ti
+                res = comm.topk_allgather(len(tv), 0, 0) if comm is not None else pdist.gather_pairs(tv, ti)
+            elif comm is not None:                   # libgpx's own RCCL binding: device -> xGMI -> device merge
+                res = comm.topk_allgather(k, lo_i, k)
+            else:
+                res = pdist.gather_topk(tv, ti, k)   # RCCL all-gather + deterministic merge
+        else:
+            res = (tv, ti)
+        split['local'].append(t_b - t_a)
+        split['exchange'].append(time.perf_counter() - t_b)     # includes the wait for the slowest rank
+        return res
 
     if w['acq'] == 'thompson':
         dXc_full = torch.from_numpy(w['Xc']).to(dev)
@@ -440,6 +616,7 @@ def main():
     for _ in range(args.warmup):
         best = step()
     eng.timers(reset=True)
+    split['local'], split['exchange'] = [], []
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -451,6 +628,17 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     tm = eng.timers(reset=True)
+    # every rank's own view of the timed region (N > 1: gathered so that ONE line tells where the time went on WHICH rank)
+    mine_rec = {'rank': rank, 'device': local, 'local_ms': 1e3 * float(np.mean(split['local'])),
+                'exchange_ms': 1e3 * float(np.mean(split['exchange'])),
+                'exchange_ms_max': 1e3 * float(np.max(split['exchange'])),
+                'stage_ms': {kk: tm[kk] / args.steps for kk in ('gram', 'cholesky', 'trtri', 'alpha', 'cross_gram',
+                                                                'sweep_trmm', 'acq_topk', 'rff', 'rff_sweep') if tm[kk] > 0},
+                'chol_fallbacks': int(tm.get('chol_fallbacks', 0))}
+    all_recs = [mine_rec]
+    if world > 1:
+        all_recs = [None] * world
+        dist.all_gather_object(all_recs, mine_rec)
 
     # ---- warm BO step (reported SEPARATELY; the headline stays the cold step above) ------------------------
     # Iteration t+1 of the loop with fixed hyper-parameters over the same resident grid: model.add_data(x, y)
@@ -558,6 +746,45 @@ def main():
                                         ('gram', 'cholesky', 'trtri', 'alpha', 'cross_gram', 'sweep_trmm',
                                          'acq_topk', 'rff') if tm[kk] > 0},
         }
+        # min / mean / max over ALL ranks, per stage (HIP events on each rank's stream) and for the two host-side spans of
+        # a step: `local` (fit + sweep + top-k back on the host) and `exchange` (the all-gather + merge, INCLUDING the wait
+        # for the slowest rank: a straggler shows up as a large exchange on the others)
+        def _mmm(vals):
+            return {'min': float(np.min(vals)), 'mean': float(np.mean(vals)), 'max': float(np.max(vals)),
+                    'argmax_rank': int(np.argmax(vals))}
+        per = {'local': _mmm([r['local_ms'] for r in all_recs]), 'exchange': _mmm([r['exchange_ms'] for r in all_recs]),
+               'exchange_worst_step': _mmm([r['exchange_ms_max'] for r in all_recs])}
+        for kk in sorted(set().union(*[set(r['stage_ms']) for r in all_recs])):
+            per[kk] = _mmm([r['stage_ms'].get(kk, 0.0) for r in all_recs])
+        out['stage_ms_per_step_all_ranks'] = per
+        out['ranks'] = [{'rank': r['rank'], 'device': r['device'], 'local_ms': r['local_ms'], 'exchange_ms': r['exchange_ms']}
+                        for r in all_recs]
+        fb = sum(r['chol_fallbacks'] for r in all_recs)
+        if fb:
+            out['chol_taskgraph_fallbacks'] = int(fb)        # fits re-run on the stream schedule (should be 0)
+        if rccl_info is not None:
+            out['collective'] = dict(rccl_info, exchange=args.exchange)
+        # what the 1-GPU stage times predict for this rank count (the replicated fit is the serial term)
+        try:
+            one = json.load(open(os.path.join(ROOT, 'profiles', 'r04_bench_%s.json' % w['name'])))
+            st1 = one['stage_ms_per_step_rank0']
+            if w['acq'] == 'thompson':
+                par = st1.get('rff', 0.0)
+                ser = sum(v for kk, v in st1.items() if kk not in ('rff',))
+                units = 'draws'
+                share = float(np.ceil((args.draws or (8 if w['name'] == 'e' else 64)) / float(world))) / \
+                    (args.draws or (8 if w['name'] == 'e' else 64))
+            else:
+                par = st1.get('cross_gram', 0.0) + st1.get('sweep_trmm', 0.0) + st1.get('acq_topk', 0.0)
+                ser = sum(v for kk, v in st1.items() if kk not in ('cross_gram', 'sweep_trmm', 'acq_topk'))
+                units = 'candidates'
+                share = 1.0 / world
+            out['scaling_model'] = {'formula': 'serial (replicated fit) + parallel (%s sharded) x share + exchange (~0.1 ms)' % units,
+                                    'from': 'profiles/r04_bench_%s.json (1 GPU)' % w['name'], 'serial_ms': ser,
+                                    'parallel_ms_1gpu': par, 'share': share, 'predicted_ms_per_step': ser + par * share + 0.1,
+                                    'measured_ms_per_step': sec * 1e3}
+        except Exception:
+            pass
         if tm['sweep_trmm'] > 0:
             launches = tm['sweep_trmm_launches']
             # HBM traffic per launch comes from the committed PMC passes (bench.py cannot collect
@@ -584,7 +811,8 @@ def main():
         # the fit's two MFMA stages against the same peak (algorithmic N^3/3 flop each), for EVERY workload:
         # the replicated fit is what bounds strong scaling
         fit = {}
-        for stage, label in (('cholesky', 'cholesky (k_potrf16 + k_panel_solve16 + k_row_update64 + k_syrk_update)'),
+        for stage, label in (('cholesky', 'cholesky (k_chol_tg: persistent task-graph kernel; below 16 blocks k_potrf16 + k_panel_solve16 + '
+                                          'k_row_update64 + k_syrk_update)'),
                              ('trtri', 'triangular inverse (k_trtri_gemm1/2)')):
             if tm[stage] > 0:
                 ach = (float(N) ** 3 / 3.0) * args.steps / (tm[stage] * 1e-3) / 1e12
@@ -593,6 +821,19 @@ def main():
                               'ms': tm[stage] / args.steps, 'flop': float(N) ** 3 / 3.0}
         if fit:
             out['roofline_fit'] = fit
+        if tm.get('rff_sweep', 0) > 0:
+            # the Thompson sweep kernel: bound by the double-precision lanes, which its matrix instructions (the projection)
+            # and its vector instructions (the cosine epilogue) SHARE: 16 lane-operations per clock per SIMD either way
+            # (v_mfma_f64_16x16x4 = 1024 FMA in 64 clocks; a 64-lane f64 VALU instruction = 4 clocks).  Algorithmic work per
+            # (draw, feature, candidate): d multiply-adds + 26 instructions of cos_cw and the weighted sum (counted in the ISA)
+            lane_peak = 256 * 4 * 16 * 2.4e9
+            ach = tm['rff_sweep_ops'] / (tm['rff_sweep'] * 1e-3)
+            out['roofline_rff'] = {'kernel': 'k_rff_mfma', 'bound': 'fp64 lanes (MFMA projection + VALU cosine share them)',
+                                   'achieved': ach / 1e12, 'peak': lane_peak / 1e12, 'unit': 'T lane-operations/s',
+                                   'frac': ach / lane_peak, 'ms': tm['rff_sweep'] / args.steps,
+                                   'lane_ops_per_step': tm['rff_sweep_ops'] / args.steps,
+                                   'work': 'draws x features x (d + 26) x candidates, features NOT padded (n = 100)',
+                                   'traffic': None}
         if refine is not None:
             out['refine'] = refine
         if warm is not None:
@@ -613,30 +854,32 @@ def main():
         if 'roofline' not in out and 'cholesky' in fit:      # no sweep GEMM in this workload (Thompson)
             out['roofline'] = dict(fit['cholesky'], traffic=None)
         if not args.no_cpu_baseline:
-            # sample: the WHOLE sweep for N <= 2048 (config B: ~1 min of host time), otherwise 4 full oracle
-            # chunks of 8192 candidates (~25 s at N = 8192), extrapolated linearly and labelled so;
-            # --cpu-candidates 131072 gives SURVEY 8(d)'s 2^17 sample (~1.5 min).  With N > 1 ranks rank 0 times it
-            # (on the candidates at the head of its own shard) while the others wait in the closing barrier.
-            nc = min(args.cpu_candidates or (M if N <= 2048 else 32768), Ml if w['acq'] != 'thompson' else M)
+            # sample: the WHOLE sweep for N <= 2048 (config B: ~1 min of host time), otherwise SURVEY 8(d)'s 2^17
+            # candidates (~100 s at N = 8192 on 128 BLAS threads) in TWO disjoint runs timed separately (linearity of the
+            # extrapolation), labelled `extrapolated`.  With N > 1 ranks rank 0 times it (on its own shard) while the
+            # others wait in the closing barrier.
+            span = Ml if w['acq'] != 'thompson' else M
+            nc = min(args.cpu_candidates or (M if N <= 2048 else (1 << 17)), span)
+            draws = mine if w['acq'] == 'thompson' else []
             if world > 1 and os.environ.get('OMP_NUM_THREADS') == '1':
-                out['cpu_baseline'], ref_vals = cpu_baseline_unpinned(w['name'], M, nc)
+                out['cpu_baseline'], ref_vals = cpu_baseline_unpinned(w['name'], M, nc, span, draws)
             else:
-                out['cpu_baseline'], ref_vals = cpu_baseline(w, nc)
+                out['cpu_baseline'], ref_vals = cpu_baseline(w, nc, span, draws)
             # the same candidates on the device, outside any timed region: every bench line is also a parity check
             eng.fit_dev(dX.data_ptr(), N, d, dy.data_ptr(), w['kernel'], w['ell'], w['rho'], w['sn2'], w['bias'])
             dev_vals = {}
+            sidx = ref_vals['index']
             if w['acq'] == 'thompson':
-                rng = np.random.RandomState(100)
-                Wd = rng.randn(100, d)
-                if nu is not None:
-                    Wd = Wd * np.sqrt(2.0 * nu / rng.chisquare(2.0 * nu, size=100))[:, None]
-                Wd, bd, zd = Wd / w['ell'], rng.rand(100) * 2 * np.pi, rng.randn(100)
-                th = eng.rff_posterior(Wd[None], bd[None], zd[None], np.sqrt(2.0 * w['rho'] / 100))
-                dev_vals['acq'] = eng.rff_sweep(Wd[None], bd[None], th, w['bias'], w['Xc'][:nc], k=0)['vals'][0]
+                # EVERY local draw of the step, on the candidates the oracle evaluated
+                tri = [thompson_draw(w, s_) for s_ in mine]
+                Wa, ba, za = (np.array([t_[i] for t_ in tri]) for i in range(3))
+                th = eng.rff_posterior(Wa, ba, za, np.sqrt(2.0 * w['rho'] / 100))
+                dev_vals['acq'] = eng.rff_sweep(Wa, ba, th, w['bias'], w['Xc'][sidx], k=0)['vals']
             else:
                 param = eng.mean_at_obs()[1] if w['acq'] == 'ei' else ucb_beta(N)
-                buf = torch.empty(3, nc, dtype=torch.float64, device=dev)
-                eng.sweep_dev(w['acq'], param, dXc.data_ptr(), nc, 0, d_acq=buf[0].data_ptr(),
+                dsel = torch.from_numpy(np.ascontiguousarray(w['Xc'][lo_i + sidx])).to(dev)
+                buf = torch.empty(3, len(sidx), dtype=torch.float64, device=dev)
+                eng.sweep_dev(w['acq'], param, dsel.data_ptr(), len(sidx), 0, d_acq=buf[0].data_ptr(),
                               d_mu=buf[1].data_ptr(), d_s2=buf[2].data_ptr())
                 eng.sync()
                 hb = buf.cpu().numpy()

@@ -71,6 +71,12 @@ int gpx_version(void);
  *              Every setting produces bit-identical results.
  *          "super_m" = rows of the XCD super-tile of 64 workgroups (8 -> 8x8 default, 4 -> 4x16, ...).
  *          "eager_inverse" = 1: form the triangular inverse inside gpx_fit instead of on first use.
+ *          "trtri_left" = 1: the recursive doubling of the triangular inverse associated as T21 = -(T22 L21) T11 instead of
+ *              T21 = -T22 (L21 T11) (default 0).  Built in round 4 on the expectation that it keeps the LEFT residual
+ *              T R^T - I at rounding level for the same flop; MEASURED (profiles/r04_illcond_vs_long_double.txt): it does not
+ *              -- the rounding error of the OUTER product carries the same factor |T11| |L11| in either order (max |T L - I|
+ *              1.9e-11 -> 3.1e-11 on config B at sn2 = 1e-6 rho); the mean improves 1.2-1.9x, the variance does not, and it
+ *              costs one transposition pass of the factor.  Kept as an option; "refine_inverse" is what reduces the residual.
  *          "refine_inverse" = 1: one Newton step T <- (2I - T R^T) T on the triangular inverse after it is formed (2 N^3 / 3
  *              more flop, one more Np^2 buffer): squares the LEFT residual T R^T - I, the one the sweep's error is
  *              proportional to -- for hyper-parameters with cond(K) >~ 1e9 (sn2 ~ 1e-6 rho), where the plain inverse is
@@ -308,7 +314,9 @@ int gpx_topk_allgather(gpx_comm *c, int64_t n, int64_t index_offset, int64_t k, 
 /* Stage timers in milliseconds accumulated since the last reset (HIP events on the handle's
  * stream): [0] gram [1] cholesky [2] trtri [3] alpha [4] cross_gram [5] sweep_trmm [6] acq_topk
  * [7] rff [8] number of sweep_trmm launches [9] sweep_trmm algorithmic flop [10] h2d/d2h copies
- * [11] append (rank-1 extension of the fit) [12] correction passes over the sweep cache.
+ * [11] append (rank-1 extension of the fit) [12] correction passes over the sweep cache [13] the Thompson sweep kernel
+ * alone (part of [7]) [14] its algorithmic double-precision lane operations: S n (d + 26) M per launch [15] fits whose
+ * task-graph factorisation gave up and were re-run on the stream schedule.
  * Synchronises the stream.  Returns the number of slots written (<= n). */
 int gpx_timers(gpx_handle *h, double *out, int n, int reset);
 /* DIAGNOSTIC (option "chol_tg_trace" = 1): wall-clock stamps (100 MHz ticks) the task-graph factorisation of the last fit

@@ -313,6 +313,11 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             (name[4] == 0 ? h->x_bg : (name[5] == 'l' ? h->x_bg_lds : h->x_bg_iters)) = (int)value;
             return GPX_OK;
         }
+        if (!strcmp(name, "trtri_left")) {
+            if (value != 0 && value != 1) return fail(h, GPX_EARG, "trtri_left must be 0 or 1");
+            h->trtri_left = (int)value;
+            return GPX_OK;
+        }
         if (!strcmp(name, "refine_inverse")) {
             if (value != 0 && value != 1) return fail(h, GPX_EARG, "refine_inverse must be 0 or 1");
             h->refine_inverse = (value != 0);
@@ -504,6 +509,7 @@ static int fit_core(gpx_handle* h, const double* dX, int64_t N, int64_t d, const
             // a spin of the persistent kernel gave up (the device is shared with something that kept its workgroups from
             // becoming resident): S is half-consumed -- rebuild it and run the stream schedule.  Loud, and counted.
             ++h->tg_fallbacks;
+            h->tacc[T_TGFALL] += 1.0;
             fprintf(stderr, "libgpx: the task-graph factorisation gave up waiting (N = %lld); re-running the stream schedule\n",
                     (long long)N);
             h->tg_launched = false;
@@ -1088,8 +1094,12 @@ static int rff_core(gpx_handle* h, const double* W, const double* b, const doubl
     }
     {
         Span sp(h, T_RFF);
+        Span sp2(h, T_RFFSWEEP);          // the Thompson sweep kernel alone (bench.py: roofline_rff)
         launch_rff_mfma(s, dWt, dbt, dtt, (int)S, (int)nfb, (int)n, (int)d, (int)dp, bias, dXc, M, d_vals);
     }
+    // algorithmic double-precision lane operations of that launch: per (draw, feature, candidate) d multiply-adds of the
+    // projection + RFF_COS_OPS instructions of the cosine epilogue (kernels_rff.hip: cos_cw and the weighted sum)
+    h->tacc[T_RFFOPS] += (double)S * (double)n * ((double)d + 26.0) * (double)M;
     if (k > 0) {
         const int64_t nblk = topk_blocks(M);
         if ((rc = ensure(h, h->dblkv, h->cap_blk, nblk * k))) return rc;

@@ -1,16 +1,31 @@
 #!/bin/bash
 # Build libgpx.so for gfx950 in-tree (the .so is git-ignored but travels with gpurun snapshots).
+#   build.sh          compile the objects that are older than their sources (incremental: development)
+#   build.sh --force  compile EVERY object from source (what __graft_entry__.build() runs: the driver's build check must
+#                     compile all eight translation units, also on a snapshot that shipped up-to-date .o files)
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-const-variable"
+SRCS="kernels_fit kernels_chol_tg kernels_sweep kernels_rff kernels_grad kernels_ens comm api"
+FORCE=0
+[ "$1" = "--force" ] && FORCE=1
 pids=()
-for f in kernels_fit kernels_chol_tg kernels_sweep kernels_rff kernels_grad kernels_ens comm api; do
-  if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ gemm_core.h -nt $f.o ] || [ gpx_internal.h -nt $f.o ] || [ gpx_math.h -nt $f.o ] || [ fit_tiles.h -nt $f.o ] || [ ../../include/gpx.h -nt $f.o ]; then
+n=0
+for f in $SRCS; do
+  stale=$FORCE
+  if [ ! -f $f.o ]; then stale=1; fi
+  for dep in $f.hip gemm_core.h gpx_internal.h gpx_math.h fit_tiles.h ../../include/gpx.h; do
+    [ $dep -nt $f.o ] && stale=1
+  done
+  if [ $stale = 1 ]; then
     $HIPCC $FLAGS -c $f.hip -o $f.o &
     pids+=($!)
+    n=$((n + 1))
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libgpx.so kernels_fit.o kernels_chol_tg.o kernels_sweep.o kernels_rff.o kernels_grad.o kernels_ens.o comm.o api.o -ldl
-echo "built $(pwd)/libgpx.so"
+OBJS=""
+for f in $SRCS; do OBJS="$OBJS $f.o"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libgpx.so $OBJS -ldl
+echo "built $(pwd)/libgpx.so ($n of $(echo $SRCS | wc -w) objects compiled)"

@@ -19,7 +19,7 @@ constexpr int PEND_MAX = 8;   // appended observations per pass of the sweep-cac
 
 enum Timer {
     T_GRAM = 0, T_CHOL, T_TRTRI, T_ALPHA, T_XGRAM, T_TRMM, T_ACQ, T_RFF, T_NLAUNCH, T_FLOP, T_COPY, T_APPEND,
-    T_RANK1, T_COUNT
+    T_RANK1, T_RFFSWEEP, T_RFFOPS, T_TGFALL, T_COUNT
 };
 
 struct EventPair { hipEvent_t a, b; int slot; };
@@ -72,6 +72,7 @@ struct gpx_handle {
     int stage = 0;               // 0 none, 1 gram, 2 chol (fitted; T/U/a/alpha not formed yet), 3 + inverse
     bool diag_inv_pending = false;   // the diagonal blocks of T / U hold 16x16 inverses only (k_trtri_diag128 due)
     bool eager_inverse = false;  // option: form the inverse inside the fit (timing experiments)
+    int trtri_left = 0;          // option: the triangular inverse's recursion as -(T22 L21) T11 instead of -T22 (L21 T11) (measured: no better)
     bool refine_inverse = false; // option: one Newton step on the triangular inverse (left residual)
     double* drefine = nullptr;   // its Np^2 scratch (allocated on first use, capacity cap_np^2)
     int64_t cap_refine = 0;

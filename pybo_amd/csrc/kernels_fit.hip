@@ -696,6 +696,117 @@ __global__ __launch_bounds__(GEMM64_THREADS) void k_trtri_gemm2_64(const double*
         }
 }
 
+// ---- the same recursion RE-ASSOCIATED (round 4, option trtri_left):  T_21 = - (T_22 L_21) T_11 -------------------------
+// Built on the expectation that this order keeps the LEFT residual (T L - I, the one the sweep's error is proportional to)
+// at rounding level: with T_21 = -T_22 (L_21 T_11) the error d of the inner product enters it as T_22 d L_11, which carries
+// |T_11| |L_11| ~ the conditioning of the leading block.  MEASURED (profiles/r04_illcond_vs_long_double.txt): the left
+// residual does not improve (config B, sn2 = 1e-6 rho: 1.9e-11 -> 3.1e-11) -- in this order the OUTER product's rounding
+// error, ~eps |W'| |T_11|, is what gets multiplied by L_11, with the same factor.  Only a triangular SOLVE with L_11
+// (backward stable: error ~eps |T_21| |L_11|) or the Newton step of refine_inverse removes it.  The mean's error is
+// 1.2-1.9x smaller with this order, the variance's is not; it costs one transposition pass (L_21 as a RIGHT factor needs
+// L row-major: the strictly upper 128-blocks of R go to the strictly LOWER blocks of the workspace S; W' = T_22 L_21 is
+// stored TRANSPOSED into S's upper blocks, where the second product reads it as its k-major left factor).  Off by default.
+__global__ __launch_bounds__(1024) void k_transpose_offdiag(const double* __restrict__ R, int64_t Np, double* __restrict__ Lrm) {
+    // 32 x 32 tiles of the strictly upper 128-blocks of R -> the mirrored position
+    const int by = blockIdx.y, bx = blockIdx.x;
+    if ((bx >> 2) <= (by >> 2)) return;
+    __shared__ double tile[32][33];
+    const int64_t r0 = (int64_t)by * 32, c0 = (int64_t)bx * 32;
+    tile[threadIdx.y][threadIdx.x] = R[(r0 + threadIdx.y) * Np + c0 + threadIdx.x];
+    __syncthreads();
+    Lrm[(c0 + threadIdx.y) * Np + r0 + threadIdx.x] = tile[threadIdx.x][threadIdx.y];
+}
+
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_trtri_gemm1r(const double* __restrict__ U, double* __restrict__ S,
+                                                                  int64_t Np, int nP, int hb) {
+    // W'(m, n) = sum_k T_22(m, k) L_21(k, n), k <= m: heaviest (largest bm) first
+    const int g = blockIdx.z, bm = hb - 1 - (int)blockIdx.y, bn = blockIdx.x;
+    const int r1 = g * 2 * hb, r2 = r1 + hb;
+    if (r2 >= nP) return;
+    const int size2 = min(hb, nP - r2);
+    if (bm >= size2) return;
+    __shared__ __attribute__((aligned(16))) double smem[GEMM_LDS_F64];
+    const int64_t r1e = (int64_t)r1 * NB, r2e = (int64_t)r2 * NB;
+    const int64_t m0 = r2e + (int64_t)bm * NB, n0 = r1e + (int64_t)bn * NB;
+    d4 acc[4][4];
+    acc_zero(acc);
+    gemm_tile_128_g<true>(acc, U + r2e * Np + m0, Np, S + r2e * Np + n0, Np, 0, (bm + 1) * NB, smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[(n0 + acc_col(j)) * Np + m0 + acc_row(i, r)] = acc[i][j][r];     // W'^T, upper position
+}
+
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_trtri_gemm2r(const double* __restrict__ S, double* __restrict__ T,
+                                                                  double* __restrict__ U, int64_t Np, int nP, int hb) {
+    // T_21(m, n) = - sum_k W'(m, k) T_11(k, n), k >= n: bn is the SLOW grid index (heaviest first)
+    const int g = blockIdx.z, bm = blockIdx.x, bn = blockIdx.y;
+    const int r1 = g * 2 * hb, r2 = r1 + hb;
+    if (r2 >= nP) return;
+    const int size2 = min(hb, nP - r2);
+    if (bm >= size2) return;
+    __shared__ __attribute__((aligned(16))) double smem[GEMM_LDS_F64];
+    const int64_t r1e = (int64_t)r1 * NB, r2e = (int64_t)r2 * NB;
+    const int64_t m0 = r2e + (int64_t)bm * NB, n0 = r1e + (int64_t)bn * NB;
+    d4 acc[4][4];
+    acc_zero(acc);
+    gemm_tile_128_g<true>(acc, S + r1e * Np + m0, Np, T + r1e * Np + n0, Np, bn * NB, hb * NB, smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t gm = m0 + acc_row(i, r), gn = n0 + acc_col(j);
+                const double v = -acc[i][j][r];
+                T[gm * Np + gn] = v;
+                U[gn * Np + gm] = v;
+            }
+}
+
+__global__ __launch_bounds__(GEMM64_THREADS) void k_trtri_gemm1r_64(const double* __restrict__ U, double* __restrict__ S,
+                                                                   int64_t Np, int nP, int hb) {
+    const int g = blockIdx.z, bm = 2 * hb - 1 - (int)blockIdx.y, bn = blockIdx.x;   // heaviest (largest bm) first
+    const int r1 = g * 2 * hb, r2 = r1 + hb;
+    if (r2 >= nP) return;
+    const int size2 = min(hb, nP - r2);
+    if (bm >= 2 * size2) return;
+    __shared__ __attribute__((aligned(16))) double smem[GEMM64_LDS_F64];
+    const int64_t r1e = (int64_t)r1 * NB, r2e = (int64_t)r2 * NB;
+    const int64_t m0 = r2e + (int64_t)bm * T64, n0 = r1e + (int64_t)bn * T64;
+    d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}};
+    gemm_tile_64_g<false>(acc, U + r2e * Np + m0, Np, S + r2e * Np + n0, Np, 0, (bm + 1) * T64, smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(n0 + acc_col64()) * Np + m0 + acc_row64(i, r)] = acc[i][r];
+}
+
+__global__ __launch_bounds__(GEMM64_THREADS) void k_trtri_gemm2r_64(const double* __restrict__ S, double* __restrict__ T,
+                                                                   double* __restrict__ U, int64_t Np, int nP, int hb) {
+    const int g = blockIdx.z, bm = blockIdx.x, bn = blockIdx.y;
+    const int r1 = g * 2 * hb, r2 = r1 + hb;
+    if (r2 >= nP) return;
+    const int size2 = min(hb, nP - r2);
+    if (bm >= 2 * size2) return;
+    __shared__ __attribute__((aligned(16))) double smem[GEMM64_LDS_F64];
+    const int64_t r1e = (int64_t)r1 * NB, r2e = (int64_t)r2 * NB;
+    const int64_t m0 = r2e + (int64_t)bm * T64, n0 = r1e + (int64_t)bn * T64;
+    d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}};
+    gemm_tile_64_g<false>(acc, S + r1e * Np + m0, Np, T + r1e * Np + n0, Np, bn * T64, hb * NB, smem);   // T11[k][n] = 0 for k < n
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t gm = m0 + acc_row64(i, r), gn = n0 + acc_col64();
+            const double v = -acc[i][r];
+            T[gm * Np + gn] = v;
+            U[gn * Np + gm] = v;
+        }
+}
+
 void launch_trtri(gpx_handle* h) {
     const int64_t Np = h->Np;
     const int nP = (int)(Np / NB);
@@ -704,16 +815,29 @@ void launch_trtri(gpx_handle* h) {
         hipLaunchKernelGGL(k_trtri_diag128, dim3((unsigned)nP), dim3(256), 0, s, h->dR, h->dT, h->dU, Np, 0, h->dflag);
         h->diag_inv_pending = false;
     }
+    const bool left = h->trtri_left != 0;          // re-associated recursion (default)
+    if (left && nP > 1)
+        hipLaunchKernelGGL(k_transpose_offdiag, dim3((unsigned)(Np / 32), (unsigned)(Np / 32)), dim3(32, 32), 0, s, h->dR, Np, h->dS);
     for (int hb = 1; hb < nP; hb *= 2) {
         const int ngroups = (nP + 2 * hb - 1) / (2 * hb);
         if ((int64_t)hb * hb * ngroups >= 1024) {         // enough 128x128 tiles to fill the chip twice over
             dim3 grid((unsigned)hb, (unsigned)hb, (unsigned)ngroups);
-            hipLaunchKernelGGL(k_trtri_gemm1, grid, dim3(GEMM_THREADS), 0, s, h->dR, h->dT, h->dS, Np, nP, hb);
-            hipLaunchKernelGGL(k_trtri_gemm2, grid, dim3(GEMM_THREADS), 0, s, h->dS, h->dT, h->dU, Np, nP, hb);
+            if (left) {
+                hipLaunchKernelGGL(k_trtri_gemm1r, grid, dim3(GEMM_THREADS), 0, s, h->dU, h->dS, Np, nP, hb);
+                hipLaunchKernelGGL(k_trtri_gemm2r, grid, dim3(GEMM_THREADS), 0, s, h->dS, h->dT, h->dU, Np, nP, hb);
+            } else {
+                hipLaunchKernelGGL(k_trtri_gemm1, grid, dim3(GEMM_THREADS), 0, s, h->dR, h->dT, h->dS, Np, nP, hb);
+                hipLaunchKernelGGL(k_trtri_gemm2, grid, dim3(GEMM_THREADS), 0, s, h->dS, h->dT, h->dU, Np, nP, hb);
+            }
         } else {
             dim3 grid((unsigned)(2 * hb), (unsigned)(2 * hb), (unsigned)ngroups);
-            hipLaunchKernelGGL(k_trtri_gemm1_64, grid, dim3(GEMM64_THREADS), 0, s, h->dR, h->dT, h->dS, Np, nP, hb);
-            hipLaunchKernelGGL(k_trtri_gemm2_64, grid, dim3(GEMM64_THREADS), 0, s, h->dS, h->dT, h->dU, Np, nP, hb);
+            if (left) {
+                hipLaunchKernelGGL(k_trtri_gemm1r_64, grid, dim3(GEMM64_THREADS), 0, s, h->dU, h->dS, Np, nP, hb);
+                hipLaunchKernelGGL(k_trtri_gemm2r_64, grid, dim3(GEMM64_THREADS), 0, s, h->dS, h->dT, h->dU, Np, nP, hb);
+            } else {
+                hipLaunchKernelGGL(k_trtri_gemm1_64, grid, dim3(GEMM64_THREADS), 0, s, h->dR, h->dT, h->dS, Np, nP, hb);
+                hipLaunchKernelGGL(k_trtri_gemm2_64, grid, dim3(GEMM64_THREADS), 0, s, h->dS, h->dT, h->dU, Np, nP, hb);
+            }
         }
     }
 }

@@ -132,6 +132,93 @@ class Replay(object):
         assert self.diag.all() and (self.solved[1:] == np.arange(1, self.nP)[:, None]).all()
 
 
+def run_ticketed(r, nworkers=5, nside=2, greedy=0.5):
+    """The device's second protocol (kernels_chol_tg.hip: tg_take): a workgroup PEEKS a queue head; if that task is ready it
+    draws a ticket with fetch-and-add -- and may get a LATER task than the one it peeked (others drew meanwhile), possibly
+    one that is not ready: then it HOLDS it (one per queue) and keeps serving its queues.  Side-kicks (critical queue) take
+    their task on the tile's earlier chunks alone and wait for the rest inside the task.  Returns when everything is done;
+    asserts that some workgroup can always move."""
+    rng = r.rng
+    total = sum(len(q) for q in r.q) + r.nP
+    done = 0
+    # workgroup state: queues it serves, held ticket per queue, task in flight
+    wgs = [{'queues': [0], 'held': {}, 'busy': None} for _ in range(nside)] + \
+          [{'queues': [1, 2], 'held': {}, 'busy': None} for _ in range(nworkers)]
+    potrf_busy = None
+    steps = 0
+
+    def pre_ready(t):            # critical queue: the tile's earlier chunks only
+        return r.seq[int(t[1]), int(t[2])] == int(t[5])
+
+    while done < total:
+        steps += 1
+        assert steps < 200 * total + 2000, 'no progress'
+        moves = []
+        for wi, wg in enumerate(wgs):
+            if wg['busy'] is not None:
+                t = wg['busy']
+                if r.ready(t):                       # (a side-kick's task in hand may still wait for its last dependency)
+                    moves.append(('finish', wi))
+                continue
+            for qi in wg['queues']:
+                chk = pre_ready if qi == 0 else r.ready
+                if qi in wg['held']:
+                    if chk(wg['held'][qi]):
+                        moves.append(('run_held', wi, qi))
+                elif r.head[qi] < len(r.q[qi]):
+                    if chk(r.q[qi][r.head[qi]]) or rng.rand() < greedy * 0.05:      # (a stale peek: draws although not ready)
+                        moves.append(('draw', wi, qi))
+        p = r.next_potrf
+        if potrf_busy is None and p < r.nP and (p == 0 or r.quad[p] == 6):
+            moves.append(('potrf', p))
+        if potrf_busy is not None:
+            moves.append(('potrf_done',))
+        assert moves, 'dead-lock: heads %s, next diagonal block %d, held %s' % (r.head, r.next_potrf, [w['held'] for w in wgs])
+        m = moves[rng.randint(len(moves))]
+        if m[0] == 'draw':
+            wg, qi = wgs[m[1]], m[2]
+            t = r.q[qi][r.head[qi]]
+            r.head[qi] += 1
+            chk = pre_ready if qi == 0 else r.ready
+            if chk(t):
+                wg['busy'] = t
+            else:
+                wg['held'][qi] = t
+        elif m[0] == 'run_held':
+            wg, qi = wgs[m[1]], m[2]
+            wg['busy'] = wg['held'].pop(qi)
+        elif m[0] == 'finish':
+            wg = wgs[m[1]]
+            r.run_task(wg['busy'])
+            r.finish(wg['busy'])
+            wg['busy'] = None
+            done += 1
+        elif m[0] == 'potrf':
+            r.potrf(m[1])
+            potrf_busy = m[1]
+        else:
+            r.diag[potrf_busy] = True
+            r.next_potrf = potrf_busy + 1
+            potrf_busy = None
+            done += 1
+    for I in range(r.nP):
+        for J in range(I, r.nP):
+            assert r.applied[I, J] == I
+    assert r.diag.all()
+
+
+@pytest.mark.parametrize('nP,chunks,split,nworkers,nside', [(9, 0, -1, 5, 2), (9, 1124, 0, 3, 1), (14, 1248, 2002, 7, 8),
+                                                           (6, 11, 0, 1, 1), (20, 0, -1, 40, 8)])
+def test_ticketed_protocol_with_held_tickets_never_deadlocks(nP, chunks, split, nworkers, nside):
+    q = _lib.chol_tasks(nP, chunks, split)
+    for seed in range(3):
+        r = Replay(nP, q, nb=4 if seed == 0 else 0, seed=seed)
+        run_ticketed(r, nworkers=nworkers, nside=nside)
+        if r.nb:
+            R = np.triu(r.R)
+            np.testing.assert_allclose(R.T @ R, r.K, rtol=1e-12, atol=1e-10)
+
+
 @pytest.mark.parametrize('nP', [1, 2, 3, 5, 8, 17, 40])
 @pytest.mark.parametrize('chunks,split', [(0, -1), (1124, 2), (14, 0), (1128, 0), (11, 0), (1224, 4)])
 def test_lists_complete_in_order_without_deadlock(nP, chunks, split):

@@ -115,7 +115,7 @@ def single():
     return _rank_work(0, 1, w)
 
 
-@pytest.mark.parametrize('world', [2, 4])
+@pytest.mark.parametrize('world', [2, 4, 8])
 def test_ranks_sharing_one_gpu_reproduce_the_single_rank_step(world, single):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -142,6 +142,64 @@ def test_ranks_sharing_one_gpu_reproduce_the_single_rank_step(world, single):
             np.testing.assert_array_equal(a, b)
     # engine level and plugin level agree with each other too
     np.testing.assert_array_equal(single['topk'][1], single['plugin_topk'][1])
+
+
+# ---- configs D and E at world = 8: Thompson draws sharded by draw index, full 2^20 grid, ONE all-gather ----------------
+def _draw_work(rank, world, name, S):
+    """bench.py's Thompson step for this rank's draws (s = rank mod world) over ALL 2^20 candidates: replicated fit at the
+    workload's N (N = 16384 / 8192: the persistent task-graph factorisation, here with `world` copies of it sharing one
+    GPU), weight posteriors on the device, sweep, one (value, index) pair per draw, ONE all-gather."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from pybo_amd import dist as pdist
+    from pybo_amd._lib import Engine
+    w = bench.make_workload(name, 1 << 20)
+    eng = Engine(0)
+    eng.fit(w['X'], w['y'], w['kernel'], w['ell'], w['rho'], w['sn2'], w['bias'], stage=2)
+    mine = [s for s in range(S) if s % world == rank]
+    tri = [bench.thompson_draw(w, s) for s in mine]
+    Wa, ba, za = (np.array([t[i] for t in tri]) for i in range(3))
+    th = eng.rff_posterior(Wa, ba, za, np.sqrt(2.0 * w['rho'] / 100))
+    rr = eng.rff_sweep(Wa, ba, th, w['bias'], w['Xc'], k=1, want_all=False)
+    tv, ti = pdist.gather_pairs(rr['top_val'][:, 0], rr['top_idx'][:, 0])
+    order = np.argsort(np.concatenate([[s for s in range(S) if s % world == r2] for r2 in range(world)]), kind='stable')
+    fb = eng.timers()['chol_fallbacks']
+    eng.close()
+    return tv[order], ti[order], fb
+
+
+def _draw_worker(rank, world, port, q, name, S):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        q.put((rank, _draw_work(rank, world, name, S)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('name,S', [('e', 8), ('d', 64)])
+def test_eight_ranks_shard_the_thompson_draws_of_configs_d_and_e(name, S):
+    """BASELINE configs[3] / [4] as the 8-GPU node will run them (bench.py, draws mod 8), on one GPU: every rank returns the
+    winners of ALL draws after the all-gather, identical on every rank and to one rank doing all the draws."""
+    world = 8
+    want_v, want_i, _ = _draw_work(0, 1, name, S)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_draw_worker, args=(r, world, port, q, name, S)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=1500) for _ in range(world))
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    for rank in range(world):
+        np.testing.assert_array_equal(got[rank][1], want_i)
+        np.testing.assert_array_equal(got[rank][0], want_v)
+    assert len(want_i) == S
 
 
 def test_rccl_exchange_behind_the_c_abi_with_a_one_rank_communicator():
