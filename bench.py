@@ -825,14 +825,14 @@ def main():
             # the Thompson sweep kernel: bound by the double-precision lanes, which its matrix instructions (the projection)
             # and its vector instructions (the cosine epilogue) SHARE: 16 lane-operations per clock per SIMD either way
             # (v_mfma_f64_16x16x4 = 1024 FMA in 64 clocks; a 64-lane f64 VALU instruction = 4 clocks).  Algorithmic work per
-            # (draw, feature, candidate): d multiply-adds + 26 instructions of cos_cw and the weighted sum (counted in the ISA)
+            # (draw, feature, candidate): d multiply-adds + 20 instructions of cos_cw and the weighted sum (counted in the ISA)
             lane_peak = 256 * 4 * 16 * 2.4e9
             ach = tm['rff_sweep_ops'] / (tm['rff_sweep'] * 1e-3)
             out['roofline_rff'] = {'kernel': 'k_rff_mfma', 'bound': 'fp64 lanes (MFMA projection + VALU cosine share them)',
                                    'achieved': ach / 1e12, 'peak': lane_peak / 1e12, 'unit': 'T lane-operations/s',
                                    'frac': ach / lane_peak, 'ms': tm['rff_sweep'] / args.steps,
                                    'lane_ops_per_step': tm['rff_sweep_ops'] / args.steps,
-                                   'work': 'draws x features x (d + 26) x candidates, features NOT padded (n = 100)',
+                                   'work': 'draws x features x (d + 20) x candidates, features NOT padded (n = 100)',
                                    'traffic': None}
         if refine is not None:
             out['refine'] = refine

@@ -313,6 +313,10 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             (name[4] == 0 ? h->x_bg : (name[5] == 'l' ? h->x_bg_lds : h->x_bg_iters)) = (int)value;
             return GPX_OK;
         }
+        if (!strcmp(name, "x_rff")) {       // diagnostic: A/B of the Thompson sweep kernels (process-wide)
+            gpx::g_rff_variant = (int)value;
+            return GPX_OK;
+        }
         if (!strcmp(name, "trtri_left")) {
             if (value != 0 && value != 1) return fail(h, GPX_EARG, "trtri_left must be 0 or 1");
             h->trtri_left = (int)value;
@@ -1098,8 +1102,8 @@ static int rff_core(gpx_handle* h, const double* W, const double* b, const doubl
         launch_rff_mfma(s, dWt, dbt, dtt, (int)S, (int)nfb, (int)n, (int)d, (int)dp, bias, dXc, M, d_vals);
     }
     // algorithmic double-precision lane operations of that launch: per (draw, feature, candidate) d multiply-adds of the
-    // projection + RFF_COS_OPS instructions of the cosine epilogue (kernels_rff.hip: cos_cw and the weighted sum)
-    h->tacc[T_RFFOPS] += (double)S * (double)n * ((double)d + 26.0) * (double)M;
+    // projection + 20 instructions of the cosine epilogue (kernels_rff.hip: cos_cw and the weighted sum)
+    h->tacc[T_RFFOPS] += (double)S * (double)n * ((double)d + 20.0) * (double)M;
     if (k > 0) {
         const int64_t nblk = topk_blocks(M);
         if ((rc = ensure(h, h->dblkv, h->cap_blk, nblk * k))) return rc;

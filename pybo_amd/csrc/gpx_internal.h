@@ -245,6 +245,7 @@ int rff_grad_host(gpx_handle* h, const double* W, const double* b, const double*
                   double bias, const double* Xc, int64_t M, double* f, double* g);
 
 // launchers (kernels_rff.hip)
+extern int g_rff_variant;
 void launch_rff_mfma(hipStream_t s, const double* Wt, const double* bt, const double* tt, int S, int nfb, int n, int d,
                      int dp, double bias, const double* Xc, int64_t M, double* vals);
 int64_t rff_gram_batch_scratch(int64_t S, int64_t Np);

@@ -27,18 +27,23 @@ __device__ __forceinline__ double cos_cw(double z) {
     // Round 3: reduction by pi (not pi/2) and ONE even polynomial on [-pi/2, pi/2]: cos z = (-1)^n cos r, r = z - n pi.
     // The quadrant form evaluated BOTH fdlibm kernels (sine and cosine on [-pi/4, pi/4]) and selected: 37 VALU
     // instructions per evaluation, and k_rff_mfma is bound by VALU + MFMA issue on the shared double-precision pipe
-    // (profiles/r03_pmc_rff_mfma.txt: 43 % + 37 % of the cycles).  Here: 3-term Cody-Waite (n pi_hi exact for
-    // |n| < 2^20: pi_hi has 33 significant bits), the Taylor series through r^22 / 22! (the next term is 8e-20 at
-    // |r| = pi/2; no minimax fit needed), sign from the parity of n: ~22 instructions.  Absolute error <= 3e-16
-    // (Horner over terms that sum to cosh(pi/2) = 2.5 in magnitude); the features enter sums of ~100 terms of size
-    // theta ~ 0.1, compared with the oracle at 1e-9 relative.
-    const double n = rint(z * 3.18309886183790671538e-01);
+    // (profiles/r03_pmc_rff_mfma.txt: 43 % + 37 % of the cycles).
+    // Round 4 (26 -> 20 instructions, 22 -> 18 of them on the double-precision pipe):
+    //   * n = round(z / pi) by the magic-number addition t = z / pi + 1.5 * 2^52 (one FMA), n = t - 1.5 * 2^52: the integer
+    //     sits in t's low mantissa bits, so the parity of n is bit 0 of t's low word -- no v_rndne, no v_cvt_i32_f64;
+    //   * the sign (-1)^n is that bit shifted into the sign position and XORed into the result's high word (two 32-bit
+    //     operations, off the double-precision pipe) instead of a compare and two selects;
+    //   * two-term Cody-Waite: n pi_hi is exact (pi_hi has 33 significant bits, |n| < 2^20), the dropped third term is
+    //     n * 4e-21 -- below 1e-19 for any argument a feature can see;
+    //   * the Taylor series through r^20 / 20! (the next term is 1.8e-17 at |r| = pi/2).
+    // Absolute error <= 3e-16 (Horner over terms that sum to cosh(pi/2) = 2.5 in magnitude), as before; the features enter
+    // sums of ~100 terms of size theta ~ 0.1, compared with the oracle at 1e-9 relative.
+    const double t = fma(z, 3.18309886183790671538e-01, 6755399441055744.0);
+    const double n = t - 6755399441055744.0;
     double r = fma(-n, 3.14159265346825122833e+00, z);
     r = fma(-n, 1.21542010126079319532e-10, r);
-    r = fma(-n, 4.04453249759190126308e-21, r);
     const double r2 = r * r;
-    double p = -8.89679139245057328675e-22;                 // -1/22!
-    p = fma(r2, p, 4.11031762331216485548e-19);             //  1/20!
+    double p = 4.11031762331216485548e-19;                  //  1/20!
     p = fma(r2, p, -1.56192069685862264622e-16);            // -1/18!
     p = fma(r2, p, 4.77947733238738529744e-14);             //  1/16!
     p = fma(r2, p, -1.14707455977297247139e-11);            // -1/14!
@@ -49,7 +54,7 @@ __device__ __forceinline__ double cos_cw(double z) {
     p = fma(r2, p, 4.16666666666666666667e-02);             //  1/4!
     p = fma(r2, p, -0.5);
     const double cs = fma(r2, p, 1.0);
-    return (((int)n) & 1) ? -cs : cs;
+    return __hiloint2double(__double2hiint(cs) ^ (__double2loint(t) << 31), __double2loint(cs));
 }
 
 // Wt:  [S][nfb][dp][128]   feature tiles, k-major (zero padded);  bt, tt: [S][nfb][128]
@@ -203,9 +208,127 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_rff_mfma(const double* __re
     }
 }
 
+// Round 4: the candidate fragments in REGISTERS, the feature tile DOUBLE-buffered in LDS, ONE barrier per tile (dp <= 32).
+// k_rff_mfma<true> kept the candidate tile in LDS beside a single feature buffer (74 KB at d = 32: two workgroups per
+// CU) and paid two barriers per tile -- one before the buffer could be overwritten, one before it could be read.  A wave
+// only ever reads ITS 32 candidate rows: as MFMA A fragments that is 2 x dp/4 doubles per lane (<= 16), loaded once for the
+// workgroup's life.  The LDS that frees holds a second feature buffer: the next tile's 32 KB travel through registers during
+// the matrix phase (as before), are written to the OTHER buffer (no wait: nobody reads it), and the only barrier of a tile
+// stands after the cosine epilogue, where the waves meet anyway.  Same MFMAs, same order: bit-identical values.
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_rff_mfma_db(const double* __restrict__ Wt,
+                                                                 const double* __restrict__ bt,
+                                                                 const double* __restrict__ tt, int S, int nfb, int n,
+                                                                 int d, int dp, double bias,
+                                                                 const double* __restrict__ Xc, int64_t M,
+                                                                 double* __restrict__ vals) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // Bt[2][dp][LDT]
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int64_t m0 = (int64_t)blockIdx.x * TB;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int nkk = dp >> 2;
+    // this lane's A fragments: candidate rows m0 + 32 w + fr (+ 16), coordinates 4 kk + fk
+    double a0[8], a1[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        const int k = 4 * kk + fk;
+        const int64_t g0 = m0 + w * 32 + fr, g1 = g0 + 16;
+        a0[kk] = (kk < nkk && k < d && g0 < M) ? Xc[g0 * d + k] : 0.0;
+        a1[kk] = (kk < nkk && k < d && g1 < M) ? Xc[g1 * d + k] : 0.0;
+    }
+    const int ntile = S * nfb;
+    const int npiece = (TB / 2) * dp;                 // 16-byte pieces of a feature tile (<= 8 per thread)
+    {
+        const double* W0 = Wt;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = t + u * GEMM_THREADS;
+            if (e < npiece) *reinterpret_cast<d2*>(lds + (e >> 6) * LDT + (e & 63) * 2) = *reinterpret_cast<const d2*>(W0 + (int64_t)(e >> 6) * TB + (e & 63) * 2);
+        }
+    }
+    __syncthreads();
+    double rowsum[2][4];
+    for (int tile = 0; tile < ntile; ++tile) {
+        const int fb = tile % nfb, s = tile / nfb;
+        const int nv = min(TB, n - fb * TB);          // features of this tile that exist
+        const int jt = (nv + 15) >> 4;                // ... in 16-column groups (uniform)
+        if (fb == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rowsum[i][r] = 0.0;
+        }
+        d4 acc[2][8];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
+        const double* bs = lds + (tile & 1) * dp * LDT + fr;
+        double* bnext = lds + ((tile + 1) & 1) * dp * LDT;
+        d2 pre[8];
+        const bool more = tile + 1 < ntile;
+        if (more) {
+            const double* Wnext = Wt + (int64_t)(tile + 1) * dp * TB;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = t + u * GEMM_THREADS;
+                if (e < npiece) pre[u] = *reinterpret_cast<const d2*>(Wnext + (int64_t)(e >> 6) * TB + (e & 63) * 2);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            if (kk < nkk) {
+                const int kr = kk * 4 + fk;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (j < jt) {
+                        const double b = bs[kr * LDT + j * 16];
+                        acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b, acc[0][j], 0, 0, 0);
+                        acc[1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b, acc[1][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = t + u * GEMM_THREADS;
+                if (e < npiece) *reinterpret_cast<d2*>(bnext + (e >> 6) * LDT + (e & 63) * 2) = pre[u];
+            }
+        }
+        const double* bb = bt + (int64_t)tile * TB + fr;
+        const double* th = tt + (int64_t)tile * TB + fr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < jt) {
+                const double bj = bb[j * 16], tj = th[j * 16];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rowsum[i][r] = fma(tj, cos_cw(acc[i][j][r] + bj), rowsum[i][r]);
+            }
+        }
+        if (fb == nfb - 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double v = rowsum[i][r];
+                    v += __shfl_xor(v, 1);
+                    v += __shfl_xor(v, 2);
+                    v += __shfl_xor(v, 4);
+                    v += __shfl_xor(v, 8);
+                    const int64_t gm = m0 + w * 32 + i * 16 + fk + 4 * r;
+                    if (fr == 0 && gm < M) vals[(int64_t)s * M + gm] = bias + v;
+                }
+        }
+        __syncthreads();   // the next tile is complete in the other buffer; everyone is done reading this one
+    }
+}
+
 // device staging layout for the MFMA path: [Wt S*nfb*dp*128][bt S*nfb*128][tt S*nfb*128]
 // rows of the k-range the RFF kernels keep in LDS: the whole (padded) input dimension up to 64 coordinates (147 KB),
 // 32 at a time beyond (74 KB: two workgroups per CU)
+int g_rff_variant = 0;      // diagnostic (option "x_rff"): 0 = by size, 1 = round 3's single-buffer kernel, 2 = the double-buffered one
 static int rff_k_chunk(int dp) { return dp <= DMAX_RFF_RESIDENT ? dp : 32; }
 
 void launch_rff_mfma(hipStream_t s, const double* Wt, const double* bt, const double* tt, int S, int nfb, int n, int d,
@@ -213,6 +336,16 @@ void launch_rff_mfma(hipStream_t s, const double* Wt, const double* bt, const do
     dim3 grid((unsigned)((M + TB - 1) / TB));
     const int dk = rff_k_chunk(dp);
     const size_t ldsb = (size_t)(2 * dk * LDT) * sizeof(double);
+    // measured (profiles/r04_rff_kernels_ab.txt): the double-buffered kernel wins while the projection is short (config E,
+    // d = 6: 1.04 against 1.07 ms), the single-buffer one at d = 32 (config D: 13.9 against 14.4 ms: there the matrix phase
+    // dominates and the register-resident fragments cost 7 spilled registers)
+    if (dk == dp && ((dp <= 16 && g_rff_variant == 0) || g_rff_variant == 2)) {
+        const size_t ldb = (size_t)(2 * dp * LDT) * sizeof(double);
+        if (ldb > 64 * 1024)
+            hipFuncSetAttribute((const void*)k_rff_mfma_db, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldb);
+        hipLaunchKernelGGL(k_rff_mfma_db, grid, dim3(GEMM_THREADS), ldb, s, Wt, bt, tt, S, nfb, n, d, dp, bias, Xc, M, vals);
+        return;
+    }
     if (dk == dp && dp <= 32) {
         hipLaunchKernelGGL(k_rff_mfma<true>, grid, dim3(GEMM_THREADS), ldsb, s, Wt, bt, tt, S, nfb, n, d, dp, dk, bias, Xc,
                            M, vals);
