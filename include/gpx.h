@@ -114,7 +114,7 @@ int gpx_set_option(gpx_handle *h, const char *name, int64_t value);
 
 /* ---- GP fit = model.add_data(X, Y)            [pybo/bayesopt.py:114,258,269] ------------- */
 /* Limits: 1 <= d <= 1024 for every entry point (the Thompson / RFF kernels keep a whole feature tile in LDS up to
- * d = 64 and walk the coordinates 32 at a time beyond); top-k requests k <= 64.
+ * d = 64 and walk the coordinates 32 at a time beyond); top-k requests k <= 4096 (64 per pass over the values).
  * Gram build K = k(X,X) + sn2 I and Cholesky K = R^T R.  The triangular inverse T = R^-T, a = T (y - bias)
  * and alpha follow on FIRST USE (sweep, predict, mean_at_obs, loglik, append, introspection): the Thompson
  * entry points never read them.  X is (N,d), y is (N,), ell is (d,) on the HOST in both variants. */
@@ -130,7 +130,7 @@ int gpx_loglik(gpx_handle *h, double *out);
  * [sn2, rho, ell_1..d, bias] (the argument order of reggie.make_gp, pybo/bayesopt.py:105), out (B,);
  * -inf where K + sn2 I is not positive definite.  One batched Gram + Cholesky launch chain and one host
  * synchronisation for the whole batch: the evaluation a hyper-parameter sampler repeats per proposal
- * (reggie.MCMC(model, n=10, burn=100), pybo/bayesopt.py:115).  1 <= B <= 64. */
+ * (reggie.MCMC(model, n=10, burn=100), pybo/bayesopt.py:115).  Any B >= 1 (64 vectors per launch chain). */
 int gpx_loglik_batch(gpx_handle *h, int64_t B, const double *hypers, double *out);
 /* Incremental fit: absorb ONE more observation x (d,), y into the current factorisation in O(N^2)
  * (two memory-bound passes over T and U) instead of refitting -- the per-iteration

@@ -75,7 +75,7 @@ ACQ = {'ei': 0, 'pi': 1, 'ucb': 2, 'mean': 3}
 TIMER_NAMES = ['gram', 'cholesky', 'trtri', 'alpha', 'cross_gram', 'sweep_trmm', 'acq_topk', 'rff',
                'sweep_trmm_launches', 'sweep_trmm_flop', 'copies', 'append', 'rank1', 'rff_sweep', 'rff_sweep_ops',
                'chol_fallbacks']
-TOPK_MAX = 64
+TOPK_MAX = 4096
 
 _lib = None
 

@@ -860,7 +860,7 @@ static int sweep_core(gpx_handle* h, int acq_id, const double* params, int npara
     if (!dXc || M < 1) return fail(h, GPX_EARG, "sweep: need M >= 1 candidates");
     if (acq_id < GPX_ACQ_EI || acq_id > GPX_ACQ_MEAN) return fail(h, GPX_EARG, "sweep: unknown acquisition id");
     if (acq_id != GPX_ACQ_MEAN && (nparams < 1 || !params)) return fail(h, GPX_EARG, "sweep: missing acquisition parameter");
-    if (k < 0 || k > TOPK_MAX) return fail(h, GPX_EARG, "sweep: k must be in [0, 64]");
+    if (k < 0 || k > TOPK_MAX) return fail(h, GPX_EARG, "sweep: k must be in [0, 4096]");
     if (k > 0 && (!top_val || !top_idx)) return fail(h, GPX_EARG, "sweep: NULL top-k output");
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
@@ -978,7 +978,7 @@ static int sweep_update_core(gpx_handle* h, int acq_id, const double* params, in
                                    "sweep; a refit invalidates it)");
     if (acq_id < GPX_ACQ_EI || acq_id > GPX_ACQ_MEAN) return fail(h, GPX_EARG, "sweep_update: unknown acquisition id");
     if (acq_id != GPX_ACQ_MEAN && (nparams < 1 || !params)) return fail(h, GPX_EARG, "sweep_update: missing acquisition parameter");
-    if (k < 0 || k > TOPK_MAX) return fail(h, GPX_EARG, "sweep_update: k must be in [0, 64]");
+    if (k < 0 || k > TOPK_MAX) return fail(h, GPX_EARG, "sweep_update: k must be in [0, 4096]");
     if (k > 0 && (!top_val || !top_idx)) return fail(h, GPX_EARG, "sweep_update: NULL top-k output");
     HIPCHK(h, hipSetDevice(h->device));
     const int64_t M = h->cache_M;
@@ -1064,7 +1064,7 @@ static int rff_core(gpx_handle* h, const double* W, const double* b, const doubl
     if (!W || !b || !theta || !dXc) return fail(h, GPX_EARG, "rff_sweep: NULL pointer");
     if (S < 1 || n < 1 || d < 1 || M < 1) return fail(h, GPX_EARG, "rff_sweep: bad sizes");
     if (d > DMAX_RFF) return fail(h, GPX_EARG, "rff_sweep: d must be <= 1024");
-    if (k < 0 || k > TOPK_MAX) return fail(h, GPX_EARG, "rff_sweep: k must be in [0, 64]");
+    if (k < 0 || k > TOPK_MAX) return fail(h, GPX_EARG, "rff_sweep: k must be in [0, 4096]");
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
     int rc;
@@ -1295,7 +1295,7 @@ static int ensemble_core(gpx_handle* const* mem, int n, int acq_id, const double
     if (acq_id < GPX_ACQ_EI || acq_id > GPX_ACQ_MEAN) return fail(L, GPX_EARG, "ensemble_sweep: unknown acquisition id");
     if (acq_id != GPX_ACQ_MEAN && (nparams < 1 || !params)) return fail(L, GPX_EARG, "ensemble_sweep: missing acquisition parameter");
     if (!dXc || M < 1) return fail(L, GPX_EARG, "ensemble_sweep: need M >= 1 candidates");
-    if (k < 0 || k > TOPK_MAX) return fail(L, GPX_EARG, "ensemble_sweep: k must be in [0, 64]");
+    if (k < 0 || k > TOPK_MAX) return fail(L, GPX_EARG, "ensemble_sweep: k must be in [0, 4096]");
     if (k > 0 && (!top_val || !top_idx)) return fail(L, GPX_EARG, "ensemble_sweep: NULL top-k output");
     for (int m = 0; m < n; ++m) {
         if (!mem[m]->fitted) return fail(L, GPX_ESTATE, "ensemble_sweep: a member model is not fitted");

@@ -14,7 +14,8 @@ constexpr int TBH = 128;      // host-side copy of the GEMM tile edge (gemm_core
 constexpr int DMAX = 1024;    // max input dimension (buffer sizing only: the kernels walk coordinates 16 at a time)
 constexpr int DMAX_RFF = DMAX;          // max input dimension of the Thompson / RFF kernels (round 3: the projection walks d in chunks)
 constexpr int DMAX_RFF_RESIDENT = 64;   // up to here the whole k-range of a feature tile [d][144] lives in LDS at once
-constexpr int TOPK_MAX = 64;  // max k of the device top-k
+constexpr int TOPK_MAX = 4096;   // max k of the device top-k (served TOPK_PASS entries per pass)
+constexpr int TOPK_PASS = 64;
 constexpr int PEND_MAX = 8;   // appended observations per pass of the sweep-cache correction
 
 enum Timer {

@@ -12,6 +12,7 @@
 #include <math.h>
 
 #include <vector>
+#include <algorithm>
 
 #include <utility>
 
@@ -1049,9 +1050,25 @@ __global__ __launch_bounds__(256) void k_loglik_fwd(const double* __restrict__ R
     if (t == 0) out[z] = -0.5 * red[0] - red[1] - 0.5 * (double)N * 1.83787706640934548356;
 }
 
+static int loglik_batch_chunk(gpx_handle* h, int64_t B, const double* hyp, double* out);
+
+// any number of vectors: 64 (or what 16 GB of batch buffers hold) per launch chain
 int loglik_batch_host(gpx_handle* h, int64_t B, const double* hyp, double* out) {
     if (h->stage < 1) { h->err = "loglik_batch: no data on the device (fit first)"; return GPX_ESTATE; }
-    if (!hyp || !out || B < 1 || B > 64) { h->err = "loglik_batch: need 1 <= B <= 64 hyper-parameter vectors"; return GPX_EARG; }
+    if (!hyp || !out || B < 1) { h->err = "loglik_batch: need B >= 1 hyper-parameter vectors"; return GPX_EARG; }
+    const double per = (double)h->Np * (double)h->Np * 16.0;
+    int64_t step = (int64_t)(16.0e9 / per);
+    if (step < 1) { h->err = "loglik_batch: N^2 too large for the batch buffers"; return GPX_EARG; }
+    if (step > 64) step = 64;
+    for (int64_t b0 = 0; b0 < B; b0 += step) {
+        const int rc = loglik_batch_chunk(h, std::min(step, B - b0), hyp + b0 * (h->d + 3), out + b0);
+        if (rc != GPX_OK) return rc;
+    }
+    return GPX_OK;
+}
+
+static int loglik_batch_chunk(gpx_handle* h, int64_t B, const double* hyp, double* out) {
+    if (B < 1 || B > 64) { h->err = "loglik_batch: internal chunk size"; return GPX_EARG; }
     const int64_t N = h->N, Np = h->Np, d = h->d, bs = Np * Np;
     const int nP = (int)(Np / NB);
     if ((double)B * (double)bs * 16.0 > 16.0e9) { h->err = "loglik_batch: B * N^2 too large for the batch buffers"; return GPX_EARG; }

@@ -579,12 +579,18 @@ __device__ __forceinline__ void block_argmax(double& v, int64_t& i, double* sv, 
         if (better(sv[ww], si[ww], v, i)) { v = sv[ww]; i = si[ww]; }
 }
 
+// cutv / cuti (optional, device): only candidates that rank strictly AFTER the pair (*cutv, *cuti) take part -- the
+// k-th best of an earlier pass: requests beyond TOPK_PASS entries are served TOPK_PASS at a time (launch_topk).
 __global__ __launch_bounds__(256) void k_topk_block(const double* __restrict__ vals, int64_t M, int k,
                                                     double* __restrict__ blkv,
-                                                    int64_t* __restrict__ blki) {
+                                                    int64_t* __restrict__ blki, const double* __restrict__ cutv,
+                                                    const int64_t* __restrict__ cuti) {
     __shared__ double sv[4];
     __shared__ int64_t si[4];
     const int64_t base = (int64_t)blockIdx.x * TK_PER_BLOCK;
+    const bool cut = cutv != nullptr;
+    const double cv = cut ? *cutv : 0.0;
+    const int64_t ci = cut ? *cuti : 0;
     double v[TK_PER_THREAD];
 #pragma unroll
     for (int e = 0; e < TK_PER_THREAD; ++e) {
@@ -593,7 +599,15 @@ __global__ __launch_bounds__(256) void k_topk_block(const double* __restrict__ v
         if (x != x) x = GPX_NEG_INF;
         v[e] = x;
     }
-    unsigned used = 0;  // bit e set: element e already emitted
+    unsigned used = 0;  // bit e set: element e already emitted (or ranked at / before the cut)
+    if (cut) {
+#pragma unroll
+        for (int e = 0; e < TK_PER_THREAD; ++e) {
+            const int64_t idx = base + e * 256 + threadIdx.x;
+            // (ci < 0: the earlier pass already ran out of candidates -- its last entry is the -1 marker: nothing is left)
+            if (ci < 0 || !better(cv, ci, v[e], idx)) used |= 1u << e;
+        }
+    }
     for (int it = 0; it < k; ++it) {
         double bv = GPX_NEG_INF;
         int64_t bi = GPX_IDX_NONE;
@@ -641,10 +655,18 @@ void launch_topk_merge(hipStream_t s, double* vals, int64_t* idx, int64_t n, int
 
 int64_t topk_blocks(int64_t M) { return (M + TK_PER_BLOCK - 1) / TK_PER_BLOCK; }
 
+// k <= TOPK_MAX entries, TOPK_PASS per pass: pass p ranks only what comes strictly after the last entry of pass p-1
+// (value descending, index ascending: a total order, so the passes concatenate to exactly the k best).  blkv / blki need
+// nblk * min(k, TOPK_PASS) entries; topv / topi k.  The reference's ranking is a full argsort (pybo/solvers/lbfgs.py:51).
 void launch_topk(hipStream_t s, const double* vals, int64_t M, int k, double* blkv, int64_t* blki,
                  int64_t nblk, double* topv, int64_t* topi) {
-    hipLaunchKernelGGL(k_topk_block, dim3((unsigned)nblk), dim3(256), 0, s, vals, M, k, blkv, blki);
-    hipLaunchKernelGGL(k_topk_merge, dim3(1), dim3(256), 0, s, blkv, blki, nblk * k, k, topv, topi);
+    for (int done = 0; done < k; done += TOPK_PASS) {
+        const int kk = (k - done < TOPK_PASS) ? k - done : TOPK_PASS;
+        const double* cv = done ? topv + done - 1 : nullptr;
+        const int64_t* ci = done ? topi + done - 1 : nullptr;
+        hipLaunchKernelGGL(k_topk_block, dim3((unsigned)nblk), dim3(256), 0, s, vals, M, kk, blkv, blki, cv, ci);
+        hipLaunchKernelGGL(k_topk_merge, dim3(1), dim3(256), 0, s, blkv, blki, nblk * kk, kk, topv + done, topi + done);
+    }
 }
 
 }  // namespace gpx

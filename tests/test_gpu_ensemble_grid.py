@@ -71,7 +71,7 @@ def test_ensemble_errors():
     with pytest.raises(GpxError):                       # moments only exist for ucb / mean
         Engine.ensemble_sweep([dev[0]._engine()], 'ei', 0.1, np.zeros((4, 2)), k=0, want_moments=True)
     with pytest.raises(GpxError):
-        Engine.ensemble_sweep([dev[0]._engine()], 'ei', 0.1, np.zeros((4, 2)), k=65)
+        Engine.ensemble_sweep([dev[0]._engine()], 'ei', 0.1, np.zeros((4, 2)), k=4097)
 
 
 def test_mcmc_model_uses_the_device_ensemble():

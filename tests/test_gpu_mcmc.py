@@ -133,3 +133,23 @@ def test_a_default_run_reuses_its_device_handles(monkeypatch):
     monkeypatch.setattr(_lib.Engine, '__init__', counting)
     pybo_amd.solve_bayesopt(f, bounds, niter=8, rng=1)
     assert made[0] <= 8, 'handles created in a steady-state run: %d' % made[0]
+
+
+def test_loglik_batch_beyond_64_vectors():
+    """gpx_loglik_batch took at most 64 hyper-parameter vectors per call (the sampler sub-batched); now any number, 64 per
+    launch chain inside the library: 150 vectors against the per-vector values."""
+    from pybo_amd._lib import Engine
+    from helpers import synth_problem
+    X, y, ell = synth_problem(200, 3, seed=8)
+    e = Engine(0)
+    e.fit(X, y, 'se', ell, 1.0, 1e-3, 0.0, stage=2)
+    rng = np.random.RandomState(1)
+    B = 150
+    hyp = np.column_stack([10 ** rng.uniform(-4, -2, B), 10 ** rng.uniform(-0.5, 0.5, B),
+                           ell[None] * 10 ** rng.uniform(-0.3, 0.3, (B, 3)), rng.randn(B) * 0.1])
+    got = e.loglik_batch(hyp)
+    want = np.concatenate([e.loglik_batch(hyp[i:i + 50]) for i in range(0, B, 50)])
+    np.testing.assert_array_equal(got, want)
+    one = np.array([e.loglik_batch(hyp[i:i + 1])[0] for i in (0, 77, 149)])
+    np.testing.assert_allclose(got[[0, 77, 149]], one, rtol=1e-12)
+    e.close()

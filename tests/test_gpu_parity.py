@@ -172,7 +172,7 @@ def test_argument_errors():
         assert ei.value.code == GPX_EARG
     e.fit(X, y, 'se', ell, 1.0, 1e-3, 0.0)
     with pytest.raises(GpxError):
-        e.sweep('ei', 0.0, X, k=65)
+        e.sweep('ei', 0.0, X, k=4097)
     with pytest.raises(GpxError):
         e.set_option('chunk', 100)
     e.close()
@@ -706,3 +706,59 @@ def test_thompson_beyond_64_input_dimensions(d, kernel):
     smp = gp.sample_f(n, 300)
     np.testing.assert_allclose(smp.get(Z[:64]), samples[0].get(Z[:64]), rtol=1e-6, atol=1e-7)
     assert smp.topk(Z, 1)[1][0] == int(np.argmax(samples[0].get(Z)))
+
+
+@pytest.mark.parametrize('k', [65, 200, 1000])
+def test_device_topk_beyond_64_entries_is_the_full_argsort(k):
+    """VERDICT round 3 (limits the reference does not have): the solver ranks the whole grid (pybo/solvers/lbfgs.py:51 is
+    a full argsort); the device top-k served at most 64 entries.  Now any k <= 4096, 64 per pass over the values -- against
+    numpy's stable argsort of the device's own values (ties by lower index, NaN last), for a sweep, a warm re-score, a
+    Thompson draw and a shard smaller than k."""
+    X, y, ell = synth_problem(400, 3, seed=5)
+    e = _engine()
+    e.fit(X, y, 'se', ell, 1.2, 1e-3, 0.1)
+    Z = np.random.RandomState(2).rand(30011, 3)
+    Z[100:140] = Z[5]                                   # exact ties
+    r = e.sweep('ucb', 3.0, Z, k=k, want_all=True)
+    vals = r['acq']
+    order = np.lexsort((np.arange(len(vals)), -vals))[:k]
+    np.testing.assert_array_equal(r['top_idx'], order)
+    np.testing.assert_array_equal(r['top_val'], vals[order])
+    # fewer candidates than k: the tail is the -1 marker
+    r2 = e.sweep('ucb', 3.0, Z[:50], k=k, want_all=True)
+    o2 = np.lexsort((np.arange(50), -r2['acq']))
+    np.testing.assert_array_equal(r2['top_idx'][:50], o2)
+    assert np.all(r2['top_idx'][50:] == -1)
+    # a Thompson draw
+    rng = np.random.RandomState(0)
+    W, b, th = rng.randn(1, 30, 3), rng.rand(1, 30) * 6, rng.randn(1, 30)
+    rr = e.rff_sweep(W, b, th, 0.2, Z, k=k, want_all=True)
+    o3 = np.lexsort((np.arange(len(Z)), -rr['vals'][0]))[:k]
+    np.testing.assert_array_equal(rr['top_idx'][0], o3)
+    e.close()
+    # and through the solver: nbest beyond 64 seeds stays on the device
+    from pybo_amd import models, policies, solvers
+    gp = models.make_gp(1e-3, 1.2, ell, 0.1)
+    gp.add_data(X, y)
+    bounds = np.array([[0.0, 1.0]] * 3)
+    idx = policies.UCB(gp, bounds, X)
+    tv, ti = idx.topk(Z, k)
+    np.testing.assert_array_equal(ti, np.lexsort((np.arange(len(Z)), -idx(Z)))[:k])
+
+
+def test_triangular_inverse_association_option():
+    """Option trtri_left (the recursion as -(T22 L21) T11): another rounding, the same posterior within the ladder."""
+    X, y, ell = synth_problem(900, 4, seed=11)
+    ref = gp_ref.make_gp(1e-4, 1.3, ell, 0.1, 'matern5')
+    ref.add_data(X, y)
+    Z = np.random.RandomState(4).rand(500, 4)
+    mr, sr = ref.predict(Z)
+    for left in (0, 1):
+        e = _engine(trtri_left=left)
+        e.fit(X, y, 'matern5', ell, 1.3, 1e-4, 0.1)
+        mu, s2 = e.predict(Z)
+        assert np.all(np.abs(mu - mr) <= mu_tol(mr, 1.3)) and np.all(np.abs(s2 - sr) <= s2_tol(sr, 1.3))
+        T = e.get_matrix('T')
+        L = e.get_matrix('L')
+        assert np.abs(T @ L - np.eye(len(L))).max() < 1e-9
+        e.close()
