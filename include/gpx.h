@@ -240,7 +240,9 @@ int gpx_rff_gram_batch(gpx_handle *h, const double *W, const double *b, int64_t 
  * pybo/policies/simple.py:48): feature Grams as above, then per draw
  *     B = sc^2 A + sn2 I = L L^T,    theta = sc ( B^-1 (sc v) + sqrt(sn2) L^-T z )
  * with z (S,n) the caller's standard-normal draws, sc = sqrt(2 rho / n) and sn2 the fitted noise variance (> 0);
- * theta (S,n) comes back ready for gpx_rff_sweep* / gpx_rff_grad.  n <= 127.  GPX_ENOTPD if a B is not PD. */
+ * theta (S,n) comes back ready for gpx_rff_sweep* / gpx_rff_grad.  n <= 127: all S draws in one launch chain (the n x n
+ * posterior of a draw lives in LDS); 128 <= n <= 4096: per draw the blocked Cholesky kernels of the fit + two vector
+ * substitutions (`n` is a free keyword of the reference's sample_f, pybo/policies/simple.py:44).  GPX_ENOTPD if a B is not PD. */
 int gpx_rff_posterior(gpx_handle *h, const double *W, const double *b, const double *z, int64_t S, int64_t n,
                       double sc, double *theta);
 

@@ -1256,8 +1256,48 @@ extern "C" int gpx_rff_posterior(gpx_handle* h, const double* W, const double* b
         if (!h) return GPX_EARG;
         if (h->stage < 1) return fail(h, GPX_ESTATE, "rff_posterior: no data on the device (fit first)");
         if (!W || !b || !z || !theta || n < 1 || S < 1) return fail(h, GPX_EARG, "rff_posterior: bad arguments");
-        if (n >= TBH) return fail(h, GPX_EARG, "rff_posterior: n <= 127 features (the weight posterior lives in LDS)");
+        if (n > 4096) return fail(h, GPX_EARG, "rff_posterior: n <= 4096 features");
         if (!(sc > 0.0) || !(h->sn2 > 0.0)) return fail(h, GPX_EARG, "rff_posterior: needs sc > 0 and a noise variance > 0");
+        if (n >= TBH) {
+            // wide feature maps (n >= 128: the weight posterior no longer fits the LDS-resident kernel): per draw the
+            // generic feature Gram, then B = sc^2 A + sn2 I factorised by the blocked Cholesky kernels and two vector
+            // substitutions, all on the device -- nothing but theta crosses PCIe
+            HIPCHK(h, hipSetDevice(h->device));
+            hipStream_t s = h->stream;
+            const int64_t d = h->d, Np = h->Np, N = h->N, np = (n + NB - 1) / NB * NB;
+            int rc;
+            // layout: [W n*d][b n][A n*n][v n][z n][work n][theta n][B np*np][R np*np][Ft n*Np]
+            const int64_t need = n * d + 6 * n + n * n + 2 * np * np + n * Np;
+            if ((rc = ensure(h, h->drff, h->cap_rff, need))) return rc;
+            double* dW = h->drff;
+            double* db = dW + n * d;
+            double* dA = db + n;
+            double* dv = dA + n * n;
+            double* dz = dv + n;
+            double* dwork = dz + n;
+            double* dth = dwork + n;
+            double* dB = dth + n;
+            double* dR = dB + np * np;
+            double* dFt = dR + np * np;
+            int* pflag = h->dflag + 8;
+            for (int64_t q = 0; q < S; ++q) {
+                HIPCHK(h, hipMemcpyAsync(dW, W + q * n * d, (size_t)n * d * 8, hipMemcpyHostToDevice, s));
+                HIPCHK(h, hipMemcpyAsync(db, b + q * n, (size_t)n * 8, hipMemcpyHostToDevice, s));
+                HIPCHK(h, hipMemcpyAsync(dz, z + q * n, (size_t)n * 8, hipMemcpyHostToDevice, s));
+                int flag = 0;
+                {
+                    Span sp(h, T_RFF);
+                    launch_rff_gram(s, h->dXraw, dFt, N, (int)d, dW, db, (int)n, h->dy, h->bias, dA, dv);
+                    launch_posterior_wide(s, dA, dv, dz, (int)n, np, sc, h->sn2, dB, dR, dwork, pflag, dth);
+                }
+                HIPCHK(h, hipMemcpyAsync(theta + q * n, dth, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+                HIPCHK(h, hipMemcpyAsync(&flag, pflag, sizeof(int), hipMemcpyDeviceToHost, s));
+                HIPCHK(h, hipStreamSynchronize(s));
+                HIPCHK(h, hipGetLastError());
+                if (flag != 0) return fail(h, GPX_ENOTPD, "rff_posterior: the feature Gram of a draw is not positive definite");
+            }
+            return GPX_OK;
+        }
         HIPCHK(h, hipSetDevice(h->device));
         hipStream_t s = h->stream;
         int rc;

@@ -191,6 +191,8 @@ void launch_refine_inverse(gpx_handle* h, double* tmp);   // option refine_inver
 void launch_alpha(gpx_handle* h);      // a = T (y - bias); alpha = U a
 void launch_kinv_diag(gpx_handle* h, double* out);   // out[i] = [K^-1]_ii = sum_m U[i][m]^2
 void launch_transpose_lower(hipStream_t s, const double* R, int64_t Np, double* out, int64_t N);
+void launch_posterior_wide(hipStream_t s, const double* A, const double* v, const double* z, int n, int64_t np, double sc,
+                           double sn2, double* B, double* R, double* work, int* flag, double* theta);   // n >= 128 features
 
 // launchers (kernels_sweep.hip)
 void launch_cross_gram(hipStream_t s, const double* Xs, int64_t Np, int64_t N, int d, const double* Xc,

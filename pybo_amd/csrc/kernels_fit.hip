@@ -1145,6 +1145,96 @@ static int loglik_batch_chunk(gpx_handle* h, int64_t B, const double* hyp, doubl
     return GPX_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// A small SPD system on the device (the n x n weight posterior of a Thompson draw with n >= 128 random features,
+// pybo/policies/simple.py:44 -- `n` is a free keyword there; the LDS-resident k_rff_posterior stops at 127):
+//   k_form_posterior_matrix   B = sc^2 A + sn2 I into the upper 128-block triangle of an (np, np) buffer, identity padding
+//   launch_cholesky_small     B = R^T R with the blocked kernels above on ONE stream (no lookahead: a few blocks)
+//   k_posterior_solve         theta = sc R^-1 ( R^-T (sc v) + sqrt(sn2) z ): one forward and one backward substitution
+//                             on vectors, one workgroup (column sweeps over R in global memory; O(n^2))
+// ------------------------------------------------------------------------------------------------
+__global__ void k_form_posterior_matrix(const double* __restrict__ A, int n, int64_t np, double sc2, double sn2,
+                                        double* __restrict__ B) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= np * np) return;
+    const int64_t i = idx / np, j = idx - i * np;
+    double v = (i == j) ? 1.0 : 0.0;
+    if (i < n && j < n) v = sc2 * A[i * n + j] + ((i == j) ? sn2 : 0.0);
+    B[idx] = v;
+}
+
+void launch_cholesky_small(hipStream_t s, double* S, double* R, int64_t np, int* flag) {
+    const int nP = (int)(np / NB);
+    hipMemsetAsync(flag, 0, sizeof(int), s);
+    for (int P0 = 0; P0 < nP; P0 += CHOL_W) {
+        const int P1 = (P0 + CHOL_W < nP) ? P0 + CHOL_W : nP;
+        for (int I = P0; I < P1; ++I) {
+            if (I > P0)
+                hipLaunchKernelGGL(k_row_update64, dim3((unsigned)(2 * (nP - I)), 2, 1), dim3(GEMM64_THREADS), 0, s, R, S, np, P0,
+                                   I, I, (int64_t)0, nP, 0);
+            // (the 16 x 16 inverses go to the dead diagonal blocks of S, as in the batched likelihood path)
+            hipLaunchKernelGGL(k_potrf16<false>, dim3(1, 1, 1), dim3(256), 0, s, S, R, (double*)nullptr, S, np, I, flag,
+                               (long long*)nullptr, (int64_t)0);
+            const int rem = nP - 1 - I;
+            if (rem > 0)
+                hipLaunchKernelGGL(k_panel_solve16, dim3((unsigned)(2 * rem), 1, 1), dim3(256), 0, s, S, S, R, np, I, flag,
+                                   (int64_t)0);
+        }
+        if (P1 < nP)
+            hipLaunchKernelGGL(k_syrk_update, dim3((unsigned)(nP - P1), (unsigned)(nP - P1), 1), dim3(GEMM_THREADS), 0, s, R, S,
+                               np, P0, P1, P1, P1, (int64_t)0);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_posterior_solve(const double* __restrict__ R, int64_t np, int n,
+                                                         const double* __restrict__ v, const double* __restrict__ z,
+                                                         double sc, double sn2, const int* __restrict__ flag,
+                                                         double* __restrict__ work, double* __restrict__ theta) {
+    // work: n doubles of scratch (the running right-hand side)
+    if (*flag != 0) return;
+    const int t = threadIdx.x;
+    __shared__ double piv;
+    for (int i = t; i < n; i += 256) work[i] = sc * v[i];
+    __syncthreads();
+    // forward: R^T u = sc v  (R^T lower: column i of R^T = row i of R, contiguous)
+    for (int i = 0; i < n; ++i) {
+        if (t == 0) { piv = work[i] / R[(int64_t)i * np + i]; work[i] = piv; }
+        __syncthreads();
+        const double u = piv;
+        const double* row = R + (int64_t)i * np;
+        for (int j = i + 1 + t; j < n; j += 256) work[j] = fma(-row[j], u, work[j]);
+        __syncthreads();
+    }
+    const double sq = sqrt(sn2);
+    for (int i = t; i < n; i += 256) work[i] += sq * z[i];
+    __syncthreads();
+    // backward: R x = u + sqrt(sn2) z  (row i of R against the solved tail: a dot product per step)
+    __shared__ double part[256];
+    for (int i = n - 1; i >= 0; --i) {
+        const double* row = R + (int64_t)i * np;
+        double acc = 0.0;
+        for (int j = i + 1 + t; j < n; j += 256) acc = fma(row[j], work[j], acc);
+        part[t] = acc;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (t < off) part[t] += part[t + off];
+            __syncthreads();
+        }
+        if (t == 0) work[i] = (work[i] - part[0]) / row[i];
+        __syncthreads();
+    }
+    for (int i = t; i < n; i += 256) theta[i] = sc * work[i];
+}
+
+void launch_posterior_wide(hipStream_t s, const double* A, const double* v, const double* z, int n, int64_t np, double sc,
+                           double sn2, double* B, double* R, double* work, int* flag, double* theta) {
+    const int64_t tot = np * np;
+    hipLaunchKernelGGL(k_form_posterior_matrix, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, A, n, np, sc * sc, sn2, B);
+    launch_cholesky_small(s, B, R, np, flag);
+    hipLaunchKernelGGL(k_posterior_solve, dim3(1), dim3(256), 0, s, R, np, n, v, z, sc, sn2, flag, work, theta);
+}
+
 // out (N,N) row-major = transpose of the leading N x N part of src (Np,Np) keeping only the part
 // that is lower-triangular in `out` (used to hand L = R^T to the parity tests)
 __global__ void k_transpose_lower(const double* __restrict__ src, int64_t Np, double* __restrict__ out,

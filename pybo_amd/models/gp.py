@@ -449,7 +449,8 @@ class GP(object):
 
     def sample_f(self, n, rng=None):
         """RFF posterior function sample.  Host draws (order fixed: randn(n,d), [chisquare], rand(n),
-        randn(n)); the O(N n^2) feature Gram and (n < 128) the n x n weight posterior run on the device."""
+        randn(n)); the O(N n^2) feature Gram and the n x n weight posterior run on the device (n <= 4096 features; a
+        noise-free model solves on the host)."""
         rng = rstate(rng)
         d = len(self.ell)
         W = rng.randn(n, d)
@@ -463,7 +464,7 @@ class GP(object):
         sc = np.sqrt(2.0 * self.rho / n)
         if self.ndata == 0:
             return RFFSampleDevice(self, W, b, sc * z)
-        if n < 128 and self.sn2 > 0.0:      # feature Gram AND the n x n weight posterior on the device (gpx_rff_posterior)
+        if n <= 4096 and self.sn2 > 0.0:    # feature Gram AND the n x n weight posterior on the device (gpx_rff_posterior)
             theta = self._engine().rff_posterior(W[None], b[None], z[None], sc)[0]
             return RFFSampleDevice(self, W, b, theta)
         A, v = self._engine().rff_gram(W, b)           # wide feature maps / a noise-free model: the n x n solve on the host

@@ -430,7 +430,7 @@ def test_rff_paths_match_oracle(kernel):
         # cond(B) ~ 1e6-1e8 here: both solves carry ~cond * eps relative error
         np.testing.assert_allclose(th_dev[q], ths[q], rtol=0, atol=1e-7 * np.abs(ths[q]).max())
     with pytest.raises(GpxError):
-        e.rff_posterior(np.zeros((1, 128, 3)), np.zeros((1, 128)), np.zeros((1, 128)), 0.1)     # n <= 127
+        e.rff_posterior(np.zeros((1, 4097, 3)), np.zeros((1, 4097)), np.zeros((1, 4097)), 0.1)  # n <= 4096
     with pytest.raises(GpxError):
         e.rff_posterior(np.array(Ws), np.array(bs), np.array(zs), 0.0)                          # sc > 0
     # wide feature maps (n >= 128) take the per-draw path
@@ -762,3 +762,35 @@ def test_triangular_inverse_association_option():
         L = e.get_matrix('L')
         assert np.abs(T @ L - np.eye(len(L))).max() < 1e-9
         e.close()
+
+
+@pytest.mark.parametrize('kernel,n', [('se', 128), ('matern5', 300), ('se', 515)])
+def test_wide_feature_maps_keep_the_weight_posterior_on_the_device(kernel, n):
+    """`n` is a free keyword of the reference's Thompson policy (pybo/policies/simple.py:44); the device posterior stopped
+    at 127 features (LDS-resident kernel).  n >= 128: B = sc^2 A + sn2 I goes through the blocked Cholesky kernels and two
+    vector substitutions on the device (gpx_rff_posterior) -- against the oracle's sample_f with the same draws, and
+    through the model layer (GP.sample_f -> values and top-1 on a grid)."""
+    e, ref, (X, y, ell, rho, sn2, bias) = _pair(400, 3, kernel, seed=7, sn2=1e-2)
+    kid = gp_ref.KERNEL_IDS[kernel]
+    Ws, bs, zs, ths = [], [], [], []
+    for q in range(2):
+        smp = ref.sample_f(n, rng=50 + q)
+        rng = np.random.RandomState(50 + q)
+        Wq, bq = gp_ref.rff_draw_spectral(kid, n, 3, ell, rng)
+        np.testing.assert_array_equal(Wq, smp.W)
+        Ws.append(smp.W); bs.append(smp.b); ths.append(smp.theta); zs.append(rng.randn(n))
+    th = e.rff_posterior(np.array(Ws), np.array(bs), np.array(zs), np.sqrt(2.0 * rho / n))
+    for q in range(2):
+        np.testing.assert_allclose(th[q], ths[q], rtol=0, atol=1e-6 * np.abs(ths[q]).max())
+    e.close()
+    from pybo_amd import models
+    gp = models.make_gp(sn2, rho, ell, bias, kernel=kernel)
+    gp.add_data(X, y)
+    Z = np.random.RandomState(1).rand(3000, 3)
+    dev = gp.sample_f(n, rng=50)
+    want = ref.sample_f(n, rng=50).get(Z)
+    got = dev.get(Z)
+    term = np.sqrt(np.mean((want - bias) ** 2))
+    assert np.max(np.abs(got - want)) <= 1e-6 * term
+    tv, ti = dev.topk(Z, 1)
+    assert ti[0] == int(np.argmax(want)) or abs(want[ti[0]] - want.max()) <= 1e-6 * term
