@@ -100,7 +100,8 @@ int gpx_version(void);
  *              128-blocks; 0: the stream schedule above.  Bit-identical factors either way.  Tuning / diagnostics:
  *              "chol_tg_chunks" (k-chunk sizes counted back from the pivot as decimal digits, default 1248 = 1, 2, 4, 8, 8, ..),
  *              "chol_tg_split" (s + 1000 b: chunks ending within s blocks of the pivot, and every chunk of the tiles within b
- *              blocks of the diagonal, go to a queue of their own that is served first; default 200 = one queue),
+ *              blocks of the diagonal, go to a queue of their own that is served first; + 1000000: a tile's panel solve and the
+ *              final chunk of the tile below it as ONE task -- measured slower; default 200 = one queue, not fused),
  *              "chol_tg_side" (workgroups reserved for the critical tiles, default 8), "chol_tg_grid" (workgroups launched,
  *              0 = by size), "chol_tg_isolate" (1, default: the critical workgroups keep their compute units to themselves),
  *              "chol_tg_tmo_ms" (bound of every spin, default 2000: on expiry the fit re-runs on the stream schedule and

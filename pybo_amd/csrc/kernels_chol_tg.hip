@@ -40,7 +40,7 @@
 
 namespace gpx {
 
-enum { TG_TRSM = 1, TG_UPD = 2, TG_UPDQ = 3 };
+enum { TG_TRSM = 1, TG_UPD = 2, TG_UPDQ = 3, TG_TRSMU = 4 };
 struct TgTask { int16_t type, I, J, k0, k1, ord, aux, rsv; };     // 16 bytes; aux = column half (TRSM) / quadrant (UPDQ)
 
 struct TgArgs {
@@ -98,6 +98,10 @@ __device__ __forceinline__ bool tg_deps_met(const TgTask& t, const int* dd, cons
     const int s = ldi(sq + I * nP + J);
     if (PRE) return s == t.ord;
     if (t.type == TG_TRSM) return (ldi(dd + I) != 0) && (s == t.ord);
+    // the fused task: also the earlier chunks of the tile BELOW -- with two worker queues they may sit in the lower-priority
+    // one, and a workgroup that waited for them inside the task could wait for ever; only the critical solve of (p, p+1),
+    // which has workgroups of its own, is awaited in the task body
+    if (t.type == TG_TRSMU) return (ldi(dd + I) != 0) && (s == t.ord) && (ldi(sq + (I + 1) * nP + J) == t.aux);
     const int s0 = ldi(sv + 2 * I), s1 = ldi(sv + 2 * I + 1), s2 = ldi(sv + 2 * J), s3 = ldi(sv + 2 * J + 1);
     return (s == t.ord) && (min(min(s0, s1), min(s2, s3)) >= t.k1);
 }
@@ -256,6 +260,9 @@ __device__ __forceinline__ bool updq_body(const TgArgs& a, const double* __restr
 // row 4 kk + g, column n) is 64 consecutive doubles.  Same MFMAs in the same order as panel_solve16_body.
 __device__ __forceinline__ int tri_index(int r, int c) { return 8 * r - r * (r - 1) / 2 + c - r; }
 
+// NH = 2: BOTH 64-column halves of a tile by one workgroup (the fused solve + update task): the image of R_pp is staged
+// once, the second half's right-hand sides travel during the first substitution.
+template <int NH>
 __device__ __forceinline__ bool panel_solve16_lds(const TgArgs& a, const double* __restrict__ U, const double* __restrict__ S,
                                                   double* __restrict__ R, int64_t Np, int p, int cb, double* lds,
                                                   const int* diag) {
@@ -294,26 +301,40 @@ __device__ __forceinline__ bool panel_solve16_lds(const TgArgs& a, const double*
         for (int kk = 0; kk < 4; ++kk) ti[jb][kk] = ldg<true>(Ud + (int64_t)(16 * jb + 4 * kk + g) * Np + 16 * jb + n);
 #pragma unroll
     for (int q = 0; q < 18; ++q) *reinterpret_cast<u4v*>(lds + dst[q]) = stage[q];
+    d4 X2[8];
+    if (NH == 2) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) X2[r][q] = ldg<true>(S + (p0 + 16 * r + g + 4 * q) * Np + j0 + 64 + n);
+    }
     __syncthreads();
     // (2) the substitution
 #pragma unroll
-    for (int jb = 0; jb < 8; ++jb) {
-        d4 x = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int hh = 0; hh < NH; ++hh) {
+        if (hh == 1) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(ti[jb][kk], X[jb][kk], x, 0, 0, 0);
-        X[jb] = x;
-        const d4 xn = -x;
-#pragma unroll
-        for (int i = jb + 1; i < 8; ++i) {
-            const double* tl = lds + 256 * tri_index(jb, i) + g * 16 + n;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) X[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(tl[kk * 64], xn[kk], X[i], 0, 0, 0);
+            for (int r = 0; r < 8; ++r) X[r] = X2[r];
         }
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) {
+            d4 x = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(ti[jb][kk], X[jb][kk], x, 0, 0, 0);
+            X[jb] = x;
+            const d4 xn = -x;
+#pragma unroll
+            for (int i = jb + 1; i < 8; ++i) {
+                const double* tl = lds + 256 * tri_index(jb, i) + g * 16 + n;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) X[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(tl[kk * 64], xn[kk], X[i], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) stg<true>(R + (p0 + 16 * r + g + 4 * q) * Np + j0 + 64 * hh + n, X[r][q]);
     }
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) stg<true>(R + (p0 + 16 * r + g + 4 * q) * Np + j0 + n, X[r][q]);
     __syncthreads();                               // the LDS image is free again
     return true;
 }
@@ -393,7 +414,7 @@ __device__ __noinline__ bool tg_do_trsm(const TgArgs& a, int p, int cb) {
     p = __builtin_amdgcn_readfirstlane(p); cb = __builtin_amdgcn_readfirstlane(cb);
     __builtin_amdgcn_s_setprio(3);
     const int* diag = uni(a.ctl) + TG_CTL_BASE;
-    return panel_solve16_lds(a, uni(a.U), uni(a.S), uni(a.R), (int64_t)uni64((unsigned long long)a.Np), p, cb, tg_smem, diag);
+    return panel_solve16_lds<1>(a, uni(a.U), uni(a.S), uni(a.R), (int64_t)uni64((unsigned long long)a.Np), p, cb, tg_smem, diag);
 }
 __device__ __noinline__ bool tg_do_updq(const TgArgs& a, int k0, int k1, int I, int q) {
     k0 = __builtin_amdgcn_readfirstlane(k0); k1 = __builtin_amdgcn_readfirstlane(k1);
@@ -402,6 +423,46 @@ __device__ __noinline__ bool tg_do_updq(const TgArgs& a, int k0, int k1, int I, 
     const int* solved = uni(a.ctl) + TG_CTL_BASE + 2 * tg_npad(__builtin_amdgcn_readfirstlane(a.nP));
     return updq_body(a, uni(a.R), uni(a.S), (int64_t)uni64((unsigned long long)a.Np), k0, k1, I, q, solved);
 }
+// The FUSED task (type TG_TRSMU; option chol_tg_split + 1000000, OFF by default): the panel solve of the whole tile (p, J)
+// and, with its result, the final chunk [k0, p+1) of the tile below it, (p+1, J) -- the update the next block row's solve
+// waits for.  As separate tasks these are two dependent rounds through the queue per diagonal block (a solve, then a K = 1
+// update): under load each round costs its own wait for a free worker (10-55 us), take, publish and reload, and the two
+// rounds -- not the diagonal blocks -- set the pace of the first half of the factorisation (127 us per block against the
+// chain's 58; profiles/r04_chol_taskgraph.txt).  MEASURED: fusing them is slower at every size (N = 8192: 6.44 against
+// 5.44 ms, N = 2048: 1.22 against 0.90): one workgroup doing both halves of the solve and then the update is a longer
+// serial path (~65 us) than two workgroups solving in parallel followed by a third updating, and in the chain-bound second
+// half of the factorisation that path becomes the block period (86 against 58 us).  Kept for the measurement.
+// The solved flags are raised between the two parts (other tiles of block column J wait for them).
+__device__ __noinline__ bool tg_do_trsm_upd(const TgArgs& a, int p, int J, int k0, int k1, int ord2) {
+    p = __builtin_amdgcn_readfirstlane(p); J = __builtin_amdgcn_readfirstlane(J);
+    k0 = __builtin_amdgcn_readfirstlane(k0); k1 = __builtin_amdgcn_readfirstlane(k1);
+    ord2 = __builtin_amdgcn_readfirstlane(ord2);
+    const int nP = __builtin_amdgcn_readfirstlane(a.nP), npad = tg_npad(nP);
+    int* ctl = uni(a.ctl);
+    int* dd = ctl + TG_CTL_BASE;
+    int* sv = dd + 2 * npad;
+    int* sq = sv + 2 * npad;
+    double* R = uni(a.R);
+    double* S = uni(a.S);
+    const int64_t Np = (int64_t)uni64((unsigned long long)a.Np);
+    __builtin_amdgcn_s_setprio(3);
+    if (!panel_solve16_lds<2>(a, uni(a.U), S, R, Np, p, 2 * (J - p - 1), tg_smem, dd)) return false;
+    tg_drain();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sti(sv + 2 * J, p + 1);
+        sti(sv + 2 * J + 1, p + 1);
+    }
+    // the tile below: its earlier chunks (another workgroup's, ticketed before this task) and the critical solve of (p, p+1)
+    if (!tg_wait_flags(a, sq + (p + 1) * nP + J, sq + (p + 1) * nP + J, ord2)) return false;
+    if (!tg_wait_flags(a, sv + 2 * (p + 1), sv + 2 * (p + 1) + 1, k1)) return false;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
+    syrk_tile<true, 2>(R, S, Np, k0, k1, p + 1, J, tg_smem);
+    return true;
+}
+
 template <int QB, int NQ>
 __device__ __noinline__ int tg_take_call(const TgArgs& a, TgTask& out, int lane) {
     return tg_take<QB, NQ>(a, out, lane, reinterpret_cast<TgHeld*>(tg_smem + GEMM_LDS_F64 + 4));
@@ -475,6 +536,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
             else tg_do_upd<1>(a, tk.k0, tk.k1, tk.I, tk.J);
         } else if (tk.type == TG_TRSM) {
             if (!tg_do_trsm(a, tk.I, 2 * (tk.J - tk.I - 1) + tk.aux)) break;
+        } else if (tk.type == TG_TRSMU) {
+            if (!tg_do_trsm_upd(a, tk.I, tk.J, tk.k0, tk.k1, tk.aux)) break;
         } else {
             if (!tg_do_updq(a, tk.k0, tk.k1, tk.I, tk.aux)) break;
         }
@@ -492,9 +555,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
                 }
                 prof[0] += 1;
                 prof[tk.type == TG_UPD ? 2 : 3] += te - ts;
-                if (tk.type == TG_UPD) prof[5] += tk.k1 - tk.k0;
+                if (tk.type == TG_UPD || tk.type == TG_TRSMU) prof[5] += tk.k1 - tk.k0;
             }
             if (tk.type == TG_UPD) sti(sq + tk.I * nP + tk.J, tk.ord + 1);
+            else if (tk.type == TG_TRSMU) sti(sq + (tk.I + 1) * nP + tk.J, tk.aux + 1);      // (its solved flags went up mid-task)
             else if (tk.type == TG_TRSM) sti(sv + 2 * tk.J + tk.aux, tk.I + 1);
             else atomicAdd(qd + tk.I, 1);
             if (side && a.trace) {
@@ -537,7 +601,7 @@ static std::vector<int> tg_boundaries(int I, const std::vector<int>& sizes) {
 
 struct TgTables { std::vector<TgTask> q[3]; };
 
-static void tg_build(int nP, int chunk_code, int split, int band, TgTables& out) {
+static void tg_build(int nP, int chunk_code, int split, int band, bool fuse, TgTables& out) {
     std::vector<int> sizes;
     {
         std::vector<int> dg;
@@ -561,8 +625,15 @@ static void tg_build(int nP, int chunk_code, int split, int band, TgTables& out)
     for (int q = 0; q < 3; ++q) out.q[q].clear();
     for (int p = 0; p < nP; ++p) {
         const int nch = (int)bnd[p].size() - 1;        // chunks of every tile of row p (0 for row 0)
-        for (int J = p + 1; J < nP; ++J)
-            for (int h = 0; h < 2; ++h) push(J == p + 1 ? 0 : 1, TG_TRSM, p, J, 0, 0, (p == 0) ? 0 : nch, h, 0);
+        // fused: the solve of tile (p, J), J >= p + 2, carries the final chunk of the tile below it (row p + 1)
+        const bool fz = fuse && p + 1 < nP;
+        const int nb1 = fz ? (int)bnd[p + 1].size() - 1 : 0;
+        for (int J = p + 1; J < nP; ++J) {
+            if (fz && J >= p + 2)
+                push(1, TG_TRSMU, p, J, bnd[p + 1][nb1 - 1], p + 1, (p == 0) ? 0 : nch, nb1 - 1, 1);
+            else
+                for (int h = 0; h < 2; ++h) push(J == p + 1 ? 0 : 1, TG_TRSM, p, J, 0, 0, (p == 0) ? 0 : nch, h, 0);
+        }
         for (int I : ends[p + 1]) {                    // rows ascending: nearest the pivot first
             if (I == 0) continue;
             size_t j = 1;
@@ -573,6 +644,8 @@ static void tg_build(int nP, int chunk_code, int split, int band, TgTables& out)
                 const int q = (d <= split || J - I <= band) ? 1 : 2;
                 if (d == 0 && J == I) {
                     for (int qu = 0; qu < TG_NPIECE; ++qu) push(0, TG_UPDQ, I, I, k0, k1, ord, qu, 0);
+                } else if (d == 0 && fuse && J >= I + 1) {
+                    // (the final chunk of tile (I, J), J >= I + 1, rides on the solve of tile (I - 1, J))
                 } else {
                     push(q, TG_UPD, I, J, k0, k1, ord, 0, q == 1 ? 1 : 0);
                 }
@@ -587,7 +660,7 @@ int64_t tg_tasks_copy(int nP, int chunks, int split, int16_t* out, int64_t cap, 
     TgTables tb;
     if (chunks <= 0) chunks = TG_DEFAULT_CHUNKS;
     if (split < 0) split = TG_DEFAULT_SPLIT;
-    tg_build(nP, chunks, split % 1000, split / 1000, tb);
+    tg_build(nP, chunks, split % 1000, (split / 1000) % 1000, split >= 1000000, tb);
     int64_t tot = 0;
     for (int q = 0; q < 3; ++q) { counts[q] = (int64_t)tb.q[q].size(); tot += counts[q]; }
     if (out && cap >= tot) {
@@ -637,7 +710,7 @@ bool launch_cholesky_tg(gpx_handle* h) {
     const int split = h->tg_split >= 0 ? h->tg_split : TG_DEFAULT_SPLIT;
     if (c->nP != nP || c->chunks != chunks || c->split != split || !c->dq) {
         TgTables tb;
-        tg_build(nP, chunks, split % 1000, split / 1000, tb);
+        tg_build(nP, chunks, split % 1000, (split / 1000) % 1000, split >= 1000000, tb);
         const int64_t tot = (int64_t)tb.q[0].size() + (int64_t)tb.q[1].size() + (int64_t)tb.q[2].size() + 3;
         if (tot > c->cap_q) {
             if (c->dq) (void)hipFree(c->dq);

@@ -8,7 +8,7 @@ import pytest
 
 from pybo_amd import _lib
 
-TRSM, UPD, UPDQ = 1, 2, 3
+TRSM, UPD, UPDQ, TRSMU = 1, 2, 3, 4
 
 
 class Replay(object):
@@ -36,7 +36,17 @@ class Replay(object):
         typ, I, J, k0, k1, ordn = (int(v) for v in t[:6])
         if typ == TRSM:
             return bool(self.diag[I]) and self.seq[I, J] == ordn
+        if typ == TRSMU:         # ... and the earlier chunks of the tile below (taken only then: see tg_deps_met)
+            return bool(self.diag[I]) and self.seq[I, J] == ordn and self.seq[I + 1, J] == int(t[6])
         return self.seq[I, J] == ordn and min(self.solved[I].min(), self.solved[J].min()) >= k1
+
+    def can_finish(self, t):
+        """The fused solve + update task waits INSIDE the task for its second part's dependencies: the earlier chunks of
+        the tile below and the critical solve of (p, p+1)."""
+        typ, I, J, k0, k1, ordn, aux = (int(v) for v in t[:7])
+        if typ != TRSMU:
+            return True
+        return self.seq[I + 1, J] == aux and self.solved[I + 1].min() >= k1
 
     def blk(self, M, I, J):
         nb = self.nb
@@ -51,6 +61,14 @@ class Replay(object):
                 Rpp = self.blk(self.R, I, I)
                 cols = slice(J * nb + aux * h, J * nb + (aux + 1) * h)
                 self.R[I * nb:(I + 1) * nb, cols] = np.linalg.solve(Rpp.T, self.S[I * nb:(I + 1) * nb, cols])
+        elif typ == TRSMU:
+            # first part: the solve of the whole tile (I, J); its flags go up before the second part starts
+            assert self.applied[I, J] == I, 'panel solve of an incomplete tile'
+            if nb:
+                Rpp = self.blk(self.R, I, I)
+                self.blk(self.R, I, J)[...] = np.linalg.solve(Rpp.T, self.blk(self.S, I, J))
+            assert (self.solved[J] == I).all()
+            self.solved[J] = I + 1
         else:
             if typ == UPD:
                 assert self.applied[I, J] == k0, 'chunks out of order: tile (%d, %d) has %d, task starts at %d' % (I, J, self.applied[I, J], k0)
@@ -75,6 +93,16 @@ class Replay(object):
         if typ == TRSM:
             assert self.solved[J, aux] == I
             self.solved[J, aux] = I + 1
+        elif typ == TRSMU:
+            # second part: the final chunk [k0, k1) of the tile below
+            assert self.can_finish(t) and self.applied[I + 1, J] == k0 and k1 == I + 1
+            if self.nb:
+                nb = self.nb
+                A = self.R[k0 * nb:k1 * nb, (I + 1) * nb:(I + 2) * nb]
+                B = self.R[k0 * nb:k1 * nb, J * nb:(J + 1) * nb]
+                self.blk(self.S, I + 1, J)[...] -= A.T @ B
+            self.applied[I + 1, J] = k1
+            self.seq[I + 1, J] = aux + 1
         elif typ == UPD:
             self.applied[I, J] = k1
             self.seq[I, J] = ordn + 1
@@ -99,22 +127,26 @@ class Replay(object):
             steps += 1
             assert steps < 50 * total + 1000, 'no progress: dead-lock in the task lists'
             moves = []
-            if len(inflight) < max_inflight:
-                for qi in range(3):
-                    if self.head[qi] < len(self.q[qi]) and self.ready(self.q[qi][self.head[qi]]):
-                        moves.append(('take', qi))
+            # (the critical queue has its own workgroups on the device: its tasks do not compete for the workers' slots --
+            #  the fused solve + update task waits INSIDE a worker for a critical solve)
+            nwork = sum(1 for kind, t in inflight if kind == 'task' and not t[-1])
+            for qi in range(3):
+                if (qi == 0 or nwork < max_inflight) and self.head[qi] < len(self.q[qi]) and self.ready(self.q[qi][self.head[qi]]):
+                    moves.append(('take', qi))
+            if True:
                 p = self.next_potrf
                 if p < self.nP and not any(t[0] == 'potrf' for t in inflight) and (p == 0 or self.quad[p] == 6):
                     moves.append(('potrf', p))
             for i in range(len(inflight)):
-                moves.append(('finish', i))
+                if inflight[i][0] == 'potrf' or self.can_finish(inflight[i][1]):
+                    moves.append(('finish', i))
             assert moves, 'dead-lock: nothing ready, nothing in flight (heads %s, next diagonal block %d)' % (self.head, self.next_potrf)
             m = moves[self.rng.randint(len(moves))]
             if m[0] == 'take':
                 t = self.q[m[1]][self.head[m[1]]]
                 self.head[m[1]] += 1
                 self.run_task(t)           # (results become visible at 'finish'; nobody may read them before)
-                inflight.append(('task', t))
+                inflight.append(('task', tuple(int(v) for v in t) + (m[1] == 0,)))
             elif m[0] == 'potrf':
                 self.potrf(m[1])
                 inflight.append(('potrf', m[1]))
@@ -157,8 +189,11 @@ def run_ticketed(r, nworkers=5, nside=2, greedy=0.5):
         for wi, wg in enumerate(wgs):
             if wg['busy'] is not None:
                 t = wg['busy']
-                if r.ready(t):                       # (a side-kick's task in hand may still wait for its last dependency)
-                    moves.append(('finish', wi))
+                if wg.get('started'):
+                    if r.can_finish(t):              # (the fused task's second part waits inside the task)
+                        moves.append(('finish', wi))
+                elif r.ready(t):                     # (a side-kick's task in hand may still wait for its last dependency)
+                    moves.append(('start', wi))
                 continue
             for qi in wg['queues']:
                 chk = pre_ready if qi == 0 else r.ready
@@ -187,11 +222,15 @@ def run_ticketed(r, nworkers=5, nside=2, greedy=0.5):
         elif m[0] == 'run_held':
             wg, qi = wgs[m[1]], m[2]
             wg['busy'] = wg['held'].pop(qi)
-        elif m[0] == 'finish':
+        elif m[0] == 'start':
             wg = wgs[m[1]]
             r.run_task(wg['busy'])
+            wg['started'] = True
+        elif m[0] == 'finish':
+            wg = wgs[m[1]]
             r.finish(wg['busy'])
             wg['busy'] = None
+            wg['started'] = False
             done += 1
         elif m[0] == 'potrf':
             r.potrf(m[1])
@@ -220,12 +259,14 @@ def test_ticketed_protocol_with_held_tickets_never_deadlocks(nP, chunks, split, 
 
 
 @pytest.mark.parametrize('nP', [1, 2, 3, 5, 8, 17, 40])
-@pytest.mark.parametrize('chunks,split', [(0, -1), (1124, 2), (14, 0), (1128, 0), (11, 0), (1224, 4)])
+@pytest.mark.parametrize('chunks,split', [(0, -1), (1124, 2), (14, 0), (1128, 0), (11, 0), (1224, 4), (1248, 1000200), (14, 1002002)])
 def test_lists_complete_in_order_without_deadlock(nP, chunks, split):
     q = _lib.chol_tasks(nP, chunks, split)
     n_upd_tiles = nP * (nP + 1) // 2
     assert len(q[0]) == 8 * (nP - 1)
-    assert sum(int((a[:, 0] == TRSM).sum()) for a in q) == nP * (nP - 1)       # two halves per off-diagonal tile
+    ntr = sum(int((a[:, 0] == TRSM).sum()) for a in q)
+    nfu = sum(int((a[:, 0] == TRSMU).sum()) for a in q)
+    assert ntr + 2 * nfu == nP * (nP - 1)                                       # two halves per off-diagonal tile
     for seed in range(3):
         Replay(nP, q, seed=seed).run(max_inflight=1 + 3 * seed)
     assert n_upd_tiles >= 1
@@ -247,6 +288,7 @@ def test_chunks_are_graded_towards_the_pivot():
     nP = 24
     q = _lib.chol_tasks(nP)
     upd = np.vstack([a[a[:, 0] == UPD] for a in q[1:]])
+    assert not any(np.any(a[:, 0] == TRSMU) for a in q)      # (solve + update fused into one task: an option, off by default)
     for I in range(3, nP - 1):
         mine = upd[(upd[:, 1] == I) & (upd[:, 2] == nP - 1)]
         sizes = (mine[:, 4] - mine[:, 3])[np.argsort(mine[:, 3])]
@@ -259,6 +301,10 @@ def test_chunks_are_graded_towards_the_pivot():
     assert far_sizes.max() <= 5 and far_sizes.min() >= 1
     off = q2[1][(q2[1][:, 0] == UPD) & (q2[1][:, 2] > q2[1][:, 1])]      # (every chunk of a DIAGONAL tile is urgent)
     assert np.all(off[:, 1] == off[:, 4])                                # off the diagonal: final chunks only
+    q3 = _lib.chol_tasks(nP, 1124, 1000000)                              # fusion on: the final chunks ride on the solves
+    f3 = q3[1][q3[1][:, 0] == TRSMU]
+    assert len(f3) == (nP - 1) * (nP - 2) // 2 and np.all(f3[:, 4] - f3[:, 3] <= 2)
+    assert len(q3[1][(q3[1][:, 0] == UPD) & (q3[1][:, 2] > q3[1][:, 1])]) == 0
 
 
 def test_bad_arguments():
