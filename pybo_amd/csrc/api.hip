@@ -499,12 +499,12 @@ static int fit_core(gpx_handle* h, const double* dX, int64_t N, int64_t d, const
             Span sp(h, T_CHOL);
             // the persistent task-graph kernel (kernels_chol_tg.hip) unless switched off, diagnosed in parts, or too small
             h->tg_launched = false;
+            // the side streams of a model this size (the stream schedule's lookahead; the announced-observation pass of the
+            // warm loop runs on the third one) are created HERE, in the cold fit, whichever factorisation runs: created
+            // on first use by gpx_append_begin they cost the first warm iteration ~18 ms (three HSA queues)
+            if (h->Np / NB > (h->chol_w ? h->chol_w : 4) && (rc = ensure_side_streams(h))) return rc;
             const bool tg = h->chol_tg && h->x_skip == 0 && h->x_bg <= 0 && h->Np / NB >= h->tg_min && launch_cholesky_tg(h);
-            if (!tg) {
-                // more than one outer panel: the lookahead needs its streams (see launch_cholesky)
-                if (h->Np / NB > (h->chol_w ? h->chol_w : 4) && (rc = ensure_side_streams(h))) return rc;
-                launch_cholesky(h);
-            }
+            if (!tg) launch_cholesky(h);
         }
         int flag = 0;
         HIPCHK(h, hipMemcpyAsync(&flag, h->dflag, sizeof(int), hipMemcpyDeviceToHost, s));

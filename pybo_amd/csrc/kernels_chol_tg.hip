@@ -122,6 +122,7 @@ __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, T
     for (unsigned spins = 0;; ++spins) {
         if (ldi(ctl + TG_CTL_ABORT) != 0) return -1;
         bool live = false, ready = false, mine = false;
+        int hpeek = -1;
         union { TgTask t; int4 v; } u;
         u.v = make_int4(0, 0, 0, 0);
         if (lane < NQ) {
@@ -131,6 +132,7 @@ __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, T
                 live = true;
             } else {
                 const int h = ldi(head);
+                hpeek = h;
                 live = h < nq;
                 if (live) u.v = *reinterpret_cast<const int4*>(tq + h);
             }
@@ -149,7 +151,9 @@ __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, T
                     got = 1;
                 } else {
                     const int k = atomicAdd(head, 1);
-                    if (k < nq) {
+                    if (k == hpeek) {
+                        got = 1;                   // the very task that was peeked (and found ready): no second look
+                    } else if (k < nq) {
                         u.v = *reinterpret_cast<const int4*>(tq + k);
                         if (tg_deps_met<QB == 0>(u.t, dd, sv, sq, nP)) {
                             got = 1;
