@@ -96,13 +96,14 @@ int gpx_version(void);
  *              Both bit-identical, both measured and off by default ("The fit -- round 3").
  *          "chol_tg" = 1 (default): the factorisation runs as ONE persistent kernel that walks its task graph (dedicated
  *              workgroups for the diagonal blocks and the two tiles between consecutive ones, everything else as
- *              throughput work from dependency-checked queues; kernels_chol_tg.hip) for fits of >= "chol_tg_min" (default 16)
- *              128-blocks; 0: the stream schedule above.  Bit-identical factors either way.  Tuning / diagnostics:
+ *              throughput work from dependency-checked queues; kernels_chol_tg.hip) for fits of "chol_tg_min" (default 16) to
+ *              "chol_tg_max" (default 160) 128-blocks; 0: the stream schedule above.  Bit-identical factors either way.  Tuning / diagnostics:
  *              "chol_tg_chunks" (k-chunk sizes counted back from the pivot as decimal digits, default 1248 = 1, 2, 4, 8, 8, ..),
  *              "chol_tg_split" (s + 1000 b: chunks ending within s blocks of the pivot, and every chunk of the tiles within b
  *              blocks of the diagonal, go to a queue of their own that is served first; + 1000000: a tile's panel solve and the
  *              final chunk of the tile below it as ONE task -- measured slower; default 200 = one queue, not fused),
- *              "chol_tg_side" (workgroups reserved for the critical tiles, default 8), "chol_tg_grid" (workgroups launched,
+ *              "chol_tg_queues" (a worker looks at this many strided sub-queues of its list at once, 1..16; default 1 --
+ *              measured much slower beyond 1), "chol_tg_side" (workgroups reserved for the critical tiles, default 8), "chol_tg_grid" (workgroups launched,
  *              0 = by size), "chol_tg_isolate" (1, default: the critical workgroups keep their compute units to themselves),
  *              "chol_tg_tmo_ms" (bound of every spin, default 2000: on expiry the fit re-runs on the stream schedule and
  *              says so on stderr), "chol_tg_trace" = 1 (stamp the critical path, read with gpx_chol_trace).

@@ -269,7 +269,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
         }
         if (!strcmp(name, "chol_tg") || !strcmp(name, "chol_tg_chunks") || !strcmp(name, "chol_tg_split") ||
             !strcmp(name, "chol_tg_side") || !strcmp(name, "chol_tg_grid") || !strcmp(name, "chol_tg_trace") ||
-            !strcmp(name, "chol_tg_tmo_ms") || !strcmp(name, "chol_tg_min") || !strcmp(name, "chol_tg_isolate")) {
+            !strcmp(name, "chol_tg_tmo_ms") || !strcmp(name, "chol_tg_min") || !strcmp(name, "chol_tg_max") || !strcmp(name, "chol_tg_isolate") || !strcmp(name, "chol_tg_queues")) {
             if (value < -1 || value > 100000000) return fail(h, GPX_EARG, "chol_tg*: out of range");
             const char* sub = name + 7;
             if (*sub == 0) { if (value != 0 && value != 1) return fail(h, GPX_EARG, "chol_tg must be 0 or 1"); h->chol_tg = (int)value; }
@@ -280,6 +280,8 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             else if (!strcmp(sub, "_trace")) h->tg_trace = (int)value;
             else if (!strcmp(sub, "_tmo_ms")) h->tg_tmo_ms = (int)value;
             else if (!strcmp(sub, "_isolate")) h->tg_isolate = (int)value;
+            else if (!strcmp(sub, "_queues")) h->tg_queues = (int)value;
+            else if (!strcmp(sub, "_max")) h->tg_max = (int)std::max<int64_t>(1, value);
             else h->tg_min = (int)std::max<int64_t>(1, value);
             return GPX_OK;
         }
@@ -503,7 +505,7 @@ static int fit_core(gpx_handle* h, const double* dX, int64_t N, int64_t d, const
             // warm loop runs on the third one) are created HERE, in the cold fit, whichever factorisation runs: created
             // on first use by gpx_append_begin they cost the first warm iteration ~18 ms (three HSA queues)
             if (h->Np / NB > (h->chol_w ? h->chol_w : 4) && (rc = ensure_side_streams(h))) return rc;
-            const bool tg = h->chol_tg && h->x_skip == 0 && h->x_bg <= 0 && h->Np / NB >= h->tg_min && launch_cholesky_tg(h);
+            const bool tg = h->chol_tg && h->x_skip == 0 && h->x_bg <= 0 && h->Np / NB >= h->tg_min && h->Np / NB <= h->tg_max && launch_cholesky_tg(h);
             if (!tg) launch_cholesky(h);
         }
         int flag = 0;

@@ -53,6 +53,8 @@ struct TgArgs {
     int n[3];
     int nside;
     int isolate;                 // the critical workgroups keep their compute units to themselves
+    int nsub;                    // strided sub-queues per worker list (1 .. TG_SUB_MAX)
+    int sub_heads;               // offset (ints) of their head counters in the control block
     long long* trace;            // optional: [p][4] critical-path stamps, then [crit task][2]
     long long tmo;               // spin bound in wall-clock ticks (100 MHz)
     long long* tasklog;          // optional (trace level 2): per workgroup TG_LOG_CAP records {task (2 words), start, end}
@@ -70,7 +72,8 @@ constexpr int TG_LOG_CAP = 1024, TG_LOG_WGS = 1024;
 constexpr int TG_NPIECE = 6;          // pieces of the critical update of a diagonal tile
 constexpr int TG_CTL_ABORT = 32, TG_CTL_HEAD = 64, TG_CTL_BASE = 192, TG_CU_KEYS = 4096;
 __host__ __device__ inline int tg_npad(int nP) { return (nP + 31) / 32 * 32; }
-__host__ __device__ inline int tg_ctl_ints(int nP) { return TG_CTL_BASE + 4 * tg_npad(nP) + nP * nP + 2 * TG_CU_KEYS; }
+__host__ __device__ inline int tg_sub_heads(int nP) { return TG_CTL_BASE + 4 * tg_npad(nP) + nP * nP + 2 * TG_CU_KEYS; }
+__host__ __device__ inline int tg_ctl_ints(int nP) { return tg_sub_heads(nP) + 32 * 2 * 16; }
 
 __device__ __forceinline__ int ldi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void sti(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -87,7 +90,6 @@ __device__ __forceinline__ void sti(int* p, int v) { __hip_atomic_store(p, v, __
 // looking: a held task is run as soon as it is ready, a higher-priority queue is served meanwhile.  No workgroup ever
 // sleeps on a task: the earliest incomplete task of the whole graph is either held by a workgroup that polls it or at the
 // head of its queue where every workgroup without a held ticket for that queue peeks -- the lists cannot dead-lock.
-struct TgHeld { TgTask t[3]; int have[3]; int pad; };       // in LDS, one per workgroup (indexed by queue)
 
 // PRE (the critical queue): only the dependency on the tile's earlier chunks -- a side-kick takes its task as soon as the
 // tile it will read first is final, starts loading it, and waits for the last dependency (the diagonal block / the two
@@ -106,6 +108,13 @@ __device__ __forceinline__ bool tg_deps_met(const TgTask& t, const int* dd, cons
     return (s == t.ord) && (min(min(s0, s1), min(s2, s3)) >= t.k1);
 }
 
+// Worker queues are read through `nsub` STRIDED sub-queues each (option chol_tg_queues; sub-queue r of a list = its tasks
+// r, r + nsub, r + 2 nsub, ... with a head counter of its own): a head that is not ready blocks only its own sub-queue, the
+// workgroup looks at nsub heads per list at once (one lane each) and takes any that is ready, starting from a different one
+// every time.  Every sub-queue is a subsequence of a topological order, so the no-dead-lock argument above holds per sub-queue.
+constexpr int TG_SUB_MAX = 16;
+struct TgHeld { TgTask t[1 + 2 * TG_SUB_MAX]; int have[1 + 2 * TG_SUB_MAX]; int turn; };     // in LDS, one per workgroup
+
 template <int QB, int NQ>
 __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, TgHeld* held) {
     const int nP = a.nP, npad = tg_npad(nP);
@@ -115,8 +124,14 @@ __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, T
     const int* sq = sv + 2 * npad;
     const long long t0 = wall_clock64();
     int nap = 0;                                   // polls since the last find: the pauses grow (QB == 0: stay alert)
-    const int q = QB + (lane < NQ ? lane : 0);
-    int* head = ctl + TG_CTL_HEAD + 32 * q;
+    // lane -> (list q, sub-queue r, stride): the critical list is read whole by lane 0; a worker's lane l reads
+    // sub-queue l % nsub of list 1 + l / nsub
+    const int nsub = (QB == 0) ? 1 : a.nsub;
+    const int nlane = NQ * nsub;
+    const int q = QB + (lane < nlane ? lane / nsub : 0);
+    const int r = (lane < nlane) ? lane % nsub : 0;
+    const int slot = (QB == 0) ? 0 : 1 + lane;     // held-ticket slot of this lane
+    int* head = (QB == 0) ? ctl + TG_CTL_HEAD : (ctl + a.sub_heads + 32 * ((q - 1) * TG_SUB_MAX + r));
     const int nq = (q == 0) ? a.n[0] : ((q == 1) ? a.n[1] : a.n[2]);
     const TgTask* tq = (q == 0) ? a.q[0] : ((q == 1) ? a.q[1] : a.q[2]);
     for (unsigned spins = 0;; ++spins) {
@@ -125,44 +140,55 @@ __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, T
         int hpeek = -1;
         union { TgTask t; int4 v; } u;
         u.v = make_int4(0, 0, 0, 0);
-        if (lane < NQ) {
-            mine = held->have[q] != 0;
+        if (lane < nlane) {
+            mine = held->have[slot] != 0;
             if (mine) {
-                u.t = held->t[q];
+                u.t = held->t[slot];
                 live = true;
             } else {
                 const int h = ldi(head);
                 hpeek = h;
-                live = h < nq;
-                if (live) u.v = *reinterpret_cast<const int4*>(tq + h);
+                live = r + nsub * h < nq;
+                if (live) u.v = *reinterpret_cast<const int4*>(tq + r + nsub * h);
             }
             if (live) ready = tg_deps_met<QB == 0>(u.t, dd, sv, sq, nP);
         }
         if (__ballot(live) == 0) return 0;
-        // a held urgent ticket that is not ready yet is about to be: do not start a long task of a lower queue under it
-        const bool hold_back = NQ > 1 && nap < 12 && __shfl((mine && !ready) ? 1 : 0, 0) != 0;
+        // (two lists, one sub-queue each: a held urgent ticket that is not ready yet is about to be -- do not start a long
+        //  task of the lower list under it)
+        const bool hold_back = NQ > 1 && nsub == 1 && nap < 12 && __shfl((mine && !ready) ? 1 : 0, 0) != 0;
         const unsigned long long mr = __ballot(ready && !(hold_back && lane > 0));
         if (mr != 0) {
-            const int pick = __ffsll((long long)mr) - 1;
+            // list 1 before list 2; inside a list start from a different sub-queue every time
+            int pick;
+            {
+                const unsigned long long m1 = mr & ((1ull << nsub) - 1ull);
+                const unsigned long long mm = m1 ? m1 : (mr >> nsub);
+                const int base = m1 ? 0 : nsub;
+                const int st = held->turn % nsub;
+                const unsigned long long rot = ((mm >> st) | (mm << (nsub - st))) & ((1ull << nsub) - 1ull);
+                pick = (QB == 0) ? 0 : base + (__ffsll((long long)rot) - 1 + st) % nsub;
+            }
             int got = 0;                            // 1: u.t is ours and ready
             if (lane == pick) {
                 if (mine) {
-                    held->have[q] = 0;
+                    held->have[slot] = 0;
                     got = 1;
                 } else {
                     const int k = atomicAdd(head, 1);
                     if (k == hpeek) {
                         got = 1;                   // the very task that was peeked (and found ready): no second look
-                    } else if (k < nq) {
-                        u.v = *reinterpret_cast<const int4*>(tq + k);
+                    } else if (r + nsub * k < nq) {
+                        u.v = *reinterpret_cast<const int4*>(tq + r + nsub * k);
                         if (tg_deps_met<QB == 0>(u.t, dd, sv, sq, nP)) {
                             got = 1;
                         } else {
-                            held->t[q] = u.t;
-                            held->have[q] = 1;
+                            held->t[slot] = u.t;
+                            held->have[slot] = 1;
                         }
                     }
                 }
+                held->turn += 1;
             }
             got = __shfl(got, pick);
             if (got) {
@@ -185,7 +211,7 @@ __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, T
     }
 }
 
-constexpr int TG_LDS_F64 = GEMM_LDS_F64 + 16;       // + the task in hand (2), flags (2), held tickets (8)
+constexpr int TG_LDS_F64 = GEMM_LDS_F64 + 96;       // + the task in hand (2), flags (2), held tickets (<= 33 x 20 bytes)
 // The workgroup's LDS: the tile engine's buffer (the diagonal kernel's panels fit inside) + a slot for the task in hand.
 // File scope, so that the role bodies below can be separate (non-inlined) functions with their own register allocation
 // and still address it with ds_* instructions: inlined into one kernel body the roles spilled 319 VGPRs.
@@ -489,7 +515,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
         // looks up what the first one became and leaves at once if that is a critical role (a grid of two workgroups
         // per CU has no third one waiting to take the slot).
         TgHeld* hd = reinterpret_cast<TgHeld*>(tg_smem + GEMM_LDS_F64 + 4);
-        hd->have[0] = hd->have[1] = hd->have[2] = 0;
+        for (int i = 0; i < 1 + 2 * TG_SUB_MAX; ++i) hd->have[i] = 0;
+        hd->turn = 0;
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf;
         const int key = (int)((xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf));
         int* cu_cnt = sq + nP * nP;
@@ -505,6 +532,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
             if (a.isolate) atomicCAS(cu_role + key, 0, r + 1);
         }
         code[0] = r;
+        hd->turn = (r > 0) ? r : 0;            // (workers start their rounds at different sub-queues)
     }
     __syncthreads();
     const int role = code[0];
@@ -783,6 +811,8 @@ bool launch_cholesky_tg(gpx_handle* h) {
     for (int q = 0; q < 3; ++q) { a.q[q] = c->dq + c->off[q]; a.n[q] = c->n[q]; }
     a.nside = nside;
     a.isolate = (h->tg_isolate != 0 && grid_is_full) ? 1 : 0;
+    a.nsub = std::max(1, std::min(h->tg_queues > 0 ? h->tg_queues : 1, TG_SUB_MAX));
+    a.sub_heads = tg_sub_heads(nP);
     a.trace = h->tg_trace ? c->dtrace : nullptr;
     a.tasklog = nlog ? c->dtrace + 20 * (int64_t)nP + 8 * 1024 + 16 : nullptr;
     a.tmo = (long long)(h->tg_tmo_ms > 0 ? h->tg_tmo_ms : 2000) * 100000LL;
