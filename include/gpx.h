@@ -103,7 +103,8 @@ int gpx_version(void);
  *              blocks of the diagonal, go to a queue of their own that is served first; + 1000000: a tile's panel solve and the
  *              final chunk of the tile below it as ONE task -- measured slower; default 200 = one queue, not fused),
  *              "chol_tg_queues" (a worker looks at this many strided sub-queues of its list at once, 1..16; default 1 --
- *              measured much slower beyond 1), "chol_tg_side" (workgroups reserved for the critical tiles, default 8), "chol_tg_grid" (workgroups launched,
+ *              measured much slower beyond 1), "chol_tg_upool" (workers that serve the urgent list only; measured slower),
+ *              "chol_tg_side" (workgroups reserved for the critical tiles, default 8), "chol_tg_grid" (workgroups launched,
  *              0 = by size), "chol_tg_isolate" (1, default: the critical workgroups keep their compute units to themselves),
  *              "chol_tg_tmo_ms" (bound of every spin, default 2000: on expiry the fit re-runs on the stream schedule and
  *              says so on stderr), "chol_tg_trace" = 1 (stamp the critical path, read with gpx_chol_trace).

@@ -59,6 +59,7 @@ struct gpx_handle {
     int tg_max = 160;             // ... and the largest (from N = 24576 on the stream schedule is 1-2 % faster: both throughput-bound)
     int tg_chunks = 0;            // chunk sizes counted back from the pivot, as decimal digits (0 = default 1248: 1, 2, 4, 8, 8, ..)
     int tg_split = -1;            // chunks ending within this many blocks of the pivot go to the urgent queue (-1 = default 200: one queue)
+    int tg_upool = 0;             // workers that serve the urgent list only (0 = none)
     int tg_queues = 0;            // strided sub-queues per worker list (0 = default 1)
     int tg_side = 0;              // workgroups reserved for the two critical tiles per block (0 = default 8)
     int tg_grid = 0;              // workgroups launched (0 = by size, bounded by residency)

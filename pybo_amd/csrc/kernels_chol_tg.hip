@@ -54,6 +54,7 @@ struct TgArgs {
     int nside;
     int isolate;                 // the critical workgroups keep their compute units to themselves
     int nsub;                    // strided sub-queues per worker list (1 .. TG_SUB_MAX)
+    int upool;                   // workers that serve the urgent list only
     int sub_heads;               // offset (ints) of their head counters in the control block
     long long* trace;            // optional: [p][4] critical-path stamps, then [crit task][2]
     long long tmo;               // spin bound in wall-clock ticks (100 MHz)
@@ -543,6 +544,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
         return;
     }
     const bool side = role <= a.nside;
+    // option chol_tg_upool: the first `upool` workers serve the urgent list ONLY (they are free when a burst of solves /
+    // final chunks arrives); meaningful with two lists (chol_tg_split < 200)
+    const bool upool = !side && (role - a.nside - 1) < a.upool;
     long long prof[6] = {0, 0, 0, 0, 0, 0};
     long long tprev = a.trace ? wall_clock64() : 0;
     for (;;) {
@@ -550,7 +554,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
             TgTask tk;
             tk.type = 0;
             __builtin_amdgcn_s_setprio(0);
-            const int c = side ? tg_take_call<0, 1>(a, tk, lane) : tg_take_call<1, 2>(a, tk, lane);
+            const int c = side ? tg_take_call<0, 1>(a, tk, lane)
+                               : (upool ? tg_take_call<1, 1>(a, tk, lane) : tg_take_call<1, 2>(a, tk, lane));
             if (lane == 0) {
                 *cur = tk;
                 code[0] = c;
@@ -813,6 +818,7 @@ bool launch_cholesky_tg(gpx_handle* h) {
     a.isolate = (h->tg_isolate != 0 && grid_is_full) ? 1 : 0;
     a.nsub = std::max(1, std::min(h->tg_queues > 0 ? h->tg_queues : 1, TG_SUB_MAX));
     a.sub_heads = tg_sub_heads(nP);
+    a.upool = std::max(0, h->tg_upool);
     a.trace = h->tg_trace ? c->dtrace : nullptr;
     a.tasklog = nlog ? c->dtrace + 20 * (int64_t)nP + 8 * 1024 + 16 : nullptr;
     a.tmo = (long long)(h->tg_tmo_ms > 0 ? h->tg_tmo_ms : 2000) * 100000LL;
