@@ -638,7 +638,7 @@ static std::vector<int> tg_boundaries(int I, const std::vector<int>& sizes) {
 
 struct TgTables { std::vector<TgTask> q[3]; };
 
-static void tg_build(int nP, int chunk_code, int split, int band, bool fuse, TgTables& out) {
+static void tg_build(int nP, int chunk_code, int split, int band, bool fuse, int order, TgTables& out) {
     std::vector<int> sizes;
     {
         std::vector<int> dg;
@@ -665,27 +665,41 @@ static void tg_build(int nP, int chunk_code, int split, int band, bool fuse, TgT
         // fused: the solve of tile (p, J), J >= p + 2, carries the final chunk of the tile below it (row p + 1)
         const bool fz = fuse && p + 1 < nP;
         const int nb1 = fz ? (int)bnd[p + 1].size() - 1 : 0;
-        for (int J = p + 1; J < nP; ++J) {
+        // one update task of this step: the chunk of tile (I, J) that ends at boundary p + 1
+        auto push_upd = [&](int I, int J) {
+            size_t j = 1;
+            while (bnd[I][j] != p + 1) ++j;
+            const int k0 = bnd[I][j - 1], k1 = p + 1, ord = (int)j - 1, d = I - k1;
+            // urgent: the chunks next to the pivot (of every tile) and every chunk of the tiles next to the diagonal
+            const int q = (d <= split || J - I <= band) ? 1 : 2;
+            if (d == 0 && J == I) {
+                for (int qu = 0; qu < TG_NPIECE; ++qu) push(0, TG_UPDQ, I, I, k0, k1, ord, qu, 0);
+            } else if (d == 0 && fuse && J >= I + 1) {
+                // (the final chunk of tile (I, J), J >= I + 1, rides on the solve of tile (I - 1, J))
+            } else {
+                push(q, TG_UPD, I, J, k0, k1, ord, 0, q == 1 ? 1 : 0);
+            }
+        };
+        auto push_trsm = [&](int J) {
             if (fz && J >= p + 2)
                 push(1, TG_TRSMU, p, J, bnd[p + 1][nb1 - 1], p + 1, (p == 0) ? 0 : nch, nb1 - 1, 1);
             else
                 for (int h = 0; h < 2; ++h) push(J == p + 1 ? 0 : 1, TG_TRSM, p, J, 0, 0, (p == 0) ? 0 : nch, h, 0);
-        }
-        for (int I : ends[p + 1]) {                    // rows ascending: nearest the pivot first
-            if (I == 0) continue;
-            size_t j = 1;
-            while (bnd[I][j] != p + 1) ++j;
-            const int k0 = bnd[I][j - 1], k1 = p + 1, ord = (int)j - 1, d = I - k1;
-            for (int J = I; J < nP; ++J) {
-                // urgent: the chunks next to the pivot (of every tile) and every chunk of the tiles next to the diagonal
-                const int q = (d <= split || J - I <= band) ? 1 : 2;
-                if (d == 0 && J == I) {
-                    for (int qu = 0; qu < TG_NPIECE; ++qu) push(0, TG_UPDQ, I, I, k0, k1, ord, qu, 0);
-                } else if (d == 0 && fuse && J >= I + 1) {
-                    // (the final chunk of tile (I, J), J >= I + 1, rides on the solve of tile (I - 1, J))
-                } else {
-                    push(q, TG_UPD, I, J, k0, k1, ord, 0, q == 1 ? 1 : 0);
-                }
+        };
+        if (order == 1) {
+            // COLUMN-major inside the step: every update right behind the LAST solve it needs -- the solve of block column J
+            // is followed by the chunks of all tiles (I, J), I <= J, that end here (rows nearest the pivot first)
+            for (int J = p + 1; J < nP; ++J) {
+                push_trsm(J);
+                for (int I : ends[p + 1])
+                    if (I != 0 && I <= J) push_upd(I, J);
+            }
+        } else {
+            // ROW-major (default): all solves of block row p, then the chunks row by row
+            for (int J = p + 1; J < nP; ++J) push_trsm(J);
+            for (int I : ends[p + 1]) {                    // rows ascending: nearest the pivot first
+                if (I == 0) continue;
+                for (int J = I; J < nP; ++J) push_upd(I, J);
             }
         }
     }
@@ -697,7 +711,7 @@ int64_t tg_tasks_copy(int nP, int chunks, int split, int16_t* out, int64_t cap, 
     TgTables tb;
     if (chunks <= 0) chunks = TG_DEFAULT_CHUNKS;
     if (split < 0) split = TG_DEFAULT_SPLIT;
-    tg_build(nP, chunks, split % 1000, (split / 1000) % 1000, split >= 1000000, tb);
+    tg_build(nP, chunks, split % 1000, (split / 1000) % 1000, (split / 1000000) % 10 == 1, (split / 10000000) % 10, tb);
     int64_t tot = 0;
     for (int q = 0; q < 3; ++q) { counts[q] = (int64_t)tb.q[q].size(); tot += counts[q]; }
     if (out && cap >= tot) {
@@ -747,7 +761,7 @@ bool launch_cholesky_tg(gpx_handle* h) {
     const int split = h->tg_split >= 0 ? h->tg_split : TG_DEFAULT_SPLIT;
     if (c->nP != nP || c->chunks != chunks || c->split != split || !c->dq) {
         TgTables tb;
-        tg_build(nP, chunks, split % 1000, (split / 1000) % 1000, split >= 1000000, tb);
+        tg_build(nP, chunks, split % 1000, (split / 1000) % 1000, (split / 1000000) % 10 == 1, (split / 10000000) % 10, tb);
         const int64_t tot = (int64_t)tb.q[0].size() + (int64_t)tb.q[1].size() + (int64_t)tb.q[2].size() + 3;
         if (tot > c->cap_q) {
             if (c->dq) (void)hipFree(c->dq);
