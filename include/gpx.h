@@ -71,6 +71,17 @@ int gpx_version(void);
  *              Every setting produces bit-identical results.
  *          "super_m" = rows of the XCD super-tile of 64 workgroups (8 -> 8x8 default, 4 -> 4x16, ...).
  *          "eager_inverse" = 1: form the triangular inverse inside gpx_fit instead of on first use.
+ *          "grad_form": the form of gpx_predict / gpx_ensemble_predict WITH gradients.  0 (default) = auto: a call with
+ *              M = 1 point -- every call of the reference's single-seed refinement [pybo/solvers/lbfgs.py:56-58] -- takes
+ *              ONE pass over the triangular inverse T with 1 + d right-hand sides, ds2/dx_j = -2 (T k).(T dk/dx_j), when
+ *              1 + d <= 16 (N = 8192, d = 8: 105 us per call instead of 159); calls with more points take two passes
+ *              (T, then U = T^T) with one right-hand side per point.  1 = always two passes, 2 = one pass for every M
+ *              (floor(16 / (1 + d)) points per pass).  Within a form a point's results do not depend on the batch it
+ *              travels in; the two forms agree to rounding, not bit for bit.  gpx_predict_mean with M = 1 likewise runs
+ *              as one launch (unless grad_form = 1).
+ *          "grad_kernel": the triangular matvec of the two-pass form: -1 (default) = register-blocked (4 rows x all
+ *              right-hand sides per wave, column segments) for batches and one wave per row for a single point, 0 / 1 =
+ *              always the one / the other.  "grad_rb_rows" (4 | 8), "grad_rb_cs" (columns per segment): experiments.
  *          "trtri_left" = 1: the recursive doubling of the triangular inverse associated as T21 = -(T22 L21) T11 instead of
  *              T21 = -T22 (L21 T11) (default 0).  Built in round 4 on the expectation that it keeps the LEFT residual
  *              T R^T - I at rounding level for the same flop; MEASURED (profiles/r04_illcond_vs_long_double.txt): it does not
@@ -98,7 +109,7 @@ int gpx_version(void);
  *              workgroups for the diagonal blocks and the two tiles between consecutive ones, everything else as
  *              throughput work from dependency-checked queues; kernels_chol_tg.hip) for fits of "chol_tg_min" (default 16) to
  *              "chol_tg_max" (default 160) 128-blocks; 0: the stream schedule above.  Bit-identical factors either way.  Tuning / diagnostics:
- *              "chol_tg_chunks" (k-chunk sizes counted back from the pivot as decimal digits, default 1248 = 1, 2, 4, 8, 8, ..),
+ *              "chol_tg_chunks" (k-chunk sizes counted back from the pivot as decimal digits, default 12489 = 1, 2, 4, 8, 16, 16, ..: the digit 9 stands for 16 blocks),
  *              "chol_tg_split" (s + 1000 b: chunks ending within s blocks of the pivot, and every chunk of the tiles within b
  *              blocks of the diagonal, go to a queue of their own that is served first; + 1000000: a tile's panel solve and the
  *              final chunk of the tile below it as ONE task -- measured slower; + 10000000: column-major order inside a step --
@@ -181,7 +192,8 @@ int gpx_var_at_obs(gpx_handle *h, double *s2_host);
 int64_t gpx_capacity(const gpx_handle *h);
 
 /* ---- posterior moments = model.predict(X, grad) [pybo/policies/simple.py:64] ------------- */
-/* Xc (M,d) -> mu (M,), s2 (M,) latent variance; dmu, ds2 (M,d) optional (NULL to skip). */
+/* Xc (M,d) -> mu (M,), s2 (M,) latent variance; dmu, ds2 (M,d) optional (NULL to skip).  With gradients a single point
+ * (M = 1) is answered in the one-pass form, batches in the two-pass form: option "grad_form" above. */
 int gpx_predict(gpx_handle *h, const double *Xc, int64_t M, double *mu, double *s2, double *dmu,
                 double *ds2);
 

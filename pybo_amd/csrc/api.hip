@@ -320,6 +320,26 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             gpx::g_rff_variant = (int)value;
             return GPX_OK;
         }
+        if (!strcmp(name, "grad_form")) {
+            if (value < 0 || value > 2) return fail(h, GPX_EARG, "grad_form must be 0 (auto), 1 (two passes) or 2 (one pass)");
+            h->grad_form = (int)value;
+            return GPX_OK;
+        }
+        if (!strcmp(name, "grad_rb_rows")) {
+            if (value != 4 && value != 8) return fail(h, GPX_EARG, "grad_rb_rows must be 4 or 8");
+            h->grad_rb_rows = (int)value;
+            return GPX_OK;
+        }
+        if (!strcmp(name, "grad_rb_cs")) {
+            if (value < 0 || value % 128 || value > 65536) return fail(h, GPX_EARG, "grad_rb_cs must be a multiple of 128 (0 = default)");
+            h->grad_rb_cs = (int)value;
+            return GPX_OK;
+        }
+        if (!strcmp(name, "grad_kernel")) {
+            if (value < -1 || value > 1) return fail(h, GPX_EARG, "grad_kernel must be -1 (auto), 0 or 1");
+            h->grad_kernel = (int)value;
+            return GPX_OK;
+        }
         if (!strcmp(name, "trtri_left")) {
             if (value != 0 && value != 1) return fail(h, GPX_EARG, "trtri_left must be 0 or 1");
             h->trtri_left = (int)value;

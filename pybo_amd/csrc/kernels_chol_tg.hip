@@ -68,7 +68,7 @@ struct TgArgs {
 // and ONE worker queue (split >= the matrix: everything is "urgent", i.e. plain generation order).  Two queues with the
 // near-pivot chunks first were measured 15-25 % slower at every size: a near chunk waits for its tile's previous chunk,
 // which then sits in the LOWER-priority queue behind a backlog -- priority inversion.
-constexpr int TG_DEFAULT_CHUNKS = 1248, TG_DEFAULT_SPLIT = 200;
+constexpr int TG_DEFAULT_CHUNKS = 12489, TG_DEFAULT_SPLIT = 200;
 constexpr int TG_LOG_CAP = 1024, TG_LOG_WGS = 1024;
 constexpr int TG_NPIECE = 6;          // pieces of the critical update of a diagonal tile
 constexpr int TG_CTL_ABORT = 32, TG_CTL_HEAD = 64, TG_CTL_BASE = 192, TG_CU_KEYS = 4096;
@@ -644,7 +644,7 @@ static void tg_build(int nP, int chunk_code, int split, int band, bool fuse, int
         std::vector<int> dg;
         for (int c = chunk_code; c > 0; c /= 10) dg.push_back(c % 10);
         std::reverse(dg.begin(), dg.end());
-        for (int v : dg) if (v > 0) sizes.push_back(v);
+        for (int v : dg) if (v > 0) sizes.push_back(v == 9 ? 16 : v);       // (digit 9 stands for a chunk of 16 blocks)
         if (sizes.empty() || sizes[0] != 1) sizes.insert(sizes.begin(), 1);      // the final chunk is one block
     }
     std::vector<std::vector<int>> bnd(nP);

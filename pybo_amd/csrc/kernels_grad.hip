@@ -10,6 +10,10 @@
 //
 // Memory-bound by design: one pass over T and one over U per batch of up to GB candidates (matvecs
 // with GB right-hand sides, one wave per matrix row, coalesced row reads).
+//
+// Round 4, the ONE-PASS form for a single point (every call of the reference's single-seed refinement, lbfgs.py:56-58):
+//   ds2/dx_j = -2 (T k*).(T dk*/dx_j):  the d derivative vectors travel as extra right-hand sides of the SAME pass over T,
+//   and U is not read at all -- 1 + d right-hand sides, one pass (k_tri_matvec_rb), instead of two dependent passes.
 #include <string.h>
 
 #include <algorithm>
@@ -151,6 +155,194 @@ static void launch_tri_matvec_multi(hipStream_t s, unsigned rows4, const double*
         hipLaunchKernelGGL(k_tri_matvec_multi<GB>, dim3(rows4), dim3(256), 0, s, Mx, Np, N, in, mb, mode, out);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Register-blocked triangular matvec with several right-hand sides.  k_tri_matvec_multi reads every right-hand side
+// once per matrix ROW (one wave per row): with 9 right-hand sides the vector loads are 9x the matrix stream and the
+// pass takes 180 us instead of 58 (N = 8192; the L1's 64 B/clk per CU is the limit).  Here a wave owns RB_R = 4
+// consecutive rows over one segment of RB_CS columns: a right-hand-side pair is loaded once and used by all four rows
+// (vector traffic 1/4), and the pieces (row group x column segment) are all about the same size, so the triangular
+// matrix needs no dynamic balancing.  Each piece writes its partial sums part[seg][m][row]; the consumer adds the
+// ceil(N / RB_CS) partials of a row in ascending order (empty pieces write zeros), so a row's value depends on neither the
+// batch it travels in nor the launch order.  mode 0: lower (columns [0, row]), mode 1: upper (columns [row, N)).
+// ------------------------------------------------------------------------------------------------
+constexpr int RB_CS_DEFAULT = 2048;
+
+template <int MBT, int R, bool MASK>
+__device__ __forceinline__ void rb_piece(const double* __restrict__ Mx, int64_t Np, int64_t N, int64_t r0,
+                                         const double* __restrict__ in, int mode, int64_t cb, int64_t ce,
+                                         double (&acc)[R][MBT]) {
+    const int lane = threadIdx.x & 63;
+    const double* mr = Mx + r0 * Np;
+#pragma unroll 2
+    for (int64_t c = cb + 2 * lane; c < ce; c += 128) {
+        double2 t[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) t[r] = *reinterpret_cast<const double2*>(mr + r * Np + c);
+        if (MASK) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int64_t row = r0 + r;
+                const bool okx = (mode == 0 ? c <= row : c >= row) && c < N && row < N;
+                const bool oky = (mode == 0 ? c + 1 <= row : c + 1 >= row) && c + 1 < N && row < N;
+                t[r].x = okx ? t[r].x : 0.0;
+                t[r].y = oky ? t[r].y : 0.0;
+            }
+        }
+        // (MBT is the EXACT number of right-hand sides: a run-time "m < mb" test around each vector load made the loads of
+        //  a step wait for one another -- nine dependent L2 round trips per step)
+        double2 v[MBT];
+#pragma unroll
+        for (int m = 0; m < MBT; ++m) v[m] = *reinterpret_cast<const double2*>(in + (int64_t)m * Np + c);
+#pragma unroll
+        for (int m = 0; m < MBT; ++m)
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r][m] = fma(t[r].x, v[m].x, fma(t[r].y, v[m].y, acc[r][m]));
+    }
+}
+
+// Sums over the 64 lanes of NV = 2^K per-lane values at once: stage s exchanges HALF of the values across lane bit 5 - s
+// (the lanes with the bit clear keep the even value of a pair, the others the odd one), so the number of live values
+// halves per stage -- NV - 1 shuffles instead of 6 NV -- and the last 6 - K stages are plain butterflies on the one value
+// left.  Every value is added in the order of the plain xor butterfly (32, 16, .., 1), whatever it is paired with: the
+// result does not depend on NV.  Afterwards the lanes whose low 6 - K bits are 0 hold value bitreverse_K(lane >> (6 - K)).
+template <int NV>
+__device__ __forceinline__ void lanes_sum_many(double (&v)[NV]) {
+    const int lane = threadIdx.x & 63;
+    int n = NV, off = 32;
+#pragma unroll
+    for (; n > 1; n >>= 1, off >>= 1) {
+        const bool up = (lane & off) != 0;
+#pragma unroll
+        for (int i = 0; i < NV / 2; ++i)
+            if (i < n / 2) {
+                const double keep = up ? v[2 * i + 1] : v[2 * i];
+                const double send = up ? v[2 * i] : v[2 * i + 1];
+                v[i] = keep + __shfl_xor(send, off);
+            }
+    }
+#pragma unroll
+    for (; off > 0; off >>= 1) v[0] += __shfl_xor(v[0], off);
+}
+constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
+constexpr int pow2_at_least(int v) { return v <= 1 ? 1 : 2 * pow2_at_least((v + 1) / 2); }
+
+// grid (Np / R, nseg), one wave per workgroup; cs = columns per segment (a multiple of 128)
+template <int MBT, int R>
+__global__ __launch_bounds__(64) void k_tri_matvec_rb(const double* __restrict__ Mx, int64_t Np, int64_t N,
+                                                      const double* __restrict__ in, int mode, int cs,
+                                                      double* __restrict__ part) {
+    const int lane = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * R;
+    const int64_t c0 = (int64_t)blockIdx.y * cs;
+    double acc[R][MBT];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int m = 0; m < MBT; ++m) acc[r][m] = 0.0;
+    // columns any of the R rows needs: lower [0, r0 + R - 1], upper [r0, N)
+    const int64_t lo = (mode == 0) ? 0 : (r0 & ~(int64_t)1);
+    const int64_t hi = (mode == 0) ? (r0 + R < N ? r0 + R : N) : N;
+    const int64_t he = (hi + 1) & ~(int64_t)1;
+    const int64_t cb = c0 > lo ? c0 : lo, ce = c0 + cs < he ? c0 + cs : he;
+    if (r0 < N && cb < ce) {
+        const bool full = (r0 + R <= N) && (mode == 0 ? (ce - 1 <= r0) : (cb >= r0 + R - 1 && ce <= N));
+        if (full) rb_piece<MBT, R, false>(Mx, Np, N, r0, in, mode, cb, ce, acc);
+        else rb_piece<MBT, R, true>(Mx, Np, N, r0, in, mode, cb, ce, acc);
+    }
+    double* out = part + (int64_t)blockIdx.y * MBT * Np;
+    constexpr int NV = pow2_at_least(R * MBT), K = ilog2c(NV);
+    static_assert(NV <= 64 || R * MBT <= 128, "too many values");
+    if constexpr (NV <= 64) {
+        double v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = (i < R * MBT) ? acc[i % R][i / R] : 0.0;       // value i = (row i % R, vector i / R)
+        lanes_sum_many<NV>(v);
+        if ((lane & ((64 >> K) - 1)) == 0) {
+            const int i = (int)(__brev((unsigned)(lane >> (6 - K))) >> (32 - K));
+            if (i < R * MBT) out[(int64_t)(i / R) * Np + r0 + (i % R)] = v[0];
+        }
+    } else {
+        // more than 64 values: two halves of the vectors, 64 values each
+        constexpr int MH = MBT / 2;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int m0 = hf * MH, mc = hf == 0 ? MH : MBT - MH;
+            double v[64];
+#pragma unroll
+            for (int i = 0; i < 64; ++i) v[i] = (i < R * mc) ? acc[i % R][m0 + i / R] : 0.0;
+            lanes_sum_many<64>(v);
+            const int i = (int)(__brev((unsigned)lane) >> 26);
+            if (i < R * mc) out[(int64_t)(m0 + i / R) * Np + r0 + (i % R)] = v[0];
+        }
+    }
+}
+
+// out[m][i] = sum over the nseg partials, ascending; grid (Np / 256, mb)
+__global__ __launch_bounds__(256) void k_part_sum(const double* __restrict__ part, int64_t Np, int mb, int nseg,
+                                                  double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int m = blockIdx.y;
+    if (i >= Np) return;
+    double a = 0.0;
+    for (int s2 = 0; s2 < nseg; ++s2) a += part[((int64_t)s2 * mb + m) * Np + i];
+    out[(int64_t)m * Np + i] = a;
+}
+
+static inline int rb_cs(const gpx_handle* h) { return h->grad_rb_cs > 0 ? h->grad_rb_cs : RB_CS_DEFAULT; }
+static inline int rb_nseg(const gpx_handle* h, int64_t N) { return (int)((N + rb_cs(h) - 1) / rb_cs(h)); }
+
+template <int R>
+static void launch_tri_matvec_rb_r(hipStream_t s, const double* Mx, int64_t Np, int64_t N, const double* in, int mb,
+                                   int mode, int cs, double* part) {
+    const dim3 g((unsigned)(Np / R), (unsigned)((N + cs - 1) / cs));
+#define GPX_RB_CASE(n) case n: hipLaunchKernelGGL((k_tri_matvec_rb<n, R>), g, dim3(64), 0, s, Mx, Np, N, in, mode, cs, part); break;
+    switch (mb) {
+        GPX_RB_CASE(1) GPX_RB_CASE(2) GPX_RB_CASE(3) GPX_RB_CASE(4) GPX_RB_CASE(5) GPX_RB_CASE(6) GPX_RB_CASE(7) GPX_RB_CASE(8)
+        GPX_RB_CASE(9) GPX_RB_CASE(10) GPX_RB_CASE(11) GPX_RB_CASE(12) GPX_RB_CASE(13) GPX_RB_CASE(14) GPX_RB_CASE(15)
+        GPX_RB_CASE(16)
+    }
+#undef GPX_RB_CASE
+}
+static void launch_tri_matvec_rb(const gpx_handle* h, hipStream_t s, const double* Mx, int64_t Np, int64_t N,
+                                 const double* in, int mb, int mode, double* part) {
+    if (h->grad_rb_rows == 8) launch_tri_matvec_rb_r<8>(s, Mx, Np, N, in, mb, mode, rb_cs(h), part);
+    else launch_tri_matvec_rb_r<4>(s, Mx, Np, N, in, mb, mode, rb_cs(h), part);
+}
+
+// A single query point travels in the kernel arguments (an H2D copy of 64 bytes costs 4 us of stream time and more of the
+// host's); batches read the uploaded array.
+struct XArg { double v[GB]; };
+
+// One-pass form, right-hand sides of point m: rhs[(m (1 + d) + 0)][i] = k*_i, rhs[m (1 + d) + 1 + j][i] = dk*_i / dx_j
+// (0 beyond N); grid (Np / 256, 1 + d, mb): every vector has its own blocks (the distance is recomputed, the 1 + d
+// stores of a point no longer wait for one another in 32 blocks)
+__global__ __launch_bounds__(256) void k_kstar_d(const double* __restrict__ Xs, int64_t N, int64_t Np, int d,
+                                                 const double* __restrict__ Xc, XArg xa,
+                                                 const double* __restrict__ invell,
+                                                 int kid, double rho, double* __restrict__ rhs) {
+    const int m = blockIdx.z, c = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Np) return;
+    double kv = 0.0, gv = 0.0, out = 0.0;
+    if (i < N) {
+        double r2 = 0.0;
+        for (int k = 0; k < d; ++k) {
+            const double xk = Xc ? Xc[(int64_t)m * d + k] : xa.v[k];
+            const double df = Xs[i * d + k] - xk * invell[k];
+            r2 = fma(df, df, r2);
+        }
+        kern_and_grad(kid, r2, rho, kv, gv);
+        if (c == 0) {
+            out = kv;
+        } else {
+            const int j = c - 1;
+            const double cj = (Xc ? Xc[(int64_t)m * d + j] : xa.v[j]) * invell[j];
+            out = gv * (2.0 * invell[j] * (cj - Xs[i * d + j]));
+        }
+    }
+    rhs[((int64_t)m * (1 + d) + c) * Np + i] = out;
+}
+
 __device__ __forceinline__ double block_sum(double v, double* sh) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -232,17 +424,109 @@ __global__ __launch_bounds__(256) void k_mean_reduce(const double* __restrict__ 
     if (threadIdx.x == 0) o[2 + j] = acc;
 }
 
-// One chunk (mb <= GB points) of predict-with-gradients, ENQUEUED on the handle's stream: upload, the four kernels,
-// download into the handle's pinned staging buffer.  No synchronisation: the ensemble entry point enqueues a chunk on
-// every member's stream before it waits for any of them.
-static int predict_grad_enqueue(gpx_handle* h, const double* Xc, int mb, bool mean_only = false) {
+// One-pass form: grid (d + 1, mb), 1024 threads, same output layout as k_grad_reduce.  part[s][m (1 + d) + c][i]: the partial
+// sums of T applied to right-hand side c of point m (k_tri_matvec_rb); V = sum_s part[s][.. + 0], Vd_j = sum_s part[s][.. + 1 + j].
+__device__ __forceinline__ double block_sum16(double v, double* sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    double a = 0.0;
+    for (int i = 0; i < 16; ++i) a += sh[i];
+    return a;
+}
+__global__ __launch_bounds__(1024) void k_grad_reduce_1p(int64_t N, int64_t Np, int d, const double* __restrict__ rhs,
+                                                         const double* __restrict__ part, int nseg, int nrhs,
+                                                         const double* __restrict__ a,
+                                                         const double* __restrict__ alpha, double rho, double bias,
+                                                         double* __restrict__ out) {
+    __shared__ double sh[16];
+    const int j = blockIdx.x, m = blockIdx.y;
+    const int c0 = m * (1 + d);
+    double* o = out + (int64_t)m * (2 + 2 * d);
+    // T applied to right-hand side c, element i: the partial sums of the column segments, ascending
+    auto applied = [&](int c, int64_t i) {
+        double v = 0.0;
+#pragma unroll 4
+        for (int sg = 0; sg < nseg; ++sg) v += part[((int64_t)sg * nrhs + c) * Np + i];
+        return v;
+    };
+    if (j == d) {
+        double p = 0.0, q = 0.0;
+        for (int64_t i = threadIdx.x; i < N; i += 1024) {
+            const double v = applied(c0, i);
+            p = fma(v, a[i], p);
+            q = fma(v, v, q);
+        }
+        p = block_sum16(p, sh);
+        q = block_sum16(q, sh);
+        if (threadIdx.x == 0) {
+            o[0] = bias + p;
+            o[1] = fmax(rho - q, 1e-100);
+        }
+        return;
+    }
+    const double* dk = rhs + (int64_t)(c0 + 1 + j) * Np;
+    double s1 = 0.0, s2v = 0.0;
+    for (int64_t i = threadIdx.x; i < N; i += 1024) {
+        s1 = fma(dk[i], alpha[i], s1);
+        s2v = fma(applied(c0, i), applied(c0 + 1 + j, i), s2v);
+    }
+    s1 = block_sum16(s1, sh);
+    s2v = block_sum16(s2v, sh);
+    if (threadIdx.x == 0) {
+        o[2 + j] = s1;
+        o[2 + d + j] = -2.0 * s2v;
+    }
+}
+
+// The mean and its gradient of ONE point in one launch (the recommender's refinement, pybo/recommenders.py:22 through
+// solve_lbfgs): grid (d + 1), 1024 threads; every block recomputes the N distances (N d flops: nothing) instead of
+// reading k* and g back from memory, the point travels in the arguments and the results go straight to the pinned host
+// buffer.  Same sums in the same order as k_kstar + k_mean_reduce would give with 1024 threads -- NOT the same bits as the
+// batched path (256 threads per block there): a single point is a different summation tree.
+__global__ __launch_bounds__(1024) void k_mean_direct(const double* __restrict__ Xs, int64_t N, int d, XArg xa,
+                                                      const double* __restrict__ invell, int kid, double rho,
+                                                      const double* __restrict__ alpha, double bias,
+                                                      double* __restrict__ out) {
+    __shared__ double sh[16];
+    const int j = blockIdx.x;
+    double acc = 0.0;
+    for (int64_t i = threadIdx.x; i < N; i += 1024) {
+        double r2 = 0.0;
+        for (int k = 0; k < d; ++k) {
+            const double df = Xs[i * d + k] - xa.v[k] * invell[k];
+            r2 = fma(df, df, r2);
+        }
+        double kv, gv;
+        kern_and_grad(kid, r2, rho, kv, gv);
+        if (j == d) acc = fma(kv, alpha[i], acc);
+        else acc = fma(gv * (2.0 * invell[j] * (xa.v[j] * invell[j] - Xs[i * d + j])), alpha[i], acc);
+    }
+    acc = block_sum16(acc, sh);
+    if (threadIdx.x == 0) out[j == d ? 0 : 2 + j] = (j == d) ? bias + acc : acc;
+}
+
+// Which form a predict-with-gradients call of M points takes (option grad_form): 0 = auto -- a single point (the
+// reference's single-seed refinement) goes the one-pass way when its 1 + d right-hand sides fit one pass; 1 = always two
+// passes (batch-independent: the lock-step refinement pins this); 2 = one pass whenever d allows.
+static bool grad_one_pass(const gpx_handle* h, int64_t M) {
+    if (1 + h->d > GB || h->grad_form == 1) return false;
+    return h->grad_form == 2 || M == 1;
+}
+static int grad_chunk(const gpx_handle* h, bool one_pass) { return one_pass ? GB / (1 + (int)h->d) : GB; }
+
+static int predict_grad_enqueue(gpx_handle* h, const double* Xc, int mb, bool mean_only = false, bool one_pass = false) {
     if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return GPX_EHIP; }
     hipStream_t s = h->stream;
     const int64_t Np = h->Np, N = h->N;
     const int d = (int)h->d;
     const int64_t per = 2 + 2 * d;
-    // scratch: [Xc GB*d][ks][g][V][w] (GB*Np each) [out GB*per]
-    const int64_t need = GB * d + 4 * GB * Np + GB * per;
+    // scratch: [Xc GB*d][ks][g][V][w] (GB*Np each) [out GB*per] [part nseg*GB*Np]
+    const int nseg = rb_nseg(h, N);
+    const int64_t need = GB * d + 4 * GB * Np + GB * per + (int64_t)nseg * GB * Np;
     if (need > h->cap_grad) {
         if (h->dgrad) hipFree(h->dgrad);
         h->dgrad = nullptr;
@@ -257,11 +541,17 @@ static int predict_grad_enqueue(gpx_handle* h, const double* Xc, int mb, bool me
         if (h->hpin) hipHostFree(h->hpin);
         h->hpin = nullptr;
         h->cap_hpin = 0;
-        if (hipHostMalloc((void**)&h->hpin, (size_t)GB * per * 8, hipHostMallocDefault) != hipSuccess) {
+        if (hipHostMalloc((void**)&h->hpin, (size_t)GB * per * 8, hipHostMallocMapped) != hipSuccess) {
             h->err = "predict: pinned host allocation failed";
             return GPX_EOOM;
         }
         h->cap_hpin = GB * per;
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, h->hpin, 0) != hipSuccess || !dp) {
+            h->err = "predict: pinned host buffer is not mapped into the device";
+            return GPX_EHIP;
+        }
+        h->hpin_dev = (double*)dp;
     }
     double* dX = h->dgrad;
     double* dks = dX + GB * d;
@@ -269,7 +559,38 @@ static int predict_grad_enqueue(gpx_handle* h, const double* Xc, int mb, bool me
     double* dV = dg + GB * Np;
     double* dw = dV + GB * Np;
     double* dout = dw + GB * Np;
+    double* dpart = dout + GB * per;
     const unsigned rows4 = (unsigned)((Np + 3) / 4);
+    if (one_pass && !mean_only) {
+        // [ks] holds the mb (1 + d) right-hand sides, one pass over T, U untouched.  A single point travels in the kernel
+        // arguments and its results are written straight into the pinned host buffer (no copies on the stream).
+        const int nrhs = mb * (1 + d);
+        const bool direct = (mb == 1);
+        XArg xa;
+        if (direct) {
+            for (int k = 0; k < d; ++k) xa.v[k] = Xc[k];
+        } else if (hipMemcpyAsync(dX, Xc, (size_t)mb * d * 8, hipMemcpyHostToDevice, s) != hipSuccess) {
+            h->err = "predict: H2D copy failed";
+            return GPX_EHIP;
+        }
+        hipLaunchKernelGGL(k_kstar_d, dim3((unsigned)((Np + 255) / 256), (unsigned)(1 + d), (unsigned)mb), dim3(256), 0, s,
+                           h->dXs, N, Np, d, direct ? (const double*)nullptr : dX, xa, h->dinvell, h->kernel_id, h->rho, dks);
+        launch_tri_matvec_rb(h, s, h->dT, Np, N, dks, nrhs, 0, dpart);
+        hipLaunchKernelGGL(k_grad_reduce_1p, dim3((unsigned)(d + 1), (unsigned)mb), dim3(1024), 0, s, N, Np, d, dks, dpart,
+                           nseg, nrhs, h->da, h->dalpha, h->rho, h->bias, direct ? h->hpin_dev : dout);
+        if (!direct && hipMemcpyAsync(h->hpin, dout, (size_t)mb * per * 8, hipMemcpyDeviceToHost, s) != hipSuccess) {
+            h->err = "predict: D2H copy failed";
+            return GPX_EHIP;
+        }
+        return GPX_OK;
+    }
+    if (mean_only && one_pass && mb == 1) {      // (decided per CALL by the caller: the last row of a 17-row batch is not 'a single point')
+        XArg xa;
+        for (int k = 0; k < d; ++k) xa.v[k] = Xc[k];
+        hipLaunchKernelGGL(k_mean_direct, dim3((unsigned)(d + 1)), dim3(1024), 0, s, h->dXs, N, d, xa, h->dinvell,
+                           h->kernel_id, h->rho, h->dalpha, h->bias, h->hpin_dev);
+        return GPX_OK;
+    }
     if (hipMemcpyAsync(dX, Xc, (size_t)mb * d * 8, hipMemcpyHostToDevice, s) != hipSuccess) {
         h->err = "predict: H2D copy failed";
         return GPX_EHIP;
@@ -280,8 +601,16 @@ static int predict_grad_enqueue(gpx_handle* h, const double* Xc, int mb, bool me
         hipLaunchKernelGGL(k_mean_reduce, dim3((unsigned)(d + 1), (unsigned)mb), dim3(256), 0, s, h->dXs, N, Np, d,
                            dX, h->dinvell, dks, dg, h->dalpha, h->bias, dout);
     } else {
-        launch_tri_matvec_multi(s, rows4, h->dT, Np, N, dks, mb, 0, dV);
-        launch_tri_matvec_multi(s, rows4, h->dU, Np, N, dV, mb, 1, dw);
+        if (h->grad_kernel == 1 || (h->grad_kernel < 0 && mb > 1)) {
+            const dim3 gs((unsigned)((Np + 255) / 256), (unsigned)mb);
+            launch_tri_matvec_rb(h, s, h->dT, Np, N, dks, mb, 0, dpart);
+            hipLaunchKernelGGL(k_part_sum, gs, dim3(256), 0, s, dpart, Np, mb, nseg, dV);
+            launch_tri_matvec_rb(h, s, h->dU, Np, N, dV, mb, 1, dpart);
+            hipLaunchKernelGGL(k_part_sum, gs, dim3(256), 0, s, dpart, Np, mb, nseg, dw);
+        } else {
+            launch_tri_matvec_multi(s, rows4, h->dT, Np, N, dks, mb, 0, dV);
+            launch_tri_matvec_multi(s, rows4, h->dU, Np, N, dV, mb, 1, dw);
+        }
         hipLaunchKernelGGL(k_grad_reduce, dim3((unsigned)(d + 1), (unsigned)mb), dim3(256), 0, s, h->dXs, N, Np,
                            d, dX, h->dinvell, dg, dV, dw, h->da, h->dalpha, h->rho, h->bias, dout);
     }
@@ -319,9 +648,11 @@ int predict_grad_host(gpx_handle* h, const double* Xc, int64_t M, double* mu, do
     if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return GPX_EHIP; }
     if (int rc0 = ensure_inverse(h)) return rc0;
     const int d = (int)h->d;
-    for (int64_t m0 = 0; m0 < M; m0 += GB) {
-        const int mb = (int)std::min<int64_t>(GB, M - m0);
-        if (int rc = predict_grad_enqueue(h, Xc + m0 * d, mb)) return rc;
+    const bool op = grad_one_pass(h, M);
+    const int cs = grad_chunk(h, op);
+    for (int64_t m0 = 0; m0 < M; m0 += cs) {
+        const int mb = (int)std::min<int64_t>(cs, M - m0);
+        if (int rc = predict_grad_enqueue(h, Xc + m0 * d, mb, false, op)) return rc;
         if (int rc = predict_grad_collect(h, mb, mu + m0, s2 + m0, dmu + m0 * d, ds2 + m0 * d)) return rc;
     }
     return GPX_OK;
@@ -337,7 +668,7 @@ int predict_mean_host(gpx_handle* h, const double* Xc, int64_t M, double* mu, do
     const int d = (int)h->d;
     for (int64_t m0 = 0; m0 < M; m0 += GB) {
         const int mb = (int)std::min<int64_t>(GB, M - m0);
-        if (int rc = predict_grad_enqueue(h, Xc + m0 * d, mb, true)) return rc;
+        if (int rc = predict_grad_enqueue(h, Xc + m0 * d, mb, true, M == 1 && d <= GB && h->grad_form != 1)) return rc;
         if (int rc = predict_grad_collect(h, mb, mu + m0, nullptr, dmu ? dmu + m0 * d : nullptr, nullptr)) return rc;
     }
     return GPX_OK;
@@ -354,10 +685,12 @@ int ensemble_predict_grad_host(gpx_handle* const* mem, int n, const double* Xc, 
         if (!mem[i]->fitted) { h0->err = "ensemble_predict: a member is not fitted"; return GPX_ESTATE; }
         if (int rc0 = ensure_inverse(mem[i])) { if (mem[i] != h0) h0->err = mem[i]->err; return rc0; }
     }
-    for (int64_t m0 = 0; m0 < M; m0 += GB) {
-        const int mb = (int)std::min<int64_t>(GB, M - m0);
+    const bool op = grad_one_pass(h0, M);
+    const int cs = grad_chunk(h0, op);
+    for (int64_t m0 = 0; m0 < M; m0 += cs) {
+        const int mb = (int)std::min<int64_t>(cs, M - m0);
         for (int i = 0; i < n; ++i)
-            if (int rc = predict_grad_enqueue(mem[i], Xc + m0 * d, mb)) { if (mem[i] != h0) h0->err = mem[i]->err; return rc; }
+            if (int rc = predict_grad_enqueue(mem[i], Xc + m0 * d, mb, false, op)) { if (mem[i] != h0) h0->err = mem[i]->err; return rc; }
         for (int i = 0; i < n; ++i)
             if (int rc = predict_grad_collect(mem[i], mb, mu + i * M + m0, s2 + i * M + m0, dmu + (i * M + m0) * d,
                                               ds2 + (i * M + m0) * d)) { if (mem[i] != h0) h0->err = mem[i]->err; return rc; }

@@ -39,6 +39,17 @@ def _rank_host(finit, k):
     return order[:k]
 
 
+def _batch_form(f, X):
+    """f(X, grad=True) with every row answered in the form a BATCH gets.  A device model answers a single-row call by a
+    different (cheaper: one pass over the factor's inverse instead of two) summation than the rows of a batch, whose
+    values do not depend on the batch they travel in; the all-seeds refinement must give one seed the same numbers
+    whether it is alone or not, so a single row travels twice."""
+    if len(X) == 1:
+        F, G = f(np.vstack([X, X]), grad=True)
+        return F[:1], G[:1]
+    return f(X, grad=True)
+
+
 def _refine_lockstep(f, seeds, bounds):
     """Run one scipy L-BFGS-B per seed, all in lock-step: the objective calls of the live instances are
     collected and answered by a single `f(X, grad=True)` per round.  Returns [(xmin, fmin of -f)]."""
@@ -84,7 +95,7 @@ def _refine_lockstep(f, seeds, bounds):
             ids = sorted(pending)
             X = np.array([pending.pop(i) for i in ids])
         try:
-            F, G = f(X, grad=True)          # ONE call for all live instances
+            F, G = _batch_form(f, X)        # ONE call for all live instances
         except BaseException as exc:
             with cond:
                 errors.insert(0, exc)
@@ -151,7 +162,10 @@ def solve_lbfgs(f, bounds, nbest=10, ngrid=10000, xgrid=None, rng=None, select='
         if batched and len(seeds) > 1:
             result = _refine_lockstep(f, seeds, bounds)
         else:
-            result = [scipy.optimize.fmin_l_bfgs_b(negated, x0, bounds=bounds)[:2] for x0 in seeds]
+            def negated_b(x):
+                fx, gx = _batch_form(f, x[None])
+                return -fx[0], -gx[0]
+            result = [scipy.optimize.fmin_l_bfgs_b(negated_b, x0, bounds=bounds)[:2] for x0 in seeds]
         xmin, fmin = min(result, key=lambda r: r[1])
     else:
         # reference behaviour (F6): every seed is refined but only result[0] is returned.  The index has no

@@ -259,7 +259,7 @@ def test_ticketed_protocol_with_held_tickets_never_deadlocks(nP, chunks, split, 
 
 
 @pytest.mark.parametrize('nP', [1, 2, 3, 5, 8, 17, 40])
-@pytest.mark.parametrize('chunks,split', [(0, -1), (1124, 2), (14, 0), (1128, 0), (11, 0), (1224, 4), (1248, 1000200), (14, 1002002)])
+@pytest.mark.parametrize('chunks,split', [(0, -1), (1124, 2), (14, 0), (1128, 0), (11, 0), (1224, 4), (1248, 1000200), (14, 1002002), (12489, 200), (1248, 10000200), (149, 0)])
 def test_lists_complete_in_order_without_deadlock(nP, chunks, split):
     q = _lib.chol_tasks(nP, chunks, split)
     n_upd_tiles = nP * (nP + 1) // 2

@@ -186,8 +186,10 @@ def test_solver_with_a_device_grid_gives_the_host_grid_answer():
 
 # ---- batched multi-start refinement ------------------------------------------------------
 def test_lockstep_refinement_on_the_device_equals_sequential():
-    """Rows of a batched predict-with-gradient call are independent of the batch they travel in, so the
-    lock-step refinement of all seeds reproduces the one-after-the-other refinement exactly."""
+    """Rows of a batched predict-with-gradient call (two or more rows) are independent of the batch they travel in, so the
+    lock-step refinement of all seeds reproduces the one-after-the-other refinement exactly (a lone seed travels twice:
+    solvers.lbfgs._batch_form).  A SINGLE-row call takes the one-pass form (ds2 = -2 (T k).(T dk)): same value to
+    rounding, not the same bits."""
     from pybo_amd import models, policies, solvers
     X, y, ell = synth_problem(200, 3, seed=8)
     gp = models.make_gp(1e-3, 1.0, ell, 0.0, kernel='matern5')
@@ -197,9 +199,12 @@ def test_lockstep_refinement_on_the_device_equals_sequential():
     P = np.random.RandomState(0).rand(11, 3)
     fb, gb = index(P, grad=True)
     for i in range(len(P)):
-        fi, gi = index(P[i:i + 1], grad=True)
+        fi, gi = index(P[[i, (i + 3) % len(P)]], grad=True)
         assert fi[0] == fb[i]
         np.testing.assert_array_equal(gi[0], gb[i])
+        f1, g1 = index(P[i:i + 1], grad=True)
+        np.testing.assert_allclose(f1[0], fb[i], rtol=1e-11, atol=1e-300)
+        np.testing.assert_allclose(g1[0], gb[i], rtol=1e-9, atol=1e-12 * np.abs(gb).max())
     grid = np.random.RandomState(1).rand(3000, 3)
     xa, fa = solvers.solve_lbfgs(index, bounds, nbest=5, xgrid=grid, select='best', batched=False)
     xb, fb_ = solvers.solve_lbfgs(index, bounds, nbest=5, xgrid=grid, select='best', batched=True)

@@ -231,6 +231,53 @@ def test_rccl_exchange_behind_the_c_abi_with_a_one_rank_communicator():
     e.close()
 
 
+def _nccl_one_rank_worker(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    import datetime
+    import torch
+    import torch.distributed as dist
+    from pybo_amd import dist as pdist
+    try:
+        dev = torch.device('cuda', 0)
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=120))
+        probe = torch.tensor([1.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(probe)
+        te = torch.tensor([2.5], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+        table = pdist._allgather_f64(np.arange(6, dtype=np.float64))        # the device-tensor all-gather of the exchange
+        recs = [None]
+        dist.all_gather_object(recs, {'rank': 0, 'ms': 1.5})
+        box = [7]
+        dist.broadcast_object_list(box, src=0)
+        ver = torch.cuda.nccl.version()
+        dist.destroy_process_group()
+        q.put(('ok', float(probe.item()), float(te.item()), table.tolist(), recs, box, tuple(ver)))
+    except BaseException as exc:      # noqa: reported to the parent
+        q.put(('error', repr(exc)))
+
+
+def test_torch_distributed_over_rccl_with_one_rank():
+    """The calls bench.py and pybo_amd.dist make at N > 1 -- init_process_group('nccl', device_id=...), all_reduce (SUM and
+    MAX) of device float64 tensors, barrier, the all-gather of the exchange, all_gather_object, broadcast_object_list,
+    the RCCL version query -- on the REAL RCCL with a one-rank world (the most a one-GPU box can run: RCCL refuses two
+    ranks on one device).  Proves the library loads and every call has the signature this torch build expects."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    got = q.get(timeout=600)
+    p.join(timeout=120)
+    assert got[0] == 'ok', got
+    assert got[1] == 1.0 and got[2] == 2.5
+    assert got[3] == [[0.0, 1.0, 2.0, 3.0, 4.0, 5.0]]
+    assert got[4] == [{'rank': 0, 'ms': 1.5}] and got[5] == [7]
+    assert len(got[6]) >= 2
+
+
 # ---- the whole loop SPMD: rank 0 evaluates the objective, everyone absorbs the same observation --------------------
 def _spmd_loop_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)

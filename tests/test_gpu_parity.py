@@ -368,6 +368,53 @@ def test_predict_with_gradients(kernel):
     e.close()
 
 
+@pytest.mark.parametrize('N,d,kernel', [(300, 5, 'se'), (2500, 8, 'matern5'), (4100, 15, 'matern3'), (700, 16, 'se'),
+                                        (129, 1, 'matern1')])
+def test_single_point_gradients_take_one_pass_over_the_inverse(N, d, kernel):
+    """A single-point predict-with-gradients call (every call of the reference's single-seed refinement,
+    pybo/solvers/lbfgs.py:56-58) uses ds2/dx = -2 (T k).(T dk/dx): the d derivative vectors are extra right-hand sides of
+    ONE pass over T (k_tri_matvec_rb), U is not read.  Against the oracle at the batch tolerances; against the two-pass form
+    to rounding; every form's rows are independent of the batch they travel in (one-pass: option grad_form = 2 for batches);
+    d = 16 has 17 right-hand sides, more than a pass takes: two passes, whatever the option says.  The mean-only call of a
+    single point (k_mean_direct) the same."""
+    e, ref, (X, y, ell, rho, sn2, bias) = _pair(N, d, kernel, seed=31 + d)
+    Z = np.random.RandomState(8).rand(7, d)
+    if kernel != 'matern1':                           # (exp(-r) has a kink there: its own test below)
+        Z[3] = X[5]                                   # a query on top of an observation
+    want = ref.predict(Z, grad=True)
+    forms = {}
+    for form, kern in ((1, 0), (1, 1), (2, -1), (0, -1)):
+        e.set_option('grad_form', form)
+        e.set_option('grad_kernel', kern)
+        batch = e.predict(Z, grad=True)
+        singles = [e.predict(Z[i:i + 1], grad=True) for i in range(len(Z))]
+        pairs = [e.predict(Z[[i, (i + 2) % len(Z)]], grad=True) for i in range(len(Z))]
+        for j in range(4):
+            np.testing.assert_array_equal(np.concatenate([p[j][:1] for p in pairs]), batch[j])
+            one = np.concatenate([s1[j] for s1 in singles])
+            if form != 0:
+                np.testing.assert_array_equal(one, batch[j])           # a fixed form: the batch size does not matter
+            forms[(form, kern, j)] = one
+        for got in (batch, [np.concatenate([s1[j] for s1 in singles]) for j in range(4)]):
+            assert np.all(np.abs(got[0] - want[0]) <= mu_tol(want[0], rho))
+            assert np.all(np.abs(got[1] - want[1]) <= s2_tol(want[1], rho))
+            np.testing.assert_allclose(got[2], want[2], rtol=1e-6, atol=1e-8)
+            np.testing.assert_allclose(got[3], want[3], rtol=1e-6, atol=1e-8)
+        m1 = [e.predict_mean(Z[i:i + 1], grad=True) for i in range(len(Z))]
+        mb_, dmb = e.predict_mean(Z, grad=True)
+        np.testing.assert_allclose(np.concatenate([m[0] for m in m1]), mb_, rtol=1e-12, atol=1e-13 * np.sqrt(rho))
+        np.testing.assert_allclose(np.concatenate([m[1] for m in m1]), dmb, rtol=1e-9, atol=1e-11 * np.abs(dmb).max())
+        if form == 1:
+            np.testing.assert_array_equal(np.concatenate([m[0] for m in m1]), mb_)
+    for j in range(4):
+        scale = np.abs(want[j]).max()
+        # auto = one pass for a single point (when 1 + d right-hand sides fit), the same bits as the pinned one-pass form
+        np.testing.assert_array_equal(forms[(0, -1, j)], forms[(2, -1, j)] if d < 16 else forms[(1, 1, j)])
+        np.testing.assert_allclose(forms[(2, -1, j)], forms[(1, 0, j)], rtol=0, atol=2e-9 * scale)
+        np.testing.assert_allclose(forms[(1, 1, j)], forms[(1, 0, j)], rtol=0, atol=2e-9 * scale)
+    e.close()
+
+
 def test_predict_mean_is_the_first_call_after_a_fit():
     """gpx_fit leaves the inverse (and with it alpha) to the first call that needs it: the mean-only path is one."""
     e, ref, (X, y, ell, rho, sn2, bias) = _pair(300, 4, 'se', seed=23)
