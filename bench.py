@@ -24,6 +24,10 @@ import time
 
 import numpy as np
 
+# (pybo_amd/_lib.py sets the same default on import; here it has to happen before `import torch` can initialise the runtime:
+#  bench.py keeps its own engine alive beside the plug-in layer's handles -- see the comment there)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -311,6 +315,7 @@ def plugin_step(w, nsteps, k):
     if len(spans):
         rec['warm_ms'] = float(np.mean(spans) * 1e3)
         rec['warm_ms_each'] = [float(s * 1e3) for s in spans]
+        rec['warm_ms_median'] = float(np.median(spans) * 1e3)     # (the first span holds the factor's growth by a block: N sits on a 128-boundary)
     if between:
         rec['warm_ms_beside_a_%d_ms_objective' % int(slow_ms)] = float(np.mean(between))
         rec['beside_what'] = ('time from the return of one objective call to the start of the next (add_data + recommender + '
@@ -441,7 +446,7 @@ def main():
     ap.add_argument('--exchange', default='torch', choices=['torch', 'gpx'],
                     help="transport of the top-k exchange: torch.distributed (default) or libgpx's own RCCL "
                          "binding (gpx_topk_allgather; needs one GPU per rank)")
-    ap.add_argument('--plugin-steps', type=int, default=4,
+    ap.add_argument('--plugin-steps', type=int, default=12,
                     help='also time this many iterations of pybo_amd.solve_bayesopt THROUGH THE PLUGIN API at the '
                          'workload size (cold + warm; reported separately as plugin_step); 0 = skip')
     ap.add_argument('--cpu-baseline-worker', default='', help=argparse.SUPPRESS)

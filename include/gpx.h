@@ -124,7 +124,9 @@ int gpx_version(void);
  *              x_bg workgroups (x_bg_lds KB of LDS each, x_bg_iters rounds) runs beside the factorisation.
  *          "x_skip" = DIAGNOSTIC (scripts/chol_parts.py): leave out the far updates (bit 0), the chain kernels
  *              (bit 1) or the near updates (bit 2) of the factorisation to time its parts alone -- the result is
- *              then NOT a factorisation; 0 (default) = everything. */
+ *              then NOT a factorisation; 0 (default) = everything.
+ * Environment: GPX_OPTIONS="name=value,name=value" applies these options to every handle at creation (A/B runs through a
+ * plug-in layer whose handles the caller never sees); a bad entry fails gpx_create with GPX_EARG. */
 int gpx_set_option(gpx_handle *h, const char *name, int64_t value);
 
 /* ---- GP fit = model.add_data(X, Y)            [pybo/bayesopt.py:114,258,269] ------------- */

@@ -8,6 +8,15 @@ import os
 
 import numpy as np
 
+# A handle owns up to four HIP streams (its own + three side streams: the factorisation's lookahead, and the correction
+# pass of an ANNOUNCED observation that runs beside the recommender's calls).  ROCm multiplexes a process's streams onto
+# GPU_MAX_HW_QUEUES hardware queues, 4 by default: with a second live handle (an ensemble, a second model, torch's own
+# streams) two streams of one handle can land on the same queue and what was meant to overlap runs back to back --
+# measured: the warm plug-in iteration 14.0 -> 16.3 ms at N = 8192 merely because another handle existed
+# (scripts/plugin_phases.py).  Eight queues keep two handles apart.  Read by the HIP runtime when it initialises: this
+# default only takes effect if nothing has touched the GPU in this process yet, and never overrides the caller's value.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libgpx.so')
 

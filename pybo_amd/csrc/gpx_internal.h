@@ -246,6 +246,7 @@ int loglik_batch_host(gpx_handle* h, int64_t B, const double* hyp, double* out);
 int append_host(gpx_handle* h, const double* x, double ynew);
 // the y-independent kernels of an append, enqueued on s: k* = k(X, x), r = T k*, {d, 1/d, (resid - r.a)/d, d^2} -> scal
 // (a non-positive d^2 sets *flag), tu = U r.  dx: the point on the device.
+int grow_factor_if_full(gpx_handle* h);
 void launch_append_prepare(gpx_handle* h, hipStream_t s, const double* dx, double* dks, double* dg, double* dr,
                            double* dtu, double resid, double* scal, int* flag);
 // layout of the announcement scratch (pointers into h->dspec)

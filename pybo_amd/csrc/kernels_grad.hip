@@ -851,6 +851,9 @@ static int grow_block(gpx_handle* h) {
     return GPX_OK;
 }
 
+// for gpx_append_begin: an announced point at a block boundary grows the factor first, like the append itself would
+int grow_factor_if_full(gpx_handle* h) { return h->N >= h->Np ? grow_block(h) : GPX_OK; }
+
 void launch_append_prepare(gpx_handle* h, hipStream_t s, const double* dx, double* dks, double* dg, double* dr,
                            double* dtu, double resid, double* scal, int* flag) {
     const int64_t Np = h->Np, N = h->N;

@@ -164,15 +164,28 @@ def test_announced_append_is_bit_identical_and_survives_every_way_of_not_using_i
     r = ahead.sweep('ei', 0.4, Z[:3000], k=3)
     ref = engine().sweep('ei', 0.4, Z[:3000], k=3)
     np.testing.assert_array_equal(r['acq'], ref['acq'])
-    # at a block boundary the next append adds a block first: no announcement
+    # at a block boundary (N = 256 = Np: the benchmark's N = 8192 is such a size) the announcement adds the block itself,
+    # as the append would have; same bits as the unannounced run
     Xb, yb, ellb = synth_problem(256, 2, seed=3)
-    e = Engine(0)
-    e.fit(Xb, yb, 'se', ellb, 1.0, 1e-3, 0.0)
-    e.set_option('sweep_cache', 1)
-    e.sweep('ucb', 2.0, Z[:1000, :2], k=1, want_all=False)
-    assert not e.append_begin(np.array([0.3, 0.4]))
-    assert e.append(np.array([0.3, 0.4]), 0.1) and e.append_begin(np.array([0.5, 0.1]))
-    assert e.append(np.array([0.5, 0.1]), -0.2)
+    pair = []
+    for announce in (False, True):
+        e = Engine(0)
+        e.fit(Xb, yb, 'se', ellb, 1.0, 1e-3, 0.0)
+        e.set_option('sweep_cache', 1)
+        e.sweep('ucb', 2.0, Z[:1000, :2], k=1, want_all=False)
+        e.set_option('sweep_cache', 0)
+        rs = []
+        for xn, yn in ((np.array([0.3, 0.4]), 0.1), (np.array([0.5, 0.1]), -0.2)):
+            if announce:
+                assert e.append_begin(xn)
+            assert e.append(xn, yn)
+            rs.append(e.sweep_update('ucb', 2.0, k=3, want_moments=True))      # (one correction per re-score, as in the loop)
+        pair.append((rs, e.get_matrix('L'), e.get_matrix('T')))
+    for ra, rb in zip(pair[0][0], pair[1][0]):
+        for key in ('acq', 'mu', 's2', 'top_val', 'top_idx'):
+            np.testing.assert_array_equal(ra[key], rb[key])
+    np.testing.assert_array_equal(pair[0][1], pair[1][1])
+    np.testing.assert_array_equal(pair[0][2], pair[1][2])
 
 
 def test_the_loop_announces_its_query_point_and_results_do_not_change():
