@@ -53,5 +53,21 @@ cd $R
   echo; echo "# PMC (rocprofv3 --pmc, k_chol_tg launches of scripts/tg/tg_sweep.py):"
   for n in 16384 8192; do echo "## N = $n"; cat $O/pmc_chol_$n.txt 2>/dev/null; done
 } > $O/chol_taskgraph.txt 2>&1
+# predict-with-gradients: wall time per call of the three forms, the kernels of the one-pass form, and where a warm plug-in
+# iteration spends its time (alone; beside a second live handle with the runtime's default 4 hardware queues and with 8)
+{
+  for o in "grad_form=1 grad_kernel=0" "grad_form=1 grad_kernel=1" "grad_form=2" ""; do timeout 200 python scripts/grad_call_probe.py 8192 8 $o; done
+  timeout 200 python scripts/grad_call_probe.py 2048 2
+  bash scripts/grad_rb_sweep.sh 8192 8 "grad_form=0"
+} > $O/grad_forms.txt 2>&1
+{
+  echo "# alone"; timeout 300 python scripts/plugin_phases.py ns 12
+  echo; echo "# a second handle alive (as in bench.py's process), GPU_MAX_HW_QUEUES=4 (the runtime's default)"
+  GPU_MAX_HW_QUEUES=4 PHASES_PRE=1 timeout 300 python scripts/plugin_phases.py ns 12 | head -8
+  echo; echo "# a second handle alive, GPU_MAX_HW_QUEUES=8 (pybo_amd's default)"
+  PHASES_PRE=1 timeout 300 python scripts/plugin_phases.py ns 12 | head -8
+  echo; echo "# one-pass against two-pass gradients through the plug-in layer (GPX_OPTIONS), same box"
+  bash scripts/plugin_ab.sh 12
+} > $O/plugin_phases.txt 2>&1
 python scripts/r04_roofline.py $O > $O/roofline.json 2> $O/roofline.err
 cut -c1-400 $O/bench_ns.json; echo; cat $O/pmc_traffic.json 2>/dev/null | head -30; tail -5 $O/bench_gpus2_rccl_on_one_gpu.log; head -40 $O/roofline.json
