@@ -15,6 +15,11 @@
  *     device; they enqueue on the handle's stream and are synchronous on return only where an
  *     output lands in a host buffer (top-k, status).
  *   - a handle is not re-entrant; distinct handles may be driven from distinct threads.
+ *   - a handle owns up to four HIP streams (its own or the caller's + three side streams created on first need).  The HIP
+ *     runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): a process that keeps
+ *     more than one handle alive should export GPU_MAX_HW_QUEUES=8 (or more) BEFORE its first HIP call, or work that is
+ *     meant to overlap inside a handle (gpx_append_begin's pass beside gpx_predict_mean) may share a queue and serialise
+ *     (measured: +2.3 ms per warm iteration at N = 8192).  Results never depend on it.
  *   - no C++ exception crosses this boundary.
  */
 #ifndef GPX_H
