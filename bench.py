@@ -195,7 +195,7 @@ def cpu_baseline(w, budget_candidates, span, draws):
 def cpu_baseline_unpinned(workload, M, nc, span, draws):
     """torch.distributed.run pins OMP_NUM_THREADS=1 in every rank of a multi-rank launch, and a BLAS that was
     initialised with one thread cannot safely be widened afterwards: rank 0 therefore times the baseline in a child
-    process of its own with the pin removed (the other ranks wait in the closing barrier), and reads the record and
+    process of its own with the pin removed (the other ranks have left the process group and exited by then), and reads the record and
     the oracle's values back from a scratch file."""
     import pickle
     import subprocess
@@ -706,6 +706,18 @@ def main():
                 'selected': {'index': int(wbest[1][0]), 'value': float(wbest[0][0])},
                 'speedup_vs_cold_step': (elapsed / args.steps) / wsec}
 
+    # ---- every collective of the run is behind us: leave the process group NOW, together.  What follows is rank 0's alone
+    # (the refinement, the CPU baseline: minutes of host time, the parity record, the plug-in loop); ranks waiting for it
+    # inside an RCCL barrier would sit under the process group's collective timeout -- a baseline slower than that timeout
+    # would have turned a finished measurement into a watchdog abort.  The other ranks exit 0 here.
+    if world > 1:
+        dist.barrier()
+        if comm is not None:
+            comm.close()
+        dist.destroy_process_group()
+        if rank != 0:
+            return
+
     # ---- the solver's refinement (A7) and the recommender (A8), reported SEPARATELY (excluded from the
     # headline): L-BFGS-B from the sweep's seeds with device gradients, exactly what solve_lbfgs does after the
     # grid sweep (pybo/solvers/lbfgs.py:56-68) -- the reference's behaviour (only the best seed's refinement is
@@ -878,8 +890,8 @@ def main():
         if not args.no_cpu_baseline:
             # sample: the WHOLE sweep for N <= 2048 (config B: ~1 min of host time), otherwise SURVEY 8(d)'s 2^17
             # candidates (~100 s at N = 8192 on 128 BLAS threads) in TWO disjoint runs timed separately (linearity of the
-            # extrapolation), labelled `extrapolated`.  With N > 1 ranks rank 0 times it (on its own shard) while the
-            # others wait in the closing barrier.
+            # extrapolation), labelled `extrapolated`.  With N > 1 ranks rank 0 times it (on its own shard) after the
+            # process group has been left (the other ranks have exited).
             span = Ml if w['acq'] != 'thompson' else M
             nc = min(args.cpu_candidates or (M if N <= 2048 else (1 << 17)), span)
             draws = mine if w['acq'] == 'thompson' else []
@@ -910,9 +922,6 @@ def main():
         if args.plugin_steps > 0 and world == 1 and w['acq'] in ('ei', 'ucb'):
             out['plugin_step'] = plugin_step(w, args.plugin_steps, k)
         print(json.dumps(out))
-    if world > 1:
-        dist.barrier()       # rank 0 may still be in the (untimed) refinement block: leave together
-        dist.destroy_process_group()
 
 
 if __name__ == '__main__':
