@@ -484,10 +484,18 @@ def main():
         local = args.share_device
     ndev = torch.cuda.device_count()
     if args.share_device < 0 and world > ndev:
-        # one rank per GPU is the layout: more ranks than visible devices would put two ranks on one GPU and RCCL refuses
-        # that ("invalid usage") only after a long rendezvous -- fail at once, and loudly
-        sys.stderr.write('bench.py: FATAL: WORLD_SIZE=%d but only %d GPU(s) visible to rank %d\n' % (world, ndev, rank))
-        raise SystemExit(3)
+        masked = [v for v in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES') if os.environ.get(v)]
+        if ndev >= 1 and masked:
+            # a launcher that shows every rank its own device(s) only: this rank cannot see that the others hold different
+            # GPUs -- go on with what is visible; if two ranks DO share a device RCCL refuses the communicator (exit code 4)
+            sys.stderr.write('bench.py: rank %d sees %d device(s) of a %d-rank job under %s=%s: using local device %d\n'
+                             % (rank, ndev, world, masked[0], os.environ[masked[0]], local % ndev))
+            local = local % ndev
+        else:
+            # one rank per GPU is the layout: more ranks than visible devices would put two ranks on one GPU and RCCL
+            # refuses that ("invalid usage") only after a long rendezvous -- fail at once, and loudly
+            sys.stderr.write('bench.py: FATAL: WORLD_SIZE=%d but only %d GPU(s) visible to rank %d\n' % (world, ndev, rank))
+            raise SystemExit(3)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None

@@ -86,7 +86,7 @@ int gpx_version(void);
  *              as one launch (unless grad_form = 1).
  *          "grad_kernel": the triangular matvec of the two-pass form: -1 (default) = register-blocked (4 rows x all
  *              right-hand sides per wave, column segments) for batches and one wave per row for a single point, 0 / 1 =
- *              always the one / the other.  "grad_rb_rows" (4 | 8), "grad_rb_cs" (columns per segment): experiments.
+ *              always the one / the other.  "grad_rb_cs" (columns per segment, a multiple of 128): experiment.
  *          "trtri_left" = 1: the recursive doubling of the triangular inverse associated as T21 = -(T22 L21) T11 instead of
  *              T21 = -T22 (L21 T11) (default 0).  Built in round 4 on the expectation that it keeps the LEFT residual
  *              T R^T - I at rounding level for the same flop; MEASURED (profiles/r04_illcond_vs_long_double.txt): it does not

@@ -348,11 +348,6 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             h->grad_form = (int)value;
             return GPX_OK;
         }
-        if (!strcmp(name, "grad_rb_rows")) {
-            if (value != 4 && value != 8) return fail(h, GPX_EARG, "grad_rb_rows must be 4 or 8");
-            h->grad_rb_rows = (int)value;
-            return GPX_OK;
-        }
         if (!strcmp(name, "grad_rb_cs")) {
             if (value < 0 || value % 128 || value > 65536) return fail(h, GPX_EARG, "grad_rb_cs must be a multiple of 128 (0 = default)");
             h->grad_rb_cs = (int)value;

@@ -77,7 +77,7 @@ struct gpx_handle {
     bool diag_inv_pending = false;   // the diagonal blocks of T / U hold 16x16 inverses only (k_trtri_diag128 due)
     bool eager_inverse = false;  // option: form the inverse inside the fit (timing experiments)
     int grad_form = 0;           // option: predict-with-gradients form (0 auto: one pass for a single point, 1 two passes, 2 one pass)
-    int grad_rb_rows = 4, grad_rb_cs = 0;   // options (experiments): rows per wave (4 or 8) and columns per segment of k_tri_matvec_rb
+    int grad_rb_cs = 0;          // option (experiment): columns per segment of k_tri_matvec_rb (0 = 2048)
     int grad_kernel = -1;        // option: triangular matvec of the two-pass form (-1 auto, 0 one wave per row, 1 register-blocked)
     int trtri_left = 0;          // option: the triangular inverse's recursion as -(T22 L21) T11 instead of -T22 (L21 T11) (measured: no better)
     bool refine_inverse = false; // option: one Newton step on the triangular inverse (left residual)

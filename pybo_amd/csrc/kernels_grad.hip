@@ -303,10 +303,11 @@ static void launch_tri_matvec_rb_r(hipStream_t s, const double* Mx, int64_t Np, 
     }
 #undef GPX_RB_CASE
 }
+// (8 rows per wave -- half the vector traffic again -- was measured slower: 256 registers, one wave per SIMD, 139-144 us per
+//  one-pass call under the profiler against 119-128; segments of 1024-2048 columns tie, 512 and 4096 lose)
 static void launch_tri_matvec_rb(const gpx_handle* h, hipStream_t s, const double* Mx, int64_t Np, int64_t N,
                                  const double* in, int mb, int mode, double* part) {
-    if (h->grad_rb_rows == 8) launch_tri_matvec_rb_r<8>(s, Mx, Np, N, in, mb, mode, rb_cs(h), part);
-    else launch_tri_matvec_rb_r<4>(s, Mx, Np, N, in, mb, mode, rb_cs(h), part);
+    launch_tri_matvec_rb_r<4>(s, Mx, Np, N, in, mb, mode, rb_cs(h), part);
 }
 
 // A single query point travels in the kernel arguments (an H2D copy of 64 bytes costs 4 us of stream time and more of the
