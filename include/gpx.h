@@ -119,6 +119,8 @@ int gpx_version(void);
  *              blocks of the diagonal, go to a queue of their own that is served first; + 1000000: a tile's panel solve and the
  *              final chunk of the tile below it as ONE task -- measured slower; + 10000000: column-major order inside a step --
  *              measured slower; default 200 = one queue, not fused, row-major),
+ *              "chol_tg_affine" (G > 0: runs of G consecutive tickets are served by one XCD each, from eight heads -- built to
+ *              cut the kernel's HBM traffic, measured slower at every size; default 0 = one FIFO),
  *              "chol_tg_queues" (a worker looks at this many strided sub-queues of its list at once, 1..16; default 1 --
  *              measured much slower beyond 1), "chol_tg_upool" (workers that serve the urgent list only; measured slower),
  *              "chol_tg_side" (workgroups reserved for the critical tiles, default 8), "chol_tg_grid" (workgroups launched,

@@ -57,9 +57,10 @@ struct gpx_handle {
     int chol_tg = 1;              // 1 (default): task-graph kernel for fits of >= tg_min blocks; 0: the stream schedule
     int tg_min = 16;              // smallest number of 128-blocks the task-graph kernel is used for (below: the stream schedule is faster)
     int tg_max = 160;             // ... and the largest (from N = 24576 on the stream schedule is 1-2 % faster: both throughput-bound)
-    int tg_chunks = 0;            // chunk sizes counted back from the pivot, as decimal digits (0 = default 1248: 1, 2, 4, 8, 8, ..)
+    int tg_chunks = 0;            // chunk sizes counted back from the pivot, as decimal digits (0 = default 12489: 1, 2, 4, 8, 16, 16, ..)
     int tg_split = -1;            // chunks ending within this many blocks of the pivot go to the urgent queue (-1 = default 200: one queue)
     int tg_upool = 0;             // workers that serve the urgent list only (0 = none)
+    int tg_affine = 0;            // XCD-affine runs of this many consecutive tickets (0 = off: one FIFO)
     int tg_queues = 0;            // strided sub-queues per worker list (0 = default 1)
     int tg_side = 0;              // workgroups reserved for the two critical tiles per block (0 = default 8)
     int tg_grid = 0;              // workgroups launched (0 = by size, bounded by residency)

@@ -55,6 +55,7 @@ struct TgArgs {
     int isolate;                 // the critical workgroups keep their compute units to themselves
     int nsub;                    // strided sub-queues per worker list (1 .. TG_SUB_MAX)
     int upool;                   // workers that serve the urgent list only
+    int affine;                  // > 0: XCD-affine runs of this many consecutive tickets (tg_take_affine)
     int sub_heads;               // offset (ints) of their head counters in the control block
     long long* trace;            // optional: [p][4] critical-path stamps, then [crit task][2]
     long long tmo;               // spin bound in wall-clock ticks (100 MHz)
@@ -202,6 +203,80 @@ __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, T
             continue;                              // drew a ticket that has to wait (or the queue ran out): look again
         }
         if (QB == 0 || nap < 4) __builtin_amdgcn_s_sleep(4);
+        else if (nap < 16) __builtin_amdgcn_s_sleep(32);
+        else __builtin_amdgcn_s_sleep(127);
+        ++nap;
+        if ((spins & 63) == 63 && wall_clock64() - t0 > a.tmo) {
+            if (lane == 0) sti(ctl + TG_CTL_ABORT, 2);
+            return -1;
+        }
+    }
+}
+
+// XCD-AFFINE tickets (option chol_tg_affine = G, off by default).  One FIFO hands consecutive tiles -- which share the row
+// panel R[k, I] -- to whichever workgroup arrives, on any of the eight XCDs, so every XCD's L2 sees every panel once: the
+// persistent kernel fetches 73 GB from HBM at N = 16384, 80 % of what its updates would read with no reuse at all
+// (profiles/r04_chol_taskgraph.txt).  Here the list is cut into RUNS of G consecutive tasks; run j belongs to XCD j % 8, which
+// has a head counter of its own and whose workgroups draw that XCD's runs strictly in order: tasks that share a panel run on
+// one XCD at about the same time.  An XCD whose runs are used up helps the next one.  Each of the eight queues is a
+// subsequence of the topological order and every queue always has workgroups drawing from it, so the earliest incomplete
+// task of the graph is held by a polling workgroup or at a head that is being peeked: no dead-lock (same argument as above).
+__device__ __forceinline__ int tg_affine_index(int h, int r, int G) { return ((h / G) * 8 + r) * G + (h % G); }
+
+__device__ __forceinline__ int tg_take_affine(const TgArgs& a, TgTask& out, int lane, TgHeld* held) {
+    const int nP = a.nP, npad = tg_npad(nP), G = a.affine, nq = a.n[1];
+    int* ctl = a.ctl;
+    const int* dd = ctl + TG_CTL_BASE;
+    const int* sv = dd + 2 * npad;
+    const int* sq = sv + 2 * npad;
+    const TgTask* tq = a.q[1];
+    const int xcc = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7);
+    const long long t0 = wall_clock64();
+    int nap = 0;
+    for (unsigned spins = 0;; ++spins) {
+        if (ldi(ctl + TG_CTL_ABORT) != 0) return -1;
+        int code = 0;                               // 1: task in u, 2: everything is exhausted
+        union { TgTask t; int4 v; } u;
+        u.v = make_int4(0, 0, 0, 0);
+        if (lane == 0) {
+            if (held->have[1]) {
+                u.t = held->t[1];
+                if (tg_deps_met<false>(u.t, dd, sv, sq, nP)) { held->have[1] = 0; code = 1; }
+            } else {
+                int off = held->turn, h = 0, r = 0;
+                int* head = nullptr;
+                for (; off < 8; ++off) {            // my XCD's queue, then (once it is used up) the following ones
+                    r = (xcc + off) & 7;
+                    head = ctl + a.sub_heads + 32 * r;
+                    h = ldi(head);
+                    if (tg_affine_index(h, r, G) < nq) break;
+                }
+                held->turn = off;
+                if (off >= 8) {
+                    code = 2;
+                } else {
+                    u.v = *reinterpret_cast<const int4*>(tq + tg_affine_index(h, r, G));
+                    if (tg_deps_met<false>(u.t, dd, sv, sq, nP)) {
+                        const int k = atomicAdd(head, 1);
+                        if (k == h) {
+                            code = 1;
+                        } else if (tg_affine_index(k, r, G) < nq) {
+                            u.v = *reinterpret_cast<const int4*>(tq + tg_affine_index(k, r, G));
+                            if (tg_deps_met<false>(u.t, dd, sv, sq, nP)) code = 1;
+                            else { held->t[1] = u.t; held->have[1] = 1; }
+                        }
+                    }
+                }
+            }
+        }
+        code = __shfl(code, 0);
+        if (code == 1) {
+            u.v.x = __shfl(u.v.x, 0); u.v.y = __shfl(u.v.y, 0); u.v.z = __shfl(u.v.z, 0); u.v.w = __shfl(u.v.w, 0);
+            out = u.t;
+            return 1;
+        }
+        if (code == 2) return 0;
+        if (nap < 4) __builtin_amdgcn_s_sleep(4);
         else if (nap < 16) __builtin_amdgcn_s_sleep(32);
         else __builtin_amdgcn_s_sleep(127);
         ++nap;
@@ -498,6 +573,9 @@ template <int QB, int NQ>
 __device__ __noinline__ int tg_take_call(const TgArgs& a, TgTask& out, int lane) {
     return tg_take<QB, NQ>(a, out, lane, reinterpret_cast<TgHeld*>(tg_smem + GEMM_LDS_F64 + 4));
 }
+__device__ __noinline__ int tg_take_affine_call(const TgArgs& a, TgTask& out, int lane) {
+    return tg_take_affine(a, out, lane, reinterpret_cast<TgHeld*>(tg_smem + GEMM_LDS_F64 + 4));
+}
 
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
     TgTask* cur = reinterpret_cast<TgTask*>(tg_smem + GEMM_LDS_F64);           // 16 bytes
@@ -533,7 +611,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
             if (a.isolate) atomicCAS(cu_role + key, 0, r + 1);
         }
         code[0] = r;
-        hd->turn = (r > 0) ? r : 0;            // (workers start their rounds at different sub-queues)
+        hd->turn = (r > 0 && a.affine == 0) ? r : 0;      // (workers start their rounds at different sub-queues; affine: the steal offset)
     }
     __syncthreads();
     const int role = code[0];
@@ -555,7 +633,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
             tk.type = 0;
             __builtin_amdgcn_s_setprio(0);
             const int c = side ? tg_take_call<0, 1>(a, tk, lane)
-                               : (upool ? tg_take_call<1, 1>(a, tk, lane) : tg_take_call<1, 2>(a, tk, lane));
+                               : (a.affine > 0 ? tg_take_affine_call(a, tk, lane)
+                                               : (upool ? tg_take_call<1, 1>(a, tk, lane) : tg_take_call<1, 2>(a, tk, lane)));
             if (lane == 0) {
                 *cur = tk;
                 code[0] = c;
@@ -833,6 +912,7 @@ bool launch_cholesky_tg(gpx_handle* h) {
     a.nsub = std::max(1, std::min(h->tg_queues > 0 ? h->tg_queues : 1, TG_SUB_MAX));
     a.sub_heads = tg_sub_heads(nP);
     a.upool = std::max(0, h->tg_upool);
+    a.affine = (c->n[2] == 0) ? std::max(0, std::min(h->tg_affine, 1024)) : 0;      // (one worker list only)
     a.trace = h->tg_trace ? c->dtrace : nullptr;
     a.tasklog = nlog ? c->dtrace + 20 * (int64_t)nP + 8 * 1024 + 16 : nullptr;
     a.tmo = (long long)(h->tg_tmo_ms > 0 ? h->tg_tmo_ms : 2000) * 100000LL;
