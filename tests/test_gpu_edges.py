@@ -76,3 +76,30 @@ def test_ties_nan_candidates_and_candidates_at_observations():
         with pytest.raises(GpxError):                                               # the library refuses M = 0
             call()
     e.close()
+
+
+def test_gpx_options_environment_applies_to_new_handles_and_fails_loudly(monkeypatch):
+    """GPX_OPTIONS="name=value,..." (include/gpx.h): options every new handle starts with -- how an A/B run reaches the
+    handles the plug-in layer creates.  A bad entry must fail the creation, never be ignored."""
+    from pybo_amd._lib import Engine, GpxError
+    from helpers import synth_problem
+    X, y, ell = synth_problem(200, 3, seed=5)
+    Z = np.random.RandomState(2).rand(1, 3)
+    res = {}
+    for env in ('', 'grad_form=1', 'grad_form=2,grad_rb_cs=1024'):
+        monkeypatch.setenv('GPX_OPTIONS', env)
+        e = Engine(0)
+        e.fit(X, y, 'se', ell, 1.0, 1e-3, 0.0)
+        res[env] = e.predict(Z, grad=True)
+        e.close()
+    # a single point: auto = the one-pass form (what grad_form=2 pins); grad_form=1 is the two-pass form, equal to rounding
+    for a, b in zip(res[''], res['grad_form=2,grad_rb_cs=1024']):
+        np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-14)
+    for a, b in zip(res[''], res['grad_form=1']):
+        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12)
+    for bad in ('no_such_option=1', 'grad_form=7', 'grad_form', 'grad_form=x'):
+        monkeypatch.setenv('GPX_OPTIONS', bad)
+        with pytest.raises(GpxError):
+            Engine(0)
+    monkeypatch.delenv('GPX_OPTIONS')
+    Engine(0).close()
