@@ -527,7 +527,11 @@ static int predict_grad_enqueue(gpx_handle* h, const double* Xc, int mb, bool me
     const int64_t per = 2 + 2 * d;
     // scratch: [Xc GB*d][ks][g][V][w] (GB*Np each) [out GB*per] [part nseg*GB*Np]
     const int nseg = rb_nseg(h, N);
-    const int64_t need = GB * d + 4 * GB * Np + GB * per + (int64_t)nseg * GB * Np;
+    // sized for the factor's CAPACITY, not its current size: when an append adds a 128-block (Np grows inside cap_np) the
+    // scratch must not be re-allocated -- hipFree waits for the whole device, i.e. for the announced correction pass on the
+    // third stream (measured: the recommender's first call after a growth stalled 7.5 ms)
+    const int64_t Ncap = std::max<int64_t>(Np, h->cap_np);
+    const int64_t need = GB * d + 4 * GB * Ncap + GB * per + (int64_t)rb_nseg(h, Ncap) * GB * Ncap;
     if (need > h->cap_grad) {
         if (h->dgrad) hipFree(h->dgrad);
         h->dgrad = nullptr;
@@ -894,7 +898,7 @@ int append_host(gpx_handle* h, const double* x, double ynew) {
     const int d = (int)h->d;
     // scratch: [x d (padded to a multiple of 64)][ks Np][g Np][r Np][tu Np]
     const int64_t xpad = (d + 63) / 64 * 64;
-    const int64_t need = xpad + 4 * Np;
+    const int64_t need = xpad + 4 * std::max<int64_t>(Np, h->cap_np);      // (capacity: see predict_grad_enqueue)
     if (need > h->cap_grad) {
         if (h->dgrad) hipFree(h->dgrad);
         h->dgrad = nullptr;
