@@ -1150,20 +1150,26 @@ static int rff_core(gpx_handle* h, const double* W, const double* b, const doubl
     h->tacc[T_RFFOPS] += (double)S * (double)n * ((double)d + 20.0) * (double)M;
     if (k > 0) {
         const int64_t nblk = topk_blocks(M);
-        if ((rc = ensure(h, h->dblkv, h->cap_blk, nblk * k))) return rc;
-        if (!h->dblki || h->cap_blki < nblk * k) {
+        // all draws ranked by one pair of launches while their block lists fit a modest buffer (k <= 64 per pass, S rows)
+        const bool rows = k <= TOPK_PASS && S * nblk * k <= ((int64_t)1 << 24) && S <= 65535;
+        const int64_t nlist = rows ? S * nblk * k : nblk * k;
+        if ((rc = ensure(h, h->dblkv, h->cap_blk, nlist))) return rc;
+        if (!h->dblki || h->cap_blki < nlist) {
             if (h->dblki) HIPCHK(h, hipFree(h->dblki));
             h->dblki = nullptr;
-            HIPCHK(h, hipMalloc((void**)&h->dblki, (size_t)nblk * k * 8));
-            h->cap_blki = nblk * k;
+            HIPCHK(h, hipMalloc((void**)&h->dblki, (size_t)nlist * 8));
+            h->cap_blki = nlist;
         }
         if ((rc = ensure(h, h->dtopv, h->cap_top, std::max<int64_t>((int64_t)TOPK_MAX * 2, S * k * 2)))) return rc;
         double* tv = h->dtopv;
         int64_t* ti = reinterpret_cast<int64_t*>(h->dtopv + S * k);
         {
             Span sp(h, T_RFF);
-            for (int64_t q = 0; q < S; ++q)
-                launch_topk(s, d_vals + q * M, M, (int)k, h->dblkv, h->dblki, nblk, tv + q * k, ti + q * k);
+            if (rows)
+                launch_topk_rows(s, d_vals, M, S, (int)k, h->dblkv, h->dblki, nblk, tv, ti);
+            else
+                for (int64_t q = 0; q < S; ++q)
+                    launch_topk(s, d_vals + q * M, M, (int)k, h->dblkv, h->dblki, nblk, tv + q * k, ti + q * k);
         }
         h->last_topv = tv; h->last_topi = ti; h->last_topn = S * k;
         HIPCHK(h, hipMemcpyAsync(top_val, tv, (size_t)S * k * 8, hipMemcpyDeviceToHost, s));

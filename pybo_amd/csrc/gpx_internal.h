@@ -230,6 +230,8 @@ void launch_topk(hipStream_t s, const double* vals, int64_t M, int k, double* bl
                  int64_t nblk, double* topv, int64_t* topi);
 // merge n candidate (value, index) pairs (index == INT64_MAX: no entry; consumed in place) into the k best
 void launch_topk_merge(hipStream_t s, double* vals, int64_t* idx, int64_t n, int k, double* topv, int64_t* topi);
+void launch_topk_rows(hipStream_t s, const double* vals, int64_t M, int64_t S, int k, double* blkv, int64_t* blki,
+                      int64_t nblk, double* topv, int64_t* topi);
 int64_t topk_blocks(int64_t M);
 
 // predict with gradients (small M path)

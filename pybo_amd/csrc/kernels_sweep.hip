@@ -587,6 +587,11 @@ __global__ __launch_bounds__(256) void k_topk_block(const double* __restrict__ v
                                                     const int64_t* __restrict__ cuti) {
     __shared__ double sv[4];
     __shared__ int64_t si[4];
+    // blockIdx.y: one of several value rows ranked by the same launch (the draws of a Thompson sweep): row q's values start
+    // at vals + q M, its block lists at blkv / blki + q gridDim.x k
+    vals += (int64_t)blockIdx.y * M;
+    blkv += (int64_t)blockIdx.y * gridDim.x * k;
+    blki += (int64_t)blockIdx.y * gridDim.x * k;
     const int64_t base = (int64_t)blockIdx.x * TK_PER_BLOCK;
     const bool cut = cutv != nullptr;
     const double cv = cut ? *cutv : 0.0;
@@ -633,6 +638,10 @@ __global__ __launch_bounds__(256) void k_topk_merge(double* __restrict__ blkv, i
                                                     int64_t* __restrict__ topi) {
     __shared__ double sv[4];
     __shared__ int64_t si[4];
+    blkv += (int64_t)blockIdx.x * n;          // blockIdx.x: the value row (see k_topk_block)
+    blki += (int64_t)blockIdx.x * n;
+    topv += (int64_t)blockIdx.x * k;
+    topi += (int64_t)blockIdx.x * k;
     for (int it = 0; it < k; ++it) {
         double bv = GPX_NEG_INF;
         int64_t bi = GPX_IDX_NONE;
@@ -654,6 +663,15 @@ void launch_topk_merge(hipStream_t s, double* vals, int64_t* idx, int64_t n, int
 }
 
 int64_t topk_blocks(int64_t M) { return (M + TK_PER_BLOCK - 1) / TK_PER_BLOCK; }
+
+// The k <= TOPK_PASS best of EACH of S value rows (row q at vals + q M) in two launches instead of 2 S (a Thompson sweep of
+// 64 draws ranked its rows one after the other: 128 launches of 5 us).  blkv / blki: S * nblk * k entries; topv / topi: (S, k).
+void launch_topk_rows(hipStream_t s, const double* vals, int64_t M, int64_t S, int k, double* blkv, int64_t* blki,
+                      int64_t nblk, double* topv, int64_t* topi) {
+    hipLaunchKernelGGL(k_topk_block, dim3((unsigned)nblk, (unsigned)S), dim3(256), 0, s, vals, M, k, blkv, blki,
+                       (const double*)nullptr, (const int64_t*)nullptr);
+    hipLaunchKernelGGL(k_topk_merge, dim3((unsigned)S), dim3(256), 0, s, blkv, blki, nblk * k, k, topv, topi);
+}
 
 // k <= TOPK_MAX entries, TOPK_PASS per pass: pass p ranks only what comes strictly after the last entry of pass p-1
 // (value descending, index ascending: a total order, so the passes concatenate to exactly the k best).  blkv / blki need
