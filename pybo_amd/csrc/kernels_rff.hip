@@ -388,7 +388,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_rff_phi(const double* __res
     };
     if (resident) load_a(0, dp);
     const int fr = lane & 15, fk = lane >> 4;
-    for (int s = 0; s < S; ++s) {
+    // blockIdx.y strides over the draws: with Np / 128 workgroups alone (128 at N = 16384, 64 at 8192) half the chip or more sat
+    // idle while each workgroup walked all S draws (1.0 ms for 1 GB of Phi at config D); a draw's tile does not depend on the others
+    for (int s = blockIdx.y; s < S; s += gridDim.y) {
         d4 acc[4][4];
         acc_zero(acc);
         const double* as = At + wm * 64 + fr;
@@ -550,7 +552,8 @@ void launch_rff_gram_batch(hipStream_t s, const double* Xraw, int64_t N, int64_t
     const size_t ldsb = (size_t)(2 * dk * LDT) * sizeof(double);
     if (ldsb > 64 * 1024)
         hipFuncSetAttribute((const void*)k_rff_phi, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    hipLaunchKernelGGL(k_rff_phi, dim3((unsigned)(Np / TB)), dim3(GEMM_THREADS), ldsb, s, Wt, bt, S, n, d, dp, dk,
+    const unsigned ny = (unsigned)std::max<int64_t>(1, std::min<int64_t>(S, 2048 / std::max<int64_t>(1, Np / TB)));
+    hipLaunchKernelGGL(k_rff_phi, dim3((unsigned)(Np / TB), ny), dim3(GEMM_THREADS), ldsb, s, Wt, bt, S, n, d, dp, dk,
                        Xraw, N, Np, y, bias, Phi);
     hipLaunchKernelGGL(k_rff_gram_sk, dim3(RFF_SPLIT, (unsigned)S), dim3(GEMM_THREADS), 0, s, Phi, Np, part);
     const int64_t outs = (int64_t)S * n * (n + 1);
