@@ -119,6 +119,8 @@ int gpx_version(void);
  *              blocks of the diagonal, go to a queue of their own that is served first; + 1000000: a tile's panel solve and the
  *              final chunk of the tile below it as ONE task -- measured slower; + 10000000: column-major order inside a step --
  *              measured slower; default 200 = one queue, not fused, row-major),
+ *              "chol_tg_peek" (1: a workgroup looks at the queue head and draws a ticket only when that task is ready;
+ *              0, the default: it draws its next ticket at once and waits with it in hand -- 1-2 % faster at every size),
  *              "chol_tg_affine" (G > 0: runs of G consecutive tickets are served by one XCD each, from eight heads -- built to
  *              cut the kernel's HBM traffic, measured slower at every size; default 0 = one FIFO),
  *              "chol_tg_queues" (a worker looks at this many strided sub-queues of its list at once, 1..16; default 1 --

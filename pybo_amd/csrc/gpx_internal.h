@@ -60,6 +60,7 @@ struct gpx_handle {
     int tg_chunks = 0;            // chunk sizes counted back from the pivot, as decimal digits (0 = default 12489: 1, 2, 4, 8, 16, 16, ..)
     int tg_split = -1;            // chunks ending within this many blocks of the pivot go to the urgent queue (-1 = default 200: one queue)
     int tg_upool = 0;             // workers that serve the urgent list only (0 = none)
+    int tg_peek = 0;              // 0 (default): a workgroup draws its next ticket at once and waits with it in hand; 1: it peeks at the queue head first and draws only when that task is ready
     int tg_affine = 0;            // XCD-affine runs of this many consecutive tickets (0 = off: one FIFO)
     int tg_queues = 0;            // strided sub-queues per worker list (0 = default 1)
     int tg_side = 0;              // workgroups reserved for the two critical tiles per block (0 = default 8)

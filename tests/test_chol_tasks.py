@@ -164,12 +164,13 @@ class Replay(object):
         assert self.diag.all() and (self.solved[1:] == np.arange(1, self.nP)[:, None]).all()
 
 
-def run_ticketed(r, nworkers=5, nside=2, greedy=0.5):
+def run_ticketed(r, nworkers=5, nside=2, greedy=0.5, peek=True):
     """The device's second protocol (kernels_chol_tg.hip: tg_take): a workgroup PEEKS a queue head; if that task is ready it
     draws a ticket with fetch-and-add -- and may get a LATER task than the one it peeked (others drew meanwhile), possibly
     one that is not ready: then it HOLDS it (one per queue) and keeps serving its queues.  Side-kicks (critical queue) take
-    their task on the tile's earlier chunks alone and wait for the rest inside the task.  Returns when everything is done;
-    asserts that some workgroup can always move."""
+    their task on the tile's earlier chunks alone and wait for the rest inside the task.  peek=False (the device's default since
+    late in round 4, option chol_tg_peek = 0): a workgroup without a ticket draws one AT ONCE, ready or not, and waits with it
+    in hand.  Returns when everything is done; asserts that some workgroup can always move."""
     rng = r.rng
     total = sum(len(q) for q in r.q) + r.nP
     done = 0
@@ -201,7 +202,7 @@ def run_ticketed(r, nworkers=5, nside=2, greedy=0.5):
                     if chk(wg['held'][qi]):
                         moves.append(('run_held', wi, qi))
                 elif r.head[qi] < len(r.q[qi]):
-                    if chk(r.q[qi][r.head[qi]]) or rng.rand() < greedy * 0.05:      # (a stale peek: draws although not ready)
+                    if not peek or chk(r.q[qi][r.head[qi]]) or rng.rand() < greedy * 0.05:      # (a stale peek: draws although not ready)
                         moves.append(('draw', wi, qi))
         p = r.next_potrf
         if potrf_busy is None and p < r.nP and (p == 0 or r.quad[p] == 6):
@@ -250,9 +251,9 @@ def run_ticketed(r, nworkers=5, nside=2, greedy=0.5):
                                                            (6, 11, 0, 1, 1), (20, 0, -1, 40, 8)])
 def test_ticketed_protocol_with_held_tickets_never_deadlocks(nP, chunks, split, nworkers, nside):
     q = _lib.chol_tasks(nP, chunks, split)
-    for seed in range(3):
+    for seed in range(4):
         r = Replay(nP, q, nb=4 if seed == 0 else 0, seed=seed)
-        run_ticketed(r, nworkers=nworkers, nside=nside)
+        run_ticketed(r, nworkers=nworkers, nside=nside, peek=(seed % 2 == 0))      # odd seeds: tickets drawn without a peek
         if r.nb:
             R = np.triu(r.R)
             np.testing.assert_allclose(R.T @ R, r.K, rtol=1e-12, atol=1e-10)

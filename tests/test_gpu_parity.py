@@ -97,7 +97,7 @@ def test_factor_does_not_depend_on_the_schedule(N):
                  dict(tg, chol_tg_grid=512, chol_tg_chunks=1128), dict(tg, chol_tg_split=1000200),
                  dict(tg, chol_tg_split=1002000, chol_tg_chunks=1124), dict(tg, chol_tg_queues=5),
                  dict(tg, chol_tg_queues=16, chol_tg_split=2, chol_tg_chunks=1124), dict(tg, chol_tg_split=10000200),
-                 dict(tg, chol_tg_affine=3), dict(tg, chol_tg_affine=8, chol_tg_chunks=12489, chol_tg_grid=512)]:
+                 dict(tg, chol_tg_peek=1), dict(tg, chol_tg_peek=1, chol_tg_chunks=1124, chol_tg_split=0), dict(tg, chol_tg_affine=3), dict(tg, chol_tg_affine=8, chol_tg_chunks=12489, chol_tg_grid=512)]:
         e = _engine(**opts)
         for rep in range(2 if ('chol_graph' in opts or opts.get('chol_tg')) else 1):
             e.fit(X, y, 'matern5', ell, 1.3, 1e-4, 0.1, stage=2)
