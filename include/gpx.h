@@ -121,6 +121,8 @@ int gpx_version(void);
  *              measured slower; default 200 = one queue, not fused, row-major),
  *              "chol_tg_peek" (1: a workgroup looks at the queue head and draws a ticket only when that task is ready;
  *              0, the default: it draws its next ticket at once and waits with it in hand -- 1-2 % faster at every size),
+ *              "chol_tg_nap" (longest pause of a waiting workgroup between two looks at its dependencies, in units of 64
+ *              clocks: 8, 16 (default), 32, 64 or 127),
  *              "chol_tg_affine" (G > 0: runs of G consecutive tickets are served by one XCD each, from eight heads -- built to
  *              cut the kernel's HBM traffic, measured slower at every size; default 0 = one FIFO),
  *              "chol_tg_queues" (a worker looks at this many strided sub-queues of its list at once, 1..16; default 1 --

@@ -61,6 +61,7 @@ struct gpx_handle {
     int tg_split = -1;            // chunks ending within this many blocks of the pivot go to the urgent queue (-1 = default 200: one queue)
     int tg_upool = 0;             // workers that serve the urgent list only (0 = none)
     int tg_peek = 0;              // 0 (default): a workgroup draws its next ticket at once and waits with it in hand; 1: it peeks at the queue head first and draws only when that task is ready
+    int tg_nap = 0;               // longest polling pause of a waiting workgroup in units of 64 clocks (0 = default 16; round 4 until late: 127)
     int tg_affine = 0;            // XCD-affine runs of this many consecutive tickets (0 = off: one FIFO)
     int tg_queues = 0;            // strided sub-queues per worker list (0 = default 1)
     int tg_side = 0;              // workgroups reserved for the two critical tiles per block (0 = default 8)

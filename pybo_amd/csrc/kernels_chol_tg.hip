@@ -57,6 +57,7 @@ struct TgArgs {
     int upool;                   // workers that serve the urgent list only
     int affine;                  // > 0: XCD-affine runs of this many consecutive tickets (tg_take_affine)
     int nopeek;                  // 1: tickets are drawn without peeking at the head (option chol_tg_peek = 0)
+    int nap;                     // longest pause between two looks at a waiting task's dependencies, in units of 64 clocks (8, 16, 32, 64 or 127)
     int sub_heads;               // offset (ints) of their head counters in the control block
     long long* trace;            // optional: [p][4] critical-path stamps, then [crit task][2]
     long long tmo;               // spin bound in wall-clock ticks (100 MHz)
@@ -221,8 +222,14 @@ __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, T
             nap = 0;
             continue;                              // drew a ticket that has to wait (or the queue ran out): look again
         }
+        // pauses between two looks: 256 clocks at first, then a.nap x 64 (default 16: 0.4 us).  Until late in round 4 the long
+        // pause was 127 x 64 clocks = 3.4 us -- half of that, on average, between a dependency's arrival and the task's start:
+        // N = 2048 0.945 -> 0.876 ms, 4096 1.98 -> 1.83, 8192 5.30 -> 5.19, 16384 27.2 -> 26.9 (profiles/r04_chol_tg_polling_ab.txt)
         if (QB == 0 || nap < 4) __builtin_amdgcn_s_sleep(4);
-        else if (nap < 16) __builtin_amdgcn_s_sleep(32);
+        else if (a.nap <= 8) __builtin_amdgcn_s_sleep(8);
+        else if (a.nap <= 16) __builtin_amdgcn_s_sleep(16);
+        else if (a.nap <= 32) __builtin_amdgcn_s_sleep(32);
+        else if (a.nap <= 64) __builtin_amdgcn_s_sleep(64);
         else __builtin_amdgcn_s_sleep(127);
         ++nap;
         if ((spins & 63) == 63 && wall_clock64() - t0 > a.tmo) {
@@ -931,6 +938,7 @@ bool launch_cholesky_tg(gpx_handle* h) {
     a.nsub = std::max(1, std::min(h->tg_queues > 0 ? h->tg_queues : 1, TG_SUB_MAX));
     a.sub_heads = tg_sub_heads(nP);
     a.upool = std::max(0, h->tg_upool);
+    a.nap = h->tg_nap > 0 ? h->tg_nap : 16;
     a.nopeek = (h->tg_peek == 0 && a.nsub == 1 && c->n[2] == 0) ? 1 : 0;      // (one list, one sub-queue)
     a.affine = (c->n[2] == 0) ? std::max(0, std::min(h->tg_affine, 1024)) : 0;      // (one worker list only)
     a.trace = h->tg_trace ? c->dtrace : nullptr;
