@@ -55,7 +55,7 @@ struct gpx_handle {
     int chol_w = 0;               // outer panel width of the factorisation in 128-blocks (2..8; 0 = by size)
     // the factorisation as ONE persistent task-graph kernel (kernels_chol_tg.hip)
     int chol_tg = 1;              // 1 (default): task-graph kernel for fits of >= tg_min blocks; 0: the stream schedule
-    int tg_min = 16;              // smallest number of 128-blocks the task-graph kernel is used for (below: the stream schedule is faster)
+    int tg_min = 12;              // smallest number of 128-blocks the task-graph kernel is used for (N = 1536: 0.67 against 0.72 ms; at N = 1024 the stream schedule still wins, 0.43 against 0.46)
     int tg_max = 160;             // ... and the largest (from N = 24576 on the stream schedule is 1-2 % faster: both throughput-bound)
     int tg_chunks = 0;            // chunk sizes counted back from the pivot, as decimal digits (0 = default 12489: 1, 2, 4, 8, 16, 16, ..)
     int tg_split = -1;            // chunks ending within this many blocks of the pivot go to the urgent queue (-1 = default 200: one queue)
