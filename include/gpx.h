@@ -118,7 +118,8 @@ int gpx_version(void);
  *              "chol_tg_split" (s + 1000 b: chunks ending within s blocks of the pivot, and every chunk of the tiles within b
  *              blocks of the diagonal, go to a queue of their own that is served first; + 1000000: a tile's panel solve and the
  *              final chunk of the tile below it as ONE task -- measured slower; + 10000000: column-major order inside a step --
- *              measured slower; default 200 = one queue, not fused, row-major),
+ *              measured slower; + 100000000: the solve of tile (p, p+2) and the final chunk of tile (p+1, p+2) on the critical
+ *              list too -- no effect; default 200 = one queue, not fused, row-major),
  *              "chol_tg_peek" (1: a workgroup looks at the queue head and draws a ticket only when that task is ready;
  *              0, the default: it draws its next ticket at once and waits with it in hand -- 1-2 % faster at every size),
  *              "chol_tg_nap" (longest pause of a waiting workgroup between two looks at its dependencies, in units of 64

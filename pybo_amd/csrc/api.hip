@@ -293,7 +293,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
         if (!strcmp(name, "chol_tg") || !strcmp(name, "chol_tg_chunks") || !strcmp(name, "chol_tg_split") ||
             !strcmp(name, "chol_tg_side") || !strcmp(name, "chol_tg_grid") || !strcmp(name, "chol_tg_trace") ||
             !strcmp(name, "chol_tg_tmo_ms") || !strcmp(name, "chol_tg_min") || !strcmp(name, "chol_tg_max") || !strcmp(name, "chol_tg_isolate") || !strcmp(name, "chol_tg_queues") || !strcmp(name, "chol_tg_upool") || !strcmp(name, "chol_tg_affine") || !strcmp(name, "chol_tg_peek") || !strcmp(name, "chol_tg_nap")) {
-            if (value < -1 || value > 100000000) return fail(h, GPX_EARG, "chol_tg*: out of range");
+            if (value < -1 || value > 1000000000) return fail(h, GPX_EARG, "chol_tg*: out of range");
             const char* sub = name + 7;
             if (*sub == 0) { if (value != 0 && value != 1) return fail(h, GPX_EARG, "chol_tg must be 0 or 1"); h->chol_tg = (int)value; }
             else if (!strcmp(sub, "_peek")) h->tg_peek = value != 0 ? 1 : 0;

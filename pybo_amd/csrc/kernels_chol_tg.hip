@@ -105,7 +105,7 @@ template <bool PRE>
 __device__ __forceinline__ bool tg_deps_met(const TgTask& t, const int* dd, const int* sv, const int* sq, int nP) {
     const int I = t.I, J = t.J;
     const int s = ldi(sq + I * nP + J);
-    if (PRE) return s == t.ord;
+    if (PRE && t.type != TG_UPD) return s == t.ord;      // (a plain update on the critical list has no wait inside its body)
     if (t.type == TG_TRSM) return (ldi(dd + I) != 0) && (s == t.ord);
     // the fused task: also the earlier chunks of the tile BELOW -- with two worker queues they may sit in the lower-priority
     // one, and a workgroup that waited for them inside the task could wait for ever; only the critical solve of (p, p+1),
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
             else if (tk.type == TG_TRSMU) sti(sq + (tk.I + 1) * nP + tk.J, tk.aux + 1);      // (its solved flags went up mid-task)
             else if (tk.type == TG_TRSM) sti(sv + 2 * tk.J + tk.aux, tk.I + 1);
             else atomicAdd(qd + tk.I, 1);
-            if (side && a.trace) {
+            if (side && a.trace && (tk.type == TG_UPDQ || (tk.type == TG_TRSM && tk.J == tk.I + 1))) {
                 const int slot = (tk.type == TG_TRSM) ? (8 * tk.I + tk.aux) : (8 * (tk.I - 1) + 2 + tk.aux);
                 a.trace[4 * nP + 2 * slot] = ts;
                 a.trace[4 * nP + 2 * slot + 1] = wall_clock64();
@@ -743,7 +743,7 @@ static std::vector<int> tg_boundaries(int I, const std::vector<int>& sizes) {
 
 struct TgTables { std::vector<TgTask> q[3]; };
 
-static void tg_build(int nP, int chunk_code, int split, int band, bool fuse, int order, TgTables& out) {
+static void tg_build(int nP, int chunk_code, int split, int band, bool fuse, int order, bool cone, TgTables& out) {
     std::vector<int> sizes;
     {
         std::vector<int> dg;
@@ -781,6 +781,10 @@ static void tg_build(int nP, int chunk_code, int split, int band, bool fuse, int
                 for (int qu = 0; qu < TG_NPIECE; ++qu) push(0, TG_UPDQ, I, I, k0, k1, ord, qu, 0);
             } else if (d == 0 && fuse && J >= I + 1) {
                 // (the final chunk of tile (I, J), J >= I + 1, rides on the solve of tile (I - 1, J))
+            } else if (cone && d == 0 && J == I + 1) {
+                // option (split + 100000000): the dependency cone of the NEXT critical solve -- the solve of tile (p, p+2) above and
+                // this final chunk of tile (p+1, p+2) -- runs on the side-kicks too
+                push(0, TG_UPD, I, J, k0, k1, ord, 0, 1);
             } else {
                 push(q, TG_UPD, I, J, k0, k1, ord, 0, q == 1 ? 1 : 0);
             }
@@ -789,7 +793,8 @@ static void tg_build(int nP, int chunk_code, int split, int band, bool fuse, int
             if (fz && J >= p + 2)
                 push(1, TG_TRSMU, p, J, bnd[p + 1][nb1 - 1], p + 1, (p == 0) ? 0 : nch, nb1 - 1, 1);
             else
-                for (int h = 0; h < 2; ++h) push(J == p + 1 ? 0 : 1, TG_TRSM, p, J, 0, 0, (p == 0) ? 0 : nch, h, 0);
+                for (int h = 0; h < 2; ++h)
+                    push((J == p + 1 || (cone && J == p + 2)) ? 0 : 1, TG_TRSM, p, J, 0, 0, (p == 0) ? 0 : nch, h, 0);
         };
         if (order == 1) {
             // COLUMN-major inside the step: every update right behind the LAST solve it needs -- the solve of block column J
@@ -816,7 +821,7 @@ int64_t tg_tasks_copy(int nP, int chunks, int split, int16_t* out, int64_t cap, 
     TgTables tb;
     if (chunks <= 0) chunks = TG_DEFAULT_CHUNKS;
     if (split < 0) split = TG_DEFAULT_SPLIT;
-    tg_build(nP, chunks, split % 1000, (split / 1000) % 1000, (split / 1000000) % 10 == 1, (split / 10000000) % 10, tb);
+    tg_build(nP, chunks, split % 1000, (split / 1000) % 1000, (split / 1000000) % 10 == 1, (split / 10000000) % 10, (split / 100000000) % 10 == 1, tb);
     int64_t tot = 0;
     for (int q = 0; q < 3; ++q) { counts[q] = (int64_t)tb.q[q].size(); tot += counts[q]; }
     if (out && cap >= tot) {
@@ -866,7 +871,7 @@ bool launch_cholesky_tg(gpx_handle* h) {
     const int split = h->tg_split >= 0 ? h->tg_split : TG_DEFAULT_SPLIT;
     if (c->nP != nP || c->chunks != chunks || c->split != split || !c->dq) {
         TgTables tb;
-        tg_build(nP, chunks, split % 1000, (split / 1000) % 1000, (split / 1000000) % 10 == 1, (split / 10000000) % 10, tb);
+        tg_build(nP, chunks, split % 1000, (split / 1000) % 1000, (split / 1000000) % 10 == 1, (split / 10000000) % 10, (split / 100000000) % 10 == 1, tb);
         const int64_t tot = (int64_t)tb.q[0].size() + (int64_t)tb.q[1].size() + (int64_t)tb.q[2].size() + 3;
         if (tot > c->cap_q) {
             if (c->dq) (void)hipFree(c->dq);

@@ -180,7 +180,9 @@ def run_ticketed(r, nworkers=5, nside=2, greedy=0.5, peek=True):
     potrf_busy = None
     steps = 0
 
-    def pre_ready(t):            # critical queue: the tile's earlier chunks only
+    def pre_ready(t):            # critical queue: the tile's earlier chunks only (a plain update has no wait in its body)
+        if int(t[0]) == UPD:
+            return r.ready(t)
         return r.seq[int(t[1]), int(t[2])] == int(t[5])
 
     while done < total:
@@ -248,7 +250,7 @@ def run_ticketed(r, nworkers=5, nside=2, greedy=0.5, peek=True):
 
 
 @pytest.mark.parametrize('nP,chunks,split,nworkers,nside', [(9, 0, -1, 5, 2), (9, 1124, 0, 3, 1), (14, 1248, 2002, 7, 8),
-                                                           (6, 11, 0, 1, 1), (20, 0, -1, 40, 8)])
+                                                           (6, 11, 0, 1, 1), (20, 0, -1, 40, 8), (12, 12489, 100000200, 9, 3), (17, 0, 100000200, 30, 12)])
 def test_ticketed_protocol_with_held_tickets_never_deadlocks(nP, chunks, split, nworkers, nside):
     q = _lib.chol_tasks(nP, chunks, split)
     for seed in range(4):
@@ -260,11 +262,12 @@ def test_ticketed_protocol_with_held_tickets_never_deadlocks(nP, chunks, split, 
 
 
 @pytest.mark.parametrize('nP', [1, 2, 3, 5, 8, 17, 40])
-@pytest.mark.parametrize('chunks,split', [(0, -1), (1124, 2), (14, 0), (1128, 0), (11, 0), (1224, 4), (1248, 1000200), (14, 1002002), (12489, 200), (1248, 10000200), (149, 0)])
+@pytest.mark.parametrize('chunks,split', [(0, -1), (1124, 2), (14, 0), (1128, 0), (11, 0), (1224, 4), (1248, 1000200), (14, 1002002), (12489, 200), (1248, 10000200), (149, 0), (12489, 100000200), (1124, 100000002)])
 def test_lists_complete_in_order_without_deadlock(nP, chunks, split):
     q = _lib.chol_tasks(nP, chunks, split)
     n_upd_tiles = nP * (nP + 1) // 2
-    assert len(q[0]) == 8 * (nP - 1)
+    cone = (split // 100000000) % 10 == 1
+    assert len(q[0]) == 8 * (nP - 1) + (3 * (nP - 2) if cone and nP > 2 else 0)
     ntr = sum(int((a[:, 0] == TRSM).sum()) for a in q)
     nfu = sum(int((a[:, 0] == TRSMU).sum()) for a in q)
     assert ntr + 2 * nfu == nP * (nP - 1)                                       # two halves per off-diagonal tile
