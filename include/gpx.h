@@ -71,9 +71,10 @@ int gpx_version(void);
  *          "tile_order" = sweep-kernel schedule: bits 0-1 blockIdx->tile map (0 linear heavy-first,
  *              1 per-XCD candidate slices, 2 per-XCD 8x8 super-tiles, 3 the same with every workgroup
  *              computing the PAIR of tiles (nP-1-i, nt), (i, nt): equal work per workgroup), bits 2-4 k-loop schedule
- *              (5 = k-step 32 through a single LDS buffer, the default; 2 = k-step 16 through a 2-deep LDS
- *              ring, kept as an independently scheduled witness).  Default 23 = paired super-tiles + schedule 5.
- *              Every setting produces bit-identical results.
+ *              (6 = k-step 32 through a single LDS buffer with buffer loads, a second fragment set and the wave further
+ *              into its matrix phase at the higher priority, the default; 5 = the same k-step without those; 2 = k-step 16
+ *              through a 2-deep LDS ring -- both kept as independently scheduled witnesses).  Default 27 = paired
+ *              super-tiles + schedule 6.  Every setting produces bit-identical results.
  *          "super_m" = rows of the XCD super-tile of 64 workgroups (8 -> 8x8 default, 4 -> 4x16, ...).
  *          "eager_inverse" = 1: form the triangular inverse inside gpx_fit instead of on first use.
  *          "grad_form": the form of gpx_predict / gpx_ensemble_predict WITH gradients.  0 (default) = auto: a call with

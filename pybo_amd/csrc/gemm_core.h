@@ -199,6 +199,100 @@ __device__ __forceinline__ void gemm_tile_128_g(d4 (&acc)[4][4], const double* _
     }
 }
 
+// The SWEEP's k-loop (round 5; the same arithmetic in the same order as gemm_tile_128_g: bit-identical results).
+// What the phase stamps of scripts/sweep_phase showed about two workgroups sharing a compute unit (one wave of each per SIMD):
+//  * the MFMA pipe serves ONE wave's matrix phase at a time; the other wave's phase starts when that one ends.  A wave
+//    that still has VALU instructions ahead of its first MFMA (the 64-bit address arithmetic of 16 global loads) gets
+//    them issued only in the gaps of the streaming wave -- it is NOT ready at the hand-over: ~280 idle clocks, twice
+//    per 17.4 k-clock period.  Here the loads are BUFFER loads: the step's base lives in SGPRs and is bumped by SALU,
+//    the row of load p is an SGPR offset, the thread's position one constant VGPR offset per operand -- no VALU.
+//  * with both waves ready early the pipe is shared fairly, the two workgroups fall into lock-step and then stage at the
+//    same time.  The wave further into its matrix phase therefore outranks the other one (s_setprio 1 for the first four
+//    MFMA groups, 2 for the last four): whoever leads finishes first and stages while the other streams -- anti-phase is
+//    the attractor, and the waiting wave sits at its first MFMA with its fragments loaded.
+//  * the fragments of MFMA group kk+1 are requested before the MFMAs of group kk (a second fragment set; the buffer loads
+//    freed the registers).
+// 61.8 -> 59.7 ms per 65536-column launch at N = 8192 (0.905 -> 0.937 of the fp64-MFMA peak), profiles/r05_sweep_idle_attribution.txt.
+__device__ __forceinline__ void gemm_tile_128_s(d4 (&acc)[4][4], const double* __restrict__ A, int64_t lda,
+                                                const double* __restrict__ B, int64_t ldb, int k_lo, int k_hi,
+                                                double* smem) {
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    double* As = smem;                 // [BK32][LDT]
+    double* Bs = smem + BK32 * LDT;    // [BK32][LDT]
+    const int lrow = w;
+    const int lcol = lane * 2;
+    d2 ra[8], rb[8];
+    const int nk = (k_hi - k_lo) / BK32;
+    if (nk <= 0) return;
+    const char* Abase = reinterpret_cast<const char*>(A + (int64_t)k_lo * lda);
+    const char* Bbase = reinterpret_cast<const char*>(B + (int64_t)k_lo * ldb);
+    const int voA = (int)(((int64_t)lrow * lda + lcol) * 8), voB = (int)(((int64_t)lrow * ldb + lcol) * 8);
+    const int soA = (int)(4 * lda * 8), soB = (int)(4 * ldb * 8);      // four rows on: the SGPR offset of load p is p * so
+    auto gload = [&]() {
+        // (no bounds: num_records = 2^32 - 1; the base moves with the step, so the offsets stay below 32 rows)
+        __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)Abase, 0, -1, 0x00020000);
+        __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)Bbase, 0, -1, 0x00020000);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            ra[p] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rA, voA, p * soA, 0));
+            rb[p] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rB, voB, p * soB, 0));
+        }
+        Abase += (int64_t)BK32 * lda * 8;
+        Bbase += (int64_t)BK32 * ldb * 8;
+    };
+    auto swrite = [&]() {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            *reinterpret_cast<d2*>(As + (lrow + 4 * p) * LDT + lcol) = ra[p];
+            *reinterpret_cast<d2*>(Bs + (lrow + 4 * p) * LDT + lcol) = rb[p];
+        }
+    };
+    const int fr = lane & 15, fk = lane >> 4;
+    const double* as = As + wm * 64 + fr;
+    const double* bs = Bs + wn * 64 + fr;
+    gload();
+    swrite();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        __builtin_amdgcn_s_setprio(2);              // the load issue itself ahead of the partner's stream
+        if (kt + 1 < nk) gload();
+        __builtin_amdgcn_s_setprio(1);
+        double a[2][4], b[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[0][i] = as[fk * LDT + i * 16];
+            b[0][i] = bs[fk * LDT + i * 16];
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK32 / 4; ++kk) {
+            if (kk == 4) __builtin_amdgcn_s_setprio(2);
+            if (kk + 1 < BK32 / 4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a[(kk + 1) & 1][i] = as[((kk + 1) * 4 + fk) * LDT + i * 16];
+                    b[(kk + 1) & 1][i] = bs[((kk + 1) * 4 + fk) * LDT + i * 16];
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);      // the LDS reads of group kk+1 first,
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);     // then the 16 MFMAs of group kk
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __syncthreads();               // everyone has finished reading the buffer
+        if (kt + 1 < nk) {
+            swrite();
+            __syncthreads();
+        }
+    }
+}
+
 // element coordinates of accumulator register acc[i][j][r] inside the 128x128 tile
 __device__ __forceinline__ int acc_row(int i, int r) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;

@@ -117,7 +117,7 @@ struct gpx_handle {
     // sweep workspace
     int64_t chunk = 65536;    // candidate columns per chunk (multiple of 128)
     int super_m = 8;          // rows (mt) of an XCD super-tile of 64 workgroups: 8 -> 8x8, 4 -> 4x16, 2 -> 2x32
-    int tile_order = 23;      // bits 0-1 tile map (3 = XCD 8x8 super-tiles of PAIRED tiles), bits 2-4 k-loop variant (5 = BK 32, single LDS buffer, setprio)
+    int tile_order = 27;      // bits 0-1 tile map (3 = XCD 8x8 super-tiles of PAIRED tiles), bits 2-4 k-loop variant (6 = BK 32, single LDS buffer, buffer loads, banded priority; 5 = the same without those, 2 = 2 x 16 ring)
     int64_t cap_ks = 0;       // elements of dKs
     double* dKs = nullptr;    // cross-Gram chunk, tile-blocked [chunk/128][Np][128]
     double* dQp = nullptr;    // (Np/128, chunk) per-row-block partials of colsum(V^2)

@@ -201,7 +201,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __
     d4 acc[4][4];
     acc_zero(acc);
     if (VAR == 2) gemm_tile_128_b<true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
-    else gemm_tile_128_g<true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
+    else if (VAR == 5) gemm_tile_128_g<true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
+    else gemm_tile_128_s(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
 
     // epilogue: column sums of V^2 and V*a over this tile's 128 rows
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -272,9 +273,12 @@ void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double*
     } else {
         nblk = (unsigned)(NT * nP);
     }
-    const int order = tile_order & 3, var = tile_order >> 2;   // bits 0-1: tile map, bits 2-4: k-loop (2 or 5)
+    const int order = tile_order & 3, var = tile_order >> 2;   // bits 0-1: tile map, bits 2-4: k-loop (6 = default; 5, 2: the earlier schedules, kept as witnesses)
     if (var == 2)
         hipLaunchKernelGGL(k_sweep_trmm<2>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
+                           ldp, order, super_m);
+    else if (var == 6)
+        hipLaunchKernelGGL(k_sweep_trmm<6>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
                            ldp, order, super_m);
     else
         hipLaunchKernelGGL(k_sweep_trmm<5>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,

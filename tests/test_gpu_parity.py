@@ -256,6 +256,8 @@ def test_posterior_moments_match_oracle(kernel, N, d, M):
                                   dict(chunk=256, tile_order=10), dict(chunk=384, tile_order=11),
                                   dict(chunk=512, super_m=4), dict(chunk=256, super_m=2),
                                   dict(chunk=384, tile_order=22), dict(chunk=640, tile_order=23, super_m=4),
+                                  dict(chunk=256, tile_order=24), dict(chunk=384, tile_order=26),
+                                  dict(chunk=640, tile_order=27, super_m=4),
                                   dict(chunk=512, eager_inverse=1)])
 def test_chunking_and_tile_order_do_not_change_results(opts):
     e0, ref, (X, y, ell, rho, sn2, bias) = _pair(300, 3, 'matern5', seed=5)
