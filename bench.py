@@ -850,6 +850,11 @@ def main():
                                                  'launch geometry, committed as profiles/%s -- a profile-time '
                                                  'constant, NOT collected during this run' % PMC_TRAFFIC_FILE,
                                'launches': int(launches),
+                               # the shader clock the kernel's own workgroups measured during these launches (s_memtime over
+                               # s_memrealtime ticks, accumulated by the kernel): the peak above is quoted at 2400 MHz
+                               'sclk_mhz': tm.get('sweep_sclk_mhz') or None,
+                               'frac_at_measured_clock': (ach / (FP64_MFMA_PEAK_TFLOPS * tm['sweep_sclk_mhz'] / 2400.0))
+                               if tm.get('sweep_sclk_mhz') else None,
                                'avg_launch_ms': tm['sweep_trmm'] / max(launches, 1),
                                'flop_per_launch': tm['sweep_trmm_flop'] / max(launches, 1)}
         # the fit's two MFMA stages against the same peak (algorithmic N^3/3 flop each), for EVERY workload:

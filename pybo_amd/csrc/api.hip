@@ -165,7 +165,7 @@ static int create_impl(int device, void* stream, gpx_handle** out) {
     }
     // (the factorisation's side streams and events are created on first use: gpx::ensure_side_streams)
     // one allocation for the small per-handle device scalars
-    if (hipMalloc((void**)&h->dsmall, 64 + 16 * 8 + DMAX * 8) != hipSuccess) {
+    if (hipMalloc((void**)&h->dsmall, 64 + 16 * 8 + DMAX * 8 + 16) != hipSuccess) {
         g_create_err = "gpx_create: device allocation failed";
         delete h;
         return GPX_EOOM;
@@ -180,6 +180,8 @@ static int create_impl(int device, void* stream, gpx_handle** out) {
     h->dflag = reinterpret_cast<int*>(h->dsmall);
     h->dscal = reinterpret_cast<double*>(h->dsmall + 64);
     h->dinvell = h->dscal + 16;
+    h->dclk = reinterpret_cast<unsigned long long*>(h->dinvell + DMAX);
+    hipMemset(h->dclk, 0, 16);
     *out = h;
     // GPX_OPTIONS="name=value,name=value": options every new handle starts with (A/B runs THROUGH the plug-in layer, whose
     // handles the caller never sees); an unknown name or a bad value fails the creation loudly
@@ -409,10 +411,15 @@ extern "C" int gpx_timers(gpx_handle* h, double* out, int n, int reset) {
         if (!h) return GPX_EARG;
         if (!out || n < 0) return fail(h, GPX_EARG, "timers: NULL output");
         harvest(h);
+        unsigned long long clk[2] = {0, 0};
+        hipMemcpy(clk, h->dclk, 16, hipMemcpyDeviceToHost);
+        h->tacc[T_SCLK] = clk[1] ? 100.0 * (double)clk[0] / (double)clk[1] : 0.0;    // MHz
         const int m = std::min(n, (int)T_COUNT);
         for (int i = 0; i < m; ++i) out[i] = h->tacc[i];
-        if (reset)
+        if (reset) {
             for (int i = 0; i < T_COUNT; ++i) h->tacc[i] = 0;
+            hipMemset(h->dclk, 0, 16);
+        }
         return m;
     });
 }
@@ -949,7 +956,7 @@ static int sweep_core(gpx_handle* h, int acq_id, const double* params, int npara
         {
             Span sp(h, T_TRMM);
             launch_sweep_trmm(s, h->dU, Np, h->dKs, chunk, cols, h->da, h->dQp, h->dPp, chunk,
-                              h->tile_order, h->super_m);
+                              h->tile_order, h->super_m, h->dclk);
         }
         h->tacc[T_NLAUNCH] += 1.0;
         // ALGORITHMIC work of this launch: N^2 flop per candidate (N^2/2 multiply-adds of the

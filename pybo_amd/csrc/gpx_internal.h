@@ -20,7 +20,7 @@ constexpr int PEND_MAX = 8;   // appended observations per pass of the sweep-cac
 
 enum Timer {
     T_GRAM = 0, T_CHOL, T_TRTRI, T_ALPHA, T_XGRAM, T_TRMM, T_ACQ, T_RFF, T_NLAUNCH, T_FLOP, T_COPY, T_APPEND,
-    T_RANK1, T_RFFSWEEP, T_RFFOPS, T_TGFALL, T_COUNT
+    T_RANK1, T_RFFSWEEP, T_RFFOPS, T_TGFALL, T_SCLK, T_COUNT
 };
 
 struct EventPair { hipEvent_t a, b; int slot; };
@@ -110,7 +110,8 @@ struct gpx_handle {
     double* hpin = nullptr;   // pinned host staging of predict-with-gradients (GB points)
     int64_t cap_hpin = 0;
     double* hpin_dev = nullptr;   // the same buffer as the device sees it (single-point results are written there directly)
-    char* dsmall = nullptr;   // ONE allocation behind dflag / dscal / dinvell
+    char* dsmall = nullptr;   // ONE allocation behind dflag / dscal / dinvell / dclk
+    unsigned long long* dclk = nullptr;   // {sum of s_memtime ticks, sum of 100 MHz ticks} over the sweep kernel's workgroups: the sustained shader clock
     int* dflag = nullptr;     // [0] = failing pivot + 1 (0 = ok)
     double* dscal = nullptr;  // small scalar scratch (16 doubles)
 
@@ -210,7 +211,7 @@ void launch_cross_gram(hipStream_t s, const double* Xs, int64_t Np, int64_t N, i
                        double rho, double* Ks, int64_t ldk);
 void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double* Ks, int64_t ldk,
                        int64_t cols, const double* a, double* Qp, double* Pp, int64_t ldp,
-                       int tile_order, int super_m);
+                       int tile_order, int super_m, unsigned long long* clk);
 // reduce partials, form mu/s2/acq for columns [0,cols) of this chunk -> global candidate m0+..
 // nrb = 0: Qp/Pp are reduced per-candidate sums (the sweep cache); qsum/psum (optional) receive the reduced sums
 void launch_acq(hipStream_t s, const double* Qp, const double* Pp, int64_t ldp, int nrb, int64_t m0,

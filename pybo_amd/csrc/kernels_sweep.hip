@@ -138,8 +138,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __
                                                                 const double* __restrict__ avec,
                                                                 double* __restrict__ Qp,
                                                                 double* __restrict__ Pp, int64_t ldp,
-                                                                int order, int sm) {
+                                                                int order, int sm, unsigned long long* clk) {
     __shared__ __attribute__((aligned(16))) double smem[GEMM_LDS_F64];
+    // the sustained shader clock of this launch: every workgroup adds its lifetime in s_memtime ticks (shader clocks) and in
+    // s_memrealtime ticks (100 MHz) to two counters -- the bench line's roofline.frac_at_measured_clock (two atomics per
+    // workgroup of ~1.8 ms)
+    const unsigned long long clk_c0 = __builtin_readcyclecounter();
+    const unsigned long long clk_r0 = wall_clock64();
     const int nP = (int)(Np / TB);
     int mt, nt, mt2 = -1;      // mt2 >= 0: this workgroup also computes tile (mt2, nt) afterwards
     {
@@ -247,11 +252,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __
         Pp[(int64_t)mt * ldp + n0 + c] = red[c * 2 + 1] + red[(TB + c) * 2 + 1];
     }
   }
+    if (clk && threadIdx.x == 0) {
+        atomicAdd(clk, (unsigned long long)__builtin_readcyclecounter() - clk_c0);
+        atomicAdd(clk + 1, (unsigned long long)wall_clock64() - clk_r0);
+    }
 }
 
 void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double* Ks, int64_t ldk,
                        int64_t cols, const double* a, double* Qp, double* Pp, int64_t ldp,
-                       int tile_order, int super_m) {
+                       int tile_order, int super_m, unsigned long long* clk) {
     const int NT = (int)(cols / TB);
     const int nP = (int)(Np / TB);
     unsigned nblk;
@@ -276,13 +285,13 @@ void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double*
     const int order = tile_order & 3, var = tile_order >> 2;   // bits 0-1: tile map, bits 2-4: k-loop (6 = default; 5, 2: the earlier schedules, kept as witnesses)
     if (var == 2)
         hipLaunchKernelGGL(k_sweep_trmm<2>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
-                           ldp, order, super_m);
+                           ldp, order, super_m, clk);
     else if (var == 6)
         hipLaunchKernelGGL(k_sweep_trmm<6>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
-                           ldp, order, super_m);
+                           ldp, order, super_m, clk);
     else
         hipLaunchKernelGGL(k_sweep_trmm<5>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
-                           ldp, order, super_m);
+                           ldp, order, super_m, clk);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -148,6 +148,60 @@ __device__ __forceinline__ void kloop(d4 (&acc)[4][4], const double* __restrict_
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i], b1[j], acc[i][j], 0, 0, 0);
             }
+        } else if ((MODE & (1 << 22)) && (MODE & (1 << 21))) {
+            // bits 21 + 22: the double-buffered fragments read through one opaque LDS base register per k-group and operand
+            double a[2][4], b[2][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[0][i] = asb[0][i * 16];
+                b[0][i] = bsb[0][i * 16];
+            }
+#pragma unroll
+            for (int kk = 0; kk < BK32 / 4; ++kk) {
+                if ((MODE & 32768) && kk == 4) __builtin_amdgcn_s_setprio(2);
+                if (kk + 1 < BK32 / 4) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        a[(kk + 1) & 1][i] = asb[kk + 1][i * 16];
+                        b[(kk + 1) & 1][i] = bsb[kk + 1][i * 16];
+                    }
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            }
+        } else if (MODE & (1 << 23)) {
+            // bit 23: fragments two groups ahead (three register sets)
+            double a[3][4], b[3][4];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a[g][i] = as[(g * 4 + fk) * LDT + i * 16];
+                    b[g][i] = bs[(g * 4 + fk) * LDT + i * 16];
+                }
+#pragma unroll
+            for (int kk = 0; kk < BK32 / 4; ++kk) {
+                if ((MODE & 32768) && kk == 4) __builtin_amdgcn_s_setprio(2);
+                if (kk + 2 < BK32 / 4) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        a[(kk + 2) % 3][i] = as[((kk + 2) * 4 + fk) * LDT + i * 16];
+                        b[(kk + 2) % 3][i] = bs[((kk + 2) * 4 + fk) * LDT + i * 16];
+                    }
+                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk % 3][i], b[kk % 3][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            }
         } else if (MODE & (1 << 22)) {
             // bit 22: fragments of group kk+1 requested before the MFMAs of group kk (explicit double buffer in registers)
             double a[2][4], b[2][4];
@@ -404,7 +458,7 @@ int main(int argc, char** argv) {
         hipEventRecord(e0);
         switch (mode) {
 #define C(M) case M: launch<M>(nblk, U, Np, Ks, cols, NT, a, Qp, Pp, cols, pa); break;
-            C(0) C(41472) C(4235776)
+            C(0) C(1) C(512) C(8192) C(8704) C(32768) C(40960) C(41472) C(4194304) C(4202496) C(4203008) C(4235776) C(4235777) C(48) C(304)
 #undef C
             default: fprintf(stderr, "mode not built\n"); return 1;
         }
