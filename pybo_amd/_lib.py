@@ -18,7 +18,7 @@ import numpy as np
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libgpx.so')
+LIB_PATH = os.environ.get('GPX_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libgpx.so')     # (GPX_LIB_PATH: A/B runs against another build of the same ABI)
 
 # every symbol include/gpx.h declares: name -> (restype, argtypes)
 _P = C.c_void_p

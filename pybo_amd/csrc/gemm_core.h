@@ -213,6 +213,9 @@ __device__ __forceinline__ void gemm_tile_128_g(d4 (&acc)[4][4], const double* _
 //  * the fragments of MFMA group kk+1 are requested before the MFMAs of group kk (a second fragment set; the buffer loads
 //    freed the registers).
 // 61.8 -> 59.7 ms per 65536-column launch at N = 8192 (0.905 -> 0.937 of the fp64-MFMA peak), profiles/r05_sweep_idle_attribution.txt.
+// PRIO / NEGA as in gemm_tile_128_g (PRIO = 0: no priority changes at all; otherwise PRIO for the first half of a step's
+// MFMAs, PRIO + 1 for the second half and while the loads are issued, PRIO - 1 outside the matrix phase).
+template <int PRIO = 1, bool NEGA = false>
 __device__ __forceinline__ void gemm_tile_128_s(d4 (&acc)[4][4], const double* __restrict__ A, int64_t lda,
                                                 const double* __restrict__ B, int64_t ldb, int k_lo, int k_hi,
                                                 double* smem) {
@@ -246,7 +249,7 @@ __device__ __forceinline__ void gemm_tile_128_s(d4 (&acc)[4][4], const double* _
     auto swrite = [&]() {
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            *reinterpret_cast<d2*>(As + (lrow + 4 * p) * LDT + lcol) = ra[p];
+            *reinterpret_cast<d2*>(As + (lrow + 4 * p) * LDT + lcol) = NEGA ? -ra[p] : ra[p];
             *reinterpret_cast<d2*>(Bs + (lrow + 4 * p) * LDT + lcol) = rb[p];
         }
     };
@@ -257,9 +260,9 @@ __device__ __forceinline__ void gemm_tile_128_s(d4 (&acc)[4][4], const double* _
     swrite();
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        __builtin_amdgcn_s_setprio(2);              // the load issue itself ahead of the partner's stream
+        if (PRIO) __builtin_amdgcn_s_setprio(PRIO + 1);              // the load issue itself ahead of the partner's stream
         if (kt + 1 < nk) gload();
-        __builtin_amdgcn_s_setprio(1);
+        if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
         double a[2][4], b[2][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -268,7 +271,7 @@ __device__ __forceinline__ void gemm_tile_128_s(d4 (&acc)[4][4], const double* _
         }
 #pragma unroll
         for (int kk = 0; kk < BK32 / 4; ++kk) {
-            if (kk == 4) __builtin_amdgcn_s_setprio(2);
+            if (PRIO && kk == 4) __builtin_amdgcn_s_setprio(PRIO + 1);
             if (kk + 1 < BK32 / 4) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -284,7 +287,7 @@ __device__ __forceinline__ void gemm_tile_128_s(d4 (&acc)[4][4], const double* _
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);     // then the 16 MFMAs of group kk
         }
-        __builtin_amdgcn_s_setprio(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(PRIO - 1);
         __syncthreads();               // everyone has finished reading the buffer
         if (kt + 1 < nk) {
             swrite();

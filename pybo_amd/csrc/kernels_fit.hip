@@ -608,7 +608,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trtri_gemm1(const double* _
     const int64_t m0 = r2e + (int64_t)bm * NB, n0 = r1e + (int64_t)bn * NB;
     d4 acc[4][4];
     acc_zero(acc);
-    gemm_tile_128_g<true>(acc, R + r1e * Np + m0, Np, T + r1e * Np + n0, Np, bn * NB, hb * NB, smem);
+    gemm_tile_128_s<1>(acc, R + r1e * Np + m0, Np, T + r1e * Np + n0, Np, bn * NB, hb * NB, smem);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trtri_gemm2(const double* _
     d4 acc[4][4];
     acc_zero(acc);
     // A(m,k) = T_22(m,k) = U[r2e+k][m0+m], k <= m  ->  k-blocks [0, bm]
-    gemm_tile_128_g<true>(acc, U + r2e * Np + m0, Np, W + r2e * Np + n0, Np, 0, (bm + 1) * NB, smem);
+    gemm_tile_128_s<1>(acc, U + r2e * Np + m0, Np, W + r2e * Np + n0, Np, 0, (bm + 1) * NB, smem);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -731,7 +731,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trtri_gemm1r(const double* 
     const int64_t m0 = r2e + (int64_t)bm * NB, n0 = r1e + (int64_t)bn * NB;
     d4 acc[4][4];
     acc_zero(acc);
-    gemm_tile_128_g<true>(acc, U + r2e * Np + m0, Np, S + r2e * Np + n0, Np, 0, (bm + 1) * NB, smem);
+    gemm_tile_128_s<1>(acc, U + r2e * Np + m0, Np, S + r2e * Np + n0, Np, 0, (bm + 1) * NB, smem);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trtri_gemm2r(const double* 
     const int64_t m0 = r2e + (int64_t)bm * NB, n0 = r1e + (int64_t)bn * NB;
     d4 acc[4][4];
     acc_zero(acc);
-    gemm_tile_128_g<true>(acc, S + r1e * Np + m0, Np, T + r1e * Np + n0, Np, bn * NB, hb * NB, smem);
+    gemm_tile_128_s<1>(acc, S + r1e * Np + m0, Np, T + r1e * Np + n0, Np, bn * NB, hb * NB, smem);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -892,8 +892,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_tri_lower_prod(const double
                 const int m = acc_row(i, r), n = acc_col(j);
                 acc[i][j][r] = (MODE == 1) ? ((I == J && m == n) ? 1.0 : 0.0) : T0[(i0 + m) * Np + j0 + n];
             }
-    if (MODE == 1) gemm_tile_128_g<true, true>(acc, Ak + i0, Np, Bk + j0, Np, J * NB, (I + 1) * NB, smem);
-    else gemm_tile_128_g<true, false>(acc, Ak + i0, Np, Bk + j0, Np, J * NB, (I + 1) * NB, smem);
+    if (MODE == 1) gemm_tile_128_g<1, true>(acc, Ak + i0, Np, Bk + j0, Np, J * NB, (I + 1) * NB, smem);
+    else gemm_tile_128_g<1, false>(acc, Ak + i0, Np, Bk + j0, Np, J * NB, (I + 1) * NB, smem);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll

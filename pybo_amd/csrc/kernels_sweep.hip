@@ -207,7 +207,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __
     acc_zero(acc);
     if (VAR == 2) gemm_tile_128_b<true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
     else if (VAR == 5) gemm_tile_128_g<true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
-    else gemm_tile_128_s(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
+    else gemm_tile_128_s<1>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
 
     // epilogue: column sums of V^2 and V*a over this tile's 128 rows
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
