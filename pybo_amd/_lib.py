@@ -13,9 +13,23 @@ import numpy as np
 # GPU_MAX_HW_QUEUES hardware queues, 4 by default: with a second live handle (an ensemble, a second model, torch's own
 # streams) two streams of one handle can land on the same queue and what was meant to overlap runs back to back --
 # measured: the warm plug-in iteration 14.0 -> 16.3 ms at N = 8192 merely because another handle existed
-# (scripts/plugin_phases.py).  Eight queues keep two handles apart.  Read by the HIP runtime when it initialises: this
-# default only takes effect if nothing has touched the GPU in this process yet, and never overrides the caller's value.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# (scripts/plugin_phases.py).  Eight queues keep two handles apart.  The variable is read by the HIP runtime when it
+# initialises, so it is the APPLICATION's to set (bench.py does, before importing torch): a
+# library import does not change its host's environment -- see hw_queues_hint() below.
+
+
+def hw_queues_hint():
+    """None, or a one-line warning when this process runs several device handles on the runtime's default of 4 hardware
+    queues (GPU_MAX_HW_QUEUES unset or < 8): streams meant to overlap may then share a queue."""
+    try:
+        q = int(os.environ.get('GPU_MAX_HW_QUEUES', '4'))
+    except ValueError:
+        q = 4
+    if q >= 8:
+        return None
+    return ('pybo_amd: several device handles on GPU_MAX_HW_QUEUES=%d hardware queues; export GPU_MAX_HW_QUEUES=8 before '
+            'the HIP runtime starts to keep their streams apart (see INTEGRATION.md)' % q)
+
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GPX_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libgpx.so')     # (GPX_LIB_PATH: A/B runs against another build of the same ABI)
@@ -386,11 +400,22 @@ class Engine(object):
         self.device = int(device)
         self.N = 0
         self.d = 0
+        Engine._live += 1
+        if Engine._live > 1 and not Engine._hinted:
+            hint = hw_queues_hint()
+            Engine._hinted = True
+            if hint:
+                import warnings
+                warnings.warn(hint, RuntimeWarning, stacklevel=2)
+
+    _live = 0            # handles alive in this process
+    _hinted = False      # the GPU_MAX_HW_QUEUES hint is given once
 
     def close(self):
         if getattr(self, '_h', None):
             self._lib.gpx_destroy(self._h)
             self._h = None
+            Engine._live -= 1
 
     def __del__(self):
         try:

@@ -63,8 +63,7 @@ def safe_dump(model, info, filename=None):
     os.replace(scratch, filename)
 
 
-def safe_load(filename=None):
-    """Return the stored (model, trace), or (None, empty trace) when there is nothing to resume."""
+def _load_local(filename):
     if filename is None or not os.path.exists(filename):
         return None, Info([], [], [])
     with open(filename, 'rb') as fh:
@@ -72,6 +71,24 @@ def safe_load(filename=None):
     if isinstance(info, _PackedTrace):
         info = Info(list(info.x), [float(v) for v in info.y], list(info.xbest))
     return model, info
+
+
+def safe_load(filename=None):
+    """Return the stored (model, trace), or (None, empty trace) when there is nothing to resume.
+
+    SPMD runs: only rank 0 writes the checkpoint, so only rank 0 READS it -- what it found (possibly nothing) is
+    broadcast, and every rank resumes from the same state.  (Each rank reading the file on its own raced rank 0's next
+    write, and needed a shared file system: ranks could load different traces, issue different numbers of objective
+    exchanges and record rank 0's pair under the wrong index.)"""
+    if filename is not None and _SPMD['on']:
+        from . import dist as pdist
+        d = pdist._dist()
+        if d is not None and d.get_world_size(_SPMD['group']) > 1:
+            box = [_load_local(filename)] if _spmd_rank() == 0 else [None]
+            d.broadcast_object_list(box, src=0, group=_SPMD['group'])
+            model, info = box[0]
+            return model, Info(list(info.x), list(info.y), list(info.xbest))
+    return _load_local(filename)
 
 
 _PackedTrace = collections.namedtuple('_PackedTrace', ['x', 'y', 'xbest'])

@@ -345,6 +345,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             return GPX_OK;
         }
         if (!strcmp(name, "x_rff")) {       // diagnostic: A/B of the Thompson sweep kernels (process-wide)
+            if (value < 0 || value > 2) return fail(h, GPX_EARG, "x_rff must be 0 (by size), 1 or 2");
             gpx::g_rff_variant = (int)value;
             return GPX_OK;
         }
@@ -683,7 +684,6 @@ extern "C" int gpx_append_begin(gpx_handle* h, const double* x) {
         if ((rc = flush_pending(h))) return rc;                 // earlier appends' corrections: apply them now
         // padding of the last 128-block used up (N = 8192 exactly: the benchmark's first warm iteration): add the block now,
         // as gpx_append would have -- round 3 declined here and that iteration ran its correction pass unhidden (+4.5 ms)
-        if ((rc = grow_factor_if_full(h))) return rc;
         if ((rc = ensure_side_streams(h))) return rc;
         if (!h->ev_spec_go &&
             (hipEventCreateWithFlags(&h->ev_spec_go, hipEventDisableTiming) != hipSuccess ||
@@ -691,6 +691,9 @@ extern "C" int gpx_append_begin(gpx_handle* h, const double* x) {
             return fail(h, GPX_EHIP, "append_begin: event creation failed");
         spec_cancel(h);                                          // a previous announcement's pass has ended
         if (h->ev_spec_go) HIPCHK(h, hipEventSynchronize(h->ev_spec_go));   // ... and its copy of spec_x too
+        // (only now: growing re-strides or re-allocates S / R / T / U and Xs on the main stream, which the previous
+        //  announcement's pass on the third stream may still have been reading -- ADVICE round 4)
+        if ((rc = grow_factor_if_full(h))) return rc;
         const int64_t d = h->d, M = h->cache_M, ld = h->cap_np;
         const int64_t xpad = (h->cap_d + 63) / 64 * 64;
         const int64_t need = 2 * xpad + 5 * ld + 64 + M;

@@ -196,7 +196,7 @@ extern "C" int gpx_topk_allgather(gpx_comm* c, int64_t n, int64_t index_offset, 
                                   int64_t* out_idx) {
     try {
         if (!c || !out_val || !out_idx || n < 1 || k < 0 || k > TOPK_MAX) {
-            g_comm_err = "topk_allgather: bad arguments (need n >= 1, 0 <= k <= 64, output buffers)";
+            g_comm_err = "topk_allgather: bad arguments (need n >= 1, 0 <= k <= 4096, output buffers)";
             return GPX_EARG;
         }
         gpx_handle* h = c->h;

@@ -519,7 +519,9 @@ static bool grad_one_pass(const gpx_handle* h, int64_t M) {
 }
 static int grad_chunk(const gpx_handle* h, bool one_pass) { return one_pass ? GB / (1 + (int)h->d) : GB; }
 
-static int predict_grad_enqueue(gpx_handle* h, const double* Xc, int mb, bool mean_only = false, bool one_pass = false) {
+// rb_call: the two-pass kernel of the whole CALL (decided once from the call's M, not per chunk: a row's value must not
+// depend on whether it travels in a chunk of one -- M % 16 == 1 -- or of several)
+static int predict_grad_enqueue(gpx_handle* h, const double* Xc, int mb, bool mean_only = false, bool one_pass = false, bool rb_call = false) {
     if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return GPX_EHIP; }
     hipStream_t s = h->stream;
     const int64_t Np = h->Np, N = h->N;
@@ -606,7 +608,7 @@ static int predict_grad_enqueue(gpx_handle* h, const double* Xc, int mb, bool me
         hipLaunchKernelGGL(k_mean_reduce, dim3((unsigned)(d + 1), (unsigned)mb), dim3(256), 0, s, h->dXs, N, Np, d,
                            dX, h->dinvell, dks, dg, h->dalpha, h->bias, dout);
     } else {
-        if (h->grad_kernel == 1 || (h->grad_kernel < 0 && mb > 1)) {
+        if (h->grad_kernel == 1 || (h->grad_kernel < 0 && rb_call)) {
             const dim3 gs((unsigned)((Np + 255) / 256), (unsigned)mb);
             launch_tri_matvec_rb(h, s, h->dT, Np, N, dks, mb, 0, dpart);
             hipLaunchKernelGGL(k_part_sum, gs, dim3(256), 0, s, dpart, Np, mb, nseg, dV);
@@ -657,7 +659,7 @@ int predict_grad_host(gpx_handle* h, const double* Xc, int64_t M, double* mu, do
     const int cs = grad_chunk(h, op);
     for (int64_t m0 = 0; m0 < M; m0 += cs) {
         const int mb = (int)std::min<int64_t>(cs, M - m0);
-        if (int rc = predict_grad_enqueue(h, Xc + m0 * d, mb, false, op)) return rc;
+        if (int rc = predict_grad_enqueue(h, Xc + m0 * d, mb, false, op, M > 1)) return rc;
         if (int rc = predict_grad_collect(h, mb, mu + m0, s2 + m0, dmu + m0 * d, ds2 + m0 * d)) return rc;
     }
     return GPX_OK;
@@ -695,7 +697,7 @@ int ensemble_predict_grad_host(gpx_handle* const* mem, int n, const double* Xc, 
     for (int64_t m0 = 0; m0 < M; m0 += cs) {
         const int mb = (int)std::min<int64_t>(cs, M - m0);
         for (int i = 0; i < n; ++i)
-            if (int rc = predict_grad_enqueue(mem[i], Xc + m0 * d, mb, false, op)) { if (mem[i] != h0) h0->err = mem[i]->err; return rc; }
+            if (int rc = predict_grad_enqueue(mem[i], Xc + m0 * d, mb, false, op, M > 1)) { if (mem[i] != h0) h0->err = mem[i]->err; return rc; }
         for (int i = 0; i < n; ++i)
             if (int rc = predict_grad_collect(mem[i], mb, mu + i * M + m0, s2 + i * M + m0, dmu + (i * M + m0) * d,
                                               ds2 + (i * M + m0) * d)) { if (mem[i] != h0) h0->err = mem[i]->err; return rc; }

@@ -339,7 +339,8 @@ void launch_rff_mfma(hipStream_t s, const double* Wt, const double* bt, const do
     // measured (profiles/r04_rff_kernels_ab.txt): the double-buffered kernel wins while the projection is short (config E,
     // d = 6: 1.04 against 1.07 ms), the single-buffer one at d = 32 (config D: 13.9 against 14.4 ms: there the matrix phase
     // dominates and the register-resident fragments cost 7 spilled registers)
-    if (dk == dp && ((dp <= 16 && g_rff_variant == 0) || g_rff_variant == 2)) {
+    // (the double-buffered kernel holds 8 candidate fragments per thread: dp <= 32, whatever the diagnostic option says)
+    if (dk == dp && dp <= 32 && ((dp <= 16 && g_rff_variant == 0) || g_rff_variant == 2)) {
         const size_t ldb = (size_t)(2 * dp * LDT) * sizeof(double);
         if (ldb > 64 * 1024)
             hipFuncSetAttribute((const void*)k_rff_mfma_db, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldb);

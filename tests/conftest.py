@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the application's choice, made before the HIP runtime starts (pybo_amd itself no longer touches the environment): eight
+# hardware queues keep the streams of several live handles apart
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -177,7 +177,18 @@ def _spmd_worker(rank, world, port, q, mode):
 
         bounds = [[0.0, 1.0], [0.0, 1.0]]
         kw = dict(model=SmootherModel(), niter=5, policy='ei', solver=('lbfgs', {'ngrid': 200}), recommender='incumbent')
-        if mode == 'seeded':
+        if mode == 'resume':
+            # a run that is resumed from rank 0's checkpoint: the file exists ONLY where rank 0 looks (rank 1's path is a
+            # directory of its own: no shared file system) -- 3 iterations are on disk, 5 are asked for
+            import tempfile
+            log = os.path.join(tempfile.mkdtemp(prefix='rank%d_' % rank), 'bo.pkl')
+            if rank == 0:
+                first = dict(kw, niter=3, rng=3, log=log)
+                pybo_amd.solve_bayesopt(lambda x: float(-np.sum((np.ravel(x) - 0.3) ** 2)), bounds, **first)
+                assert os.path.exists(log)
+            dist.barrier()
+            kw.update(rng=3, spmd=True, log=log)
+        elif mode == 'seeded':
             kw.update(rng=3, spmd=True)
         elif mode == 'unseeded':          # rng=None: OS entropy per rank unless the loop broadcasts one seed
             kw.update(rng=None, spmd=True)
@@ -213,6 +224,17 @@ def test_world2_spmd_loop_evaluates_the_objective_on_one_rank_and_keeps_the_mode
     for a, b in zip(got[0][1:], got[1][1:]):            # traces, model data and recommendation: bitwise equal
         np.testing.assert_array_equal(a, b)
     assert len(got[0][2]) == 6
+
+
+def test_world2_spmd_resume_loads_the_checkpoint_on_rank_0_and_broadcasts_it():
+    """every rank used to safe_load(log) on its own although only rank 0 writes that file: without
+    a shared file system (or with start-up skew) the ranks resumed from different traces, issued different numbers of
+    objective exchanges and recorded rank 0's pair under the wrong index.  Rank 0 loads, the state is broadcast."""
+    got = _run_spmd('resume')
+    assert got[0][0] == 2 and got[1][0] == 0            # iterations 3 and 4 only, on rank 0
+    for a, b in zip(got[0][1:], got[1][1:]):
+        np.testing.assert_array_equal(a, b)
+    assert len(got[0][2]) == 6                          # box centre + 5 iterations in the trace of BOTH ranks
 
 
 def test_a_process_group_alone_does_not_make_the_loop_collective():
