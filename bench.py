@@ -61,6 +61,17 @@ def make_workload(name, M):
         f = lambda Z: -((Z - 0.5) ** 2).sum(1)                       # noqa: E731
         y = f(X) + 1e-3 * rng.randn(N)
         desc = 'north-star: d=8 synthetic quadratic, N=8192 observed, SE-ARD, EI over 2^20 Sobol candidates'
+    elif name == 'ns2':   # the north-star workload with its optimum moved off the Sobol' centre (0.5, ..): the winner of 'ns'
+        # is Sobol' point 1, which any sane implementation picks; here the selection has to be earned.  A second, recorded
+        # run (profiles/); the headline stays 'ns'.
+        N, d, seed, kernel, acq = 8192, 8, 2, 'se', 'ei'
+        lo, hi = np.zeros(d), np.ones(d)
+        rng = np.random.RandomState(seed)
+        X = lo + (hi - lo) * rng.rand(N, d)
+        opt = np.array([0.37, 0.61, 0.43, 0.58, 0.29, 0.66, 0.52, 0.41])
+        f = lambda Z: -((Z - opt) ** 2).sum(1)                       # noqa: E731
+        y = f(X) + 1e-3 * rng.randn(N)
+        desc = 'north-star variant: d=8 quadratic with its optimum off the grid centre, N=8192, SE-ARD, EI over 2^20 Sobol candidates'
     elif name == 'b':     # BASELINE configs[1]
         N, d, seed, kernel, acq = 2048, 2, 0, 'se', 'ei'
         lo, hi = np.array([-5.0, 0.0]), np.array([10.0, 15.0])
@@ -128,7 +139,7 @@ def thompson_draw(w, s):
     return Wd / w['ell'], rng.rand(100) * 2 * np.pi, rng.randn(100)
 
 
-def cpu_baseline(w, budget_candidates, span, draws):
+def cpu_baseline(w, budget_candidates, span, draws, topk_idx=()):
     """Time the CPU restatement (oracle/, numpy+scipy on the host's BLAS threads) on a bounded sample: the fit in full,
     the sweep on `budget_candidates` of the M candidates in two disjoint halves (sample_indices), extrapolated linearly.
     Thompson workloads: every one of the step's `draws` posterior samples (sample_f + its values on the sample).
@@ -174,6 +185,19 @@ def cpu_baseline(w, budget_candidates, span, draws):
     for key in parts[0]:
         vals[key] = np.concatenate([p_[key] for p_ in parts], axis=-1)
     vals['best'] = np.argmax(vals['acq'], axis=-1)
+    if len(topk_idx) and w['acq'] in ('ei', 'ucb'):
+        # NOT timed: the oracle at the candidates the DEVICE ranked best over the whole grid (global indices), for the
+        # order check of the parity record
+        ti = np.asarray(topk_idx, dtype=np.int64)
+        mu, s2 = ref.predict(w['Xc'][ti])
+        if w['acq'] == 'ei':
+            target = ref.mean_at_obs().max()
+            s_ = np.sqrt(s2)
+            z_ = (mu - target) / s_
+            v = (mu - target) * gp_ref.norm_cdf(z_) + s_ * gp_ref.norm_pdf(z_)
+        else:
+            v = mu + np.sqrt(ucb_beta(w['N']) * s2)
+        vals['topk'] = dict(index=ti, mu=mu, s2=s2, acq=v)
     nsamp = len(vals['index'])
     t_sw = float(sum(times))
     step = t_fit + t_draws + t_sw * (w['M'] / float(nsamp))
@@ -192,7 +216,7 @@ def cpu_baseline(w, budget_candidates, span, draws):
     return rec, vals
 
 
-def cpu_baseline_unpinned(workload, M, nc, span, draws):
+def cpu_baseline_unpinned(workload, M, nc, span, draws, topk_idx=()):
     """torch.distributed.run pins OMP_NUM_THREADS=1 in every rank of a multi-rank launch, and a BLAS that was
     initialised with one thread cannot safely be widened afterwards: rank 0 therefore times the baseline in a child
     process of its own with the pin removed (the other ranks have left the process group and exited by then), and reads the record and
@@ -207,7 +231,8 @@ def cpu_baseline_unpinned(workload, M, nc, span, draws):
         path = os.path.join(tmp, 'cpu.pkl')
         subprocess.check_call([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', path, '--workload',
                                workload, '--candidates', str(M), '--cpu-candidates', str(nc), '--cpu-span', str(span),
-                               '--cpu-draws', ','.join(str(v) for v in draws)], env=env,
+                               '--cpu-draws', ','.join(str(v) for v in draws),
+                               '--cpu-topk', ','.join(str(int(v)) for v in topk_idx)], env=env,
                               stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL)
         with open(path, 'rb') as fh:
             return pickle.load(fh)
@@ -250,6 +275,32 @@ def parity_record(w, ref_vals, dev_vals):
     out['selected_index'] = {'oracle': int(ref_vals['best']), 'device': int(np.argmax(ad))}
     if 'target' in ref_vals:
         out['abs_err_target'] = float(abs(dev_vals['target'] - ref_vals['target']))
+    if 'topk' in ref_vals and 'top_idx' in dev_vals:
+        # The ORDER of the device's top-k over the whole grid, judged by the oracle (the winner alone can be
+        # a trivial candidate).  Tolerance of one value: the stated moment tolerances propagated to first order,
+        # |d acq| <= Phi(z) dmu + phi(z) ds2 / (2 s) for EI, dmu + sqrt(beta) ds2 / (2 s) for UCB; two neighbours may
+        # swap only if the oracle's gap between them is within the sum of their tolerances.
+        tk = ref_vals['topk']
+        mu_, s2_ = tk['mu'], tk['s2']
+        s_ = np.sqrt(s2_)
+        dmu = 1e-6 * np.abs(mu_) + 1e-9 * np.sqrt(rho)
+        ds2 = 1e-6 * s2_ + 1e-10 * rho
+        if w['acq'] == 'ei':
+            from oracle import gp_ref
+            z_ = (mu_ - ref_vals['target']) / s_
+            tol = gp_ref.norm_cdf(z_) * dmu + gp_ref.norm_pdf(z_) * ds2 / (2.0 * s_)
+        else:
+            tol = dmu + np.sqrt(ucb_beta(w['N'])) * ds2 / (2.0 * s_)
+        ov = tk['acq']                                    # oracle values IN THE DEVICE'S ORDER
+        gaps = ov[:-1] - ov[1:]
+        out['topk_order_matches'] = bool(np.all(gaps >= -(tol[:-1] + tol[1:])))
+        out['topk_compared'] = int(len(ov))
+        out['topk_strictly_ordered_pairs'] = int(np.sum(gaps > (tol[:-1] + tol[1:])))     # pairs the check can actually tell apart
+        out['topk_max_rel_val'] = float(np.max(np.abs(dev_vals['top_val'][:len(ov)] - ov) / np.maximum(np.abs(ov), 1e-300)))
+        # no candidate of the oracle's sample outranks the device's k-th by more than the tolerance unless it IS in the top-k
+        outside = ~np.isin(dev_vals['sample_global_index'], tk['index'])
+        out['sample_outranks_topk'] = int(np.sum(ar[outside] > ov[-1] + tol[-1])) if len(ar) == len(outside) else None
+        out['winner_is_trivial'] = bool(int(tk['index'][0]) < 2)      # Sobol' points 0 / 1: the origin / the centre of the box
     return out
 
 
@@ -422,7 +473,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--workload', default='ns', choices=['ns', 'b', 'c', 'd', 'e'])
+    ap.add_argument('--workload', default='ns', choices=['ns', 'ns2', 'b', 'c', 'd', 'e'])
     ap.add_argument('--candidates', type=int, default=1 << 20)
     ap.add_argument('--topk', type=int, default=10)
     ap.add_argument('--chunk', type=int, default=0)
@@ -452,6 +503,7 @@ def main():
     ap.add_argument('--cpu-baseline-worker', default='', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-span', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-draws', default='', help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-topk', default='', help=argparse.SUPPRESS)
     ap.add_argument('--mode', default='spmd', choices=['spmd', 'sharded'],
                     help="spmd (default): one process per GPU under torch.distributed, RCCL all-gather of the top-k; "
                          "sharded: ONE process drives --gpus devices through pybo_amd.models.ShardedGP + "
@@ -462,7 +514,8 @@ def main():
     if args.cpu_baseline_worker:                      # child of cpu_baseline_unpinned: no GPU, no process group
         import pickle
         res = cpu_baseline(make_workload(args.workload, args.candidates), args.cpu_candidates, args.cpu_span,
-                           [int(v) for v in args.cpu_draws.split(',') if v != ''])
+                           [int(v) for v in args.cpu_draws.split(',') if v != ''],
+                           [int(v) for v in args.cpu_topk.split(',') if v != ''])
         with open(args.cpu_baseline_worker, 'wb') as fh:
             pickle.dump(res, fh)
         return
@@ -910,10 +963,13 @@ def main():
             span = Ml if w['acq'] != 'thompson' else M
             nc = min(args.cpu_candidates or (M if N <= 2048 else (1 << 17)), span)
             draws = mine if w['acq'] == 'thompson' else []
+            # the candidates the timed step ranked best over the WHOLE grid (merged over the ranks): the oracle evaluates them
+            # too (untimed) and the parity record checks their ORDER
+            tk_idx = [int(v) for v in np.asarray(best[1]).ravel() if v >= 0] if w['acq'] in ('ei', 'ucb') else []
             if world > 1 and os.environ.get('OMP_NUM_THREADS') == '1':
-                out['cpu_baseline'], ref_vals = cpu_baseline_unpinned(w['name'], M, nc, span, draws)
+                out['cpu_baseline'], ref_vals = cpu_baseline_unpinned(w['name'], M, nc, span, draws, tk_idx)
             else:
-                out['cpu_baseline'], ref_vals = cpu_baseline(w, nc, span, draws)
+                out['cpu_baseline'], ref_vals = cpu_baseline(w, nc, span, draws, tk_idx)
             # the same candidates on the device, outside any timed region: every bench line is also a parity check
             eng.fit_dev(dX.data_ptr(), N, d, dy.data_ptr(), w['kernel'], w['ell'], w['rho'], w['sn2'], w['bias'])
             dev_vals = {}
@@ -933,6 +989,9 @@ def main():
                 eng.sync()
                 hb = buf.cpu().numpy()
                 dev_vals.update(acq=hb[0], mu=hb[1], s2=hb[2], target=float(param))
+            if w['acq'] in ('ei', 'ucb'):
+                dev_vals['top_val'], dev_vals['top_idx'] = np.asarray(best[0]).ravel(), np.asarray(best[1]).ravel()
+                dev_vals['sample_global_index'] = lo_i + sidx
             out['parity'] = parity_record(w, ref_vals, dev_vals)
         if args.plugin_steps > 0 and world == 1 and w['acq'] in ('ei', 'ucb'):
             out['plugin_step'] = plugin_step(w, args.plugin_steps, k)
