@@ -113,22 +113,11 @@ int gpx_version(void);
  *              Both bit-identical, both measured and off by default ("The fit -- round 3").
  *          "chol_tg" = 1 (default): the factorisation runs as ONE persistent kernel that walks its task graph (dedicated
  *              workgroups for the diagonal blocks and the two tiles between consecutive ones, everything else as
- *              throughput work from dependency-checked queues; kernels_chol_tg.hip) for fits of "chol_tg_min" (default 12) to
+ *              throughput work from ONE ticketed, dependency-checked list; kernels_chol_tg.hip) for fits of "chol_tg_min" (default 12) to
  *              "chol_tg_max" (default 160) 128-blocks; 0: the stream schedule above.  Bit-identical factors either way.  Tuning / diagnostics:
  *              "chol_tg_chunks" (k-chunk sizes counted back from the pivot as decimal digits, default 12489 = 1, 2, 4, 8, 16, 16, ..: the digit 9 stands for 16 blocks),
- *              "chol_tg_split" (s + 1000 b: chunks ending within s blocks of the pivot, and every chunk of the tiles within b
- *              blocks of the diagonal, go to a queue of their own that is served first; + 1000000: a tile's panel solve and the
- *              final chunk of the tile below it as ONE task -- measured slower; + 10000000: column-major order inside a step --
- *              measured slower; + 100000000: the solve of tile (p, p+2) and the final chunk of tile (p+1, p+2) on the critical
- *              list too -- no effect; default 200 = one queue, not fused, row-major),
- *              "chol_tg_peek" (1: a workgroup looks at the queue head and draws a ticket only when that task is ready;
- *              0, the default: it draws its next ticket at once and waits with it in hand -- 1-2 % faster at every size),
  *              "chol_tg_nap" (longest pause of a waiting workgroup between two looks at its dependencies, in units of 64
  *              clocks: 8, 16 (default), 32, 64 or 127),
- *              "chol_tg_affine" (G > 0: runs of G consecutive tickets are served by one XCD each, from eight heads -- built to
- *              cut the kernel's HBM traffic, measured slower at every size; default 0 = one FIFO),
- *              "chol_tg_queues" (a worker looks at this many strided sub-queues of its list at once, 1..16; default 1 --
- *              measured much slower beyond 1), "chol_tg_upool" (workers that serve the urgent list only; measured slower),
  *              "chol_tg_side" (workgroups reserved for the critical tiles, default 8), "chol_tg_grid" (workgroups launched,
  *              0 = by size), "chol_tg_isolate" (1, default: the critical workgroups keep their compute units to themselves),
  *              "chol_tg_tmo_ms" (bound of every spin, default 2000: on expiry the fit re-runs on the stream schedule and
@@ -362,11 +351,11 @@ int gpx_timers(gpx_handle *h, double *out, int n, int reset);
 int64_t gpx_chol_trace(gpx_handle *h, int64_t *out, int64_t n);
 /* The task lists the task-graph factorisation of an nblocks x nblocks block matrix walks (host only, no device needed:
  * what the CPU tests replay to prove that every tile receives every block row once, in order, and that the lists never
- * dead-lock): counts[3] = tasks in the critical / urgent / far queue, out (total, 8) int16 = {type (1 panel solve,
- * 2 tile update, 3 diagonal-tile quadrant update), I, J, k0, k1, ordinal, aux, urgent}, queues back to back.  chunks /
- * split as the options "chol_tg_chunks" / "chol_tg_split" (<= 0 / < 0: defaults).  Returns the total number of tasks
- * (written only when cap >= total), -1 on bad arguments. */
-int64_t gpx_chol_tasks(int nblocks, int chunks, int split, int16_t *out, int64_t cap, int64_t *counts);
+ * dead-lock): counts[2] = tasks in the critical list / the workers' list, out (total, 8) int16 = {type (1 panel solve,
+ * 2 tile update, 3 piece of a diagonal-tile update), I, J, k0, k1, ordinal, aux, reserved}, the lists back to back.
+ * chunks as the option "chol_tg_chunks" (<= 0: default).  Returns the total number of tasks (written only when
+ * cap >= total), -1 on bad arguments. */
+int64_t gpx_chol_tasks(int nblocks, int chunks, int16_t *out, int64_t cap, int64_t *counts);
 int gpx_sync(gpx_handle *h);
 
 #ifdef __cplusplus

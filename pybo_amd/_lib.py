@@ -87,7 +87,7 @@ SYMBOLS = {
     'gpx_topk_allgather': (C.c_int, [_P, _i64, _i64, _i64, _P, _P]),
     'gpx_timers': (C.c_int, [_P, _P, C.c_int, C.c_int]),
     'gpx_chol_trace': (_i64, [_P, _P, _i64]),
-    'gpx_chol_tasks': (_i64, [C.c_int, C.c_int, C.c_int, _P, _i64, _P]),
+    'gpx_chol_tasks': (_i64, [C.c_int, C.c_int, _P, _i64, _P]),
     'gpx_sync': (C.c_int, [_P]),
 }
 
@@ -103,18 +103,18 @@ TOPK_MAX = 4096
 _lib = None
 
 
-def chol_tasks(nblocks, chunks=0, split=-1):
-    """The task lists of the task-graph factorisation (host only): three (n, 8) int16 arrays
-    {type, I, J, k0, k1, ordinal, aux, urgent} -- critical, urgent and far queue (include/gpx.h: gpx_chol_tasks)."""
+def chol_tasks(nblocks, chunks=0):
+    """The task lists of the task-graph factorisation (host only): two (n, 8) int16 arrays
+    {type, I, J, k0, k1, ordinal, aux, reserved} -- the critical list and the workers' list (include/gpx.h: gpx_chol_tasks)."""
     lib = load()
-    counts = np.zeros(3, dtype=np.int64)
-    tot = lib.gpx_chol_tasks(nblocks, chunks, split, None, 0, _ptr(counts))
+    counts = np.zeros(2, dtype=np.int64)
+    tot = lib.gpx_chol_tasks(nblocks, chunks, None, 0, _ptr(counts))
     if tot < 0:
         raise ValueError('gpx_chol_tasks: bad arguments')
     out = np.zeros((max(int(tot), 1), 8), dtype=np.int16)
-    lib.gpx_chol_tasks(nblocks, chunks, split, _ptr(out), int(tot), _ptr(counts))
+    lib.gpx_chol_tasks(nblocks, chunks, _ptr(out), int(tot), _ptr(counts))
     o = np.cumsum(np.r_[0, counts])
-    return [out[o[q]:o[q + 1]] for q in range(3)]
+    return [out[o[q]:o[q + 1]] for q in range(2)]
 
 
 class GpxError(RuntimeError):

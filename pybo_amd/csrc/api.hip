@@ -118,7 +118,7 @@ static void harvest(gpx_handle* h) {
 }
 
 // ---- lifetime ---------------------------------------------------------------------------------
-extern "C" int gpx_version(void) { return 400; }   // round * 100: 300 added gpx_predict_mean, gpx_var_at_obs, gpx_capacity, gpx_append_begin; 400 gpx_chol_trace, gpx_chol_tasks, GPX_OPTIONS
+extern "C" int gpx_version(void) { return 500; }   // round * 100: 300 added gpx_predict_mean, gpx_var_at_obs, gpx_capacity, gpx_append_begin; 400 gpx_chol_trace, gpx_chol_tasks, GPX_OPTIONS; 500: gpx_chol_tasks lost its `split` argument (two lists), timers slot 16
 
 extern "C" const char* gpx_last_error(const gpx_handle* h) {
     return h ? h->err.c_str() : g_create_err.c_str();
@@ -292,24 +292,20 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             h->chol_w = (int)value;
             return GPX_OK;
         }
-        if (!strcmp(name, "chol_tg") || !strcmp(name, "chol_tg_chunks") || !strcmp(name, "chol_tg_split") ||
-            !strcmp(name, "chol_tg_side") || !strcmp(name, "chol_tg_grid") || !strcmp(name, "chol_tg_trace") ||
-            !strcmp(name, "chol_tg_tmo_ms") || !strcmp(name, "chol_tg_min") || !strcmp(name, "chol_tg_max") || !strcmp(name, "chol_tg_isolate") || !strcmp(name, "chol_tg_queues") || !strcmp(name, "chol_tg_upool") || !strcmp(name, "chol_tg_affine") || !strcmp(name, "chol_tg_peek") || !strcmp(name, "chol_tg_nap")) {
+        if (!strcmp(name, "chol_tg") || !strcmp(name, "chol_tg_chunks") || !strcmp(name, "chol_tg_side") ||
+            !strcmp(name, "chol_tg_grid") || !strcmp(name, "chol_tg_trace") || !strcmp(name, "chol_tg_tmo_ms") ||
+            !strcmp(name, "chol_tg_min") || !strcmp(name, "chol_tg_max") || !strcmp(name, "chol_tg_isolate") ||
+            !strcmp(name, "chol_tg_nap")) {
             if (value < -1 || value > 1000000000) return fail(h, GPX_EARG, "chol_tg*: out of range");
             const char* sub = name + 7;
             if (*sub == 0) { if (value != 0 && value != 1) return fail(h, GPX_EARG, "chol_tg must be 0 or 1"); h->chol_tg = (int)value; }
-            else if (!strcmp(sub, "_peek")) h->tg_peek = value != 0 ? 1 : 0;
             else if (!strcmp(sub, "_nap")) h->tg_nap = (int)std::max<int64_t>(0, std::min<int64_t>(127, value));
-            else if (!strcmp(sub, "_affine")) h->tg_affine = (int)std::max<int64_t>(0, value);
             else if (!strcmp(sub, "_chunks")) h->tg_chunks = (int)value;
-            else if (!strcmp(sub, "_split")) h->tg_split = (int)value;
             else if (!strcmp(sub, "_side")) h->tg_side = (int)value;
             else if (!strcmp(sub, "_grid")) h->tg_grid = (int)value;
             else if (!strcmp(sub, "_trace")) h->tg_trace = (int)value;
             else if (!strcmp(sub, "_tmo_ms")) h->tg_tmo_ms = (int)value;
             else if (!strcmp(sub, "_isolate")) h->tg_isolate = (int)value;
-            else if (!strcmp(sub, "_queues")) h->tg_queues = (int)value;
-            else if (!strcmp(sub, "_upool")) h->tg_upool = (int)value;
             else if (!strcmp(sub, "_max")) h->tg_max = (int)std::max<int64_t>(1, value);
             else h->tg_min = (int)std::max<int64_t>(1, value);
             return GPX_OK;
@@ -391,10 +387,10 @@ extern "C" int gpx_sync(gpx_handle* h) {
     });
 }
 
-extern "C" int64_t gpx_chol_tasks(int nblocks, int chunks, int split, int16_t* out, int64_t cap, int64_t* counts) {
+extern "C" int64_t gpx_chol_tasks(int nblocks, int chunks, int16_t* out, int64_t cap, int64_t* counts) {
     if (!counts) return -1;
     try {
-        return gpx::tg_tasks_copy(nblocks, chunks, split, out, cap, counts);
+        return gpx::tg_tasks_copy(nblocks, chunks, out, cap, counts);
     } catch (...) {
         return -1;
     }

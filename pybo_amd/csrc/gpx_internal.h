@@ -58,12 +58,7 @@ struct gpx_handle {
     int tg_min = 12;              // smallest number of 128-blocks the task-graph kernel is used for (N = 1536: 0.67 against 0.72 ms; at N = 1024 the stream schedule still wins, 0.43 against 0.46)
     int tg_max = 160;             // ... and the largest (from N = 24576 on the stream schedule is 1-2 % faster: both throughput-bound)
     int tg_chunks = 0;            // chunk sizes counted back from the pivot, as decimal digits (0 = default 12489: 1, 2, 4, 8, 16, 16, ..)
-    int tg_split = -1;            // chunks ending within this many blocks of the pivot go to the urgent queue (-1 = default 200: one queue)
-    int tg_upool = 0;             // workers that serve the urgent list only (0 = none)
-    int tg_peek = 0;              // 0 (default): a workgroup draws its next ticket at once and waits with it in hand; 1: it peeks at the queue head first and draws only when that task is ready
     int tg_nap = 0;               // longest polling pause of a waiting workgroup in units of 64 clocks (0 = default 16; round 4 until late: 127)
-    int tg_affine = 0;            // XCD-affine runs of this many consecutive tickets (0 = off: one FIFO)
-    int tg_queues = 0;            // strided sub-queues per worker list (0 = default 1)
     int tg_side = 0;              // workgroups reserved for the two critical tiles per block (0 = default 8)
     int tg_grid = 0;              // workgroups launched (0 = by size, bounded by residency)
     int tg_isolate = 1;           // the critical workgroups keep their compute units to themselves (full grids only)
@@ -196,7 +191,7 @@ bool launch_cholesky_tg(gpx_handle* h);    // the same by the persistent task-gr
 int tg_abort_code(gpx_handle* h);          // after the stream has drained: 0 ok, 1 not PD, 2 a spin gave up
 int64_t tg_trace_copy(gpx_handle* h, long long* out, int64_t n);
 void tg_free(gpx_handle* h);
-int64_t tg_tasks_copy(int nP, int chunks, int split, int16_t* out, int64_t cap, int64_t* counts);
+int64_t tg_tasks_copy(int nP, int chunks, int16_t* out, int64_t cap, int64_t* counts);
 void launch_trtri(gpx_handle* h);      // R, diag blocks -> T, U (uses S as workspace)
 void launch_refine_inverse(gpx_handle* h, double* tmp);   // option refine_inverse: one Newton step on T / U (tmp: Np^2 scratch)
 void launch_alpha(gpx_handle* h);      // a = T (y - bias); alpha = U a

@@ -8,25 +8,31 @@
 // flags in device memory.
 //
 //   role C (1 workgroup)    POTRF(p), p = 0 .. nP-1: the 16-wide MFMA-blocked diagonal factorisation (potrf16_body).
-//   role S (a few)          the two tiles on the critical path between POTRF(p) and POTRF(p+1): the panel solve of tile
+//   role S (8 by default)   the two tiles on the critical path between POTRF(p) and POTRF(p+1): the panel solve of tile
 //                           (p, p+1) in two 64-column halves, then the update of the diagonal tile (p+1, p+1) with block
-//                           row p in three 64 x 64 quadrants, operands straight from global memory (no LDS staging).
-//   role W (everyone else)  the throughput work, from two queues (urgent first): panel solves TRSM(p, J), J >= p+2, and the
-//                           tile updates  S_IJ -= sum_{k in [k0,k1)} R_kI^T R_kJ  on the 128 x 128 fp64-MFMA tile engine.
+//                           row p in six 32-column pieces, operands straight from global memory (no LDS staging).
+//   role W (everyone else)  the throughput work, from ONE list: panel solves TRSM(p, J), J >= p+2, and the tile updates
+//                           S_IJ -= sum_{k in [k0,k1)} R_kI^T R_kJ  on the 128 x 128 fp64-MFMA tile engine.
 //
-// Tile (I, J) receives its I block updates in CHUNKS of consecutive k, graded by distance from the pivot (default 1, 1, 2,
-// 4, 4, ... blocks counted back from k = I): far from the pivot a chunk is long (arithmetic intensity), next to it the
+// Tile (I, J) receives its I block updates in CHUNKS of consecutive k, graded by distance from the pivot (default 1, 2, 4, 8,
+// 16, 16, ... blocks counted back from k = I): far from the pivot a chunk is long (arithmetic intensity), next to it the
 // chunks are single blocks (latency: the final chunk of row I becomes available when block row I-1 is solved and is
 // needed one diagonal block later).  Accumulators start from the S tile and k ascends within and across chunks, so every
 // element sees the same sequence of FMAs as in the stream-scheduled kernels: the factor is BIT-IDENTICAL.
 //
-// Scheduling: task lists are built on the host in the order the tasks become available (a valid topological order);
-// a worker takes the head of a queue ONLY when its dependencies are already met (compare-and-swap on the head), so no
-// workgroup ever waits while holding a task -- progress needs nothing but the role-C / role-S workgroups and one worker
-// being resident, and roles are handed out in order of arrival.  Every spin is bounded (abort code 2 -> the launcher's
-// caller re-runs the stream schedule).  Dependencies are counters: seq[I][J] = chunks applied to tile (I, J),
-// solved[2J + h] = block rows solved in the 64-column half h of block column J, diag[p], and quad[p] = quadrants of the
-// diagonal tile p that have received block row p-1.
+// Scheduling: the task lists are built on the host in the order the tasks become available (a valid topological order): one
+// list for the side-kicks, one for the workers, oldest first.  A workgroup without a task DRAWS the next ticket of its list
+// with one fetch-and-add and waits for THAT task's dependencies with the ticket in hand (bounded polling, 0.4 us between
+// looks): nothing stands between "ready" and "running".  Every ticket is held by a polling workgroup, tickets are drawn in
+// topological order and a task only waits for earlier tasks, so the earliest incomplete task of the graph is always held by
+// a workgroup that will run it: the lists cannot dead-lock as long as the role-C / role-S workgroups and one worker are
+// resident, and roles are handed out in order of arrival.  Every spin is bounded (abort code 2 -> the launcher's caller
+// re-runs the stream schedule).  Dependencies are counters: seq[I][J] = chunks applied to tile (I, J), solved[2J + h] =
+// block rows solved in the 64-column half h of block column J, diag[p], and quad[p] = pieces of the diagonal tile p that
+// have received block row p-1.
+// (Measured and removed in round 5 -- the A/B logs are profiles/r04_chol_tg_*_ab.txt: claiming a head by compare-and-swap,
+//  a peek before the draw, priority lists, strided sub-queues, an urgent-only pool, XCD-affine tickets, a fused solve + update
+//  task, column-major lists, the next solve's dependency cone on the side-kicks: every one slower or no faster.)
 //
 // Hand-offs follow MI355X_MICROARCH.md ("inter-workgroup visibility"): payloads are stored write-through at agent scope
 // (fit_tiles.h, AG = true), every storing wave drains (s_waitcnt vmcnt(0)), barrier, ONE lane stores the flag; consumers
@@ -40,8 +46,8 @@
 
 namespace gpx {
 
-enum { TG_TRSM = 1, TG_UPD = 2, TG_UPDQ = 3, TG_TRSMU = 4 };
-struct TgTask { int16_t type, I, J, k0, k1, ord, aux, rsv; };     // 16 bytes; aux = column half (TRSM) / quadrant (UPDQ)
+enum { TG_TRSM = 1, TG_UPD = 2, TG_UPDQ = 3 };
+struct TgTask { int16_t type, I, J, k0, k1, ord, aux, rsv; };     // 16 bytes; aux = column half (TRSM) / piece (UPDQ)
 
 struct TgArgs {
     double *S, *R, *T, *U;
@@ -49,80 +55,52 @@ struct TgArgs {
     int nP;
     int* dflag;                  // [0] = failing pivot + 1
     int* ctl;                    // control block (zeroed before every launch), layout below
-    const TgTask* q[3];          // 0: critical (role S), 1: urgent, 2: far
-    int n[3];
+    const TgTask* q[2];          // 0: critical (role S), 1: the workers' list
+    int n[2];
     int nside;
     int isolate;                 // the critical workgroups keep their compute units to themselves
-    int nsub;                    // strided sub-queues per worker list (1 .. TG_SUB_MAX)
-    int upool;                   // workers that serve the urgent list only
-    int affine;                  // > 0: XCD-affine runs of this many consecutive tickets (tg_take_affine)
-    int nopeek;                  // 1: tickets are drawn without peeking at the head (option chol_tg_peek = 0)
     int nap;                     // longest pause between two looks at a waiting task's dependencies, in units of 64 clocks (8, 16, 32, 64 or 127)
-    int sub_heads;               // offset (ints) of their head counters in the control block
     long long* trace;            // optional: [p][4] critical-path stamps, then [crit task][2]
     long long tmo;               // spin bound in wall-clock ticks (100 MHz)
     long long* tasklog;          // optional (trace level 2): per workgroup TG_LOG_CAP records {task (2 words), start, end}
 };
 
-// control block (ints): [0] arrivals, [32] abort (1 = not positive definite, 2 = a spin gave up), [64 + 32 q] queue heads,
+// control block (ints): [0] arrivals, [32] abort (1 = not positive definite, 2 = a spin gave up), [64 + 32 q] list heads,
 // then diag[nPad], quad[nPad], solved[2 nPad], seq[nP * nP], and per compute unit (key = xcc | se | sh | cu, 12 bits)
-// the number of workgroups that have started there and the role of the first one
-// Defaults, from the sweeps in profiles/r04_chol_taskgraph.txt: chunks of 1, 2, 4, 8, 8, .. blocks counted back from the pivot,
-// and ONE worker queue (split >= the matrix: everything is "urgent", i.e. plain generation order).  Two queues with the
-// near-pivot chunks first were measured 15-25 % slower at every size: a near chunk waits for its tile's previous chunk,
-// which then sits in the LOWER-priority queue behind a backlog -- priority inversion.
-constexpr int TG_DEFAULT_CHUNKS = 12489, TG_DEFAULT_SPLIT = 200;
+// the number of workgroups that have started there and the role of the first one.
+// Default chunks (sweeps in profiles/r04_chol_taskgraph.txt): 1, 2, 4, 8, 16, 16, .. blocks counted back from the pivot.
+constexpr int TG_DEFAULT_CHUNKS = 12489;
 constexpr int TG_LOG_CAP = 1024, TG_LOG_WGS = 1024;
 constexpr int TG_NPIECE = 6;          // pieces of the critical update of a diagonal tile
 constexpr int TG_CTL_ABORT = 32, TG_CTL_HEAD = 64, TG_CTL_BASE = 192, TG_CU_KEYS = 4096;
 __host__ __device__ inline int tg_npad(int nP) { return (nP + 31) / 32 * 32; }
-__host__ __device__ inline int tg_sub_heads(int nP) { return TG_CTL_BASE + 4 * tg_npad(nP) + nP * nP + 2 * TG_CU_KEYS; }
-__host__ __device__ inline int tg_ctl_ints(int nP) { return tg_sub_heads(nP) + 32 * 2 * 16; }
+__host__ __device__ inline int tg_ctl_ints(int nP) { return TG_CTL_BASE + 4 * tg_npad(nP) + nP * nP + 2 * TG_CU_KEYS; }
 
 __device__ __forceinline__ int ldi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void sti(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// Find the next task for this workgroup in the queues QB .. QB+NQ-1 (lowest index = highest priority).  Called by ONE
-// full wave; lane l < NQ looks after queue QB + l.  Returns 1 (task in `out`, the same in every lane), 0 (every queue is
-// exhausted and nothing is held) or -1 (abort).
-//
-// Tickets are drawn with ONE fetch-and-add per task.  (The first version claimed a head with compare-and-swap after
-// checking its dependencies: every claim had to observe the previous one -- 1.3 us per task chip-wide with 123 workers,
-// 5.9 us with 507, and the workers spent 90 % of the factorisation inside this function.)  A lane first PEEKS: the task at
-// [since late in round 4 this peek is an OPTION (chol_tg_peek = 1); by default a workgroup draws its next ticket at once and
-//  waits for that task's dependencies with the ticket in hand -- 1-2 % faster at every size: no fetch-and-add between "ready"
-//  and "running", no rush of all idle workgroups for one head]
-// the head it reads, if its dependencies are met, is worth a ticket; the ticket it then draws may be a later one (others
-// drew at the same moment), and if that task is not ready yet the workgroup HOLDS it (one per queue, in `held`) and keeps
-// looking: a held task is run as soon as it is ready, a higher-priority queue is served meanwhile.  No workgroup ever
-// sleeps on a task: the earliest incomplete task of the whole graph is either held by a workgroup that polls it or at the
-// head of its queue where every workgroup without a held ticket for that queue peeks -- the lists cannot dead-lock.
-
-// PRE (the critical queue): only the dependency on the tile's earlier chunks -- a side-kick takes its task as soon as the
+// PRE (the critical list): only the dependency on the tile's earlier chunks -- a side-kick takes its task as soon as the
 // tile it will read first is final, starts loading it, and waits for the last dependency (the diagonal block / the two
 // solves) inside the task body: the loads of the S tile are off the critical path.
 template <bool PRE>
 __device__ __forceinline__ bool tg_deps_met(const TgTask& t, const int* dd, const int* sv, const int* sq, int nP) {
     const int I = t.I, J = t.J;
     const int s = ldi(sq + I * nP + J);
-    if (PRE && t.type != TG_UPD) return s == t.ord;      // (a plain update on the critical list has no wait inside its body)
+    if (PRE) return s == t.ord;
     if (t.type == TG_TRSM) return (ldi(dd + I) != 0) && (s == t.ord);
-    // the fused task: also the earlier chunks of the tile BELOW -- with two worker queues they may sit in the lower-priority
-    // one, and a workgroup that waited for them inside the task could wait for ever; only the critical solve of (p, p+1),
-    // which has workgroups of its own, is awaited in the task body
-    if (t.type == TG_TRSMU) return (ldi(dd + I) != 0) && (s == t.ord) && (ldi(sq + (I + 1) * nP + J) == t.aux);
     const int s0 = ldi(sv + 2 * I), s1 = ldi(sv + 2 * I + 1), s2 = ldi(sv + 2 * J), s3 = ldi(sv + 2 * J + 1);
     return (s == t.ord) && (min(min(s0, s1), min(s2, s3)) >= t.k1);
 }
 
-// Worker queues are read through `nsub` STRIDED sub-queues each (option chol_tg_queues; sub-queue r of a list = its tasks
-// r, r + nsub, r + 2 nsub, ... with a head counter of its own): a head that is not ready blocks only its own sub-queue, the
-// workgroup looks at nsub heads per list at once (one lane each) and takes any that is ready, starting from a different one
-// every time.  Every sub-queue is a subsequence of a topological order, so the no-dead-lock argument above holds per sub-queue.
-constexpr int TG_SUB_MAX = 16;
-struct TgHeld { TgTask t[1 + 2 * TG_SUB_MAX]; int have[1 + 2 * TG_SUB_MAX]; int turn; };     // in LDS, one per workgroup
+struct TgHeld { TgTask t; int have; };     // in LDS, one per workgroup: the ticket in hand (have: 0 none, 1 a task, 2 the list ran out)
 
-template <int QB, int NQ>
+// The next task of list Q (0: critical, 1: workers) for this workgroup.  Called by ONE full wave; lane 0 works, the
+// result is the same in every lane: 1 (task in `out`), 0 (the list is exhausted) or -1 (abort).
+// A workgroup without a ticket draws one at once (ONE fetch-and-add) and waits for that task's dependencies with the
+// ticket in hand.  (History, profiles/r04_chol_taskgraph.txt: claiming a head with compare-and-swap after checking its
+// dependencies serialised the chip -- 1.3 us per task with 123 workers, 5.9 us with 507, N = 8192 in 107 ms; peeking at the
+// head before drawing made every idle workgroup rush for the one head that had just become ready: 1-2 % slower.)
+template <int Q>
 __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, TgHeld* held) {
     const int nP = a.nP, npad = tg_npad(nP);
     int* ctl = a.ctl;
@@ -130,102 +108,47 @@ __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, T
     const int* sv = dd + 2 * npad;
     const int* sq = sv + 2 * npad;
     const long long t0 = wall_clock64();
-    int nap = 0;                                   // polls since the last find: the pauses grow (QB == 0: stay alert)
-    // lane -> (list q, sub-queue r, stride): the critical list is read whole by lane 0; a worker's lane l reads
-    // sub-queue l % nsub of list 1 + l / nsub
-    const int nsub = (QB == 0) ? 1 : a.nsub;
-    const int nlane = NQ * nsub;
-    const int q = QB + (lane < nlane ? lane / nsub : 0);
-    const int r = (lane < nlane) ? lane % nsub : 0;
-    const int slot = (QB == 0) ? 0 : 1 + lane;     // held-ticket slot of this lane
-    int* head = (QB == 0) ? ctl + TG_CTL_HEAD : (ctl + a.sub_heads + 32 * ((q - 1) * TG_SUB_MAX + r));
-    const int nq = (q == 0) ? a.n[0] : ((q == 1) ? a.n[1] : a.n[2]);
-    const TgTask* tq = (q == 0) ? a.q[0] : ((q == 1) ? a.q[1] : a.q[2]);
+    int nap = 0;                                   // polls since the draw: the pauses grow (Q == 0: stay alert)
+    int* head = ctl + TG_CTL_HEAD + 32 * Q;
+    const int nq = a.n[Q];
+    const TgTask* tq = a.q[Q];
     for (unsigned spins = 0;; ++spins) {
         if (ldi(ctl + TG_CTL_ABORT) != 0) return -1;
-        bool live = false, ready = false, mine = false;
-        int hpeek = -1;
+        int code = 0;                              // 1: the held task is ready, 2: the list ran out
         union { TgTask t; int4 v; } u;
         u.v = make_int4(0, 0, 0, 0);
-        if (lane < nlane) {
-            // option chol_tg_peek = 0: a workgroup without a ticket DRAWS one at once and waits for that task's dependencies
-            // with the ticket in hand (no look at the head first): when they are met the task starts -- no fetch-and-add
-            // between "ready" and "running", and no rush of every idle workgroup for the one head that just became ready.
-            // have == 2: this list ran out under this lane.
-            if (a.nopeek && held->have[slot] == 0 && nq > 0) {
-                const int k = atomicAdd(head, 1);
-                if (r + nsub * k < nq) {
-                    held->t[slot] = *reinterpret_cast<const TgTask*>(tq + r + nsub * k);
-                    held->have[slot] = 1;
+        if (lane == 0) {
+            if (held->have == 0) {
+                const int k = (nq > 0) ? atomicAdd(head, 1) : nq;
+                if (k < nq) {
+                    held->t = *reinterpret_cast<const TgTask*>(tq + k);
+                    held->have = 1;
                 } else {
-                    held->have[slot] = 2;
+                    held->have = 2;
                 }
             }
-            mine = held->have[slot] == 1;
-            if (mine) {
-                u.t = held->t[slot];
-                live = true;
-            } else if (a.nopeek) {
-                live = false;
+            if (held->have == 2) {
+                code = 2;
             } else {
-                const int h = ldi(head);
-                hpeek = h;
-                live = r + nsub * h < nq;
-                if (live) u.v = *reinterpret_cast<const int4*>(tq + r + nsub * h);
-            }
-            if (live) ready = tg_deps_met<QB == 0>(u.t, dd, sv, sq, nP);
-        }
-        if (__ballot(live) == 0) return 0;
-        // (two lists, one sub-queue each: a held urgent ticket that is not ready yet is about to be -- do not start a long
-        //  task of the lower list under it)
-        const bool hold_back = NQ > 1 && nsub == 1 && nap < 12 && __shfl((mine && !ready) ? 1 : 0, 0) != 0;
-        const unsigned long long mr = __ballot(ready && !(hold_back && lane > 0));
-        if (mr != 0) {
-            // list 1 before list 2; inside a list start from a different sub-queue every time
-            int pick;
-            {
-                const unsigned long long m1 = mr & ((1ull << nsub) - 1ull);
-                const unsigned long long mm = m1 ? m1 : (mr >> nsub);
-                const int base = m1 ? 0 : nsub;
-                const int st = held->turn % nsub;
-                const unsigned long long rot = ((mm >> st) | (mm << (nsub - st))) & ((1ull << nsub) - 1ull);
-                pick = (QB == 0) ? 0 : base + (__ffsll((long long)rot) - 1 + st) % nsub;
-            }
-            int got = 0;                            // 1: u.t is ours and ready
-            if (lane == pick) {
-                if (mine) {
-                    held->have[slot] = 0;
-                    got = 1;
-                } else {
-                    const int k = atomicAdd(head, 1);
-                    if (k == hpeek) {
-                        got = 1;                   // the very task that was peeked (and found ready): no second look
-                    } else if (r + nsub * k < nq) {
-                        u.v = *reinterpret_cast<const int4*>(tq + r + nsub * k);
-                        if (tg_deps_met<QB == 0>(u.t, dd, sv, sq, nP)) {
-                            got = 1;
-                        } else {
-                            held->t[slot] = u.t;
-                            held->have[slot] = 1;
-                        }
-                    }
+                u.t = held->t;
+                if (tg_deps_met<Q == 0>(u.t, dd, sv, sq, nP)) {
+                    held->have = 0;
+                    code = 1;
                 }
-                held->turn += 1;
             }
-            got = __shfl(got, pick);
-            if (got) {
-                u.v.x = __shfl(u.v.x, pick); u.v.y = __shfl(u.v.y, pick);
-                u.v.z = __shfl(u.v.z, pick); u.v.w = __shfl(u.v.w, pick);
-                out = u.t;
-                return 1;
-            }
-            nap = 0;
-            continue;                              // drew a ticket that has to wait (or the queue ran out): look again
         }
-        // pauses between two looks: 256 clocks at first, then a.nap x 64 (default 16: 0.4 us).  Until late in round 4 the long
+        code = __shfl(code, 0);
+        if (code == 2) return 0;
+        if (code == 1) {
+            u.v.x = __shfl(u.v.x, 0); u.v.y = __shfl(u.v.y, 0);
+            u.v.z = __shfl(u.v.z, 0); u.v.w = __shfl(u.v.w, 0);
+            out = u.t;
+            return 1;
+        }
+        // pauses between two looks: 256 clocks at first, then a.nap x 64 (default 16: 0.4 us; until late in round 4 the long
         // pause was 127 x 64 clocks = 3.4 us -- half of that, on average, between a dependency's arrival and the task's start:
-        // N = 2048 0.945 -> 0.876 ms, 4096 1.98 -> 1.83, 8192 5.30 -> 5.19, 16384 27.2 -> 26.9 (profiles/r04_chol_tg_polling_ab.txt)
-        if (QB == 0 || nap < 4) __builtin_amdgcn_s_sleep(4);
+        // N = 2048 0.945 -> 0.876 ms, 8192 5.30 -> 5.19; profiles/r04_chol_tg_polling_ab.txt)
+        if (Q == 0 || nap < 4) __builtin_amdgcn_s_sleep(4);
         else if (a.nap <= 8) __builtin_amdgcn_s_sleep(8);
         else if (a.nap <= 16) __builtin_amdgcn_s_sleep(16);
         else if (a.nap <= 32) __builtin_amdgcn_s_sleep(32);
@@ -239,81 +162,7 @@ __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, T
     }
 }
 
-// XCD-AFFINE tickets (option chol_tg_affine = G, off by default).  One FIFO hands consecutive tiles -- which share the row
-// panel R[k, I] -- to whichever workgroup arrives, on any of the eight XCDs, so every XCD's L2 sees every panel once: the
-// persistent kernel fetches 73 GB from HBM at N = 16384, 80 % of what its updates would read with no reuse at all
-// (profiles/r04_chol_taskgraph.txt).  Here the list is cut into RUNS of G consecutive tasks; run j belongs to XCD j % 8, which
-// has a head counter of its own and whose workgroups draw that XCD's runs strictly in order: tasks that share a panel run on
-// one XCD at about the same time.  An XCD whose runs are used up helps the next one.  Each of the eight queues is a
-// subsequence of the topological order and every queue always has workgroups drawing from it, so the earliest incomplete
-// task of the graph is held by a polling workgroup or at a head that is being peeked: no dead-lock (same argument as above).
-__device__ __forceinline__ int tg_affine_index(int h, int r, int G) { return ((h / G) * 8 + r) * G + (h % G); }
-
-__device__ __forceinline__ int tg_take_affine(const TgArgs& a, TgTask& out, int lane, TgHeld* held) {
-    const int nP = a.nP, npad = tg_npad(nP), G = a.affine, nq = a.n[1];
-    int* ctl = a.ctl;
-    const int* dd = ctl + TG_CTL_BASE;
-    const int* sv = dd + 2 * npad;
-    const int* sq = sv + 2 * npad;
-    const TgTask* tq = a.q[1];
-    const int xcc = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7);
-    const long long t0 = wall_clock64();
-    int nap = 0;
-    for (unsigned spins = 0;; ++spins) {
-        if (ldi(ctl + TG_CTL_ABORT) != 0) return -1;
-        int code = 0;                               // 1: task in u, 2: everything is exhausted
-        union { TgTask t; int4 v; } u;
-        u.v = make_int4(0, 0, 0, 0);
-        if (lane == 0) {
-            if (held->have[1]) {
-                u.t = held->t[1];
-                if (tg_deps_met<false>(u.t, dd, sv, sq, nP)) { held->have[1] = 0; code = 1; }
-            } else {
-                int off = held->turn, h = 0, r = 0;
-                int* head = nullptr;
-                for (; off < 8; ++off) {            // my XCD's queue, then (once it is used up) the following ones
-                    r = (xcc + off) & 7;
-                    head = ctl + a.sub_heads + 32 * r;
-                    h = ldi(head);
-                    if (tg_affine_index(h, r, G) < nq) break;
-                }
-                held->turn = off;
-                if (off >= 8) {
-                    code = 2;
-                } else {
-                    u.v = *reinterpret_cast<const int4*>(tq + tg_affine_index(h, r, G));
-                    if (tg_deps_met<false>(u.t, dd, sv, sq, nP)) {
-                        const int k = atomicAdd(head, 1);
-                        if (k == h) {
-                            code = 1;
-                        } else if (tg_affine_index(k, r, G) < nq) {
-                            u.v = *reinterpret_cast<const int4*>(tq + tg_affine_index(k, r, G));
-                            if (tg_deps_met<false>(u.t, dd, sv, sq, nP)) code = 1;
-                            else { held->t[1] = u.t; held->have[1] = 1; }
-                        }
-                    }
-                }
-            }
-        }
-        code = __shfl(code, 0);
-        if (code == 1) {
-            u.v.x = __shfl(u.v.x, 0); u.v.y = __shfl(u.v.y, 0); u.v.z = __shfl(u.v.z, 0); u.v.w = __shfl(u.v.w, 0);
-            out = u.t;
-            return 1;
-        }
-        if (code == 2) return 0;
-        if (nap < 4) __builtin_amdgcn_s_sleep(4);
-        else if (nap < 16) __builtin_amdgcn_s_sleep(32);
-        else __builtin_amdgcn_s_sleep(127);
-        ++nap;
-        if ((spins & 63) == 63 && wall_clock64() - t0 > a.tmo) {
-            if (lane == 0) sti(ctl + TG_CTL_ABORT, 2);
-            return -1;
-        }
-    }
-}
-
-constexpr int TG_LDS_F64 = GEMM_LDS_F64 + 96;       // + the task in hand (2), flags (2), held tickets (<= 33 x 20 bytes)
+constexpr int TG_LDS_F64 = GEMM_LDS_F64 + 8;        // + the task in hand (2), flags (2), the held ticket (20 bytes)
 // The workgroup's LDS: the tile engine's buffer (the diagonal kernel's panels fit inside) + a slot for the task in hand.
 // File scope, so that the role bodies below can be separate (non-inlined) functions with their own register allocation
 // and still address it with ds_* instructions: inlined into one kernel body the roles spilled 319 VGPRs.
@@ -392,9 +241,6 @@ __device__ __forceinline__ bool updq_body(const TgArgs& a, const double* __restr
 // row 4 kk + g, column n) is 64 consecutive doubles.  Same MFMAs in the same order as panel_solve16_body.
 __device__ __forceinline__ int tri_index(int r, int c) { return 8 * r - r * (r - 1) / 2 + c - r; }
 
-// NH = 2: BOTH 64-column halves of a tile by one workgroup (the fused solve + update task): the image of R_pp is staged
-// once, the second half's right-hand sides travel during the first substitution.
-template <int NH>
 __device__ __forceinline__ bool panel_solve16_lds(const TgArgs& a, const double* __restrict__ U, const double* __restrict__ S,
                                                   double* __restrict__ R, int64_t Np, int p, int cb, double* lds,
                                                   const int* diag) {
@@ -433,40 +279,26 @@ __device__ __forceinline__ bool panel_solve16_lds(const TgArgs& a, const double*
         for (int kk = 0; kk < 4; ++kk) ti[jb][kk] = ldg<true>(Ud + (int64_t)(16 * jb + 4 * kk + g) * Np + 16 * jb + n);
 #pragma unroll
     for (int q = 0; q < 18; ++q) *reinterpret_cast<u4v*>(lds + dst[q]) = stage[q];
-    d4 X2[8];
-    if (NH == 2) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) X2[r][q] = ldg<true>(S + (p0 + 16 * r + g + 4 * q) * Np + j0 + 64 + n);
-    }
     __syncthreads();
     // (2) the substitution
 #pragma unroll
-    for (int hh = 0; hh < NH; ++hh) {
-        if (hh == 1) {
+    for (int jb = 0; jb < 8; ++jb) {
+        d4 x = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int r = 0; r < 8; ++r) X[r] = X2[r];
+        for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(ti[jb][kk], X[jb][kk], x, 0, 0, 0);
+        X[jb] = x;
+        const d4 xn = -x;
+#pragma unroll
+        for (int i = jb + 1; i < 8; ++i) {
+            const double* tl = lds + 256 * tri_index(jb, i) + g * 16 + n;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) X[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(tl[kk * 64], xn[kk], X[i], 0, 0, 0);
         }
-#pragma unroll
-        for (int jb = 0; jb < 8; ++jb) {
-            d4 x = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(ti[jb][kk], X[jb][kk], x, 0, 0, 0);
-            X[jb] = x;
-            const d4 xn = -x;
-#pragma unroll
-            for (int i = jb + 1; i < 8; ++i) {
-                const double* tl = lds + 256 * tri_index(jb, i) + g * 16 + n;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) X[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(tl[kk * 64], xn[kk], X[i], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) stg<true>(R + (p0 + 16 * r + g + 4 * q) * Np + j0 + 64 * hh + n, X[r][q]);
     }
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) stg<true>(R + (p0 + 16 * r + g + 4 * q) * Np + j0 + n, X[r][q]);
     __syncthreads();                               // the LDS image is free again
     return true;
 }
@@ -535,18 +367,17 @@ __device__ __noinline__ void tg_role_diag(const TgArgs& a) {
     }
 }
 
-template <int PRIO>
 __device__ __noinline__ void tg_do_upd(const TgArgs& a, int k0, int k1, int I, int J) {
     // (arguments of a non-inlined function travel in VGPRs: tell the compiler they are wave-uniform)
     k0 = __builtin_amdgcn_readfirstlane(k0); k1 = __builtin_amdgcn_readfirstlane(k1);
     I = __builtin_amdgcn_readfirstlane(I); J = __builtin_amdgcn_readfirstlane(J);
-    syrk_tile<true, PRIO>(uni(a.R), uni(a.S), (int64_t)uni64((unsigned long long)a.Np), k0, k1, I, J, tg_smem);
+    syrk_tile<true, 2>(uni(a.R), uni(a.S), (int64_t)uni64((unsigned long long)a.Np), k0, k1, I, J, tg_smem);
 }
 __device__ __noinline__ bool tg_do_trsm(const TgArgs& a, int p, int cb) {
     p = __builtin_amdgcn_readfirstlane(p); cb = __builtin_amdgcn_readfirstlane(cb);
     __builtin_amdgcn_s_setprio(3);
     const int* diag = uni(a.ctl) + TG_CTL_BASE;
-    return panel_solve16_lds<1>(a, uni(a.U), uni(a.S), uni(a.R), (int64_t)uni64((unsigned long long)a.Np), p, cb, tg_smem, diag);
+    return panel_solve16_lds(a, uni(a.U), uni(a.S), uni(a.R), (int64_t)uni64((unsigned long long)a.Np), p, cb, tg_smem, diag);
 }
 __device__ __noinline__ bool tg_do_updq(const TgArgs& a, int k0, int k1, int I, int q) {
     k0 = __builtin_amdgcn_readfirstlane(k0); k1 = __builtin_amdgcn_readfirstlane(k1);
@@ -555,52 +386,9 @@ __device__ __noinline__ bool tg_do_updq(const TgArgs& a, int k0, int k1, int I, 
     const int* solved = uni(a.ctl) + TG_CTL_BASE + 2 * tg_npad(__builtin_amdgcn_readfirstlane(a.nP));
     return updq_body(a, uni(a.R), uni(a.S), (int64_t)uni64((unsigned long long)a.Np), k0, k1, I, q, solved);
 }
-// The FUSED task (type TG_TRSMU; option chol_tg_split + 1000000, OFF by default): the panel solve of the whole tile (p, J)
-// and, with its result, the final chunk [k0, p+1) of the tile below it, (p+1, J) -- the update the next block row's solve
-// waits for.  As separate tasks these are two dependent rounds through the queue per diagonal block (a solve, then a K = 1
-// update): under load each round costs its own wait for a free worker (10-55 us), take, publish and reload, and the two
-// rounds -- not the diagonal blocks -- set the pace of the first half of the factorisation (127 us per block against the
-// chain's 58; profiles/r04_chol_taskgraph.txt).  MEASURED: fusing them is slower at every size (N = 8192: 6.44 against
-// 5.44 ms, N = 2048: 1.22 against 0.90): one workgroup doing both halves of the solve and then the update is a longer
-// serial path (~65 us) than two workgroups solving in parallel followed by a third updating, and in the chain-bound second
-// half of the factorisation that path becomes the block period (86 against 58 us).  Kept for the measurement.
-// The solved flags are raised between the two parts (other tiles of block column J wait for them).
-__device__ __noinline__ bool tg_do_trsm_upd(const TgArgs& a, int p, int J, int k0, int k1, int ord2) {
-    p = __builtin_amdgcn_readfirstlane(p); J = __builtin_amdgcn_readfirstlane(J);
-    k0 = __builtin_amdgcn_readfirstlane(k0); k1 = __builtin_amdgcn_readfirstlane(k1);
-    ord2 = __builtin_amdgcn_readfirstlane(ord2);
-    const int nP = __builtin_amdgcn_readfirstlane(a.nP), npad = tg_npad(nP);
-    int* ctl = uni(a.ctl);
-    int* dd = ctl + TG_CTL_BASE;
-    int* sv = dd + 2 * npad;
-    int* sq = sv + 2 * npad;
-    double* R = uni(a.R);
-    double* S = uni(a.S);
-    const int64_t Np = (int64_t)uni64((unsigned long long)a.Np);
-    __builtin_amdgcn_s_setprio(3);
-    if (!panel_solve16_lds<2>(a, uni(a.U), S, R, Np, p, 2 * (J - p - 1), tg_smem, dd)) return false;
-    tg_drain();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        sti(sv + 2 * J, p + 1);
-        sti(sv + 2 * J + 1, p + 1);
-    }
-    // the tile below: its earlier chunks (another workgroup's, ticketed before this task) and the critical solve of (p, p+1)
-    if (!tg_wait_flags(a, sq + (p + 1) * nP + J, sq + (p + 1) * nP + J, ord2)) return false;
-    if (!tg_wait_flags(a, sv + 2 * (p + 1), sv + 2 * (p + 1) + 1, k1)) return false;
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
-    __builtin_amdgcn_s_setprio(0);
-    syrk_tile<true, 2>(R, S, Np, k0, k1, p + 1, J, tg_smem);
-    return true;
-}
-
-template <int QB, int NQ>
+template <int Q>
 __device__ __noinline__ int tg_take_call(const TgArgs& a, TgTask& out, int lane) {
-    return tg_take<QB, NQ>(a, out, lane, reinterpret_cast<TgHeld*>(tg_smem + GEMM_LDS_F64 + 4));
-}
-__device__ __noinline__ int tg_take_affine_call(const TgArgs& a, TgTask& out, int lane) {
-    return tg_take_affine(a, out, lane, reinterpret_cast<TgHeld*>(tg_smem + GEMM_LDS_F64 + 4));
+    return tg_take<Q>(a, out, lane, reinterpret_cast<TgHeld*>(tg_smem + GEMM_LDS_F64 + 4));
 }
 
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
@@ -619,9 +407,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
         // critical solves twice their time (profiles/r04_chol_taskgraph.txt).  The second workgroup to start on a CU
         // looks up what the first one became and leaves at once if that is a critical role (a grid of two workgroups
         // per CU has no third one waiting to take the slot).
-        TgHeld* hd = reinterpret_cast<TgHeld*>(tg_smem + GEMM_LDS_F64 + 4);
-        for (int i = 0; i < 1 + 2 * TG_SUB_MAX; ++i) hd->have[i] = 0;
-        hd->turn = 0;
+        reinterpret_cast<TgHeld*>(tg_smem + GEMM_LDS_F64 + 4)->have = 0;
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf;
         const int key = (int)((xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf));
         int* cu_cnt = sq + nP * nP;
@@ -637,7 +423,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
             if (a.isolate) atomicCAS(cu_role + key, 0, r + 1);
         }
         code[0] = r;
-        hd->turn = (r > 0 && a.affine == 0) ? r : 0;      // (workers start their rounds at different sub-queues; affine: the steal offset)
     }
     __syncthreads();
     const int role = code[0];
@@ -648,9 +433,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
         return;
     }
     const bool side = role <= a.nside;
-    // option chol_tg_upool: the first `upool` workers serve the urgent list ONLY (they are free when a burst of solves /
-    // final chunks arrives); meaningful with two lists (chol_tg_split < 200)
-    const bool upool = !side && (role - a.nside - 1) < a.upool;
     long long prof[6] = {0, 0, 0, 0, 0, 0};
     long long tprev = a.trace ? wall_clock64() : 0;
     for (;;) {
@@ -658,9 +440,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
             TgTask tk;
             tk.type = 0;
             __builtin_amdgcn_s_setprio(0);
-            const int c = side ? tg_take_call<0, 1>(a, tk, lane)
-                               : (a.affine > 0 ? tg_take_affine_call(a, tk, lane)
-                                               : (upool ? tg_take_call<1, 1>(a, tk, lane) : tg_take_call<1, 2>(a, tk, lane)));
+            const int c = side ? tg_take_call<0>(a, tk, lane) : tg_take_call<1>(a, tk, lane);
             if (lane == 0) {
                 *cur = tk;
                 code[0] = c;
@@ -674,12 +454,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
         long long ts = 0;
         if (a.trace && t == 0) { ts = wall_clock64(); prof[1] += ts - tprev; }
         if (tk.type == TG_UPD) {
-            if (tk.rsv) tg_do_upd<2>(a, tk.k0, tk.k1, tk.I, tk.J);
-            else tg_do_upd<1>(a, tk.k0, tk.k1, tk.I, tk.J);
+            tg_do_upd(a, tk.k0, tk.k1, tk.I, tk.J);
         } else if (tk.type == TG_TRSM) {
             if (!tg_do_trsm(a, tk.I, 2 * (tk.J - tk.I - 1) + tk.aux)) break;
-        } else if (tk.type == TG_TRSMU) {
-            if (!tg_do_trsm_upd(a, tk.I, tk.J, tk.k0, tk.k1, tk.aux)) break;
         } else {
             if (!tg_do_updq(a, tk.k0, tk.k1, tk.I, tk.aux)) break;
         }
@@ -697,10 +474,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
                 }
                 prof[0] += 1;
                 prof[tk.type == TG_UPD ? 2 : 3] += te - ts;
-                if (tk.type == TG_UPD || tk.type == TG_TRSMU) prof[5] += tk.k1 - tk.k0;
+                if (tk.type == TG_UPD) prof[5] += tk.k1 - tk.k0;
             }
             if (tk.type == TG_UPD) sti(sq + tk.I * nP + tk.J, tk.ord + 1);
-            else if (tk.type == TG_TRSMU) sti(sq + (tk.I + 1) * nP + tk.J, tk.aux + 1);      // (its solved flags went up mid-task)
             else if (tk.type == TG_TRSM) sti(sv + 2 * tk.J + tk.aux, tk.I + 1);
             else atomicAdd(qd + tk.I, 1);
             if (side && a.trace && (tk.type == TG_UPDQ || (tk.type == TG_TRSM && tk.J == tk.I + 1))) {
@@ -741,9 +517,14 @@ static std::vector<int> tg_boundaries(int I, const std::vector<int>& sizes) {
     return b;
 }
 
-struct TgTables { std::vector<TgTask> q[3]; };
+struct TgTables { std::vector<TgTask> q[2]; };
 
-static void tg_build(int nP, int chunk_code, int split, int band, bool fuse, int order, bool cone, TgTables& out) {
+// The two lists, in generation order = a topological order of the graph.  Per step p (the block row that POTRF(p) releases):
+// first ALL solves of block row p (the two halves of tile (p, p+1) on the critical list, the others on the workers'), then
+// the chunks that end at boundary p + 1, row by row, nearest the pivot first (the final chunk of the diagonal tile
+// (p+1, p+1) as six pieces on the critical list).  (Column-major inside the step -- every update right behind the last
+// solve it needs -- puts long far chunks in front of later solves: 7.8 against 5.5 ms at N = 8192, removed.)
+static void tg_build(int nP, int chunk_code, TgTables& out) {
     std::vector<int> sizes;
     {
         std::vector<int> dg;
@@ -758,75 +539,44 @@ static void tg_build(int nP, int chunk_code, int split, int band, bool fuse, int
         bnd[I] = tg_boundaries(I, sizes);
         for (size_t j = 1; j < bnd[I].size(); ++j) ends[bnd[I][j]].push_back(I);
     }
-    auto push = [&](int q, int type, int I, int J, int k0, int k1, int ord, int aux, int rsv) {
+    auto push = [&](int q, int type, int I, int J, int k0, int k1, int ord, int aux) {
         TgTask t;
         t.type = (int16_t)type; t.I = (int16_t)I; t.J = (int16_t)J; t.k0 = (int16_t)k0; t.k1 = (int16_t)k1;
-        t.ord = (int16_t)ord; t.aux = (int16_t)aux; t.rsv = (int16_t)rsv;
+        t.ord = (int16_t)ord; t.aux = (int16_t)aux; t.rsv = 0;
         out.q[q].push_back(t);
     };
-    for (int q = 0; q < 3; ++q) out.q[q].clear();
+    for (int q = 0; q < 2; ++q) out.q[q].clear();
     for (int p = 0; p < nP; ++p) {
         const int nch = (int)bnd[p].size() - 1;        // chunks of every tile of row p (0 for row 0)
-        // fused: the solve of tile (p, J), J >= p + 2, carries the final chunk of the tile below it (row p + 1)
-        const bool fz = fuse && p + 1 < nP;
-        const int nb1 = fz ? (int)bnd[p + 1].size() - 1 : 0;
-        // one update task of this step: the chunk of tile (I, J) that ends at boundary p + 1
-        auto push_upd = [&](int I, int J) {
+        for (int J = p + 1; J < nP; ++J)
+            for (int h = 0; h < 2; ++h) push(J == p + 1 ? 0 : 1, TG_TRSM, p, J, 0, 0, (p == 0) ? 0 : nch, h);
+        for (int I : ends[p + 1]) {                    // rows ascending: nearest the pivot first
+            if (I == 0) continue;
             size_t j = 1;
             while (bnd[I][j] != p + 1) ++j;
-            const int k0 = bnd[I][j - 1], k1 = p + 1, ord = (int)j - 1, d = I - k1;
-            // urgent: the chunks next to the pivot (of every tile) and every chunk of the tiles next to the diagonal
-            const int q = (d <= split || J - I <= band) ? 1 : 2;
-            if (d == 0 && J == I) {
-                for (int qu = 0; qu < TG_NPIECE; ++qu) push(0, TG_UPDQ, I, I, k0, k1, ord, qu, 0);
-            } else if (d == 0 && fuse && J >= I + 1) {
-                // (the final chunk of tile (I, J), J >= I + 1, rides on the solve of tile (I - 1, J))
-            } else if (cone && d == 0 && J == I + 1) {
-                // option (split + 100000000): the dependency cone of the NEXT critical solve -- the solve of tile (p, p+2) above and
-                // this final chunk of tile (p+1, p+2) -- runs on the side-kicks too
-                push(0, TG_UPD, I, J, k0, k1, ord, 0, 1);
-            } else {
-                push(q, TG_UPD, I, J, k0, k1, ord, 0, q == 1 ? 1 : 0);
-            }
-        };
-        auto push_trsm = [&](int J) {
-            if (fz && J >= p + 2)
-                push(1, TG_TRSMU, p, J, bnd[p + 1][nb1 - 1], p + 1, (p == 0) ? 0 : nch, nb1 - 1, 1);
-            else
-                for (int h = 0; h < 2; ++h)
-                    push((J == p + 1 || (cone && J == p + 2)) ? 0 : 1, TG_TRSM, p, J, 0, 0, (p == 0) ? 0 : nch, h, 0);
-        };
-        if (order == 1) {
-            // COLUMN-major inside the step: every update right behind the LAST solve it needs -- the solve of block column J
-            // is followed by the chunks of all tiles (I, J), I <= J, that end here (rows nearest the pivot first)
-            for (int J = p + 1; J < nP; ++J) {
-                push_trsm(J);
-                for (int I : ends[p + 1])
-                    if (I != 0 && I <= J) push_upd(I, J);
-            }
-        } else {
-            // ROW-major (default): all solves of block row p, then the chunks row by row
-            for (int J = p + 1; J < nP; ++J) push_trsm(J);
-            for (int I : ends[p + 1]) {                    // rows ascending: nearest the pivot first
-                if (I == 0) continue;
-                for (int J = I; J < nP; ++J) push_upd(I, J);
+            const int k0 = bnd[I][j - 1], k1 = p + 1, ord = (int)j - 1;
+            for (int J = I; J < nP; ++J) {
+                if (I == k1 && J == I) {
+                    for (int qu = 0; qu < TG_NPIECE; ++qu) push(0, TG_UPDQ, I, I, k0, k1, ord, qu);
+                } else {
+                    push(1, TG_UPD, I, J, k0, k1, ord, 0);
+                }
             }
         }
     }
 }
 
-// host-only view of the lists for the CPU tests (gpx_chol_tasks): 8 int16 per task, queues back to back
-int64_t tg_tasks_copy(int nP, int chunks, int split, int16_t* out, int64_t cap, int64_t* counts) {
+// host-only view of the lists for the CPU tests (gpx_chol_tasks): 8 int16 per task, the two lists back to back
+int64_t tg_tasks_copy(int nP, int chunks, int16_t* out, int64_t cap, int64_t* counts) {
     if (nP < 1 || nP > 2047) return -1;
     TgTables tb;
     if (chunks <= 0) chunks = TG_DEFAULT_CHUNKS;
-    if (split < 0) split = TG_DEFAULT_SPLIT;
-    tg_build(nP, chunks, split % 1000, (split / 1000) % 1000, (split / 1000000) % 10 == 1, (split / 10000000) % 10, (split / 100000000) % 10 == 1, tb);
+    tg_build(nP, chunks, tb);
     int64_t tot = 0;
-    for (int q = 0; q < 3; ++q) { counts[q] = (int64_t)tb.q[q].size(); tot += counts[q]; }
+    for (int q = 0; q < 2; ++q) { counts[q] = (int64_t)tb.q[q].size(); tot += counts[q]; }
     if (out && cap >= tot) {
         int64_t o = 0;
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < 2; ++q) {
             if (!tb.q[q].empty()) std::memcpy(out + 8 * o, tb.q[q].data(), tb.q[q].size() * sizeof(TgTask));
             o += counts[q];
         }
@@ -835,11 +585,11 @@ int64_t tg_tasks_copy(int nP, int chunks, int split, int16_t* out, int64_t cap, 
 }
 
 struct TgCache {                 // per handle (gpx_handle::tg): device copies of the tables and the control block
-    int nP = 0, chunks = 0, split = 0;
+    int nP = 0, chunks = 0;
     TgTask* dq = nullptr;
     int64_t cap_q = 0;
-    int n[3] = {0, 0, 0};
-    int64_t off[3] = {0, 0, 0};
+    int n[2] = {0, 0};
+    int64_t off[2] = {0, 0};
     int* dctl = nullptr;
     int64_t cap_ctl = 0;
     long long* dtrace = nullptr;
@@ -868,11 +618,10 @@ bool launch_cholesky_tg(gpx_handle* h) {
     TgCache* c = static_cast<TgCache*>(h->tg);
     hipStream_t s = h->stream;
     const int chunks = h->tg_chunks > 0 ? h->tg_chunks : TG_DEFAULT_CHUNKS;
-    const int split = h->tg_split >= 0 ? h->tg_split : TG_DEFAULT_SPLIT;
-    if (c->nP != nP || c->chunks != chunks || c->split != split || !c->dq) {
+    if (c->nP != nP || c->chunks != chunks || !c->dq) {
         TgTables tb;
-        tg_build(nP, chunks, split % 1000, (split / 1000) % 1000, (split / 1000000) % 10 == 1, (split / 10000000) % 10, (split / 100000000) % 10 == 1, tb);
-        const int64_t tot = (int64_t)tb.q[0].size() + (int64_t)tb.q[1].size() + (int64_t)tb.q[2].size() + 3;
+        tg_build(nP, chunks, tb);
+        const int64_t tot = (int64_t)tb.q[0].size() + (int64_t)tb.q[1].size() + 2;
         if (tot > c->cap_q) {
             if (c->dq) (void)hipFree(c->dq);
             c->dq = nullptr; c->cap_q = 0;
@@ -881,7 +630,7 @@ bool launch_cholesky_tg(gpx_handle* h) {
         }
         int64_t o = 0;
         (void)hipStreamSynchronize(s);                 // (an earlier launch may still be reading the old tables)
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < 2; ++q) {
             c->off[q] = o;
             c->n[q] = (int)tb.q[q].size();
             if (c->n[q] > 0 &&
@@ -892,7 +641,7 @@ bool launch_cholesky_tg(gpx_handle* h) {
             }
             o += c->n[q] + 1;
         }
-        c->nP = nP; c->chunks = chunks; c->split = split;
+        c->nP = nP; c->chunks = chunks;
     }
     const int64_t nctl = tg_ctl_ints(nP);
     if (nctl > c->cap_ctl) {
@@ -937,15 +686,10 @@ bool launch_cholesky_tg(gpx_handle* h) {
     std::memset(&a, 0, sizeof a);
     a.S = h->dS; a.R = h->dR; a.T = h->dT; a.U = h->dU;
     a.Np = Np; a.nP = nP; a.dflag = h->dflag; a.ctl = c->dctl;
-    for (int q = 0; q < 3; ++q) { a.q[q] = c->dq + c->off[q]; a.n[q] = c->n[q]; }
+    for (int q = 0; q < 2; ++q) { a.q[q] = c->dq + c->off[q]; a.n[q] = c->n[q]; }
     a.nside = nside;
     a.isolate = (h->tg_isolate != 0 && grid_is_full) ? 1 : 0;
-    a.nsub = std::max(1, std::min(h->tg_queues > 0 ? h->tg_queues : 1, TG_SUB_MAX));
-    a.sub_heads = tg_sub_heads(nP);
-    a.upool = std::max(0, h->tg_upool);
     a.nap = h->tg_nap > 0 ? h->tg_nap : 16;
-    a.nopeek = (h->tg_peek == 0 && a.nsub == 1 && c->n[2] == 0) ? 1 : 0;      // (one list, one sub-queue)
-    a.affine = (c->n[2] == 0) ? std::max(0, std::min(h->tg_affine, 1024)) : 0;      // (one worker list only)
     a.trace = h->tg_trace ? c->dtrace : nullptr;
     a.tasklog = nlog ? c->dtrace + 20 * (int64_t)nP + 8 * 1024 + 16 : nullptr;
     a.tmo = (long long)(h->tg_tmo_ms > 0 ? h->tg_tmo_ms : 2000) * 100000LL;

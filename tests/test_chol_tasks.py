@@ -1,6 +1,6 @@
 """CPU tests of the task-graph factorisation's task lists (pybo_amd/csrc/kernels_chol_tg.hip, host part; exported as
-gpx_chol_tasks): replayed under the device's own protocol -- a queue head is taken only when its dependencies are met,
-tasks complete in any order -- the lists must (1) never dead-lock, (2) apply every block row to every tile exactly once and
+gpx_chol_tasks): replayed under the device's own protocol -- tickets drawn in list order, a task starts when its
+dependencies are met, tasks complete in any order -- the lists must (1) never dead-lock, (2) apply every block row to every tile exactly once and
 in ascending order (what makes the factor bit-identical to the stream schedule's), (3) BE a Cholesky factorisation when the
 tasks are executed with numpy on a small block size.  Serves `model.add_data` (pybo/bayesopt.py:114,258,269)."""
 import numpy as np
@@ -8,7 +8,7 @@ import pytest
 
 from pybo_amd import _lib
 
-TRSM, UPD, UPDQ, TRSMU = 1, 2, 3, 4
+TRSM, UPD, UPDQ = 1, 2, 3
 
 
 class Replay(object):
@@ -16,7 +16,7 @@ class Replay(object):
 
     def __init__(self, nP, queues, nb=0, seed=0):
         self.nP, self.q = nP, queues
-        self.head = [0, 0, 0]
+        self.head = [0, 0]
         self.seq = np.zeros((nP, nP), dtype=int)        # chunks applied per tile
         self.applied = np.zeros((nP, nP), dtype=int)    # block rows applied per tile
         self.solved = np.zeros((nP, 2), dtype=int)
@@ -36,17 +36,7 @@ class Replay(object):
         typ, I, J, k0, k1, ordn = (int(v) for v in t[:6])
         if typ == TRSM:
             return bool(self.diag[I]) and self.seq[I, J] == ordn
-        if typ == TRSMU:         # ... and the earlier chunks of the tile below (taken only then: see tg_deps_met)
-            return bool(self.diag[I]) and self.seq[I, J] == ordn and self.seq[I + 1, J] == int(t[6])
         return self.seq[I, J] == ordn and min(self.solved[I].min(), self.solved[J].min()) >= k1
-
-    def can_finish(self, t):
-        """The fused solve + update task waits INSIDE the task for its second part's dependencies: the earlier chunks of
-        the tile below and the critical solve of (p, p+1)."""
-        typ, I, J, k0, k1, ordn, aux = (int(v) for v in t[:7])
-        if typ != TRSMU:
-            return True
-        return self.seq[I + 1, J] == aux and self.solved[I + 1].min() >= k1
 
     def blk(self, M, I, J):
         nb = self.nb
@@ -61,14 +51,6 @@ class Replay(object):
                 Rpp = self.blk(self.R, I, I)
                 cols = slice(J * nb + aux * h, J * nb + (aux + 1) * h)
                 self.R[I * nb:(I + 1) * nb, cols] = np.linalg.solve(Rpp.T, self.S[I * nb:(I + 1) * nb, cols])
-        elif typ == TRSMU:
-            # first part: the solve of the whole tile (I, J); its flags go up before the second part starts
-            assert self.applied[I, J] == I, 'panel solve of an incomplete tile'
-            if nb:
-                Rpp = self.blk(self.R, I, I)
-                self.blk(self.R, I, J)[...] = np.linalg.solve(Rpp.T, self.blk(self.S, I, J))
-            assert (self.solved[J] == I).all()
-            self.solved[J] = I + 1
         else:
             if typ == UPD:
                 assert self.applied[I, J] == k0, 'chunks out of order: tile (%d, %d) has %d, task starts at %d' % (I, J, self.applied[I, J], k0)
@@ -93,16 +75,6 @@ class Replay(object):
         if typ == TRSM:
             assert self.solved[J, aux] == I
             self.solved[J, aux] = I + 1
-        elif typ == TRSMU:
-            # second part: the final chunk [k0, k1) of the tile below
-            assert self.can_finish(t) and self.applied[I + 1, J] == k0 and k1 == I + 1
-            if self.nb:
-                nb = self.nb
-                A = self.R[k0 * nb:k1 * nb, (I + 1) * nb:(I + 2) * nb]
-                B = self.R[k0 * nb:k1 * nb, J * nb:(J + 1) * nb]
-                self.blk(self.S, I + 1, J)[...] -= A.T @ B
-            self.applied[I + 1, J] = k1
-            self.seq[I + 1, J] = aux + 1
         elif typ == UPD:
             self.applied[I, J] = k1
             self.seq[I, J] = ordn + 1
@@ -127,10 +99,9 @@ class Replay(object):
             steps += 1
             assert steps < 50 * total + 1000, 'no progress: dead-lock in the task lists'
             moves = []
-            # (the critical queue has its own workgroups on the device: its tasks do not compete for the workers' slots --
-            #  the fused solve + update task waits INSIDE a worker for a critical solve)
+            # (the critical list has its own workgroups on the device: its tasks do not compete for the workers' slots)
             nwork = sum(1 for kind, t in inflight if kind == 'task' and not t[-1])
-            for qi in range(3):
+            for qi in range(2):
                 if (qi == 0 or nwork < max_inflight) and self.head[qi] < len(self.q[qi]) and self.ready(self.q[qi][self.head[qi]]):
                     moves.append(('take', qi))
             if True:
@@ -138,8 +109,7 @@ class Replay(object):
                 if p < self.nP and not any(t[0] == 'potrf' for t in inflight) and (p == 0 or self.quad[p] == 6):
                     moves.append(('potrf', p))
             for i in range(len(inflight)):
-                if inflight[i][0] == 'potrf' or self.can_finish(inflight[i][1]):
-                    moves.append(('finish', i))
+                moves.append(('finish', i))
             assert moves, 'dead-lock: nothing ready, nothing in flight (heads %s, next diagonal block %d)' % (self.head, self.next_potrf)
             m = moves[self.rng.randint(len(moves))]
             if m[0] == 'take':
@@ -164,25 +134,20 @@ class Replay(object):
         assert self.diag.all() and (self.solved[1:] == np.arange(1, self.nP)[:, None]).all()
 
 
-def run_ticketed(r, nworkers=5, nside=2, greedy=0.5, peek=True):
-    """The device's second protocol (kernels_chol_tg.hip: tg_take): a workgroup PEEKS a queue head; if that task is ready it
-    draws a ticket with fetch-and-add -- and may get a LATER task than the one it peeked (others drew meanwhile), possibly
-    one that is not ready: then it HOLDS it (one per queue) and keeps serving its queues.  Side-kicks (critical queue) take
-    their task on the tile's earlier chunks alone and wait for the rest inside the task.  peek=False (the device's default since
-    late in round 4, option chol_tg_peek = 0): a workgroup without a ticket draws one AT ONCE, ready or not, and waits with it
-    in hand.  Returns when everything is done; asserts that some workgroup can always move."""
+def run_ticketed(r, nworkers=5, nside=2):
+    """The device's protocol (kernels_chol_tg.hip: tg_take): a workgroup without a ticket draws the next one of its list AT
+    ONCE (fetch-and-add), ready or not, and waits with it in hand; side-kicks (critical list) START their task on the tile's
+    earlier chunks alone and wait for the last dependency inside the task.  Returns when everything is done; asserts that
+    some workgroup can always move."""
     rng = r.rng
     total = sum(len(q) for q in r.q) + r.nP
     done = 0
-    # workgroup state: queues it serves, held ticket per queue, task in flight
-    wgs = [{'queues': [0], 'held': {}, 'busy': None} for _ in range(nside)] + \
-          [{'queues': [1, 2], 'held': {}, 'busy': None} for _ in range(nworkers)]
+    wgs = [{'queue': 0, 'held': None, 'busy': None, 'started': False} for _ in range(nside)] + \
+          [{'queue': 1, 'held': None, 'busy': None, 'started': False} for _ in range(nworkers)]
     potrf_busy = None
     steps = 0
 
-    def pre_ready(t):            # critical queue: the tile's earlier chunks only (a plain update has no wait in its body)
-        if int(t[0]) == UPD:
-            return r.ready(t)
+    def pre_ready(t):            # critical list: the tile's earlier chunks only
         return r.seq[int(t[1]), int(t[2])] == int(t[5])
 
     while done < total:
@@ -190,22 +155,18 @@ def run_ticketed(r, nworkers=5, nside=2, greedy=0.5, peek=True):
         assert steps < 200 * total + 2000, 'no progress'
         moves = []
         for wi, wg in enumerate(wgs):
+            qi = wg['queue']
             if wg['busy'] is not None:
-                t = wg['busy']
-                if wg.get('started'):
-                    if r.can_finish(t):              # (the fused task's second part waits inside the task)
-                        moves.append(('finish', wi))
-                elif r.ready(t):                     # (a side-kick's task in hand may still wait for its last dependency)
+                if wg['started']:
+                    moves.append(('finish', wi))
+                elif r.ready(wg['busy']):            # (a side-kick's task in hand may still wait for its last dependency)
                     moves.append(('start', wi))
                 continue
-            for qi in wg['queues']:
-                chk = pre_ready if qi == 0 else r.ready
-                if qi in wg['held']:
-                    if chk(wg['held'][qi]):
-                        moves.append(('run_held', wi, qi))
-                elif r.head[qi] < len(r.q[qi]):
-                    if not peek or chk(r.q[qi][r.head[qi]]) or rng.rand() < greedy * 0.05:      # (a stale peek: draws although not ready)
-                        moves.append(('draw', wi, qi))
+            if wg['held'] is not None:
+                if (pre_ready if qi == 0 else r.ready)(wg['held']):
+                    moves.append(('run_held', wi))
+            elif r.head[qi] < len(r.q[qi]):
+                moves.append(('draw', wi))
         p = r.next_potrf
         if potrf_busy is None and p < r.nP and (p == 0 or r.quad[p] == 6):
             moves.append(('potrf', p))
@@ -214,17 +175,13 @@ def run_ticketed(r, nworkers=5, nside=2, greedy=0.5, peek=True):
         assert moves, 'dead-lock: heads %s, next diagonal block %d, held %s' % (r.head, r.next_potrf, [w['held'] for w in wgs])
         m = moves[rng.randint(len(moves))]
         if m[0] == 'draw':
-            wg, qi = wgs[m[1]], m[2]
-            t = r.q[qi][r.head[qi]]
+            wg = wgs[m[1]]
+            qi = wg['queue']
+            wg['held'] = r.q[qi][r.head[qi]]
             r.head[qi] += 1
-            chk = pre_ready if qi == 0 else r.ready
-            if chk(t):
-                wg['busy'] = t
-            else:
-                wg['held'][qi] = t
         elif m[0] == 'run_held':
-            wg, qi = wgs[m[1]], m[2]
-            wg['busy'] = wg['held'].pop(qi)
+            wg = wgs[m[1]]
+            wg['busy'], wg['held'] = wg['held'], None
         elif m[0] == 'start':
             wg = wgs[m[1]]
             r.run_task(wg['busy'])
@@ -249,36 +206,32 @@ def run_ticketed(r, nworkers=5, nside=2, greedy=0.5, peek=True):
     assert r.diag.all()
 
 
-@pytest.mark.parametrize('nP,chunks,split,nworkers,nside', [(9, 0, -1, 5, 2), (9, 1124, 0, 3, 1), (14, 1248, 2002, 7, 8),
-                                                           (6, 11, 0, 1, 1), (20, 0, -1, 40, 8), (12, 12489, 100000200, 9, 3), (17, 0, 100000200, 30, 12)])
-def test_ticketed_protocol_with_held_tickets_never_deadlocks(nP, chunks, split, nworkers, nside):
-    q = _lib.chol_tasks(nP, chunks, split)
+@pytest.mark.parametrize('nP,chunks,nworkers,nside', [(9, 0, 5, 2), (9, 1124, 3, 1), (14, 1248, 7, 8), (6, 11, 1, 1),
+                                                      (20, 0, 40, 8), (12, 12489, 9, 3), (17, 0, 30, 12)])
+def test_ticketed_protocol_with_held_tickets_never_deadlocks(nP, chunks, nworkers, nside):
+    q = _lib.chol_tasks(nP, chunks)
     for seed in range(4):
         r = Replay(nP, q, nb=4 if seed == 0 else 0, seed=seed)
-        run_ticketed(r, nworkers=nworkers, nside=nside, peek=(seed % 2 == 0))      # odd seeds: tickets drawn without a peek
+        run_ticketed(r, nworkers=nworkers, nside=nside)
         if r.nb:
             R = np.triu(r.R)
             np.testing.assert_allclose(R.T @ R, r.K, rtol=1e-12, atol=1e-10)
 
 
 @pytest.mark.parametrize('nP', [1, 2, 3, 5, 8, 17, 40])
-@pytest.mark.parametrize('chunks,split', [(0, -1), (1124, 2), (14, 0), (1128, 0), (11, 0), (1224, 4), (1248, 1000200), (14, 1002002), (12489, 200), (1248, 10000200), (149, 0), (12489, 100000200), (1124, 100000002)])
-def test_lists_complete_in_order_without_deadlock(nP, chunks, split):
-    q = _lib.chol_tasks(nP, chunks, split)
-    n_upd_tiles = nP * (nP + 1) // 2
-    cone = (split // 100000000) % 10 == 1
-    assert len(q[0]) == 8 * (nP - 1) + (3 * (nP - 2) if cone and nP > 2 else 0)
+@pytest.mark.parametrize('chunks', [0, 1124, 14, 1128, 11, 1224, 1248, 12489, 149])
+def test_lists_complete_in_order_without_deadlock(nP, chunks):
+    q = _lib.chol_tasks(nP, chunks)
+    assert len(q) == 2 and len(q[0]) == 8 * (nP - 1)                            # two half solves + six pieces per block
     ntr = sum(int((a[:, 0] == TRSM).sum()) for a in q)
-    nfu = sum(int((a[:, 0] == TRSMU).sum()) for a in q)
-    assert ntr + 2 * nfu == nP * (nP - 1)                                       # two halves per off-diagonal tile
+    assert ntr == nP * (nP - 1)                                                 # two halves per off-diagonal tile
     for seed in range(3):
         Replay(nP, q, seed=seed).run(max_inflight=1 + 3 * seed)
-    assert n_upd_tiles >= 1
 
 
-@pytest.mark.parametrize('nP,chunks,split', [(2, 0, -1), (7, 0, -1), (12, 1124, 0), (12, 13, 2), (9, 1128, 8)])
-def test_lists_are_a_cholesky_factorisation(nP, chunks, split):
-    q = _lib.chol_tasks(nP, chunks, split)
+@pytest.mark.parametrize('nP,chunks', [(2, 0), (7, 0), (12, 1124), (12, 13), (9, 1128)])
+def test_lists_are_a_cholesky_factorisation(nP, chunks):
+    q = _lib.chol_tasks(nP, chunks)
     r = Replay(nP, q, nb=4, seed=nP)
     r.run(max_inflight=5)
     R = np.triu(r.R)
@@ -287,30 +240,23 @@ def test_lists_are_a_cholesky_factorisation(nP, chunks, split):
 
 
 def test_chunks_are_graded_towards_the_pivot():
-    """Default lists: every tile's last chunk is one block (the update the next diagonal block waits for is short), chunks
-    never grow towards the pivot, and the far queue holds the long ones."""
+    """Default lists: every tile's last chunk is one block (the update the next diagonal block waits for is short) and
+    chunks never grow towards the pivot; within a step the solves come first, then the rows nearest the pivot."""
     nP = 24
     q = _lib.chol_tasks(nP)
-    upd = np.vstack([a[a[:, 0] == UPD] for a in q[1:]])
-    assert not any(np.any(a[:, 0] == TRSMU) for a in q)      # (solve + update fused into one task: an option, off by default)
+    upd = q[1][q[1][:, 0] == UPD]
     for I in range(3, nP - 1):
         mine = upd[(upd[:, 1] == I) & (upd[:, 2] == nP - 1)]
         sizes = (mine[:, 4] - mine[:, 3])[np.argsort(mine[:, 3])]
         assert sizes[-1] == 1 and sizes.sum() == I
         assert np.all(np.diff(sizes[1:]) <= 0)              # (the first chunk absorbs a short remainder)
-    assert len(q[2]) == 0                                    # default: ONE worker queue in generation order
-    q2 = _lib.chol_tasks(nP, 1124, 0)                        # two queues: the final chunks (and the solves) first
-    assert np.all(q2[1][q2[1][:, 0] == UPD][:, 7] == 1) and np.all(q2[2][:, 7] == 0)
-    far_sizes = q2[2][:, 4] - q2[2][:, 3]
-    assert far_sizes.max() <= 5 and far_sizes.min() >= 1
-    off = q2[1][(q2[1][:, 0] == UPD) & (q2[1][:, 2] > q2[1][:, 1])]      # (every chunk of a DIAGONAL tile is urgent)
-    assert np.all(off[:, 1] == off[:, 4])                                # off the diagonal: final chunks only
-    q3 = _lib.chol_tasks(nP, 1124, 1000000)                              # fusion on: the final chunks ride on the solves
-    f3 = q3[1][q3[1][:, 0] == TRSMU]
-    assert len(f3) == (nP - 1) * (nP - 2) // 2 and np.all(f3[:, 4] - f3[:, 3] <= 2)
-    assert len(q3[1][(q3[1][:, 0] == UPD) & (q3[1][:, 2] > q3[1][:, 1])]) == 0
+    # generation order inside step p = 3: every solve of block row 3 precedes every chunk that ends at boundary 4
+    w = q[1]
+    first_upd = min(i for i in range(len(w)) if w[i, 0] == UPD and w[i, 4] == 4)
+    last_trsm = max(i for i in range(len(w)) if w[i, 0] == TRSM and w[i, 1] == 3)
+    assert last_trsm < first_upd
 
 
 def test_bad_arguments():
-    assert _lib.load().gpx_chol_tasks(0, 0, -1, None, 0, _lib._ptr(np.zeros(3, dtype=np.int64))) == -1
-    assert _lib.load().gpx_chol_tasks(4, 0, -1, None, 0, None) == -1
+    assert _lib.load().gpx_chol_tasks(0, 0, None, 0, _lib._ptr(np.zeros(2, dtype=np.int64))) == -1
+    assert _lib.load().gpx_chol_tasks(4, 0, None, 0, None) == -1
