@@ -304,6 +304,159 @@ def parity_record(w, ref_vals, dev_vals):
     return out
 
 
+def ensemble_hypers(w, n):
+    """n hyper-parameter vectors around the workload's own (what an MCMC chain over (sn2, rho, ell, bias) holds): member 0 is
+    the workload's point estimate.  Shared by bench.py --ensemble and tests/test_gpu_ensemble_grid.py."""
+    rng = np.random.RandomState(77)
+    out = [(w['sn2'], w['rho'], np.array(w['ell'], dtype=float), w['bias'])]
+    for _ in range(n - 1):
+        out.append((w['sn2'] * np.exp(0.5 * rng.randn()), w['rho'] * np.exp(0.2 * rng.randn()),
+                    w['ell'] * np.exp(0.15 * rng.randn(w['d'])), w['bias'] + 0.1 * np.sqrt(w['rho']) * rng.randn()))
+    return out
+
+
+def ensemble_bench(args):
+    """`--ensemble n`: the step with the reference's DEFAULT model, MCMC(gp, n=10) (pybo/bayesopt.py:115): n member GPs
+    (one hyper-parameter vector each) are fitted and the acquisition is averaged over them on the whole grid by ONE
+    gpx_ensemble_sweep_dev call; top-k of the average.  Candidates sharded contiguously over the ranks like the headline
+    step (every rank fits all n members; the one exchange is the top-k all-gather): with n = 10 members on 8 ranks a split
+    by members would leave six ranks with half the work of the other two."""
+    import torch
+    from pybo_amd._lib import Engine, DeviceGrid
+    from pybo_amd import dist as pdist
+    rank, world = int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.share_device >= 0:
+        local = args.share_device
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(args.backend, **({'device_id': dev} if args.backend == 'nccl' else {}))
+    n = args.ensemble
+    w = make_workload(args.workload, args.candidates)
+    if w['acq'] not in ('ei', 'ucb'):
+        raise SystemExit('--ensemble needs an EI / UCB workload')
+    N, d, M, k = w['N'], w['d'], w['M'], args.topk
+    lo_i, hi_i = (M * rank) // world, (M * (rank + 1)) // world
+    Ml = hi_i - lo_i
+    dX = torch.from_numpy(w['X']).to(dev)
+    dy = torch.from_numpy(w['y']).to(dev)
+    grid = DeviceGrid('sobol', np.stack([w['lo'], w['hi']], axis=1), Ml, first=lo_i, device=local)   # = w['Xc'][lo_i:hi_i], in HBM
+    hyp = ensemble_hypers(w, n)
+    engines = [Engine(local) for _ in range(n)]
+    target = float(np.max(w['y'])) if w['acq'] == 'ei' else ucb_beta(N)
+
+    def step():
+        for e, (sn2, rho, ell, bias) in zip(engines, hyp):
+            e.fit_dev(dX.data_ptr(), N, d, dy.data_ptr(), w['kernel'], ell, rho, sn2, bias)
+        r = Engine.ensemble_sweep(engines, w['acq'], target, grid, k=k)
+        tv, ti = r['top_val'], np.where(r['top_idx'] >= 0, r['top_idx'] + lo_i, r['top_idx'])
+        if world > 1:
+            return pdist.gather_topk(tv, ti, k)
+        return tv, ti
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+    for _ in range(args.warmup):
+        best = step()
+    for e in engines:
+        e.timers(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        best = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+    tms = [e.timers(reset=True) for e in engines]
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank != 0:
+            return
+    sec = elapsed / args.steps
+    tot = {kk: sum(t[kk] for t in tms) for kk in ('gram', 'cholesky', 'trtri', 'alpha', 'cross_gram', 'sweep_trmm', 'acq_topk',
+                                                  'sweep_trmm_launches', 'sweep_trmm_flop')}
+    ach = tot['sweep_trmm_flop'] / (tot['sweep_trmm'] * 1e-3) / 1e12
+    sclk = [t['sweep_sclk_mhz'] for t in tms if t.get('sweep_sclk_mhz')]
+    sclk = float(np.mean(sclk)) if sclk else None
+    out = {'metric': 'BO-step wall-clock with the default model (ensemble of %d GPs: %d fits + acquisition averaged over the members '
+                     'on the candidate grid) at N obs; steps/sec' % (n, n),
+           'value': 1.0 / sec, 'unit': 'steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+           'ms_per_step': sec * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64',
+           'data': 'synthetic',
+           'config': {'workload': w['desc'] + '; model = ensemble of %d hyper-parameter vectors (pybo/bayesopt.py:115)' % n, 'N': N,
+                      'd': d, 'candidates': M, 'kernel': w['kernel'], 'acquisition': w['acq'], 'members': n, 'topk': k,
+                      'parallelism': 'candidates sharded contiguously over %d rank(s), every rank fits all members' % world},
+           'selected': {'index': int(best[1][0]), 'value': float(best[0][0])},
+           'stage_ms_per_step_rank0_all_members': {kk: tot[kk] / args.steps for kk in ('gram', 'cholesky', 'trtri', 'alpha', 'cross_gram',
+                                                                                   'sweep_trmm', 'acq_topk')},
+           'roofline': {'kernel': 'k_sweep_trmm', 'bound': 'mfma', 'achieved': ach, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': ach / FP64_MFMA_PEAK_TFLOPS, 'traffic': None, 'launches': int(tot['sweep_trmm_launches']),
+                        'avg_launch_ms': tot['sweep_trmm'] / max(tot['sweep_trmm_launches'], 1),
+                        'flop_per_launch': tot['sweep_trmm_flop'] / max(tot['sweep_trmm_launches'], 1),
+                        'work': 'members x N^2 flop per candidate (algorithmic)', 'sclk_mhz': sclk,
+                        'frac_at_measured_clock': ach / (FP64_MFMA_PEAK_TFLOPS * sclk / 2400.0) if sclk else None}}
+    if not args.no_cpu_baseline:
+        # the oracle's ensemble on a bounded sample: ALL n member fits in full + the members' EI / UCB on nc candidates
+        from oracle import gp_ref
+        nc = min(args.cpu_candidates or max(4096, (1 << 17) // n), Ml)
+        threads = len(os.sched_getaffinity(0))
+        idx = np.concatenate(sample_indices(nc, Ml))
+        Z = w['Xc'][lo_i + idx]
+        t_fit = t_sw = 0.0
+        acc = np.zeros(len(idx))
+        mus, s2s = [], []
+        for sn2, rho, ell, bias in hyp:
+            t0 = time.perf_counter()
+            ref = gp_ref.make_gp(sn2, rho, ell, bias, w['kernel'])
+            ref.add_data(w['X'], w['y'])
+            t_fit += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            mu, s2 = ref.predict(Z)
+            if w['acq'] == 'ei':
+                s_ = np.sqrt(s2)
+                z_ = (mu - target) / s_
+                acc += (mu - target) * gp_ref.norm_cdf(z_) + s_ * gp_ref.norm_pdf(z_)
+            else:
+                mus.append(mu)
+                s2s.append(s2)
+            t_sw += time.perf_counter() - t0
+        if w['acq'] == 'ei':
+            want = acc / n
+        else:
+            mm = np.mean(mus, axis=0)
+            want = mm + np.sqrt(target * np.maximum(np.mean(np.array(s2s) + np.array(mus) ** 2, axis=0) - mm ** 2, 0.0))
+        step_cpu = t_fit + t_sw * (M / float(len(idx)))
+        out['cpu_baseline'] = {'value': 1.0 / step_cpu, 'unit': 'steps/s', 'cores': int(threads), 'kind': 'port',
+                               'sample': '%d member fits in full (N=%d: %.1f s) + the members\' sweeps on %d of %d candidates '
+                                         '(%.1f s), extrapolated linearly; numpy/scipy' % (n, N, t_fit, len(idx), M, t_sw),
+                               'sample_frac': len(idx) / float(M), 'extrapolated': True, 'seconds_per_step': step_cpu}
+        # parity on the same candidates (outside the timed region)
+        dsel = torch.from_numpy(np.ascontiguousarray(Z)).to(dev)
+        buf = torch.empty(len(idx), dtype=torch.float64, device=dev)
+        import ctypes as C
+        lead = engines[0]
+        handles = (C.c_void_p * n)(*[e._h for e in engines])
+        prm = np.array([target])
+        lead._check(lead._lib.gpx_ensemble_sweep_dev(handles, n, {'ei': 0, 'pi': 1, 'ucb': 2}[w['acq']], prm.ctypes.data_as(C.c_void_p), 1,
+                                                     dsel.data_ptr(), len(idx), 0, None, None, buf.data_ptr(), None, None))
+        got = buf.cpu().numpy()
+        live = np.abs(want) > 1e-9 * np.max(np.abs(want))
+        out['parity'] = {'n_compared': int(len(idx)), 'against': 'oracle/gp_ref.py: %d member models on the cpu_baseline sample' % n,
+                         'max_rel_acq': float(np.max(np.abs(got[live] - want[live]) / np.abs(want[live]))),
+                         'n_acq_compared': int(live.sum()),
+                         'selected_index_matches': bool(int(np.argmax(got)) == int(np.argmax(want)))}
+    print(json.dumps(out))
+
+
 def plugin_step(w, nsteps, k):
     """One BO iteration THROUGH THE PLUGIN API at the workload size, end to end: `pybo_amd.solve_bayesopt` resumed
     from a checkpoint that holds the N observations (model + trace, the reference's own resume path,
@@ -500,6 +653,9 @@ def main():
     ap.add_argument('--plugin-steps', type=int, default=12,
                     help='also time this many iterations of pybo_amd.solve_bayesopt THROUGH THE PLUGIN API at the '
                          'workload size (cold + warm; reported separately as plugin_step); 0 = skip')
+    ap.add_argument('--ensemble', type=int, default=0,
+                    help='n > 0: time the step with the reference\'s DEFAULT model instead -- an ensemble of n GPs (pybo/bayesopt.py:115: '
+                         'MCMC(gp, n=10)): n fits + ONE gpx_ensemble_sweep over the grid; own roofline (n x N^2 x M flop) and cpu_baseline')
     ap.add_argument('--cpu-baseline-worker', default='', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-span', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-draws', default='', help=argparse.SUPPRESS)
@@ -525,6 +681,8 @@ def main():
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         # invoked as `python bench.py --gpus N`: start the N ranks ourselves
         raise SystemExit(self_launch(args.gpus))
+    if args.ensemble > 0:
+        return ensemble_bench(args)
 
     import torch
     rank = int(os.environ.get('RANK', '0'))

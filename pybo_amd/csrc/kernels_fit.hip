@@ -1050,6 +1050,103 @@ __global__ __launch_bounds__(256) void k_loglik_fwd(const double* __restrict__ R
     if (t == 0) out[z] = -0.5 * red[0] - red[1] - 0.5 * (double)N * 1.83787706640934548356;
 }
 
+// ---- the same forward substitution for LARGE factors (round 5): k_loglik_fwd walks the whole factor with ONE workgroup per
+// vector -- 28 ms at N = 8192 (268 MB through one CU), against 5 ms for the factorisation itself.  Right-looking and blocked
+// instead: per 128-block p one small launch solves R_pp^T a_p = r_p (the same 16 x 16 substitution) and one launch over all
+// column blocks q > p applies  r_q -= R[p, q]^T a_p  at HBM rate.  2 nP launches; values do not depend on the batch.
+__global__ void k_fwd_init(const double* __restrict__ y, const double* __restrict__ hyp, int64_t N, int64_t Np,
+                           double* __restrict__ r, double* __restrict__ acc) {
+    const int z = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Np) r[(int64_t)z * Np + i] = (i < N) ? y[i] - hyp[3 * z + 2] : 0.0;
+    if (i < 2) acc[2 * z + i] = 0.0;
+}
+
+__global__ __launch_bounds__(128) void k_fwd_diag(const double* __restrict__ R, const double* __restrict__ Ud, int64_t bs,
+                                                  int64_t Np, int64_t N, int p, int last, const int* __restrict__ flag,
+                                                  double* __restrict__ rbuf, double* __restrict__ a,
+                                                  double* __restrict__ acc, double* __restrict__ out) {
+    __shared__ double r[NB], x[16];
+    const int z = blockIdx.x, t = threadIdx.x;
+    if (flag[z] != 0) {
+        if (t == 0 && last) out[z] = -__builtin_huge_val();
+        return;
+    }
+    R += (int64_t)z * bs;
+    Ud += (int64_t)z * bs;
+    const int64_t p0 = (int64_t)p * NB;
+    r[t] = rbuf[(int64_t)z * Np + p0 + t];
+    double q = 0.0, ld = 0.0;
+    // the operands of step jb do not depend on x: they are loaded one step ahead (the first version read them inside the
+    // dependent FMA chains: 16 global round trips per step, 30 us per block)
+    double ud[2][16], rr[2][16], dgv[2];
+    auto fetch = [&](int jb, int slot) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            ud[slot][k] = (t < 16) ? Ud[(p0 + 16 * jb + k) * Np + p0 + 16 * jb + t] : 0.0;
+            rr[slot][k] = R[(p0 + 16 * jb + k) * Np + p0 + t];
+        }
+        dgv[slot] = (t < 16) ? R[(p0 + 16 * jb + t) * Np + p0 + 16 * jb + t] : 1.0;
+    };
+    fetch(0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int jb = 0; jb < 8; ++jb) {
+        const int cur = jb & 1;
+        if (jb + 1 < 8) fetch(jb + 1, cur ^ 1);
+        if (t < 16) {                       // x_jb = T_d r_jb,  T_d[m][k] = Ud[(16jb + k) Np + 16jb + m]
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (k <= t) v = fma(ud[cur][k], r[16 * jb + k], v);
+            x[t] = v;
+            a[(int64_t)z * Np + p0 + 16 * jb + t] = v;
+            if (p0 + 16 * jb + t < N) { q = fma(v, v, q); ld += log(dgv[cur]); }
+        }
+        __syncthreads();
+        if (t >= 16 * (jb + 1)) {
+            double v = r[t];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v = fma(-rr[cur][k], x[k], v);
+            r[t] = v;
+        }
+        __syncthreads();
+    }
+    if (t < 64) {                           // threads 0..15 carry the partial sums (one wave)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            q += __shfl_xor(q, off);
+            ld += __shfl_xor(ld, off);
+        }
+        if (t == 0) {
+            const double qq = acc[2 * z] + q, ll = acc[2 * z + 1] + ld;
+            acc[2 * z] = qq;
+            acc[2 * z + 1] = ll;
+            if (last) out[z] = -0.5 * qq - ll - 0.5 * (double)N * 1.83787706640934548356;
+        }
+    }
+}
+
+// r[q0 + j] -= sum_{k < 128} R[(p0 + k) Np + q0 + j] a[p0 + k]   for the column blocks q > p (blockIdx.x), vector blockIdx.y
+__global__ __launch_bounds__(256) void k_fwd_update(const double* __restrict__ R, int64_t bs, int64_t Np, int p,
+                                                    const int* __restrict__ flag, const double* __restrict__ a,
+                                                    double* __restrict__ rbuf) {
+    __shared__ double av[NB], part[NB];
+    const int z = blockIdx.y, t = threadIdx.x;
+    if (flag[z] != 0) return;
+    R += (int64_t)z * bs;
+    const int64_t p0 = (int64_t)p * NB, q0 = (int64_t)(p + 1 + blockIdx.x) * NB;
+    if (t < NB) av[t] = a[(int64_t)z * Np + p0 + t];
+    __syncthreads();
+    const int j = t & 127, half = t >> 7;
+    double s = 0.0;
+#pragma unroll 8
+    for (int k = half; k < NB; k += 2) s = fma(R[(p0 + k) * Np + q0 + j], av[k], s);
+    if (half) part[j] = s;
+    __syncthreads();
+    if (!half) rbuf[(int64_t)z * Np + q0 + j] -= (s + part[j]);
+}
+
 static int loglik_batch_chunk(gpx_handle* h, int64_t B, const double* hyp, double* out);
 
 // any number of vectors: 64 (or what 16 GB of batch buffers hold) per launch chain
@@ -1087,7 +1184,7 @@ static int loglik_batch_chunk(gpx_handle* h, int64_t B, const double* hyp, doubl
     if (hipSetDevice(h->device) != hipSuccess) { h->err = "hipSetDevice failed"; return GPX_EHIP; }
     hipStream_t s = h->stream;
     // one allocation: [S B bs][R B bs][Xs B Np d][a B Np][hyp 3B][invell B DMAX][out B][flag B ints]
-    const int64_t need = 2 * B * bs + B * Np * d + B * Np + B * (3 + DMAX) + B + (B + 1) / 2 + 8;
+    const int64_t need = 2 * B * bs + B * Np * d + 2 * B * Np + B * (3 + DMAX) + 3 * B + (B + 1) / 2 + 8;
     if (need > h->cap_batch) {
         if (h->dbatch) hipFree(h->dbatch);
         h->dbatch = nullptr;
@@ -1102,7 +1199,9 @@ static int loglik_batch_chunk(gpx_handle* h, int64_t B, const double* hyp, doubl
     double* bhyp = ba + B * Np;
     double* binv = bhyp + 3 * B;
     double* bout = binv + B * DMAX;
-    int* bflag = reinterpret_cast<int*>(bout + B);
+    double* br = bout + B;                     // (large factors) the running right-hand sides, B x Np
+    double* bacc = br + B * Np;                // ... and {a.a, sum log R_ii} per vector
+    int* bflag = reinterpret_cast<int*>(bacc + 2 * B);
     if (hipMemcpyAsync(bhyp, stage.data(), stage.size() * 8, hipMemcpyHostToDevice, s) != hipSuccess ||
         hipMemsetAsync(bflag, 0, (size_t)B * sizeof(int), s) != hipSuccess) {
         h->err = "loglik_batch: H2D copy failed";
@@ -1116,6 +1215,46 @@ static int loglik_batch_chunk(gpx_handle* h, int64_t B, const double* hyp, doubl
         const unsigned g = (unsigned)(Np / GT);
         hipLaunchKernelGGL(k_gram_sym, dim3(g, g, Bz), dim3(256), 0, s, bXs, N, Np, (int)d, h->kernel_id, 1.0, 0.0, bS,
                            (const double*)bhyp);
+    }
+    // LARGE factors (round 5; the reference's default model at BASELINE scale, pybo/bayesopt.py:115): the persistent task-graph
+    // kernel, vector after vector, on the batch's buffers (the 16 x 16 inverses land in the dead diagonal tiles of the Gram
+    // buffer, exactly where k_potrf16 puts them below).  The handle's own factor is not touched: its buffer pointers are lent
+    // to the launcher and restored.  A launch that cannot be prepared, or gives up, sends the WHOLE chunk down the batched
+    // kernels below (which rebuild nothing: they start from the Gram matrices, so those are formed again first).
+    bool big = h->chol_tg && nP >= 16 && nP >= h->tg_min && nP <= h->tg_max;
+    if (big) {
+        double *sS = h->dS, *sR = h->dR, *sT = h->dT, *sU = h->dU;
+        const bool s_pending = h->diag_inv_pending, s_launched = h->tg_launched;
+        for (int64_t b = 0; b < B && big; ++b) {
+            h->dS = bS + b * bs; h->dR = bR + b * bs; h->dT = nullptr; h->dU = bS + b * bs;
+            const bool ok = launch_cholesky_tg(h);
+            if (ok) (void)hipMemcpyAsync(bflag + b, h->dflag, sizeof(int), hipMemcpyDeviceToDevice, s);
+            if (!ok || hipStreamSynchronize(s) != hipSuccess || tg_abort_code(h) == 2) big = false;
+        }
+        h->dS = sS; h->dR = sR; h->dT = sT; h->dU = sU;
+        h->diag_inv_pending = s_pending; h->tg_launched = s_launched;
+        if (!big) {
+            (void)hipGetLastError();
+            (void)hipMemsetAsync(bflag, 0, (size_t)B * sizeof(int), s);
+            const unsigned g = (unsigned)(Np / GT);
+            hipLaunchKernelGGL(k_gram_sym, dim3(g, g, Bz), dim3(256), 0, s, bXs, N, Np, (int)d, h->kernel_id, 1.0, 0.0, bS,
+                               (const double*)bhyp);
+        }
+    }
+    if (big) {
+        hipLaunchKernelGGL(k_fwd_init, dim3((unsigned)((Np + 255) / 256), Bz), dim3(256), 0, s, h->dy, bhyp, N, Np, br, bacc);
+        for (int p = 0; p < nP; ++p) {
+            hipLaunchKernelGGL(k_fwd_diag, dim3(Bz), dim3(128), 0, s, bR, bS, bs, Np, N, p, p == nP - 1 ? 1 : 0, bflag, br, ba,
+                               bacc, bout);
+            if (p + 1 < nP)
+                hipLaunchKernelGGL(k_fwd_update, dim3((unsigned)(nP - 1 - p), Bz), dim3(256), 0, s, bR, bs, Np, p, bflag, ba, br);
+        }
+        if (hipMemcpyAsync(out, bout, (size_t)B * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) {
+            h->err = "loglik_batch: kernel or D2H copy failed";
+            return GPX_EHIP;
+        }
+        return GPX_OK;
     }
     // right-looking blocked factorisation, every launch over the whole batch; single stream, no lookahead (the
     // sizes a sampler works at are a few blocks)

@@ -245,3 +245,58 @@ def test_ensemble_predict_equals_the_members_own_gradients(N, d, kernel, M):
     np.testing.assert_allclose(got[2], dmus.mean(0), rtol=1e-13, atol=1e-16)
     with pytest.raises(GpxError):
         Engine.ensemble_predict(engines, np.zeros((0, d)))
+
+
+# ---- the reference's DEFAULT model at BASELINE scale -----------------------------------------------
+def test_ten_member_ensemble_sweep_at_the_north_star_size():
+    """pybo's default model is MCMC(gp, n=10) (pybo/bayesopt.py:115): ten member GPs at N = 8192, d = 8, EI averaged over the
+    members on the full 2^20 Sobol grid, ONE gpx_ensemble_sweep call.  The oracle (ten CPU fits) on every 512th candidate
+    plus the device's top-k: values at the EI tolerance, the winner, the order of the top-k."""
+    import bench
+    from pybo_amd._lib import Engine
+    from helpers import ei_tol
+    M, n, k = 1 << 20, 10, 32
+    w = bench.make_workload('ns', M)
+    X, y, Z = w['X'], w['y'], w['Xc']
+    hyp = bench.ensemble_hypers(w, n)              # the members bench.py --ensemble times
+    engines = []
+    for sn2, rho, ell, bias in hyp:
+        e = Engine(0)
+        e.fit(X, y, w['kernel'], ell, rho, sn2, bias)
+        engines.append(e)
+    target = float(np.max(y))                      # one incumbent for all members (the policy's target is a model-level scalar)
+    out = Engine.ensemble_sweep(engines, 'ei', target, Z, k=k, want_all=True)
+    ei = out['acq']
+    assert np.all(np.isfinite(ei)) and np.all(ei >= -1e-300)
+    np.testing.assert_array_equal(out['top_idx'], gp_ref.topk_desc(ei, k))          # top-k = ranking of the returned average
+    np.testing.assert_array_equal(out['top_val'], ei[out['top_idx']])
+    # the average is the member-order sum of the members' own sweeps, divided once by n: bitwise on a slice of the grid
+    sl = slice(0, 1 << 16)
+    own = np.zeros(1 << 16)
+    for e in engines:
+        own += e.sweep('ei', target, Z[sl], k=0)['acq']
+    np.testing.assert_array_equal(ei[sl], own / n)
+    # oracle members on a sub-sample + the device's top-k
+    pick = np.unique(np.concatenate([np.arange(0, M, 512), out['top_idx']]))
+    assert len(pick) >= 2048
+    want = np.zeros(len(pick))
+    tol = np.zeros(len(pick))
+    for sn2, rho, ell, bias in hyp:
+        ref = gp_ref.make_gp(sn2, rho, ell, bias, w['kernel'])
+        ref.add_data(X, y)
+        mr, sr = ref.predict(Z[pick])
+        want += ref.get_improvement(target, Z[pick])
+        tol += ei_tol(mr, sr, target, rho)
+    want /= n
+    tol /= n
+    big = want > 1e-9 * want.max()
+    assert big.sum() > 500
+    np.testing.assert_allclose(ei[pick][big], want[big], rtol=1e-6, atol=0)
+    assert np.all(np.abs(ei[pick] - want) <= tol)
+    assert out['top_idx'][0] == pick[int(np.argmax(want))]
+    pos = np.searchsorted(pick, out['top_idx'])
+    vals = want[pos]
+    gaps = vals[:-1] - vals[1:]
+    assert np.all(gaps >= -(tol[pos][:-1] + tol[pos][1:]))
+    for e in engines:
+        e.close()

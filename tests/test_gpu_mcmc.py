@@ -115,6 +115,41 @@ def test_batched_loglik_matches_oracle_and_leaves_the_fit_alone(N, d, kernel):
     assert np.isfinite(out[0]) and out[1] == -np.inf
 
 
+def test_batched_loglik_of_a_large_factor_uses_the_task_graph_and_a_blocked_substitution():
+    """From 16 blocks (N > 1920) gpx_loglik_batch factorises each vector's covariance with the persistent task-graph kernel on
+    the batch's own buffers and substitutes right-looking over 128-blocks (the one-workgroup walk took 28 ms at N = 8192):
+    against the oracle, independent of the grouping, the handle's own factor bitwise untouched, -inf for a non-PD vector."""
+    from pybo_amd import models
+    N, d = 2200, 3
+    X, y, ell = synth_problem(N, d, seed=5)
+    gp = models.make_gp(1e-3, 1.4, ell, 0.2)
+    gp.add_data(X, y)
+    L0 = gp._engine().get_matrix('L')
+    rng = np.random.RandomState(2)
+    th0 = gp.hyper_vector()
+    thetas = th0 + 0.3 * rng.randn(4, len(th0))
+    got = gp.loglik_at(thetas)
+    ref = gp_ref.make_gp(1e-3, 1.4, ell, 0.2)
+    ref.add_data(X, y)
+    want = []
+    for th in thetas:
+        ref.set_hyper_vector(th)
+        want.append(ref.loglikelihood())
+    np.testing.assert_allclose(got, want, rtol=1e-9)
+    np.testing.assert_array_equal(gp.loglik_at(thetas[1:3]), got[1:3])
+    np.testing.assert_array_equal(gp.loglik_at(thetas[3]), got[3:4])
+    np.testing.assert_array_equal(gp._engine().get_matrix('L'), L0)
+    ref.set_hyper_vector(th0)
+    Z = rng.rand(40, d)
+    np.testing.assert_allclose(gp.predict(Z)[0], ref.predict(Z)[0], rtol=1e-6, atol=1e-8)
+    bad = th0.copy()
+    bad[0] = -800.0                                     # sn2 = 0 with duplicated inputs below
+    gp2 = models.make_gp(1e-3, 1.0, ell, 0.0)
+    gp2.add_data(np.vstack([X[:2000], X[:3]]), np.hstack([y[:2000], y[:3]]))
+    out = gp2.loglik_at(np.array([gp2.hyper_vector(), bad, gp2.hyper_vector()]))
+    assert np.isfinite(out[0]) and out[1] == -np.inf and out[2] == out[0]
+
+
 def test_a_default_run_reuses_its_device_handles(monkeypatch):
     """pybo's default model turns over ~30 member / proposal models per iteration; their handles must come from
     the pool (creating + destroying one costs ~5-15 ms: it was 80 % of a default run before the pool kept up)."""

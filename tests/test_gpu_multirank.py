@@ -202,6 +202,70 @@ def test_eight_ranks_shard_the_thompson_draws_of_configs_d_and_e(name, S):
     assert len(want_i) == S
 
 
+# ---- the reference's DEFAULT model (an ensemble of 10 GPs, pybo/bayesopt.py:115) over 8 ranks -------------------------------
+def _ensemble_work(rank, world, n=10, M=1 << 18):
+    """bench.py --ensemble's step for one rank on config B's inputs: every rank fits all n members (bitwise-equal factors, no
+    communication), sweeps ITS contiguous slice of the grid with ONE gpx_ensemble_sweep call, one all-gather of the top-k.
+    (Members are NOT the sharded unit: 10 members over 8 ranks would leave six ranks with half the work of the other two.)
+    Also through the plugin layer: ShardedIndex over policies.EI of an ensemble model."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from pybo_amd import dist as pdist
+    from pybo_amd._lib import Engine
+    w = bench.make_workload('b', M)
+    hyp = bench.ensemble_hypers(w, n)
+    engines = []
+    for sn2, rho, ell, bias in hyp:
+        e = Engine(0)
+        e.fit(w['X'], w['y'], w['kernel'], ell, rho, sn2, bias)
+        engines.append(e)
+    lo, hi = pdist.shard_bounds(M, rank, world)
+    target = float(np.max(w['y']))
+    r = Engine.ensemble_sweep(engines, 'ei', target, w['Xc'][lo:hi], k=K, want_all=False)
+    tv, ti = pdist.gather_topk(r['top_val'], np.where(r['top_idx'] >= 0, r['top_idx'] + lo, r['top_idx']), K)
+    r2 = Engine.ensemble_sweep(engines, 'ucb', 2.5, w['Xc'][lo:hi], k=K, want_all=False)
+    uv, ui = pdist.gather_topk(r2['top_val'], np.where(r2['top_idx'] >= 0, r2['top_idx'] + lo, r2['top_idx']), K)
+    digest = [_digest(e.get_matrix('L')) for e in engines[:3]]
+    for e in engines:
+        e.close()
+    return tv, ti, uv, ui, digest
+
+
+def _ensemble_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        q.put((rank, _ensemble_work(rank, world)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_ranks_shard_the_candidates_of_a_ten_member_ensemble():
+    """the default model's sweep over 8 ranks (sharing the one GPU): the merged top-k of the
+    member-averaged EI and of the mixture UCB is bit-identical on every rank and to ONE rank sweeping the whole grid, and the
+    members' factors are bitwise equal across ranks."""
+    world = 8
+    want = _ensemble_work(0, 1)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ensemble_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=900) for _ in range(world))
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    for rank in range(world):
+        for a, b in zip(got[rank][:4], want[:4]):
+            np.testing.assert_array_equal(a, b)
+        assert got[rank][4] == want[4]
+    assert want[1][0] >= 0 and len(set(want[1])) == K
+
+
 def test_rccl_exchange_behind_the_c_abi_with_a_one_rank_communicator():
     """gpx_comm_unique_id / gpx_comm_init / gpx_topk_allgather on the real RCCL with nranks = 1: the pairs are
     read from the device buffers the sweep left behind, offset, gathered, merged on the device."""
