@@ -1088,11 +1088,16 @@ def main():
             # (draw, feature, candidate): d multiply-adds + 20 instructions of cos_cw and the weighted sum (counted in the ISA)
             lane_peak = 256 * 4 * 16 * 2.4e9
             ach = tm['rff_sweep_ops'] / (tm['rff_sweep'] * 1e-3)
-            out['roofline_rff'] = {'kernel': 'k_rff_mfma', 'bound': 'fp64 lanes (MFMA projection + VALU cosine share them)',
+            out['roofline_rff'] = {'kernel': 'k_rff_mfma5', 'bound': 'fp64 lanes (MFMA projection + VALU cosine share them)',
                                    'achieved': ach / 1e12, 'peak': lane_peak / 1e12, 'unit': 'T lane-operations/s',
                                    'frac': ach / lane_peak, 'ms': tm['rff_sweep'] / args.steps,
                                    'lane_ops_per_step': tm['rff_sweep_ops'] / args.steps,
                                    'work': 'draws x features x (d + 20) x candidates, features NOT padded (n = 100)',
+                                   # this kernel is power-bound: the shader clock its own workgroups measured (s_memtime over
+                                   # s_memrealtime) against the 2400 MHz the peak is quoted at
+                                   'sclk_mhz': tm.get('rff_sclk_mhz') or None,
+                                   'frac_at_measured_clock': (ach / (lane_peak * tm['rff_sclk_mhz'] / 2400.0))
+                                   if tm.get('rff_sclk_mhz') else None,
                                    'traffic': None}
         if refine is not None:
             out['refine'] = refine

@@ -339,7 +339,8 @@ int gpx_topk_allgather(gpx_comm *c, int64_t n, int64_t index_offset, int64_t k, 
  * [11] append (rank-1 extension of the fit) [12] correction passes over the sweep cache [13] the Thompson sweep kernel
  * alone (part of [7]) [14] its algorithmic double-precision lane operations: S n (d + 20) M per launch [15] fits whose
  * task-graph factorisation gave up and were re-run on the stream schedule [16] the shader clock in MHz sustained by the
- * sweep_trmm launches since the last reset (their workgroups' s_memtime over s_memrealtime ticks; 0 without a launch).
+ * sweep_trmm launches since the last reset (their workgroups' s_memtime over s_memrealtime ticks; 0 without a launch)
+ * [17] the same for the Thompson sweep kernel (k_rff_mfma5: it is power-bound and clocks lower).
  * Synchronises the stream.  Returns the number of slots written (<= n). */
 int gpx_timers(gpx_handle *h, double *out, int n, int reset);
 /* DIAGNOSTIC (option "chol_tg_trace" = 1): wall-clock stamps (100 MHz ticks) the task-graph factorisation of the last fit

@@ -165,7 +165,7 @@ static int create_impl(int device, void* stream, gpx_handle** out) {
     }
     // (the factorisation's side streams and events are created on first use: gpx::ensure_side_streams)
     // one allocation for the small per-handle device scalars
-    if (hipMalloc((void**)&h->dsmall, 64 + 16 * 8 + DMAX * 8 + 16) != hipSuccess) {
+    if (hipMalloc((void**)&h->dsmall, 64 + 16 * 8 + DMAX * 8 + 32) != hipSuccess) {
         g_create_err = "gpx_create: device allocation failed";
         delete h;
         return GPX_EOOM;
@@ -181,7 +181,7 @@ static int create_impl(int device, void* stream, gpx_handle** out) {
     h->dscal = reinterpret_cast<double*>(h->dsmall + 64);
     h->dinvell = h->dscal + 16;
     h->dclk = reinterpret_cast<unsigned long long*>(h->dinvell + DMAX);
-    hipMemset(h->dclk, 0, 16);
+    hipMemset(h->dclk, 0, 32);
     *out = h;
     // GPX_OPTIONS="name=value,name=value": options every new handle starts with (A/B runs THROUGH the plug-in layer, whose
     // handles the caller never sees); an unknown name or a bad value fails the creation loudly
@@ -341,7 +341,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             return GPX_OK;
         }
         if (!strcmp(name, "x_rff")) {       // diagnostic: A/B of the Thompson sweep kernels (process-wide)
-            if (value < 0 || value > 2) return fail(h, GPX_EARG, "x_rff must be 0 (by size), 1 or 2");
+            if (value < 0 || value > 1) return fail(h, GPX_EARG, "x_rff must be 0 (by size) or 1 (the round-3 kernel)");
             gpx::g_rff_variant = (int)value;
             return GPX_OK;
         }
@@ -408,14 +408,15 @@ extern "C" int gpx_timers(gpx_handle* h, double* out, int n, int reset) {
         if (!h) return GPX_EARG;
         if (!out || n < 0) return fail(h, GPX_EARG, "timers: NULL output");
         harvest(h);
-        unsigned long long clk[2] = {0, 0};
-        hipMemcpy(clk, h->dclk, 16, hipMemcpyDeviceToHost);
+        unsigned long long clk[4] = {0, 0, 0, 0};
+        hipMemcpy(clk, h->dclk, 32, hipMemcpyDeviceToHost);
         h->tacc[T_SCLK] = clk[1] ? 100.0 * (double)clk[0] / (double)clk[1] : 0.0;    // MHz
+        h->tacc[T_RFFCLK] = clk[3] ? 100.0 * (double)clk[2] / (double)clk[3] : 0.0;
         const int m = std::min(n, (int)T_COUNT);
         for (int i = 0; i < m; ++i) out[i] = h->tacc[i];
         if (reset) {
             for (int i = 0; i < T_COUNT; ++i) h->tacc[i] = 0;
-            hipMemset(h->dclk, 0, 16);
+            hipMemset(h->dclk, 0, 32);
         }
         return m;
     });
@@ -1151,7 +1152,7 @@ static int rff_core(gpx_handle* h, const double* W, const double* b, const doubl
     {
         Span sp(h, T_RFF);
         Span sp2(h, T_RFFSWEEP);          // the Thompson sweep kernel alone (bench.py: roofline_rff)
-        launch_rff_mfma(s, dWt, dbt, dtt, (int)S, (int)nfb, (int)n, (int)d, (int)dp, bias, dXc, M, d_vals);
+        launch_rff_mfma(s, dWt, dbt, dtt, (int)S, (int)nfb, (int)n, (int)d, (int)dp, bias, dXc, M, d_vals, h->dclk + 2);
     }
     // algorithmic double-precision lane operations of that launch: per (draw, feature, candidate) d multiply-adds of the
     // projection + 20 instructions of the cosine epilogue (kernels_rff.hip: cos_cw and the weighted sum)

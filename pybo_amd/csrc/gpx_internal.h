@@ -20,7 +20,7 @@ constexpr int PEND_MAX = 8;   // appended observations per pass of the sweep-cac
 
 enum Timer {
     T_GRAM = 0, T_CHOL, T_TRTRI, T_ALPHA, T_XGRAM, T_TRMM, T_ACQ, T_RFF, T_NLAUNCH, T_FLOP, T_COPY, T_APPEND,
-    T_RANK1, T_RFFSWEEP, T_RFFOPS, T_TGFALL, T_SCLK, T_COUNT
+    T_RANK1, T_RFFSWEEP, T_RFFOPS, T_TGFALL, T_SCLK, T_RFFCLK, T_COUNT
 };
 
 struct EventPair { hipEvent_t a, b; int slot; };
@@ -259,7 +259,7 @@ int rff_grad_host(gpx_handle* h, const double* W, const double* b, const double*
 // launchers (kernels_rff.hip)
 extern int g_rff_variant;
 void launch_rff_mfma(hipStream_t s, const double* Wt, const double* bt, const double* tt, int S, int nfb, int n, int d,
-                     int dp, double bias, const double* Xc, int64_t M, double* vals);
+                     int dp, double bias, const double* Xc, int64_t M, double* vals, unsigned long long* clk);
 int64_t rff_gram_batch_scratch(int64_t S, int64_t Np);
 void launch_rff_posterior(hipStream_t s, const double* A, const double* v, const double* z, int S, int n, double sc,
                           double sn2, double* theta, int* flag);

@@ -208,145 +208,205 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_rff_mfma(const double* __re
     }
 }
 
-// Round 4: the candidate fragments in REGISTERS, the feature tile DOUBLE-buffered in LDS, ONE barrier per tile (dp <= 32).
-// k_rff_mfma<true> kept the candidate tile in LDS beside a single feature buffer (74 KB at d = 32: two workgroups per
-// CU) and paid two barriers per tile -- one before the buffer could be overwritten, one before it could be read.  A wave
-// only ever reads ITS 32 candidate rows: as MFMA A fragments that is 2 x dp/4 doubles per lane (<= 16), loaded once for the
-// workgroup's life.  The LDS that frees holds a second feature buffer: the next tile's 32 KB travel through registers during
-// the matrix phase (as before), are written to the OTHER buffer (no wait: nobody reads it), and the only barrier of a tile
-// stands after the cosine epilogue, where the waves meet anyway.  Same MFMAs, same order: bit-identical values.
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_rff_mfma_db(const double* __restrict__ Wt,
-                                                                 const double* __restrict__ bt,
-                                                                 const double* __restrict__ tt, int S, int nfb, int n,
-                                                                 int d, int dp, double bias,
-                                                                 const double* __restrict__ Xc, int64_t M,
-                                                                 double* __restrict__ vals) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];   // Bt[2][dp][LDT]
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    union { double d; int i[2]; } u, o;
+    u.d = v;
+    o.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], CTRL, 0xF, 0xF, true);
+    o.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], CTRL, 0xF, 0xF, true);
+    return o.d;
+}
+
+// DB (dp <= 16: the LDS holds it beside a second workgroup): TWO images of the feature tile -- the next one is written while
+// this one is still being read, and the only barrier of a tile stands at its end.
+template <int JF, int NSUB, bool DB>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_rff_mfma5(const double* __restrict__ Wt, const double* __restrict__ bt,
+                                                               const double* __restrict__ tt, int S, int d, int dp,
+                                                               double bias, const double* __restrict__ Xc, int64_t M,
+                                                               double* __restrict__ vals, unsigned long long* clk) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // At[dp][LDT] | Bt[1 or 2][dp + 2][LDT] (rows dp, dp + 1: b, theta)
+    // the shader clock this launch sustains (it is power-bound: ~2.1 GHz against the 2.4 GHz of the peak): workgroup lifetimes
+    // in s_memtime and in 100 MHz ticks, as in k_sweep_trmm
+    const unsigned long long clk_c0 = __builtin_readcyclecounter();
+    const unsigned long long clk_r0 = wall_clock64();
+    double* At = lds;
+    double* Bt0 = lds + dp * LDT;
+    const int bstride = (dp + 2) * LDT;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int64_t m0 = (int64_t)blockIdx.x * TB;
     const int fr = lane & 15, fk = lane >> 4;
     const int nkk = dp >> 2;
-    // this lane's A fragments: candidate rows m0 + 32 w + fr (+ 16), coordinates 4 kk + fk
-    double a0[8], a1[8];
+    // the thread's 16-byte pieces of a feature tile: rows (t >> 6) + 4 u, columns 2 (t & 63); of the b / theta rows: thread t < 128
+    const int vo = (int)((((t >> 6) * TB) + (t & 63) * 2) * 8);
+    const int vo2 = (int)(((t & 63) * 2) * 8);
+    d2 pre[8], pre2;
+    auto fetch = [&](int tile) {
+        __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)(Wt + (int64_t)tile * dp * TB), 0, -1, 0x00020000);
+        __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(((t < 64) ? bt : tt) + (int64_t)tile * TB), 0, -1, 0x00020000);
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-        const int k = 4 * kk + fk;
-        const int64_t g0 = m0 + w * 32 + fr, g1 = g0 + 16;
-        a0[kk] = (kk < nkk && k < d && g0 < M) ? Xc[g0 * d + k] : 0.0;
-        a1[kk] = (kk < nkk && k < d && g1 < M) ? Xc[g1 * d + k] : 0.0;
-    }
-    const int ntile = S * nfb;
-    const int npiece = (TB / 2) * dp;                 // 16-byte pieces of a feature tile (<= 8 per thread)
-    {
-        const double* W0 = Wt;
+        for (int u = 0; u < 8; ++u)
+            if (4 * u < dp) pre[u] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rw, vo, u * 4 * TB * 8, 0));
+        if (t < 128) pre2 = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rb, vo2, 0, 0));
+    };
+    auto stash = [&](double* Bt) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int e = t + u * GEMM_THREADS;
-            if (e < npiece) *reinterpret_cast<d2*>(lds + (e >> 6) * LDT + (e & 63) * 2) = *reinterpret_cast<const d2*>(W0 + (int64_t)(e >> 6) * TB + (e & 63) * 2);
-        }
+        for (int u = 0; u < 8; ++u)
+            if (4 * u < dp) *reinterpret_cast<d2*>(Bt + ((t >> 6) + 4 * u) * LDT + (t & 63) * 2) = pre[u];
+        if (t < 128) *reinterpret_cast<d2*>(Bt + (dp + (t >> 6)) * LDT + (t & 63) * 2) = pre2;
+    };
+    fetch(0);                                             // (in flight while the candidate tile is staged)
+    for (int e = t; e < TB * dp; e += GEMM_THREADS) {     // candidate tile, transposed into k-major, for the workgroup's life
+        const int k = e >> 7, m = e & 127;
+        const int64_t gm = m0 + m;
+        At[k * LDT + m] = (k < d && gm < M) ? Xc[gm * d + k] : 0.0;
     }
+    stash(Bt0);
     __syncthreads();
-    double rowsum[2][4];
-    for (int tile = 0; tile < ntile; ++tile) {
-        const int fb = tile % nfb, s = tile / nfb;
-        const int nv = min(TB, n - fb * TB);          // features of this tile that exist
-        const int jt = (nv + 15) >> 4;                // ... in 16-column groups (uniform)
-        if (fb == 0) {
+    const double* as = At + w * 32 + fr;
+    double rmask[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+    for (int r = 0; r < 4; ++r) rmask[r] = (((lane >> 2) & 3) == r) ? 1.0 : 0.0;
+    for (int tile = 0; tile < S; ++tile) {
+        const double* Bt = Bt0 + ((DB && (tile & 1)) ? bstride : 0);
+        const double* bs = Bt + fr;
+        const double* bq = Bt + 16 * JF + (lane & 3);          // the remainder columns of this lane
+        d4 acc[2][JF > 0 ? JF : 1];
+        double accr[2][NSUB > 0 ? NSUB : 1];
+        // the draw's phases and weights: rows dp, dp + 1 of the tile's image.  The accumulators START from the phase of their
+        // column (z = b + w.x accumulates in the matrix instruction: 48 double-precision additions per tile less)
+        double bj[JF > 0 ? JF : 1], tj[JF > 0 ? JF : 1], bjr[NSUB > 0 ? NSUB : 1], tjr[NSUB > 0 ? NSUB : 1];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) rowsum[i][r] = 0.0;
+        for (int j = 0; j < JF; ++j) {
+            bj[j] = bs[dp * LDT + j * 16];
+            tj[j] = bs[(dp + 1) * LDT + j * 16];
         }
-        d4 acc[2][8];
+#pragma unroll
+        for (int q = 0; q < NSUB; ++q) {
+            bjr[q] = bq[dp * LDT + 4 * q];
+            tjr[q] = bq[(dp + 1) * LDT + 4 * q];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < JF; ++j) acc[i][j] = (d4){bj[j], bj[j], bj[j], bj[j]};
+#pragma unroll
+            for (int q = 0; q < NSUB; ++q) accr[i][q] = bjr[q];
+        }
+        const bool more = tile + 1 < S;
+        if (more) fetch(tile + 1);
+        // matrix phase: fragments of group kk + 1 requested before the MFMAs of group kk
+        double a[2][2], b[2][JF > 0 ? JF : 1], br[2][NSUB > 0 ? NSUB : 1];
+        auto frag = [&](int kk, int slot) {
+            const int kr = kk * 4 + fk;
+            a[slot][0] = as[kr * LDT];
+            a[slot][1] = as[kr * LDT + 16];
+#pragma unroll
+            for (int j = 0; j < JF; ++j) b[slot][j] = bs[kr * LDT + j * 16];
+#pragma unroll
+            for (int q = 0; q < NSUB; ++q) br[slot][q] = bq[kr * LDT + 4 * q];
+        };
+        auto mfmas = [&](int slot) {
+#pragma unroll
+            for (int j = 0; j < JF; ++j) {
+                acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[slot][0], b[slot][j], acc[0][j], 0, 0, 0);
+                acc[1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[slot][1], b[slot][j], acc[1][j], 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < NSUB; ++q) {
+                accr[0][q] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[slot][0], br[slot][q], accr[0][q], 0, 0, 0);
+                accr[1][q] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[slot][1], br[slot][q], accr[1][q], 0, 0, 0);
+            }
+        };
+        frag(0, 0);
+#pragma unroll 1
+        for (int kk = 0; kk < nkk; kk += 2) {       // two groups per trip: the fragment slots are compile-time indices
+            const bool two = kk + 1 < nkk;
+            if (two) frag(kk + 1, 1);
+            mfmas(0);
+            if (two) {
+                if (kk + 2 < nkk) frag(kk + 2, 0);
+                mfmas(1);
+            }
+        }
+        if (!DB) __syncthreads();   // everyone has read this feature tile
+        if (more) stash(Bt0 + ((DB && !(tile & 1)) ? bstride : 0));
+        double rowsum[2][4];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = (d4){0.0, 0.0, 0.0, 0.0};
-        const double* bs = lds + (tile & 1) * dp * LDT + fr;
-        double* bnext = lds + ((tile + 1) & 1) * dp * LDT;
-        d2 pre[8];
-        const bool more = tile + 1 < ntile;
-        if (more) {
-            const double* Wnext = Wt + (int64_t)(tile + 1) * dp * TB;
+            for (int r = 0; r < 4; ++r) rowsum[i][r] = 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = t + u * GEMM_THREADS;
-                if (e < npiece) pre[u] = *reinterpret_cast<const d2*>(Wnext + (int64_t)(e >> 6) * TB + (e & 63) * 2);
-            }
-        }
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            if (kk < nkk) {
-                const int kr = kk * 4 + fk;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (j < jt) {
-                        const double b = bs[kr * LDT + j * 16];
-                        acc[0][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], b, acc[0][j], 0, 0, 0);
-                        acc[1][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], b, acc[1][j], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        if (more) {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int e = t + u * GEMM_THREADS;
-                if (e < npiece) *reinterpret_cast<d2*>(bnext + (e >> 6) * LDT + (e & 63) * 2) = pre[u];
-            }
-        }
-        const double* bb = bt + (int64_t)tile * TB + fr;
-        const double* th = tt + (int64_t)tile * TB + fr;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (j < jt) {
-                const double bj = bb[j * 16], tj = th[j * 16];
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) rowsum[i][r] = fma(tj, cos_cw(acc[i][j][r] + bj), rowsum[i][r]);
-            }
-        }
-        if (fb == nfb - 1) {
+        for (int j = 0; j < JF; ++j)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double v = rowsum[i][r];
-                    v += __shfl_xor(v, 1);
-                    v += __shfl_xor(v, 2);
-                    v += __shfl_xor(v, 4);
-                    v += __shfl_xor(v, 8);
-                    const int64_t gm = m0 + w * 32 + i * 16 + fk + 4 * r;
-                    if (fr == 0 && gm < M) vals[(int64_t)s * M + gm] = bias + v;
-                }
-        }
-        __syncthreads();   // the next tile is complete in the other buffer; everyone is done reading this one
+                for (int r = 0; r < 4; ++r) rowsum[i][r] = fma(tj[j], cos_cw(acc[i][j][r]), rowsum[i][r]);
+#pragma unroll
+        for (int q = 0; q < NSUB; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const double v = tjr[q] * cos_cw(accr[i][q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rowsum[i][r] = fma(rmask[r], v, rowsum[i][r]);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // the 16 lanes of a DPP row share the candidate row: quad butterflies, then the mirrors (no LDS round trips)
+                double v = rowsum[i][r];
+                v += dpp_f64<0xB1>(v);       // quad_perm [1, 0, 3, 2]
+                v += dpp_f64<0x4E>(v);       // quad_perm [2, 3, 0, 1]
+                v += dpp_f64<0x141>(v);      // row_half_mirror: quad 0 <-> 1, 2 <-> 3
+                v += dpp_f64<0x140>(v);      // row_mirror: half 0 <-> 1
+                const int64_t gm = m0 + w * 32 + i * 16 + fk + 4 * r;
+                if (fr == 0 && gm < M) vals[(int64_t)tile * M + gm] = bias + v;
+            }
+        __syncthreads();   // the next tile's image is complete
+    }
+    if (clk && t == 0) {
+        atomicAdd(clk, (unsigned long long)__builtin_readcyclecounter() - clk_c0);
+        atomicAdd(clk + 1, (unsigned long long)wall_clock64() - clk_r0);
     }
 }
 
 // device staging layout for the MFMA path: [Wt S*nfb*dp*128][bt S*nfb*128][tt S*nfb*128]
 // rows of the k-range the RFF kernels keep in LDS: the whole (padded) input dimension up to 64 coordinates (147 KB),
 // 32 at a time beyond (74 KB: two workgroups per CU)
-int g_rff_variant = 0;      // diagnostic (option "x_rff"): 0 = by size, 1 = round 3's single-buffer kernel, 2 = the double-buffered one
+int g_rff_variant = 0;      // diagnostic (option "x_rff"): 0 = by size (round 5's kernel where it applies), 1 = round 3's single-buffer kernel everywhere (witness)
 static int rff_k_chunk(int dp) { return dp <= DMAX_RFF_RESIDENT ? dp : 32; }
 
 void launch_rff_mfma(hipStream_t s, const double* Wt, const double* bt, const double* tt, int S, int nfb, int n, int d,
-                     int dp, double bias, const double* Xc, int64_t M, double* vals) {
+                     int dp, double bias, const double* Xc, int64_t M, double* vals, unsigned long long* clk) {
     dim3 grid((unsigned)((M + TB - 1) / TB));
     const int dk = rff_k_chunk(dp);
     const size_t ldsb = (size_t)(2 * dk * LDT) * sizeof(double);
-    // measured (profiles/r04_rff_kernels_ab.txt): the double-buffered kernel wins while the projection is short (config E,
-    // d = 6: 1.04 against 1.07 ms), the single-buffer one at d = 32 (config D: 13.9 against 14.4 ms: there the matrix phase
-    // dominates and the register-resident fragments cost 7 spilled registers)
-    // (the double-buffered kernel holds 8 candidate fragments per thread: dp <= 32, whatever the diagnostic option says)
-    if (dk == dp && dp <= 32 && ((dp <= 16 && g_rff_variant == 0) || g_rff_variant == 2)) {
-        const size_t ldb = (size_t)(2 * dp * LDT) * sizeof(double);
-        if (ldb > 64 * 1024)
-            hipFuncSetAttribute((const void*)k_rff_mfma_db, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldb);
-        hipLaunchKernelGGL(k_rff_mfma_db, grid, dim3(GEMM_THREADS), ldb, s, Wt, bt, tt, S, nfb, n, d, dp, bias, Xc, M, vals);
-        return;
+    // round 5: one feature tile per draw (n <= 128) and dp <= 32 -- the reference's defaults
+    if (nfb == 1 && dp <= 32 && dk == dp && g_rff_variant == 0) {
+        const int rem = n & 15;
+        const int jf = (rem == 0 || rem > 8) ? (n + 15) / 16 : n / 16, nsub = (rem == 0 || rem > 8) ? 0 : (rem + 3) / 4;
+        const bool db = dp <= 16;
+        const size_t l5 = (size_t)((dp + (db ? 2 : 1) * (dp + 2)) * LDT) * sizeof(double);
+#define GPX_RFF5(JF, NS)                                                                                                   \
+        case (JF) * 4 + (NS):                                                                                              \
+            if (db) {                                                                                                      \
+                hipLaunchKernelGGL((k_rff_mfma5<JF, NS, true>), grid, dim3(GEMM_THREADS), l5, s, Wt, bt, tt, S, d, dp, bias, Xc, M, vals, clk); \
+            } else {                                                                                                       \
+                if (l5 > 64 * 1024) hipFuncSetAttribute((const void*)k_rff_mfma5<JF, NS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l5); \
+                hipLaunchKernelGGL((k_rff_mfma5<JF, NS, false>), grid, dim3(GEMM_THREADS), l5, s, Wt, bt, tt, S, d, dp, bias, Xc, M, vals, clk); \
+            }                                                                                                              \
+            return;
+        switch (jf * 4 + nsub) {
+            GPX_RFF5(0, 1) GPX_RFF5(0, 2)
+            GPX_RFF5(1, 0) GPX_RFF5(1, 1) GPX_RFF5(1, 2) GPX_RFF5(2, 0) GPX_RFF5(2, 1) GPX_RFF5(2, 2)
+            GPX_RFF5(3, 0) GPX_RFF5(3, 1) GPX_RFF5(3, 2) GPX_RFF5(4, 0) GPX_RFF5(4, 1) GPX_RFF5(4, 2)
+            GPX_RFF5(5, 0) GPX_RFF5(5, 1) GPX_RFF5(5, 2) GPX_RFF5(6, 0) GPX_RFF5(6, 1) GPX_RFF5(6, 2)
+            GPX_RFF5(7, 0) GPX_RFF5(7, 1) GPX_RFF5(7, 2) GPX_RFF5(8, 0)
+            default: break;
+        }
+#undef GPX_RFF5
     }
+    // several feature tiles per draw (n > 128), or the witness (x_rff = 1): round 3's kernel
     if (dk == dp && dp <= 32) {
         hipLaunchKernelGGL(k_rff_mfma<true>, grid, dim3(GEMM_THREADS), ldsb, s, Wt, bt, tt, S, nfb, n, d, dp, dk, bias, Xc,
                            M, vals);

@@ -2,7 +2,7 @@
 import os, sys, json, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for wl in ('d', 'e'):
-    for v in (1, 0, 1, 0):
+    for v in (1, 0, 1, 0):      # 1 = the round-3 kernel, 0 = the default (round 5)
         out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', wl, '--steps', '4', '--warmup', '1',
                               '--no-cpu-baseline', '--opt', 'x_rff=%d' % v], capture_output=True, text=True)
         try:
