@@ -115,9 +115,11 @@ int gpx_version(void);
  *              workgroups for the diagonal blocks and the two tiles between consecutive ones, everything else as
  *              throughput work from ONE ticketed, dependency-checked list; kernels_chol_tg.hip) for fits of "chol_tg_min" (default 12) to
  *              "chol_tg_max" (default 160) 128-blocks; 0: the stream schedule above.  Bit-identical factors either way.  Tuning / diagnostics:
- *              "chol_tg_chunks" (k-chunk sizes counted back from the pivot as decimal digits, default 12489 = 1, 2, 4, 8, 16, 16, ..: the digit 9 stands for 16 blocks),
+ *              "chol_tg_chunks" (k-chunk sizes counted back from the pivot as decimal digits, default 12499 = 1, 2, 4, 16, 16, ..: the digit 9 stands for 16 blocks),
  *              "chol_tg_nap" (longest pause of a waiting workgroup between two looks at its dependencies, in units of 64
  *              clocks: 8, 16 (default), 32, 64 or 127),
+ *              "chol_tg_db" (-1, default: up to "chol_tg_db_max" = 112 blocks every workgroup has its compute unit to itself with two
+ *              k-step images of LDS and the workers run the double-buffered k-loop; 0 / 1: never / always),
  *              "chol_tg_side" (workgroups reserved for the critical tiles, default 8), "chol_tg_grid" (workgroups launched,
  *              0 = by size), "chol_tg_isolate" (1, default: the critical workgroups keep their compute units to themselves),
  *              "chol_tg_tmo_ms" (bound of every spin, default 2000: on expiry the fit re-runs on the stream schedule and

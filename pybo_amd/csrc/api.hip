@@ -295,10 +295,12 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
         if (!strcmp(name, "chol_tg") || !strcmp(name, "chol_tg_chunks") || !strcmp(name, "chol_tg_side") ||
             !strcmp(name, "chol_tg_grid") || !strcmp(name, "chol_tg_trace") || !strcmp(name, "chol_tg_tmo_ms") ||
             !strcmp(name, "chol_tg_min") || !strcmp(name, "chol_tg_max") || !strcmp(name, "chol_tg_isolate") ||
-            !strcmp(name, "chol_tg_nap")) {
+            !strcmp(name, "chol_tg_nap") || !strcmp(name, "chol_tg_db") || !strcmp(name, "chol_tg_db_max")) {
             if (value < -1 || value > 1000000000) return fail(h, GPX_EARG, "chol_tg*: out of range");
             const char* sub = name + 7;
             if (*sub == 0) { if (value != 0 && value != 1) return fail(h, GPX_EARG, "chol_tg must be 0 or 1"); h->chol_tg = (int)value; }
+            else if (!strcmp(sub, "_db")) h->tg_db = (value < 0) ? -1 : (value != 0 ? 1 : 0);
+            else if (!strcmp(sub, "_db_max")) h->tg_db_max = (int)std::max<int64_t>(0, value);
             else if (!strcmp(sub, "_nap")) h->tg_nap = (int)std::max<int64_t>(0, std::min<int64_t>(127, value));
             else if (!strcmp(sub, "_chunks")) h->tg_chunks = (int)value;
             else if (!strcmp(sub, "_side")) h->tg_side = (int)value;

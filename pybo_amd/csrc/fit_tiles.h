@@ -478,7 +478,8 @@ __device__ __forceinline__ void panel_solve16_body(const double* __restrict__ U,
 }
 
 
-template <bool AG = false, int PRIO = 1>
+// DB: `smem` holds two k-step images and the workgroup has its compute unit to itself (gemm_tile_128_d)
+template <bool AG = false, int PRIO = 1, bool DB = false>
 __device__ __forceinline__ void syrk_tile(const double* __restrict__ R, double* __restrict__ S, int64_t Np, int kb0,
                                           int kb1, int I, int J, double* smem) {
     const int64_t i0 = (int64_t)I * NB, j0 = (int64_t)J * NB;
@@ -486,7 +487,8 @@ __device__ __forceinline__ void syrk_tile(const double* __restrict__ R, double* 
     d4 acc[4][4];
     double* tile = S + i0 * Np + j0;
     tile128_load<AG>(acc, tile, Np);
-    gemm_tile_128_g<PRIO, true>(acc, R + i0, Np, R + j0, Np, kb0 * NB, kb1 * NB, smem);
+    if constexpr (DB) gemm_tile_128_d<PRIO, true>(acc, R + i0, Np, R + j0, Np, kb0 * NB, kb1 * NB, smem);
+    else gemm_tile_128_g<PRIO, true>(acc, R + i0, Np, R + j0, Np, kb0 * NB, kb1 * NB, smem);
     tile128_store<AG>(acc, tile, Np);
 }
 

@@ -21,6 +21,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace gpx {
 
@@ -294,6 +295,118 @@ __device__ __forceinline__ void gemm_tile_128_s(d4 (&acc)[4][4], const double* _
             __syncthreads();
         }
     }
+}
+
+// The k-loop for a workgroup that has its compute unit to ITSELF (round 5: the task-graph factorisation's workers up to 72
+// blocks -- one workgroup per CU, LDS 2 x 72 KB).  A lone workgroup on the single-buffer loops above runs at 0.68 of the matrix
+// peak (scripts/sweep_phase: mode 256): barrier - LDS write - barrier stands exposed in every k-step and nobody fills it.
+// Here the k-step of 32 goes through TWO LDS buffers: while the MFMAs of step t read buffer t & 1, the registers holding tile
+// t + 1 are written to the other buffer two 16-byte pieces per MFMA group, and each register is refilled at once with its piece
+// of tile t + 2 -- every global load has a whole step to arrive, every LDS write hides behind 16 MFMAs, ONE barrier per step.
+// Same arithmetic in the same order as the other loops: bit-identical results.  smem: 2 x GEMM_LDS_F64 doubles.
+template <int PRIO = 1, bool NEGA = false>
+__device__ __forceinline__ void gemm_tile_128_d(d4 (&acc)[4][4], const double* __restrict__ A, int64_t lda,
+                                                const double* __restrict__ B, int64_t ldb, int k_lo, int k_hi,
+                                                double* smem) {
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int w = t >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int lrow = w;
+    const int lcol = lane * 2;
+    d2 ra[8], rb[8];
+    const int nk = (k_hi - k_lo) / BK32;
+    if (nk <= 0) return;
+    const char* Abase = reinterpret_cast<const char*>(A + (int64_t)k_lo * lda);
+    const char* Bbase = reinterpret_cast<const char*>(B + (int64_t)k_lo * ldb);
+    const int voA = (int)(((int64_t)lrow * lda + lcol) * 8), voB = (int)(((int64_t)lrow * ldb + lcol) * 8);
+    const int soA = (int)(4 * lda * 8), soB = (int)(4 * ldb * 8);
+    const int fr = lane & 15, fk = lane >> 4;
+    // tile 0 -> buffer 0, tile 1 -> registers
+    {
+        __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)Abase, 0, -1, 0x00020000);
+        __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)Bbase, 0, -1, 0x00020000);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            ra[p] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rA, voA, p * soA, 0));
+            rb[p] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rB, voB, p * soB, 0));
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            *reinterpret_cast<d2*>(smem + (lrow + 4 * p) * LDT + lcol) = NEGA ? -ra[p] : ra[p];
+            *reinterpret_cast<d2*>(smem + BK32 * LDT + (lrow + 4 * p) * LDT + lcol) = rb[p];
+        }
+        Abase += (int64_t)BK32 * lda * 8;
+        Bbase += (int64_t)BK32 * ldb * 8;
+        if (nk > 1) {
+            __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)Abase, 0, -1, 0x00020000);
+            __amdgpu_buffer_rsrc_t rB1 = __builtin_amdgcn_make_buffer_rsrc((void*)Bbase, 0, -1, 0x00020000);
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                ra[p] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rA1, voA, p * soA, 0));
+                rb[p] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rB1, voB, p * soB, 0));
+            }
+            Abase += (int64_t)BK32 * lda * 8;
+            Bbase += (int64_t)BK32 * ldb * 8;
+        }
+    }
+    __syncthreads();
+    if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
+    // one k-step; W1: tile kt + 1 exists (its registers go to the other buffer), W2: tile kt + 2 exists (registers refilled).
+    // Compile-time flags: with run-time tests around the writes and loads every MFMA group became a basic block of its own
+    // and nothing overlapped (0.65 instead of 0.73 of peak alone on a CU).
+    auto step = [&](int kt, auto w1_, auto w2_) {
+        constexpr bool W1 = decltype(w1_)::value, W2 = decltype(w2_)::value;
+        double* cur = smem + (kt & 1) * GEMM_LDS_F64;
+        double* nxt = smem + ((kt + 1) & 1) * GEMM_LDS_F64;
+        const double* as = cur + wm * 64 + fr;
+        const double* bs = cur + BK32 * LDT + wn * 64 + fr;
+        __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)Abase, 0, -1, 0x00020000);
+        __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)Bbase, 0, -1, 0x00020000);
+        double a[2][4], b[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[0][i] = as[fk * LDT + i * 16];
+            b[0][i] = bs[fk * LDT + i * 16];
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK32 / 4; ++kk) {
+            if (kk + 1 < BK32 / 4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a[(kk + 1) & 1][i] = as[((kk + 1) * 4 + fk) * LDT + i * 16];
+                    b[(kk + 1) & 1][i] = bs[((kk + 1) * 4 + fk) * LDT + i * 16];
+                }
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);      // the LDS reads of group kk + 1,
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);     // the 16 MFMAs of group kk,
+            if (W1) {                                               // piece kk of tile kt + 1 into the other buffer ...
+                *reinterpret_cast<d2*>(nxt + (lrow + 4 * kk) * LDT + lcol) = NEGA ? -ra[kk] : ra[kk];
+                *reinterpret_cast<d2*>(nxt + BK32 * LDT + (lrow + 4 * kk) * LDT + lcol) = rb[kk];
+                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+            }
+            if (W2) {                                               // ... and its registers refilled with tile kt + 2
+                ra[kk] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rA, voA, kk * soA, 0));
+                rb[kk] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rB, voB, kk * soB, 0));
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+            }
+        }
+        if (W2) {
+            Abase += (int64_t)BK32 * lda * 8;
+            Bbase += (int64_t)BK32 * ldb * 8;
+        }
+        __syncthreads();               // buffer kt & 1 has been read by everyone, the other one is complete
+    };
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) step(kt, std::true_type{}, std::true_type{});
+    if (kt + 1 < nk) { step(kt, std::true_type{}, std::false_type{}); ++kt; }
+    step(kt, std::false_type{}, std::false_type{});
+    if (PRIO) __builtin_amdgcn_s_setprio(PRIO - 1);
 }
 
 // element coordinates of accumulator register acc[i][j][r] inside the 128x128 tile

@@ -57,8 +57,10 @@ struct gpx_handle {
     int chol_tg = 1;              // 1 (default): task-graph kernel for fits of >= tg_min blocks; 0: the stream schedule
     int tg_min = 12;              // smallest number of 128-blocks the task-graph kernel is used for (N = 1536: 0.67 against 0.72 ms; at N = 1024 the stream schedule still wins, 0.43 against 0.46)
     int tg_max = 160;             // ... and the largest (from N = 24576 on the stream schedule is 1-2 % faster: both throughput-bound)
-    int tg_chunks = 0;            // chunk sizes counted back from the pivot, as decimal digits (0 = default 12489: 1, 2, 4, 8, 16, 16, ..)
+    int tg_chunks = 0;            // chunk sizes counted back from the pivot, as decimal digits (0 = default 12499: 1, 2, 4, 16, 16, ..)
     int tg_nap = 0;               // longest polling pause of a waiting workgroup in units of 64 clocks (0 = default 16; round 4 until late: 127)
+    int tg_db = -1;               // -1 (default): the double-buffered workers (one workgroup per CU, 2 x 72 KB of LDS) up to tg_db_max blocks; 0 / 1: never / always
+    int tg_db_max = 112;          // (N = 12288: 13.04 against 13.38 ms; N = 16384: 27.6 against 27.2: two workgroups per CU win there)
     int tg_side = 0;              // workgroups reserved for the two critical tiles per block (0 = default 8)
     int tg_grid = 0;              // workgroups launched (0 = by size, bounded by residency)
     int tg_isolate = 1;           // the critical workgroups keep their compute units to themselves (full grids only)

@@ -69,7 +69,7 @@ struct TgArgs {
 // then diag[nPad], quad[nPad], solved[2 nPad], seq[nP * nP], and per compute unit (key = xcc | se | sh | cu, 12 bits)
 // the number of workgroups that have started there and the role of the first one.
 // Default chunks (sweeps in profiles/r04_chol_taskgraph.txt): 1, 2, 4, 8, 16, 16, .. blocks counted back from the pivot.
-constexpr int TG_DEFAULT_CHUNKS = 12489;
+constexpr int TG_DEFAULT_CHUNKS = 12499;      // (round 5, with the double-buffered workers: 1, 2, 4, 16, 16, .. -- N = 8192: 4.79 against 4.88 ms for 1, 2, 4, 8, 16, ..)
 constexpr int TG_LOG_CAP = 1024, TG_LOG_WGS = 1024;
 constexpr int TG_NPIECE = 6;          // pieces of the critical update of a diagonal tile
 constexpr int TG_CTL_ABORT = 32, TG_CTL_HEAD = 64, TG_CTL_BASE = 192, TG_CU_KEYS = 4096;
@@ -162,15 +162,18 @@ __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, T
     }
 }
 
-constexpr int TG_LDS_F64 = GEMM_LDS_F64 + 8;        // + the task in hand (2), flags (2), the held ticket (20 bytes)
-// The workgroup's LDS: the tile engine's buffer (the diagonal kernel's panels fit inside) + a slot for the task in hand.
-// File scope, so that the role bodies below can be separate (non-inlined) functions with their own register allocation
-// and still address it with ds_* instructions: inlined into one kernel body the roles spilled 319 VGPRs.
-__shared__ __attribute__((aligned(16))) double tg_smem[TG_LDS_F64];
+// The workgroup's LDS (dynamic: the size is the launch's): 8 doubles of control words -- the task in hand (2), role / flags
+// (2), the held ticket (20 bytes) -- then the tile engine's buffer: ONE k-step image (72 KB; two workgroups per CU; the
+// diagonal kernel's panels fit inside) or TWO (144 KB: a workgroup alone on its CU runs the double-buffered k-loop,
+// gemm_tile_128_d).  File scope, so that the role bodies below can be separate (non-inlined) functions with their own register
+// allocation and still address it with ds_* instructions: inlined into one kernel body the roles spilled 319 VGPRs.
+constexpr int TG_CTL_F64 = 8;
+extern __shared__ __attribute__((aligned(16))) double tg_smem[];
+#define tg_buf (tg_smem + TG_CTL_F64)
 
 // The last dependency of a task in hand (every thread calls; thread 0 polls): both flags >= need.  false: abort.
 __device__ __forceinline__ bool tg_wait_flags(const TgArgs& a, const int* f0, const int* f1, int need) {
-    int* code = reinterpret_cast<int*>(tg_smem + GEMM_LDS_F64 + 2);
+    int* code = reinterpret_cast<int*>(tg_smem + 2);
     if (threadIdx.x == 0) {
         int ok = 1;
         const long long t0 = wall_clock64();
@@ -327,9 +330,9 @@ __device__ __forceinline__ T* uni(T* p) { return reinterpret_cast<T*>(uni64(rein
 __device__ __forceinline__ void tg_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __noinline__ void tg_role_diag(const TgArgs& a) {
-    double* Pn = tg_smem;                          // 2 x 16 x PFP
-    double* Ud = tg_smem + 2 * 16 * PFP;           // 256
-    int* code = reinterpret_cast<int*>(tg_smem + GEMM_LDS_F64 + 2);
+    double* Pn = tg_buf;                           // 2 x 16 x PFP
+    double* Ud = tg_buf + 2 * 16 * PFP;            // 256
+    int* code = reinterpret_cast<int*>(tg_smem + 2);
     int& sflag = code[1];
     const int t = threadIdx.x;
     const int nP = a.nP, npad = tg_npad(nP);
@@ -367,17 +370,18 @@ __device__ __noinline__ void tg_role_diag(const TgArgs& a) {
     }
 }
 
+template <bool DB>
 __device__ __noinline__ void tg_do_upd(const TgArgs& a, int k0, int k1, int I, int J) {
     // (arguments of a non-inlined function travel in VGPRs: tell the compiler they are wave-uniform)
     k0 = __builtin_amdgcn_readfirstlane(k0); k1 = __builtin_amdgcn_readfirstlane(k1);
     I = __builtin_amdgcn_readfirstlane(I); J = __builtin_amdgcn_readfirstlane(J);
-    syrk_tile<true, 2>(uni(a.R), uni(a.S), (int64_t)uni64((unsigned long long)a.Np), k0, k1, I, J, tg_smem);
+    syrk_tile<true, 2, DB>(uni(a.R), uni(a.S), (int64_t)uni64((unsigned long long)a.Np), k0, k1, I, J, tg_buf);
 }
 __device__ __noinline__ bool tg_do_trsm(const TgArgs& a, int p, int cb) {
     p = __builtin_amdgcn_readfirstlane(p); cb = __builtin_amdgcn_readfirstlane(cb);
     __builtin_amdgcn_s_setprio(3);
     const int* diag = uni(a.ctl) + TG_CTL_BASE;
-    return panel_solve16_lds(a, uni(a.U), uni(a.S), uni(a.R), (int64_t)uni64((unsigned long long)a.Np), p, cb, tg_smem, diag);
+    return panel_solve16_lds(a, uni(a.U), uni(a.S), uni(a.R), (int64_t)uni64((unsigned long long)a.Np), p, cb, tg_buf, diag);
 }
 __device__ __noinline__ bool tg_do_updq(const TgArgs& a, int k0, int k1, int I, int q) {
     k0 = __builtin_amdgcn_readfirstlane(k0); k1 = __builtin_amdgcn_readfirstlane(k1);
@@ -388,12 +392,15 @@ __device__ __noinline__ bool tg_do_updq(const TgArgs& a, int k0, int k1, int I, 
 }
 template <int Q>
 __device__ __noinline__ int tg_take_call(const TgArgs& a, TgTask& out, int lane) {
-    return tg_take<Q>(a, out, lane, reinterpret_cast<TgHeld*>(tg_smem + GEMM_LDS_F64 + 4));
+    return tg_take<Q>(a, out, lane, reinterpret_cast<TgHeld*>(tg_smem + 4));
 }
 
+// DB: the launch gives every workgroup two k-step images of LDS (one workgroup per CU): the workers' tile updates run the
+// double-buffered k-loop.
+template <bool DB>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
-    TgTask* cur = reinterpret_cast<TgTask*>(tg_smem + GEMM_LDS_F64);           // 16 bytes
-    int* code = reinterpret_cast<int*>(tg_smem + GEMM_LDS_F64 + 2);             // [0] take result / role, [1] potrf's sflag
+    TgTask* cur = reinterpret_cast<TgTask*>(tg_smem);           // 16 bytes
+    int* code = reinterpret_cast<int*>(tg_smem + 2);             // [0] take result / role, [1] potrf's sflag
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int nP = a.nP, npad = tg_npad(nP);
     int* ctl = a.ctl;
@@ -407,7 +414,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
         // critical solves twice their time (profiles/r04_chol_taskgraph.txt).  The second workgroup to start on a CU
         // looks up what the first one became and leaves at once if that is a critical role (a grid of two workgroups
         // per CU has no third one waiting to take the slot).
-        reinterpret_cast<TgHeld*>(tg_smem + GEMM_LDS_F64 + 4)->have = 0;
+        reinterpret_cast<TgHeld*>(tg_smem + 4)->have = 0;
         const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf;
         const int key = (int)((xcc << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf));
         int* cu_cnt = sq + nP * nP;
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
         long long ts = 0;
         if (a.trace && t == 0) { ts = wall_clock64(); prof[1] += ts - tprev; }
         if (tk.type == TG_UPD) {
-            tg_do_upd(a, tk.k0, tk.k1, tk.I, tk.J);
+            tg_do_upd<DB>(a, tk.k0, tk.k1, tk.I, tk.J);
         } else if (tk.type == TG_TRSM) {
             if (!tg_do_trsm(a, tk.I, 2 * (tk.J - tk.I - 1) + tk.aux)) break;
         } else {
@@ -594,7 +601,7 @@ struct TgCache {                 // per handle (gpx_handle::tg): device copies o
     int64_t cap_ctl = 0;
     long long* dtrace = nullptr;
     int64_t cap_trace = 0;
-    int max_resident = 0;
+    int max_resident = 0, max_resident_db = 0;
 };
 
 void tg_free(gpx_handle* h) {
@@ -659,15 +666,24 @@ bool launch_cholesky_tg(gpx_handle* h) {
         if (hipMalloc((void**)&c->dtrace, (size_t)ntrace * 8) != hipSuccess) { (void)hipGetLastError(); return false; }
         c->cap_trace = ntrace;
     }
-    if (c->max_resident == 0) {
+    // DB: every workgroup gets two k-step images of LDS (one workgroup per CU by its LDS alone) and the workers run the
+    // double-buffered k-loop -- the choice of the sizes that ran one workgroup per CU anyway (up to 72 blocks: latency-bound;
+    // option chol_tg_db: -1 auto, 0 / 1 force)
+    const bool db = (h->tg_db < 0) ? (nP <= h->tg_db_max) : (h->tg_db != 0);
+    const size_t lds_bytes = (size_t)(TG_CTL_F64 + (db ? 2 : 1) * GEMM_LDS_F64) * sizeof(double);
+    int& max_res = db ? c->max_resident_db : c->max_resident;
+    if (max_res == 0) {
         int nb = 0;
         hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_chol_tg, GEMM_THREADS, 0) != hipSuccess || nb < 1 ||
-            hipGetDeviceProperties(&prop, h->device) != hipSuccess) {
+        const void* fn = db ? (const void*)k_chol_tg<true> : (const void*)k_chol_tg<false>;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess ||
+            (db ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_chol_tg<true>, GEMM_THREADS, lds_bytes)
+                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_chol_tg<false>, GEMM_THREADS, lds_bytes)) != hipSuccess ||
+            nb < 1 || hipGetDeviceProperties(&prop, h->device) != hipSuccess) {
             (void)hipGetLastError();
             return false;
         }
-        c->max_resident = nb * prop.multiProcessorCount;
+        max_res = nb * prop.multiProcessorCount;
     }
     (void)hipMemsetAsync(h->dflag, 0, sizeof(int), s);
     (void)hipMemsetAsync(c->dctl, 0, (size_t)nctl * sizeof(int), s);
@@ -678,10 +694,10 @@ bool launch_cholesky_tg(gpx_handle* h) {
     // up to ~72 blocks the factorisation is bound by the latency of its dependent tasks, not by throughput: ONE workgroup
     // per compute unit runs every task ~1.6x faster (N = 4096: 1.91 against 2.23 ms, N = 8192: 5.40 against 5.98; from
     // N = 12288 on two per CU win: 13.6 against 14.4 ms)
-    if (nP <= 72) want = std::min<int64_t>(want, c->max_resident / 2 + 8);
+    if (!db && nP <= 72) want = std::min<int64_t>(want, max_res / 2 + 8);
     if (h->tg_grid > 0) want = h->tg_grid;
-    const int grid = (int)std::max<int64_t>(2 + nside, std::min<int64_t>(want, c->max_resident));
-    const bool grid_is_full = grid >= c->max_resident;      // two workgroups per CU everywhere: isolation has a meaning
+    const int grid = (int)std::max<int64_t>(2 + nside, std::min<int64_t>(want, max_res));
+    const bool grid_is_full = !db && grid >= max_res;      // two workgroups per CU everywhere: isolation has a meaning
     TgArgs a;
     std::memset(&a, 0, sizeof a);
     a.S = h->dS; a.R = h->dR; a.T = h->dT; a.U = h->dU;
@@ -693,7 +709,8 @@ bool launch_cholesky_tg(gpx_handle* h) {
     a.trace = h->tg_trace ? c->dtrace : nullptr;
     a.tasklog = nlog ? c->dtrace + 20 * (int64_t)nP + 8 * 1024 + 16 : nullptr;
     a.tmo = (long long)(h->tg_tmo_ms > 0 ? h->tg_tmo_ms : 2000) * 100000LL;
-    hipLaunchKernelGGL(k_chol_tg, dim3((unsigned)grid), dim3(GEMM_THREADS), 0, s, a);
+    if (db) hipLaunchKernelGGL(k_chol_tg<true>, dim3((unsigned)grid), dim3(GEMM_THREADS), lds_bytes, s, a);
+    else hipLaunchKernelGGL(k_chol_tg<false>, dim3((unsigned)grid), dim3(GEMM_THREADS), lds_bytes, s, a);
     h->diag_inv_pending = true;
     h->tg_launched = true;
     return true;

@@ -398,6 +398,79 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_probe(const double* __restr
     }
 }
 
+// the library's double-buffered loop for a workgroup alone on its compute unit (2 x 72 KB of LDS), same tile map
+template <int WHICH>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_probe_lone(const double* __restrict__ U, int64_t Np,
+                                                                const double* __restrict__ Ks, int64_t ldk, int NT,
+                                                                const double* __restrict__ avec, double* __restrict__ Qp,
+                                                                double* __restrict__ Pp, int64_t ldp, int sm) {
+    extern __shared__ __attribute__((aligned(16))) double dsm[];
+    const int nP = (int)(Np / TB);
+    int mt, nt, mt2 = -1;
+    {
+        const int b = blockIdx.x;
+        const int x = b & 7, q = b >> 3;
+        const int SN = 64 / sm;
+        const int per = (NT + 7) / 8;
+        const int hper = (per + SN - 1) / SN;
+        const int s = q >> 6, r = q & 63;
+        const int G = s / hper, H = s - G * hper;
+        const int i = G * sm + r / SN;
+        const int ln = H * SN + (r - (r / SN) * SN);
+        nt = x * per + ln;
+        mt = nP - 1 - i;
+        if (ln >= per || nt >= NT || i > mt) return;
+        if (i < mt) mt2 = i;
+    }
+#pragma unroll 1
+    for (int ph = 0; ph < 2; ++ph) {
+        if (ph == 1) {
+            if (mt2 < 0) break;
+            mt = mt2;
+            __syncthreads();
+        }
+        const int64_t m0 = (int64_t)mt * TB, n0 = (int64_t)nt * TB;
+        d4 acc[4][4];
+        acc_zero(acc);
+        if (WHICH == 0) gemm_tile_128_d<1>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, dsm);
+        else if (WHICH == 1) gemm_tile_128_g<1>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, dsm);
+        else gemm_tile_128_s<1>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, dsm);
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int wm = w >> 1, wn = w & 1;
+        double qs[4], ps[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double q = 0.0, p = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double v = acc[i][j][r];
+                    q = fma(v, v, q);
+                    p = fma(v, avec[m0 + wm * 64 + i * 16 + (lane >> 4) + 4 * r], p);
+                }
+            q += __shfl_xor(q, 16); p += __shfl_xor(p, 16);
+            q += __shfl_xor(q, 32); p += __shfl_xor(p, 32);
+            qs[j] = q; ps[j] = p;
+        }
+        double* red = dsm;
+        if (lane < 16) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = wn * 64 + j * 16 + lane;
+                red[(wm * TB + c) * 2 + 0] = qs[j];
+                red[(wm * TB + c) * 2 + 1] = ps[j];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < TB) {
+            const int c = threadIdx.x;
+            Qp[(int64_t)mt * ldp + n0 + c] = red[c * 2] + red[(TB + c) * 2];
+            Pp[(int64_t)mt * ldp + n0 + c] = red[c * 2 + 1] + red[(TB + c) * 2 + 1];
+        }
+    }
+}
+
 __global__ void k_fill(double* p, size_t n, unsigned seed, double scale) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -456,6 +529,16 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < reps + 2; ++rep) {
         CK(hipMemsetAsync(pa.cu_cnt, 0, 4096 * 4, 0));
         hipEventRecord(e0);
+        if (mode >= 900000) {       // 900000 + which: the library loops with ONE workgroup per CU (which: 0 double-buffered, 1 single-buffer BK32, 2 the sweep's)
+            const size_t lb = (size_t)2 * GEMM_LDS_F64 * 8;
+            const int which = mode - 900000;
+            if (which == 0) { hipFuncSetAttribute((const void*)k_probe_lone<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                hipLaunchKernelGGL(k_probe_lone<0>, dim3(nblk), dim3(GEMM_THREADS), lb, 0, U, Np, Ks, cols, NT, a, Qp, Pp, cols, 8); }
+            else if (which == 1) { hipFuncSetAttribute((const void*)k_probe_lone<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                hipLaunchKernelGGL(k_probe_lone<1>, dim3(nblk), dim3(GEMM_THREADS), lb, 0, U, Np, Ks, cols, NT, a, Qp, Pp, cols, 8); }
+            else { hipFuncSetAttribute((const void*)k_probe_lone<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb);
+                hipLaunchKernelGGL(k_probe_lone<2>, dim3(nblk), dim3(GEMM_THREADS), lb, 0, U, Np, Ks, cols, NT, a, Qp, Pp, cols, 8); }
+        } else
         switch (mode) {
 #define C(M) case M: launch<M>(nblk, U, Np, Ks, cols, NT, a, Qp, Pp, cols, pa); break;
             C(0) C(1) C(512) C(8192) C(8704) C(32768) C(40960) C(41472) C(4194304) C(4202496) C(4203008) C(4235776) C(4235777) C(48) C(304)
