@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X datasheet fp64 matrix (= fp64 vector) peak, dense
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILE = 'r04_pmc_traffic.json'
+PMC_TRAFFIC_FILES = ('r05_pmc_traffic.json', 'r05_pmc_traffic_b.json')      # (N = 8192 and config B's N = 2048 launch geometries)
 
 
 def hartmann6(X):
@@ -1021,7 +1021,7 @@ def main():
             out['collective'] = dict(rccl_info, exchange=args.exchange)
         # what the 1-GPU stage times predict for this rank count (the replicated fit is the serial term)
         try:
-            one = json.load(open(os.path.join(ROOT, 'profiles', 'r04_bench_%s.json' % w['name'])))
+            one = json.load(open(os.path.join(ROOT, 'profiles', 'r05_bench_%s.json' % w['name'])))
             st1 = one['stage_ms_per_step_rank0']
             if w['acq'] == 'thompson':
                 par = st1.get('rff', 0.0)
@@ -1035,7 +1035,7 @@ def main():
                 units = 'candidates'
                 share = 1.0 / world
             out['scaling_model'] = {'formula': 'serial (replicated fit) + parallel (%s sharded) x share + exchange (~0.1 ms)' % units,
-                                    'from': 'profiles/r04_bench_%s.json (1 GPU)' % w['name'], 'serial_ms': ser,
+                                    'from': 'profiles/r05_bench_%s.json (1 GPU)' % w['name'], 'serial_ms': ser,
                                     'parallel_ms_1gpu': par, 'share': share, 'predicted_ms_per_step': ser + par * share + 0.1,
                                     'measured_ms_per_step': sec * 1e3}
         except Exception:
@@ -1044,14 +1044,16 @@ def main():
             launches = tm['sweep_trmm_launches']
             # HBM traffic per launch comes from the committed PMC passes (bench.py cannot collect
             # counters itself); only reported when this run's launch geometry is the profiled one
-            traffic = None
-            try:
-                pmc = json.load(open(os.path.join(ROOT, 'profiles', PMC_TRAFFIC_FILE)))
-                cols = tm['sweep_trmm_flop'] / max(launches, 1) / (float(N) * N)
-                if pmc['config']['Np'] == Np_ and abs(cols - pmc['config']['cols_per_launch']) < 1:
-                    traffic = pmc['k_sweep_trmm']['traffic_bytes_per_launch']
-            except Exception:
-                traffic = None
+            traffic, traffic_file = None, None
+            for fname in PMC_TRAFFIC_FILES:
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, 'profiles', fname)))
+                    cols = tm['sweep_trmm_flop'] / max(launches, 1) / (float(N) * N)
+                    if pmc['config']['Np'] == Np_ and abs(cols - pmc['config']['cols_per_launch']) < 1:
+                        traffic, traffic_file = pmc['k_sweep_trmm']['traffic_bytes_per_launch'], fname
+                        break
+                except Exception:
+                    continue
             ach = tm['sweep_trmm_flop'] / (tm['sweep_trmm'] * 1e-3) / 1e12
             out['roofline'] = {'kernel': 'k_sweep_trmm', 'bound': 'mfma', 'achieved': ach,
                                'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -1059,7 +1061,7 @@ def main():
                                'traffic_unit': 'bytes/launch',
                                'traffic_source': 'profile: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE) of this '
                                                  'launch geometry, committed as profiles/%s -- a profile-time '
-                                                 'constant, NOT collected during this run' % PMC_TRAFFIC_FILE,
+                                                 'constant, NOT collected during this run' % (traffic_file or '(none for this geometry)'),
                                'launches': int(launches),
                                # the shader clock the kernel's own workgroups measured during these launches (s_memtime over
                                # s_memrealtime ticks, accumulated by the kernel): the peak above is quoted at 2400 MHz
