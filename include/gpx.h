@@ -77,6 +77,13 @@ int gpx_version(void);
  *              super-tiles + schedule 6.  Every setting produces bit-identical results.
  *          "super_m" = rows of the XCD super-tile of 64 workgroups (8 -> 8x8 default, 4 -> 4x16, ...).
  *          "eager_inverse" = 1: form the triangular inverse inside gpx_fit instead of on first use.
+ *          "trtri_ahead" = 1 (default): when the inverse is certain or likely to follow a fit -- "eager_inverse", gpx_fit_stage
+ *              with stage 3, or the previous model's inverse was formed -- the part of the inversion that needs only the leading
+ *              block rows of the factor (the leading group's whole recursion and the top level's first product) is queued on a side
+ *              stream behind a gate that opens when those rows are final, and runs on the compute units the factorisation's
+ *              chain-bound tail leaves idle; the first use then finds only the trailing group and one product left.  Same kernels,
+ *              same results bit for bit.  Applies to the task-graph factorisation with one workgroup per compute unit, from
+ *              "trtri_ahead_min" (default 24) 128-blocks on.  0: the inversion starts when it is asked for.
  *          "grad_form": the form of gpx_predict / gpx_ensemble_predict WITH gradients.  0 (default) = auto: a call with
  *              M = 1 point -- every call of the reference's single-seed refinement [pybo/solvers/lbfgs.py:56-58] -- takes
  *              ONE pass over the triangular inverse T with 1 + d right-hand sides, ds2/dx_j = -2 (T k).(T dk/dx_j), when
@@ -342,7 +349,8 @@ int gpx_topk_allgather(gpx_comm *c, int64_t n, int64_t index_offset, int64_t k, 
  * alone (part of [7]) [14] its algorithmic double-precision lane operations: S n (d + 20) M per launch [15] fits whose
  * task-graph factorisation gave up and were re-run on the stream schedule [16] the shader clock in MHz sustained by the
  * sweep_trmm launches since the last reset (their workgroups' s_memtime over s_memrealtime ticks; 0 without a launch)
- * [17] the same for the Thompson sweep kernel (k_rff_mfma5: it is power-bound and clocks lower).
+ * [17] the same for the Thompson sweep kernel (k_rff_mfma5: it is power-bound and clocks lower) [18] inversions whose leading
+ * part ran behind the factorisation (option "trtri_ahead"): for those [2] holds only what was left after the factor was done.
  * Synchronises the stream.  Returns the number of slots written (<= n). */
 int gpx_timers(gpx_handle *h, double *out, int n, int reset);
 /* DIAGNOSTIC (option "chol_tg_trace" = 1): wall-clock stamps (100 MHz ticks) the task-graph factorisation of the last fit

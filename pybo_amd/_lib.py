@@ -97,7 +97,7 @@ KERNELS = {'se': 0, 'matern5': 1, 'matern3': 2, 'matern1': 3}
 ACQ = {'ei': 0, 'pi': 1, 'ucb': 2, 'mean': 3}
 TIMER_NAMES = ['gram', 'cholesky', 'trtri', 'alpha', 'cross_gram', 'sweep_trmm', 'acq_topk', 'rff',
                'sweep_trmm_launches', 'sweep_trmm_flop', 'copies', 'append', 'rank1', 'rff_sweep', 'rff_sweep_ops',
-               'chol_fallbacks', 'sweep_sclk_mhz', 'rff_sclk_mhz']
+               'chol_fallbacks', 'sweep_sclk_mhz', 'rff_sclk_mhz', 'trtri_ahead']
 TOPK_MAX = 4096
 
 _lib = None

@@ -234,6 +234,7 @@ extern "C" int gpx_destroy(gpx_handle* h) {
     if (!h) return GPX_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
+    if (h->ahead_top != 0 && h->stream2) { hipStreamSynchronize(h->stream2); h->ahead_top = 0; }
     tg_free(h);
     for (auto& p : h->pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : h->pool) hipEventDestroy(e);
@@ -310,6 +311,12 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             else if (!strcmp(sub, "_isolate")) h->tg_isolate = (int)value;
             else if (!strcmp(sub, "_max")) h->tg_max = (int)std::max<int64_t>(1, value);
             else h->tg_min = (int)std::max<int64_t>(1, value);
+            return GPX_OK;
+        }
+        if (!strcmp(name, "trtri_ahead") || !strcmp(name, "trtri_ahead_min")) {
+            if (value < 0 || value > 1000000) return fail(h, GPX_EARG, "trtri_ahead*: out of range");
+            if (name[11] == 0) h->trtri_ahead = (value != 0) ? 1 : 0;
+            else h->trtri_ahead_min = (int)std::max<int64_t>(4, value);
             return GPX_OK;
         }
         if (!strcmp(name, "chol_fuse")) {
@@ -487,6 +494,13 @@ static int alloc_model(gpx_handle* h, int64_t Np, int64_t d) {
 // The triangular inverse T = R^-T (and U, a, alpha) is formed on FIRST USE, not by the fit: the Thompson path
 // (gpx_rff_gram / gpx_rff_sweep, pybo/policies/simple.py:44-48) never reads it, and it is a quarter of a fit
 // at N = 16384.  Every entry point that reads T, U, a or alpha calls this first.
+// the side stream's share of an inversion that nobody asked for in the end (a new fit, a teardown): wait for it and forget it
+static void settle_ahead(gpx_handle* h) {
+    if (h->ahead_top == 0) return;
+    (void)hipStreamSynchronize(h->stream2);
+    h->ahead_top = 0;
+}
+
 int gpx::ensure_inverse(gpx_handle* h) {
     if (h->stage >= 3) return GPX_OK;
     if (h->stage < 2) return fail(h, GPX_ESTATE, "model is not fitted");
@@ -516,6 +530,8 @@ static int fit_core(gpx_handle* h, const double* dX, int64_t N, int64_t d, const
     HIPCHK(h, hipSetDevice(h->device));
     const int64_t Np = (N + NB - 1) / NB * NB;
     spec_cancel(h);              // an announced observation belongs to the model that is being replaced
+    settle_ahead(h);             // ... and so does an inversion still running ahead on the side stream
+    const bool prev_inverse_used = h->stage >= 3;
     ++h->gen;
     h->fitted = false;
     h->stage = 0;
@@ -554,12 +570,19 @@ static int fit_core(gpx_handle* h, const double* dX, int64_t N, int64_t d, const
             // warm loop runs on the third one) are created HERE, in the cold fit, whichever factorisation runs: created
             // on first use by gpx_append_begin they cost the first warm iteration ~18 ms (three HSA queues)
             if (h->Np / NB > (h->chol_w ? h->chol_w : 4) && (rc = ensure_side_streams(h))) return rc;
+            // the inverse's leading part may ride behind the factorisation when the inverse is certain to follow (stage 3,
+            // eager_inverse) or likely to (the previous model's was formed: an acquisition loop refits and sweeps)
+            h->want_ahead = (stage >= 3 || h->eager_inverse || prev_inverse_used) && !h->refine_inverse;
             const bool tg = h->chol_tg && h->x_skip == 0 && h->x_bg <= 0 && h->Np / NB >= h->tg_min && h->Np / NB <= h->tg_max && launch_cholesky_tg(h);
             if (!tg) launch_cholesky(h);
         }
         int flag = 0;
         HIPCHK(h, hipMemcpyAsync(&flag, h->dflag, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipStreamSynchronize(s));
+        if (h->ahead_top != 0 && flag != 0) {      // not positive definite: what the side stream is doing is of no use
+            (void)hipStreamSynchronize(h->stream2);
+            h->ahead_top = 0;
+        }
         if (h->tg_launched && flag == 0 && tg_abort_code(h) == 2) {
             // a spin of the persistent kernel gave up (the device is shared with something that kept its workgroups from
             // becoming resident): S is half-consumed -- rebuild it and run the stream schedule.  Loud, and counted.
@@ -568,6 +591,7 @@ static int fit_core(gpx_handle* h, const double* dX, int64_t N, int64_t d, const
             fprintf(stderr, "libgpx: the task-graph factorisation gave up waiting (N = %lld); re-running the stream schedule\n",
                     (long long)N);
             h->tg_launched = false;
+            if (h->ahead_top != 0) { (void)hipStreamSynchronize(h->stream2); h->ahead_top = 0; }
             launch_gram_sym(s, h->dXs, N, Np, (int)d, kid, rho, sn2, h->dS);
             if (h->Np / NB > (h->chol_w ? h->chol_w : 4) && (rc = ensure_side_streams(h))) return rc;
             launch_cholesky(h);

@@ -20,7 +20,7 @@ constexpr int PEND_MAX = 8;   // appended observations per pass of the sweep-cac
 
 enum Timer {
     T_GRAM = 0, T_CHOL, T_TRTRI, T_ALPHA, T_XGRAM, T_TRMM, T_ACQ, T_RFF, T_NLAUNCH, T_FLOP, T_COPY, T_APPEND,
-    T_RANK1, T_RFFSWEEP, T_RFFOPS, T_TGFALL, T_SCLK, T_RFFCLK, T_COUNT
+    T_RANK1, T_RFFSWEEP, T_RFFOPS, T_TGFALL, T_SCLK, T_RFFCLK, T_AHEAD, T_COUNT
 };
 
 struct EventPair { hipEvent_t a, b; int slot; };
@@ -74,6 +74,10 @@ struct gpx_handle {
     // model state
     bool fitted = false;
     int stage = 0;               // 0 none, 1 gram, 2 chol (fitted; T/U/a/alpha not formed yet), 3 + inverse
+    int ahead_top = 0;               // != 0: the leading part of the inversion has been enqueued on stream2 behind the factorisation's gate (ev_rest marks its end)
+    bool want_ahead = false;         // fit_core -> launch_cholesky_tg: the inverse follows at once (stage 3 / eager_inverse)
+    int trtri_ahead = 1;             // option: allow that (task-graph factorisation with one workgroup per CU only)
+    int trtri_ahead_min = 24;        // ... from this many blocks on
     bool diag_inv_pending = false;   // the diagonal blocks of T / U hold 16x16 inverses only (k_trtri_diag128 due)
     bool eager_inverse = false;  // option: form the inverse inside the fit (timing experiments)
     int grad_form = 0;           // option: predict-with-gradients form (0 auto: one pass for a single point, 1 two passes, 2 one pass)
@@ -195,6 +199,8 @@ int64_t tg_trace_copy(gpx_handle* h, long long* out, int64_t n);
 void tg_free(gpx_handle* h);
 int64_t tg_tasks_copy(int nP, int chunks, int16_t* out, int64_t cap, int64_t* counts);
 void launch_trtri(gpx_handle* h);      // R, diag blocks -> T, U (uses S as workspace)
+void launch_trtri_ahead(gpx_handle* h, hipStream_t s, int top);   // the part that needs the leading `top` block rows only
+int trtri_top(int nP);
 void launch_refine_inverse(gpx_handle* h, double* tmp);   // option refine_inverse: one Newton step on T / U (tmp: Np^2 scratch)
 void launch_alpha(gpx_handle* h);      // a = T (y - bias); alpha = U a
 void launch_kinv_diag(gpx_handle* h, double* out);   // out[i] = [K^-1]_ii = sum_m U[i][m]^2

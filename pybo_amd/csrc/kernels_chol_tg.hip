@@ -591,6 +591,31 @@ int64_t tg_tasks_copy(int nP, int chunks, int16_t* out, int64_t cap, int64_t* co
     return tot;
 }
 
+// The gate of the inversion's leading part (launch_trtri_ahead): ONE wave on a side stream that leaves when block rows
+// 0 .. top - 1 of R are final -- the diagonal block top - 1 is factored and block row top - 1 is solved in every block column to
+// its right -- i.e. when everything the kernels queued behind it read has been stored (write-through) by the running
+// factorisation.  An abort ends it at once (the caller discards what follows); its own time-out raises the abort word, so that a
+// gate that gave up can never let kernels through onto a factor that is not there yet.
+__global__ __launch_bounds__(64) void k_tg_gate(int* ctl, int nP, int top, long long tmo) {
+    const int npad = tg_npad(nP);
+    const int* dd = ctl + TG_CTL_BASE;
+    const int* sv = dd + 2 * npad;
+    const int lane = threadIdx.x;
+    const long long t0 = wall_clock64();
+    for (unsigned spins = 0;; ++spins) {
+        if (ldi(ctl + TG_CTL_ABORT) != 0) return;
+        bool ok = ldi(dd + top - 1) != 0;
+        for (int j = 2 * top + lane; ok && j < 2 * nP; j += 64) ok = ldi(sv + j) >= top;
+        if (__all(ok)) return;
+        __builtin_amdgcn_s_sleep(64);
+        if ((spins & 63) == 63 && wall_clock64() - t0 > tmo) {
+            if (lane == 0) sti(ctl + TG_CTL_ABORT, 2);
+            return;
+        }
+    }
+}
+
+
 struct TgCache {                 // per handle (gpx_handle::tg): device copies of the tables and the control block
     int nP = 0, chunks = 0;
     TgTask* dq = nullptr;
@@ -709,10 +734,23 @@ bool launch_cholesky_tg(gpx_handle* h) {
     a.trace = h->tg_trace ? c->dtrace : nullptr;
     a.tasklog = nlog ? c->dtrace + 20 * (int64_t)nP + 8 * 1024 + 16 : nullptr;
     a.tmo = (long long)(h->tg_tmo_ms > 0 ? h->tg_tmo_ms : 2000) * 100000LL;
+    // the inversion's leading part rides on the side stream, behind a gate (one workgroup per CU only: a tile-engine workgroup
+    // of another kernel cannot move in next to the critical roles -- 144 + 72 KB of LDS do not fit a CU)
+    const int top = trtri_top(nP);
+    const bool ahead = h->want_ahead && h->trtri_ahead != 0 && db && nP >= h->trtri_ahead_min && h->trtri_left == 0 && h->stream2 &&
+                       h->dT != nullptr && hipEventRecord(h->ev_far, s) == hipSuccess;
     if (db) hipLaunchKernelGGL(k_chol_tg<true>, dim3((unsigned)grid), dim3(GEMM_THREADS), lds_bytes, s, a);
     else hipLaunchKernelGGL(k_chol_tg<false>, dim3((unsigned)grid), dim3(GEMM_THREADS), lds_bytes, s, a);
     h->diag_inv_pending = true;
     h->tg_launched = true;
+    h->ahead_top = 0;
+    if (ahead) {
+        (void)hipStreamWaitEvent(h->stream2, h->ev_far, 0);        // the control block is zeroed
+        hipLaunchKernelGGL(k_tg_gate, dim3(1), dim3(64), 0, h->stream2, c->dctl, nP, top, a.tmo);
+        launch_trtri_ahead(h, h->stream2, top);
+        (void)hipEventRecord(h->ev_rest, h->stream2);
+        h->ahead_top = top;
+    }
     return true;
 }
 

@@ -595,10 +595,10 @@ void launch_cholesky(gpx_handle* h) {
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trtri_gemm1(const double* __restrict__ R,
                                                                  const double* __restrict__ T,
                                                                  double* __restrict__ W, int64_t Np,
-                                                                 int nP, int hb) {
+                                                                 int nP, int hb, int g0) {
     // K-extent of a tile is (hb - bn) blocks: bn is the SLOW grid index so tiles are dispatched heaviest
     // first (LPT) -- with bn fastest, some CU slots drew two K = hb*128 tiles and set the makespan
-    const int g = blockIdx.z, bm = blockIdx.x, bn = blockIdx.y;
+    const int g = blockIdx.z + g0, bm = blockIdx.x, bn = blockIdx.y;
     const int r1 = g * 2 * hb, r2 = r1 + hb;
     if (r2 >= nP) return;
     const int size2 = min(hb, nP - r2);
@@ -620,9 +620,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trtri_gemm1(const double* _
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trtri_gemm2(const double* __restrict__ W,
                                                                  double* __restrict__ T,
                                                                  double* __restrict__ U, int64_t Np,
-                                                                 int nP, int hb) {
+                                                                 int nP, int hb, int g0) {
     // K-extent is (bm + 1) blocks: heaviest (largest bm) first
-    const int g = blockIdx.z, bm = hb - 1 - (int)blockIdx.y, bn = blockIdx.x;
+    const int g = blockIdx.z + g0, bm = hb - 1 - (int)blockIdx.y, bn = blockIdx.x;
     const int r1 = g * 2 * hb, r2 = r1 + hb;
     if (r2 >= nP) return;
     const int size2 = min(hb, nP - r2);
@@ -654,8 +654,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trtri_gemm2(const double* _
 __global__ __launch_bounds__(GEMM64_THREADS) void k_trtri_gemm1_64(const double* __restrict__ R,
                                                                   const double* __restrict__ T,
                                                                   double* __restrict__ W, int64_t Np, int nP,
-                                                                  int hb) {
-    const int g = blockIdx.z, bm = blockIdx.x, bn = blockIdx.y;        // 64-row / 64-column tile indices
+                                                                  int hb, int g0) {
+    const int g = blockIdx.z + g0, bm = blockIdx.x, bn = blockIdx.y;        // 64-row / 64-column tile indices
     const int r1 = g * 2 * hb, r2 = r1 + hb;
     if (r2 >= nP) return;
     const int size2 = min(hb, nP - r2);
@@ -674,8 +674,8 @@ __global__ __launch_bounds__(GEMM64_THREADS) void k_trtri_gemm1_64(const double*
 __global__ __launch_bounds__(GEMM64_THREADS) void k_trtri_gemm2_64(const double* __restrict__ W,
                                                                   double* __restrict__ T,
                                                                   double* __restrict__ U, int64_t Np, int nP,
-                                                                  int hb) {
-    const int g = blockIdx.z, bm = 2 * hb - 1 - (int)blockIdx.y, bn = blockIdx.x;   // heaviest (largest bm) first
+                                                                  int hb, int g0) {
+    const int g = blockIdx.z + g0, bm = 2 * hb - 1 - (int)blockIdx.y, bn = blockIdx.x;   // heaviest (largest bm) first
     const int r1 = g * 2 * hb, r2 = r1 + hb;
     if (r2 >= nP) return;
     const int size2 = min(hb, nP - r2);
@@ -808,37 +808,80 @@ __global__ __launch_bounds__(GEMM64_THREADS) void k_trtri_gemm2r_64(const double
         }
 }
 
+// level hb over the groups [g0, g0 + ng): `which` = 1 the first product (W = L_21 T_11), 2 the second (T_21 = -T_22 W), 3 both.
+// The tile size follows the WHOLE level (ngroups_all), so that a level computed in two parts runs the same kernels.
+static void trtri_level(gpx_handle* h, hipStream_t s, int hb, int g0, int ng, int which) {
+    const int64_t Np = h->Np;
+    const int nP = (int)(Np / NB);
+    if (ng <= 0) return;
+    const int ngroups_all = (nP + 2 * hb - 1) / (2 * hb);
+    if ((int64_t)hb * hb * ngroups_all >= 1024) {         // enough 128x128 tiles to fill the chip twice over
+        dim3 grid((unsigned)hb, (unsigned)hb, (unsigned)ng);
+        if (which & 1) hipLaunchKernelGGL(k_trtri_gemm1, grid, dim3(GEMM_THREADS), 0, s, h->dR, h->dT, h->dS, Np, nP, hb, g0);
+        if (which & 2) hipLaunchKernelGGL(k_trtri_gemm2, grid, dim3(GEMM_THREADS), 0, s, h->dS, h->dT, h->dU, Np, nP, hb, g0);
+    } else {
+        dim3 grid((unsigned)(2 * hb), (unsigned)(2 * hb), (unsigned)ng);
+        if (which & 1) hipLaunchKernelGGL(k_trtri_gemm1_64, grid, dim3(GEMM64_THREADS), 0, s, h->dR, h->dT, h->dS, Np, nP, hb, g0);
+        if (which & 2) hipLaunchKernelGGL(k_trtri_gemm2_64, grid, dim3(GEMM64_THREADS), 0, s, h->dS, h->dT, h->dU, Np, nP, hb, g0);
+    }
+}
+
+// the top level's split point: the largest power of two below nP (block rows [0, top) | [top, nP))
+int trtri_top(int nP) {
+    int hb = 1;
+    while (2 * hb < nP) hb *= 2;
+    return hb;
+}
+
+// The part of the inversion that needs only the LEADING `top` block rows of R (and R's block columns right of them, which are
+// final as soon as block row top - 1 is solved): the diagonal 128-inverses and every level inside the leading group, then the
+// top level's first product W = L_21 T_11 -- five eighths of the inversion's flop when nP is a power of two.  Enqueued on a side
+// stream behind the task-graph factorisation's gate (kernels_chol_tg.hip: tg_launch_gate), it runs on the compute units the
+// factorisation's chain-bound tail leaves idle.  W lands in the strictly LOWER blocks of S, T / U in their leading blocks:
+// nothing the factorisation still reads or writes.  launch_trtri then does the rest (h->ahead_top != 0).
+void launch_trtri_ahead(gpx_handle* h, hipStream_t s, int top) {
+    const int64_t Np = h->Np;
+    hipLaunchKernelGGL(k_trtri_diag128, dim3((unsigned)top), dim3(256), 0, s, h->dR, h->dT, h->dU, Np, 0, h->dflag);
+    for (int hb = 1; hb < top; hb *= 2) trtri_level(h, s, hb, 0, top / (2 * hb), 3);
+    trtri_level(h, s, top, 0, 1, 1);
+}
+
 void launch_trtri(gpx_handle* h) {
     const int64_t Np = h->Np;
     const int nP = (int)(Np / NB);
     hipStream_t s = h->stream;
+    if (h->ahead_top > 0) {        // the leading part is on its way (launch_trtri_ahead): wait for it, do the trailing group and the top level's second product
+        const int top = h->ahead_top;
+        h->ahead_top = 0;
+        h->tacc[T_AHEAD] += 1.0;
+        (void)hipStreamWaitEvent(s, h->ev_rest, 0);
+        hipLaunchKernelGGL(k_trtri_diag128, dim3((unsigned)(nP - top)), dim3(256), 0, s, h->dR, h->dT, h->dU, Np, top, h->dflag);
+        h->diag_inv_pending = false;
+        for (int hb = 1; hb < top; hb *= 2) {
+            const int g0 = top / (2 * hb), ngroups_all = (nP + 2 * hb - 1) / (2 * hb);
+            trtri_level(h, s, hb, g0, ngroups_all - g0, 3);
+        }
+        trtri_level(h, s, top, 0, 1, 2);
+        return;
+    }
     if (h->diag_inv_pending) {     // all diagonal 128-blocks at once, off the factorisation's critical path
         hipLaunchKernelGGL(k_trtri_diag128, dim3((unsigned)nP), dim3(256), 0, s, h->dR, h->dT, h->dU, Np, 0, h->dflag);
         h->diag_inv_pending = false;
     }
-    const bool left = h->trtri_left != 0;          // re-associated recursion (default)
+    const bool left = h->trtri_left != 0;          // re-associated recursion (option, off by default)
     if (left && nP > 1)
         hipLaunchKernelGGL(k_transpose_offdiag, dim3((unsigned)(Np / 32), (unsigned)(Np / 32)), dim3(32, 32), 0, s, h->dR, Np, h->dS);
     for (int hb = 1; hb < nP; hb *= 2) {
         const int ngroups = (nP + 2 * hb - 1) / (2 * hb);
-        if ((int64_t)hb * hb * ngroups >= 1024) {         // enough 128x128 tiles to fill the chip twice over
+        if (!left) { trtri_level(h, s, hb, 0, ngroups, 3); continue; }
+        if ((int64_t)hb * hb * ngroups >= 1024) {
             dim3 grid((unsigned)hb, (unsigned)hb, (unsigned)ngroups);
-            if (left) {
-                hipLaunchKernelGGL(k_trtri_gemm1r, grid, dim3(GEMM_THREADS), 0, s, h->dU, h->dS, Np, nP, hb);
-                hipLaunchKernelGGL(k_trtri_gemm2r, grid, dim3(GEMM_THREADS), 0, s, h->dS, h->dT, h->dU, Np, nP, hb);
-            } else {
-                hipLaunchKernelGGL(k_trtri_gemm1, grid, dim3(GEMM_THREADS), 0, s, h->dR, h->dT, h->dS, Np, nP, hb);
-                hipLaunchKernelGGL(k_trtri_gemm2, grid, dim3(GEMM_THREADS), 0, s, h->dS, h->dT, h->dU, Np, nP, hb);
-            }
+            hipLaunchKernelGGL(k_trtri_gemm1r, grid, dim3(GEMM_THREADS), 0, s, h->dU, h->dS, Np, nP, hb);
+            hipLaunchKernelGGL(k_trtri_gemm2r, grid, dim3(GEMM_THREADS), 0, s, h->dS, h->dT, h->dU, Np, nP, hb);
         } else {
             dim3 grid((unsigned)(2 * hb), (unsigned)(2 * hb), (unsigned)ngroups);
-            if (left) {
-                hipLaunchKernelGGL(k_trtri_gemm1r_64, grid, dim3(GEMM64_THREADS), 0, s, h->dU, h->dS, Np, nP, hb);
-                hipLaunchKernelGGL(k_trtri_gemm2r_64, grid, dim3(GEMM64_THREADS), 0, s, h->dS, h->dT, h->dU, Np, nP, hb);
-            } else {
-                hipLaunchKernelGGL(k_trtri_gemm1_64, grid, dim3(GEMM64_THREADS), 0, s, h->dR, h->dT, h->dS, Np, nP, hb);
-                hipLaunchKernelGGL(k_trtri_gemm2_64, grid, dim3(GEMM64_THREADS), 0, s, h->dS, h->dT, h->dU, Np, nP, hb);
-            }
+            hipLaunchKernelGGL(k_trtri_gemm1r_64, grid, dim3(GEMM64_THREADS), 0, s, h->dU, h->dS, Np, nP, hb);
+            hipLaunchKernelGGL(k_trtri_gemm2r_64, grid, dim3(GEMM64_THREADS), 0, s, h->dS, h->dT, h->dU, Np, nP, hb);
         }
     }
 }
@@ -1224,7 +1267,8 @@ static int loglik_batch_chunk(gpx_handle* h, int64_t B, const double* hyp, doubl
     bool big = h->chol_tg && nP >= 16 && nP >= h->tg_min && nP <= h->tg_max;
     if (big) {
         double *sS = h->dS, *sR = h->dR, *sT = h->dT, *sU = h->dU;
-        const bool s_pending = h->diag_inv_pending, s_launched = h->tg_launched;
+        const bool s_pending = h->diag_inv_pending, s_launched = h->tg_launched, s_want = h->want_ahead;
+        h->want_ahead = false;
         for (int64_t b = 0; b < B && big; ++b) {
             h->dS = bS + b * bs; h->dR = bR + b * bs; h->dT = nullptr; h->dU = bS + b * bs;
             const bool ok = launch_cholesky_tg(h);
@@ -1232,7 +1276,7 @@ static int loglik_batch_chunk(gpx_handle* h, int64_t B, const double* hyp, doubl
             if (!ok || hipStreamSynchronize(s) != hipSuccess || tg_abort_code(h) == 2) big = false;
         }
         h->dS = sS; h->dR = sR; h->dT = sT; h->dU = sU;
-        h->diag_inv_pending = s_pending; h->tg_launched = s_launched;
+        h->diag_inv_pending = s_pending; h->tg_launched = s_launched; h->want_ahead = s_want;
         if (!big) {
             (void)hipGetLastError();
             (void)hipMemsetAsync(bflag, 0, (size_t)B * sizeof(int), s);
