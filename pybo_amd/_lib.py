@@ -720,6 +720,7 @@ class Engine(object):
             self.last_chol_tasklog = out[20 * nblocks + 8192 + 16:].reshape(1024, 1024, 4).copy()
         out = out[:20 * nblocks]
         t0 = out[0]
+        self.last_chol_trace_origin = int(t0)      # raw ticks of the first stamp (the task log's records are raw)
         diag = (out[:4 * nblocks].reshape(nblocks, 4)[:, :3] - t0) / 100.0
         crit = out[4 * nblocks:].reshape(nblocks, 8, 2).astype(np.float64)
         crit = np.where(crit > 0, (crit - t0) / 100.0, np.nan)

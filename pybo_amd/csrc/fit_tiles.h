@@ -288,7 +288,12 @@ __device__ __forceinline__ void pf16_panel(d4 (&accA)[8], d4 (&accB)[8], int cA,
 }
 
 // returns false if the looked-ahead factorisation hit a non-positive pivot (sflag is set for the other waves)
-template <int JB, bool AG>
+// STEP (the task-graph kernel's role C): the workgroup publishes a flag after every step, for a consumer that follows the
+// factorisation 16 rows at a time.  The flag of step JB promises panel JB (rows 16 JB .. 16 JB + 15 of R right of the diagonal
+// tile) and the inverses T_d(0 .. JB): every wave leaves this phase with those stores drained -- the wave that has just
+// factored the NEXT tile keeps only that tile's own stores in flight (vector-memory stores complete in order; they are
+// covered by the next flag, or by the block's final one).
+template <int JB, bool AG, bool STEP = false>
 __device__ __forceinline__ void pf16_trail(d4 (&accA)[8], d4 (&accB)[8], int cA, int cB, double* __restrict__ Pn,
                                            double* __restrict__ Ud, volatile int* sflag, int w, int lane, int64_t p0,
                                            int* flag, double* __restrict__ Rg, double* __restrict__ Tg,
@@ -330,6 +335,14 @@ __device__ __forceinline__ void pf16_trail(d4 (&accA)[8], d4 (&accB)[8], int cA,
             }
         }
     }
+    if constexpr (STEP) {
+        if (w == OWN_NX) {
+            if (Tg) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
 }
 
 // DBG (scripts/potrf_bench.hip only): wall-clock stamps of the phases go to `dbg` (thread 0)
@@ -337,11 +350,13 @@ __device__ __forceinline__ void pf16_trail(d4 (&accA)[8], d4 (&accB)[8], int cA,
 // T may be NULL (the batched path needs U_d only and keeps it in the dead diagonal blocks of S).
 // The body of k_potrf16 (one workgroup of 256 threads; Pn / Ud / sflag are the caller's LDS).  sflag != 0 afterwards:
 // a non-positive pivot (recorded in *flag) or an earlier block's failure.
-template <bool DBG, bool AG = false>
+// STEP: after step JB thread 0 stores step0 + JB + 1 into *cstep (agent scope; see pf16_trail)
+template <bool DBG, bool AG = false, bool STEP = false>
 __device__ __forceinline__ void potrf16_body(const double* __restrict__ S, double* __restrict__ R,
                                              double* __restrict__ T, double* __restrict__ U, int64_t Np, int p,
                                              int* __restrict__ flag, long long* __restrict__ dbg,
-                                             double* __restrict__ Pn, double* __restrict__ Ud, int& sflag) {
+                                             double* __restrict__ Pn, double* __restrict__ Ud, int& sflag,
+                                             int* cstep = nullptr, int step0 = 0) {
     if (*flag != 0) {                     // an earlier block already failed (uniform)
         if (threadIdx.x == 0) sflag = 1;
         __syncthreads();
@@ -391,8 +406,9 @@ __device__ __forceinline__ void potrf16_body(const double* __restrict__ S, doubl
     if (!sflag) {                                                                                           \
         pf16_panel<JB, AG>(accA, accB, cA, cB, Pn, Ud, lane, p0, R, Np);                                        \
         __syncthreads();                                                                                    \
-        pf16_trail<JB, AG>(accA, accB, cA, cB, Pn, Ud, &sflag, w, lane, p0, flag, R, T, U, Np);                 \
+        pf16_trail<JB, AG, STEP>(accA, accB, cA, cB, Pn, Ud, &sflag, w, lane, p0, flag, R, T, U, Np);           \
         __syncthreads();                                                                                    \
+        if (STEP && t == 0) __hip_atomic_store(cstep, step0 + JB + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
     }                                                                                                       \
     if (DBG && t == 0) dbg[2 + JB] = wall_clock64();
     GPX_PF_STEP(0)

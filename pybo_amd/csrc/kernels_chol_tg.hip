@@ -46,7 +46,7 @@
 
 namespace gpx {
 
-enum { TG_TRSM = 1, TG_UPD = 2, TG_UPDQ = 3 };
+enum { TG_TRSM = 1, TG_UPD = 2, TG_UPDQ = 3, TG_SHADOW = 4 };
 struct TgTask { int16_t type, I, J, k0, k1, ord, aux, rsv; };     // 16 bytes; aux = column half (TRSM) / piece (UPDQ)
 
 struct TgArgs {
@@ -58,6 +58,7 @@ struct TgArgs {
     const TgTask* q[2];          // 0: critical (role S), 1: the workers' list
     int n[2];
     int nside;
+    int shadow;                  // role S is three workgroups that follow the diagonal factorisation step by step (tg_role_s1 / s2 / u)
     int isolate;                 // the critical workgroups keep their compute units to themselves
     int nap;                     // longest pause between two looks at a waiting task's dependencies, in units of 64 clocks (8, 16, 32, 64 or 127)
     long long* trace;            // optional: [p][4] critical-path stamps, then [crit task][2]
@@ -69,10 +70,10 @@ struct TgArgs {
 // then diag[nPad], quad[nPad], solved[2 nPad], seq[nP * nP], and per compute unit (key = xcc | se | sh | cu, 12 bits)
 // the number of workgroups that have started there and the role of the first one.
 // Default chunks (sweeps in profiles/r04_chol_taskgraph.txt): 1, 2, 4, 8, 16, 16, .. blocks counted back from the pivot.
-constexpr int TG_DEFAULT_CHUNKS = 12499;      // (round 5, with the double-buffered workers: 1, 2, 4, 16, 16, .. -- N = 8192: 4.79 against 4.88 ms for 1, 2, 4, 8, 16, ..)
+constexpr int TG_DEFAULT_CHUNKS = 11249;      // 1, 1, 2, 4, 16, 16, ..: the two chunks next to the pivot are single block rows (the shadows' U0 / U, V / V2)
 constexpr int TG_LOG_CAP = 1024, TG_LOG_WGS = 1024;
 constexpr int TG_NPIECE = 6;          // pieces of the critical update of a diagonal tile
-constexpr int TG_CTL_ABORT = 32, TG_CTL_HEAD = 64, TG_CTL_BASE = 192, TG_CU_KEYS = 4096;
+constexpr int TG_CTL_ABORT = 32, TG_CTL_HEAD = 64, TG_CTL_STEP = 128, TG_CTL_XSTEP = 160, TG_CTL_XSTEP2 = 192, TG_CTL_XSTEP3 = 224, TG_CTL_BASE = 256, TG_CU_KEYS = 4096;
 __host__ __device__ inline int tg_npad(int nP) { return (nP + 31) / 32 * 32; }
 __host__ __device__ inline int tg_ctl_ints(int nP) { return TG_CTL_BASE + 4 * tg_npad(nP) + nP * nP + 2 * TG_CU_KEYS; }
 
@@ -356,7 +357,8 @@ __device__ __noinline__ void tg_role_diag(const TgArgs& a) {
         }
         __syncthreads();
         if (code[0] != 1) break;
-        potrf16_body<false, true>(a.S, a.R, a.T, a.U, a.Np, p, a.dflag, nullptr, Pn, Ud, sflag);
+        if (a.shadow) potrf16_body<false, true, true>(a.S, a.R, a.T, a.U, a.Np, p, a.dflag, nullptr, Pn, Ud, sflag, ctl + TG_CTL_STEP, 8 * p);
+        else potrf16_body<false, true>(a.S, a.R, a.T, a.U, a.Np, p, a.dflag, nullptr, Pn, Ud, sflag);
         tg_drain();
         __syncthreads();
         if (sflag) {
@@ -365,10 +367,529 @@ __device__ __noinline__ void tg_role_diag(const TgArgs& a) {
         }
         if (t == 0) {
             sti(dd + p, 1);
+            if (a.shadow) sti(ctl + TG_CTL_STEP, 8 * p + 8);
             if (a.trace) a.trace[4 * p + 2] = wall_clock64();
         }
     }
 }
+
+// ---- the shadows of the diagonal factorisation: roles S1, S2 and U ------------------------------------------------------
+// Between POTRF(p) and POTRF(p+1) lie the solve of tile (p, p+1) and the update of the diagonal tile (p+1, p+1) with it.
+// As tasks (two solve halves, six update pieces) they start from nothing when the diagonal block's flag goes up and cost
+// three hand-offs of 4-5 us on the critical path.  The shadows do both WHILE the diagonal block is being factored: role C
+// publishes a counter after each of its eight 16-row steps (potrf16_body, STEP), and three dedicated workgroups follow it:
+//   S1  advances the substitution of tile (p, p+1) by one step per flag -- x_jb = T_d(jb) s_jb, s_i -= R[jb, i]^T x_jb, the
+//       MFMAs of panel_solve16_lds in the same order -- and publishes its own counter per 16 solved rows;
+//   U   applies every 16 rows S1 has solved to the diagonal tile (p+1, p+1) (rank-16 update; k ascends 4 at a time as in the
+//       tile engines: bit-identical) and hands the tile to role C;
+//   S2  does S1's work for tile (p, p+2): the LAST update of tile (p+1, p+2) -- the right-hand side S1 needs one block later --
+//       waits for exactly this solve, and as a worker task it arrived when the next diagonal block was already done.
+// When the last step's flag arrives 7/8 of everything is done; what is left between two diagonal blocks is, per hop, one poll,
+// one 16-row load and a handful of MFMAs.  Operands travel global memory -> LDS without registers (global_load_lds_dwordx4,
+// rings of three 16-row panels, up to two steps ahead of the arithmetic when a shadow starts late and the flags are already
+// up); each wave counts the vector-memory operations it has issued since a panel's loads and waits with the matching vmcnt.
+// Wave w owns 32 columns of a solve (8 x 2 accumulator tiles), in U the diagonal tile's column tiles w and 7 - w (9 tiles).
+__device__ __forceinline__ int tg_peek(const int* f) { return __builtin_amdgcn_readfirstlane(ldi(f)); }
+__device__ __forceinline__ bool tg_wave_wait_ge(const TgArgs& a, const int* f, int need) {
+    const long long t0 = wall_clock64();
+    for (unsigned spins = 0; tg_peek(f) < need; ++spins) {
+        if (tg_peek(a.ctl + TG_CTL_ABORT) != 0) return false;
+        __builtin_amdgcn_s_sleep(1);
+        if ((spins & 255) == 255 && wall_clock64() - t0 > a.tmo) { sti(a.ctl + TG_CTL_ABORT, 2); return false; }
+    }
+    return true;
+}
+// wait until at most n (wave-uniform, never more than were really issued since) vector-memory operations are outstanding
+__device__ __forceinline__ void tg_vmcnt_le(int n) {
+    n = __builtin_amdgcn_readfirstlane(n);
+    if (n >= 21) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+    else if (n >= 17) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+    else if (n >= 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+    else if (n >= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (n >= 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if (n >= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (n >= 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (n >= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (n >= 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// 8-byte agent-scope accesses through a buffer descriptor: ONE lane-offset register per tile walk, everything else in SGPRs
+// (with 64-bit flat addresses the compiler precomputed one address pair per access and spilled them)
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tg_rsrc(const double* base, int64_t Np) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(base), 0, (int)(128 * Np * 8), 0x00020000);
+}
+__device__ __forceinline__ double tg_bload(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    union { u2v v; double d; } u;
+    u.v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 16);
+    return u.d;
+}
+__device__ __forceinline__ void tg_bstore(__amdgpu_buffer_rsrc_t rs, int voff, int soff, double x) {
+    union { u2v v; double d; } u;
+    u.d = x;
+    __builtin_amdgcn_raw_buffer_store_b64(u.v, rs, voff, soff, 16);
+}
+
+// tile i = 0 .. 8 of wave w in the diagonal tile: column tile w (rows 0 .. w), then column tile 7 - w (rows 0 .. 7 - w) -- the
+// same nine registers in every wave, the tile's position a wave-uniform number
+__device__ __forceinline__ void tg_sh_tile(int i, int w, int& r, int& c) {
+    const bool first = i <= w;
+    r = first ? i : i - w - 1;
+    c = first ? w : 7 - w;
+}
+constexpr int TG_SH_PAN = 16 * PFP;            // one staged panel (f64)
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+// a follower's view of the counter it follows, per wave (all wave-uniform)
+struct TgFollow {
+    int avail;            // steps of this block known to be published (0 .. 8)
+    int issued;           // steps whose loads have been issued
+    int vmi;              // vector-memory operations issued by this wave (an under-count is safe, an over-count is not)
+    int mark[8];          // vmi right after the loads of step jb
+};
+
+// S roles: panel jb = rows 16 jb .. 16 jb + 15 of R_pp (wave w: rows 4 w .. 4 w + 3, one 1024-byte row per instruction, lane l:
+// columns 2 l, 2 l + 1; nothing right of the diagonal tile in the last panel) and the 16 x 16 inverse T_d(jb)^T (32 lanes)
+__device__ __forceinline__ void tg_s_issue(int jb, const double* __restrict__ Rd, const double* __restrict__ Ud, int64_t Np,
+                                           double* __restrict__ lds, TgFollow& f) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = jb % 3;
+    double* pan = lds + b * TG_SH_PAN;
+    double* td = lds + 3 * TG_SH_PAN + b * 256;
+    if (jb < 7) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+            __builtin_amdgcn_global_load_lds(Rd + (int64_t)(16 * jb + 4 * w + rr) * Np + 2 * lane, (lds_ptr)(pan + (4 * w + rr) * PFP), 16, 0, 16);
+        f.vmi += 4;
+    }
+    if (lane < 32)
+        __builtin_amdgcn_global_load_lds(Ud + (int64_t)(16 * jb + 4 * w + (lane >> 3)) * Np + 16 * jb + 2 * (lane & 7), (lds_ptr)(td + 64 * w), 16, 0, 16);
+    f.vmi += 1;
+    f.mark[jb] = f.vmi;
+}
+// U role: the 16 rows S1 solved in step jb (rows 16 jb .. of tile (p, p+1))
+__device__ __forceinline__ void tg_u_issue(int jb, const double* __restrict__ Xg, int64_t Np, double* __restrict__ lds, TgFollow& f) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* xb = lds + (jb & 3) * TG_SH_PAN;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+        __builtin_amdgcn_global_load_lds(Xg + (int64_t)(16 * jb + 4 * w + rr) * Np + 2 * lane, (lds_ptr)(xb + (4 * w + rr) * PFP), 16, 0, 16);
+    f.vmi += 4;
+    f.mark[jb] = f.vmi;
+}
+
+// The loads of step JB are on their way (issued here if they were not: that may wait for the counter), then landed in every
+// wave's share (barrier); then, the counter permitting, the next two steps' loads go out.  SROLE: tg_s_issue, else tg_u_issue.
+// DRAIN: this wave's earlier stores are complete as well before the barrier (S1 publishes the previous step behind it).
+// (Steps are issued in order, so the step to issue is always one of JB, JB + 1, JB + 2: compile-time slots of `mark`.)
+// V role: the 16 rows S1 and S2 solved in step jb of the PREVIOUS block row (tiles (p-1, p) and (p-1, p+1)): two panels
+__device__ __forceinline__ void tg_v_issue(int jb, const double* __restrict__ Ag, const double* __restrict__ Bg, int64_t Np,
+                                           double* __restrict__ lds, TgFollow& f) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* pa = lds + (2 * (jb & 1)) * TG_SH_PAN;
+    double* pb = pa + TG_SH_PAN;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        __builtin_amdgcn_global_load_lds(Ag + (int64_t)(16 * jb + 4 * w + rr) * Np + 2 * lane, (lds_ptr)(pa + (4 * w + rr) * PFP), 16, 0, 16);
+        __builtin_amdgcn_global_load_lds(Bg + (int64_t)(16 * jb + 4 * w + rr) * Np + 2 * lane, (lds_ptr)(pb + (4 * w + rr) * PFP), 16, 0, 16);
+    }
+    f.vmi += 8;
+    f.mark[jb] = f.vmi;
+}
+
+// KIND: 0 = a solve shadow (tg_s_issue), 1 = U (tg_u_issue), 2 = V (tg_v_issue)
+template <int J, int KIND>
+__device__ __forceinline__ void tg_issue(TgFollow& f, double* __restrict__ lds, const double* __restrict__ A0,
+                                         const double* __restrict__ A1, int64_t Np) {
+    if constexpr (J < 8) {
+        if constexpr (KIND == 0) tg_s_issue(J, A0, A1, Np, lds, f);
+        else if constexpr (KIND == 1) tg_u_issue(J, A0, Np, lds, f);
+        else tg_v_issue(J, A0, A1, Np, lds, f);
+        f.issued = J + 1;
+    }
+}
+// The loads of step JB are on their way (issued here if they were not: that may wait for the counter -- for both counters
+// where a role follows two), then landed in every wave's share (barrier); then, the counter(s) permitting, the next steps'
+// loads go out (as far ahead as the role's LDS ring is deep).  DRAIN: this wave's earlier stores are complete as well before
+// the barrier (a publishing role announces the previous step behind it).
+// (Steps are issued in order, so the step to issue is always one of JB .. JB + 3: compile-time slots of `mark`.)
+__device__ __forceinline__ int tg_peek2(const int* c1, const int* c2) {
+    const int v = tg_peek(c1);
+    return c2 ? min(v, tg_peek(c2)) : v;
+}
+template <int JB, int KIND, bool DRAIN>
+__device__ __forceinline__ bool tg_follow(const TgArgs& a, const int* counter, const int* counter2, int base, TgFollow& f,
+                                          double* __restrict__ lds, const double* __restrict__ A0, const double* __restrict__ A1,
+                                          int64_t Np) {
+    // (the bookkeeping is wave-uniform: say so, or the compiler keeps it in vector registers and branches on exec masks)
+    f.avail = __builtin_amdgcn_readfirstlane(f.avail); f.issued = __builtin_amdgcn_readfirstlane(f.issued);
+    f.vmi = __builtin_amdgcn_readfirstlane(f.vmi);
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (f.issued == JB) {
+        if (f.avail <= JB) {
+            if (!tg_wave_wait_ge(a, counter, base + JB + 1)) return false;
+            if (counter2 && !tg_wave_wait_ge(a, counter2, base + JB + 1)) return false;
+            f.avail = min(8, tg_peek2(counter, counter2) - base);
+        }
+        tg_issue<JB, KIND>(f, lds, A0, A1, Np);
+    }
+    if constexpr (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else tg_vmcnt_le(f.vmi - __builtin_amdgcn_readfirstlane(f.mark[JB]));
+    __syncthreads();
+    constexpr int ahead = (KIND == 0) ? 2 : (KIND == 1 ? 3 : 1);     // rings of 3 (S: panel + inverse), 4 (U) and 2 x 2 (V) buffers
+    constexpr int lim = (JB + 1 + ahead < 8) ? JB + 1 + ahead : 8;
+    if (f.issued < lim) {
+        if (f.avail < lim) f.avail = max(f.avail, min(8, tg_peek2(counter, counter2) - base));
+        if (f.issued == JB + 1 && f.avail > JB + 1) tg_issue<JB + 1, KIND>(f, lds, A0, A1, Np);
+        if (ahead >= 2 && f.issued == JB + 2 && f.avail > JB + 2) tg_issue<JB + 2, KIND>(f, lds, A0, A1, Np);
+        if (ahead >= 3 && f.issued == JB + 3 && f.avail > JB + 3) tg_issue<JB + 3, KIND>(f, lds, A0, A1, Np);
+    }
+    return true;
+}
+
+// one step of a solve shadow: x_JB and the updates of the rows below it (panel_solve16_lds's MFMAs in the same order)
+template <int JB, int XCTR>
+__device__ __forceinline__ bool tg_s_step(const TgArgs& a, int p, TgFollow& f, d4 (&X)[8][2], double* __restrict__ lds,
+                                          const double* __restrict__ Rd, const double* __restrict__ Ud,
+                                          __amdgpu_buffer_rsrc_t rout, int vo, int64_t Np) {
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), g = lane >> 4, n = lane & 15;
+    if (!tg_follow<JB, 0, true>(a, a.ctl + TG_CTL_STEP, nullptr, 8 * p, f, lds, Rd, Ud, Np)) return false;
+    if (JB > 0 && t == 0) sti(a.ctl + XCTR, 8 * p + JB);      // rows 16 (JB - 1) .. are in memory
+    const double* pan = lds + (JB % 3) * TG_SH_PAN;
+    const double* td = lds + 3 * TG_SH_PAN + (JB % 3) * 256;
+    double ti[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) ti[kk] = td[(4 * kk + g) * 16 + n];
+    d4 xn[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        d4 x = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(ti[kk], X[JB][j][kk], x, 0, 0, 0);
+        xn[j] = -x;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tg_bstore(rout, vo, (int)((((16 * JB + 4 * q) * Np) + 32 * w + 16 * j) * 8), x[q]);
+    }
+    f.vmi += 8;
+    // (all fragments of the step first: left to itself the compiler waits for every LDS read right in front of its MFMA)
+#pragma unroll
+    for (int i0 = JB + 1; i0 < 8; i0 += 4) {
+        double af[4][4];
+#pragma unroll
+        for (int i = i0; i < i0 + 4 && i < 8; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) af[i - i0][kk] = pan[(4 * kk + g) * PFP + 16 * i + n];
+#pragma unroll
+        for (int i = i0; i < i0 + 4 && i < 8; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) X[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i - i0][kk], xn[j][kk], X[i][j], 0, 0, 0);
+    }
+    return true;
+}
+
+// S1 (off = 1, PUB) and S2 (off = 2): the solve of tile (p, p + off), p = 0, 1, ..
+template <int XCTR>
+__device__ __forceinline__ void tg_role_solve(const TgArgs& a, int off) {
+    constexpr int TSLOT = (XCTR == TG_CTL_XSTEP) ? 0 : (XCTR == TG_CTL_XSTEP2 ? 4 : -1);     // trace slots of S1 / S2
+    double* lds = tg_buf;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), g = lane >> 4, n = lane & 15;
+    const int nP = __builtin_amdgcn_readfirstlane(a.nP), npad = tg_npad(nP);
+    const int64_t Np = (int64_t)uni64((unsigned long long)a.Np);
+    double* R = uni(a.R);
+    const double* S = uni(a.S);
+    const double* U = uni(a.U);
+    int* ctl = uni(a.ctl);
+    int* dd = ctl + TG_CTL_BASE;
+    int* sv = dd + 2 * npad;
+    int* sq = sv + 2 * npad;
+    __builtin_amdgcn_s_setprio(3);
+    for (int p = 0; p + off < nP; ++p) {
+        const int ord = __builtin_amdgcn_readfirstlane((int)a.q[0][p].ord);
+        const int64_t p0 = (int64_t)p * NB, j0 = p0 + (int64_t)off * NB;
+        long long ts0 = 0, ts1 = 0;
+        if (a.trace && t == 0) ts0 = wall_clock64();
+        // the right-hand sides: tile (p, p + off) with every chunk applied
+        if (!tg_wave_wait_ge(a, sq + p * nP + p + off, ord)) return;
+        const __amdgpu_buffer_rsrc_t rin = tg_rsrc(S + p0 * Np + j0, Np), rout = tg_rsrc(R + p0 * Np + j0, Np);
+        const int vo = (int)((g * Np + n) * 8);
+        d4 X[8][2];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) X[r][j][q] = tg_bload(rin, vo, (int)((((16 * r + 4 * q) * Np) + 32 * w + 16 * j) * 8));
+        if (a.trace && t == 0) ts1 = wall_clock64();
+        const double* Rd = R + p0 * Np + p0;
+        const double* Ud = U + p0 * Np + p0;
+        TgFollow f;
+        f.avail = 0; f.issued = 0; f.vmi = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f.mark[i] = 0;
+        if (!tg_s_step<0, XCTR>(a, p, f, X, lds, Rd, Ud, rout, vo, Np)) return;
+        if (!tg_s_step<1, XCTR>(a, p, f, X, lds, Rd, Ud, rout, vo, Np)) return;
+        if (!tg_s_step<2, XCTR>(a, p, f, X, lds, Rd, Ud, rout, vo, Np)) return;
+        if (!tg_s_step<3, XCTR>(a, p, f, X, lds, Rd, Ud, rout, vo, Np)) return;
+        if (!tg_s_step<4, XCTR>(a, p, f, X, lds, Rd, Ud, rout, vo, Np)) return;
+        if (!tg_s_step<5, XCTR>(a, p, f, X, lds, Rd, Ud, rout, vo, Np)) return;
+        if (!tg_s_step<6, XCTR>(a, p, f, X, lds, Rd, Ud, rout, vo, Np)) return;
+        if (!tg_s_step<7, XCTR>(a, p, f, X, lds, Rd, Ud, rout, vo, Np)) return;
+        tg_drain();
+        __syncthreads();
+        if (t == 0) {
+            sti(ctl + XCTR, 8 * p + 8);
+            sti(sv + 2 * (p + off), p + 1);
+            sti(sv + 2 * (p + off) + 1, p + 1);
+            if (a.trace && TSLOT >= 0) {         // slots 0, 1 (S1) / 2, 3 (S2) of block row p: waiting for the right-hand sides, then the eight steps
+                long long* o = a.trace + 4 * nP + 2 * 8 * p + TSLOT;
+                o[0] = ts0; o[1] = ts1; o[2] = ts1; o[3] = wall_clock64();
+            }
+        }
+    }
+}
+__device__ __noinline__ void tg_role_s1(const TgArgs& a) { tg_role_solve<TG_CTL_XSTEP>(a, 1); }
+__device__ __noinline__ void tg_role_s2(const TgArgs& a) { tg_role_solve<TG_CTL_XSTEP2>(a, 2); }
+__device__ __noinline__ void tg_role_s3(const TgArgs& a) { tg_role_solve<TG_CTL_XSTEP3>(a, 3); }
+
+// acc(r, c) -= x_r^T x_c as acc += x_r^T (-x_c): the same products with the same signs as the tile engines' (-A) B
+template <int W>
+__device__ __forceinline__ void tg_u_mfma(d4 (&acc)[9], const double (&fb)[8][4]) {
+    double nb[2][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { nb[0][kk] = -fb[W][kk]; nb[1][kk] = -fb[7 - W][kk]; }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int r = (i <= W) ? i : i - W - 1, cs = (i <= W) ? 0 : 1;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(fb[r][kk], nb[cs][kk], acc[i], 0, 0, 0);
+    }
+}
+
+template <int JB>
+__device__ __forceinline__ bool tg_u_step(const TgArgs& a, const int* counter, int base, TgFollow& f, d4 (&acc)[9],
+                                          double* __restrict__ lds, const double* __restrict__ Xg, int64_t Np) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, n = lane & 15;
+    if (!tg_follow<JB, 1, false>(a, counter, nullptr, base, f, lds, Xg, nullptr, Np)) return false;
+    const double* xb = lds + (JB & 3) * TG_SH_PAN + g * PFP + n;
+    // every fragment of the 16 rows once (the A fragment of row tile r IS the B fragment of column tile r), then the 36 MFMAs;
+    // one body per wave so that a tile's fragments are registers chosen at compile time
+    double fb[8][4];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fb[r][kk] = xb[4 * kk * PFP + 16 * r];
+    if (w == 0) tg_u_mfma<0>(acc, fb);
+    else if (w == 1) tg_u_mfma<1>(acc, fb);
+    else if (w == 2) tg_u_mfma<2>(acc, fb);
+    else tg_u_mfma<3>(acc, fb);
+    return true;
+}
+
+// U (LAST): the final chunk of the diagonal tile (p+1, p+1) -- block row p, 16 rows at a time behind S1 of block row p -- handed to
+// role C.  U0 (!LAST): the chunk before it -- block row p-1 (and, where the row's first chunks were merged, the rows before it) --
+// behind S2 of block row p-1, handed to U: as a worker task it started when S2 was done and took 24 us.
+template <bool LAST>
+__device__ __forceinline__ void tg_role_diagupd(const TgArgs& a) {
+    double* lds = tg_buf;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), g = lane >> 4, n = lane & 15;
+    const int nP = __builtin_amdgcn_readfirstlane(a.nP), npad = tg_npad(nP);
+    const int64_t Np = (int64_t)uni64((unsigned long long)a.Np);
+    const double* R = uni(a.R);
+    double* S = uni(a.S);
+    int* ctl = uni(a.ctl);
+    int* dd = ctl + TG_CTL_BASE;
+    int* qd = dd + npad;
+    int* sv = qd + npad;
+    int* sq = sv + 2 * npad;
+    __builtin_amdgcn_s_setprio(3);
+    for (int p = LAST ? 0 : 1; p + 1 < nP; ++p) {
+        union { TgTask t; int4 v; } u;
+        u.v = *reinterpret_cast<const int4*>(a.q[0] + p);
+        u.v.x = __builtin_amdgcn_readfirstlane(u.v.x); u.v.y = __builtin_amdgcn_readfirstlane(u.v.y);
+        u.v.z = __builtin_amdgcn_readfirstlane(u.v.z); u.v.w = __builtin_amdgcn_readfirstlane(u.v.w);
+        const TgTask d = u.t;
+        if (!LAST && d.rsv < 0) continue;              // the tile has no chunk of its own before the final one
+        // the chunk this role applies: block rows [ck0, ck1), the last of them (kb) from the shadow it follows
+        const int ck0 = LAST ? d.k0 : d.rsv, kb = LAST ? p : p - 1, need = LAST ? d.aux : d.aux - 1;
+        const int64_t p0 = (int64_t)kb * NB, i0 = (int64_t)(p + 1) * NB;
+        long long ts0 = 0, tsq = 0;
+        if (a.trace && t == 0) ts0 = wall_clock64();
+        // the diagonal tile (p+1, p+1) with its earlier chunks applied
+        if (!tg_wave_wait_ge(a, sq + (p + 1) * nP + p + 1, need)) return;
+        if (a.trace && t == 0) tsq = wall_clock64();
+        const __amdgpu_buffer_rsrc_t rs = tg_rsrc(S + i0 * Np + i0, Np);
+        const int vo = (int)((g * Np + n) * 8);
+        d4 acc[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            int r, c;
+            tg_sh_tile(i, w, r, c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[i][q] = tg_bload(rs, vo, (int)((((16 * r + 4 * q) * Np) + 16 * c) * 8));
+        }
+        // block rows of the chunk before the followed one (only where the first chunks of a row were merged: block rows 2 and
+        // 3): operands straight from global memory
+        if (ck0 < kb) {
+            if (!tg_wave_wait_ge(a, sv + 2 * (p + 1), kb) || !tg_wave_wait_ge(a, sv + 2 * (p + 1) + 1, kb)) return;
+            for (int kr = ck0 * NB; kr < kb * NB; kr += 4) {
+                const double* Rk = R + (int64_t)(kr + g) * Np + i0 + n;
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    int r, c;
+                    tg_sh_tile(i, w, r, c);
+                    acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ldg<true>(Rk + 16 * r), ldg<true>(Rk + 16 * c), acc[i], 0, 0, 0);
+                }
+            }
+        }
+        long long ts1 = 0;
+        if (a.trace && t == 0) ts1 = wall_clock64();
+        const double* Xg = R + p0 * Np + i0;
+        const int* counter = ctl + (LAST ? TG_CTL_XSTEP : TG_CTL_XSTEP2);
+        const int base = 8 * kb;
+        TgFollow f;
+        f.avail = 0; f.issued = 0; f.vmi = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f.mark[i] = 0;
+        if (!tg_u_step<0>(a, counter, base, f, acc, lds, Xg, Np)) return;
+        if (!tg_u_step<1>(a, counter, base, f, acc, lds, Xg, Np)) return;
+        if (!tg_u_step<2>(a, counter, base, f, acc, lds, Xg, Np)) return;
+        if (!tg_u_step<3>(a, counter, base, f, acc, lds, Xg, Np)) return;
+        if (!tg_u_step<4>(a, counter, base, f, acc, lds, Xg, Np)) return;
+        if (!tg_u_step<5>(a, counter, base, f, acc, lds, Xg, Np)) return;
+        if (!tg_u_step<6>(a, counter, base, f, acc, lds, Xg, Np)) return;
+        if (!tg_u_step<7>(a, counter, base, f, acc, lds, Xg, Np)) return;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            int r, c;
+            tg_sh_tile(i, w, r, c);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) tg_bstore(rs, vo, (int)((((16 * r + 4 * q) * Np) + 16 * c) * 8), acc[i][q]);
+        }
+        tg_drain();
+        __syncthreads();
+        if (t == 0) {
+            if (LAST) sti(qd + p + 1, TG_NPIECE);
+            else sti(sq + (p + 1) * nP + p + 1, d.aux);
+            if (LAST && a.trace) {
+                const long long te = wall_clock64();
+                long long* o = a.trace + 4 * nP + 2 * 8 * p;
+                o[8] = ts0; o[9] = tsq;            // slots 4, 5 (U): waiting for the tile's earlier chunks; loaded .. stored
+                o[10] = ts1; o[11] = te;
+                for (int k = 6; k < 8; ++k) { o[2 * k] = ts1; o[2 * k + 1] = te; }
+            }
+        }
+    }
+}
+
+__device__ __noinline__ void tg_role_u(const TgArgs& a) { tg_role_diagupd<true>(a); }
+__device__ __noinline__ void tg_role_u0(const TgArgs& a) { tg_role_diagupd<false>(a); }
+
+// V (off = 1) / V2 (off = 2): the final chunk of tile (p, p + off) -- block row p-1, 16 rows at a time behind S1 and S2 (S3) of
+// the previous block row -- so that the right-hand sides of S1 (S2) are complete a few microseconds after those two are, not
+// one worker task (24 us) later.  Wave w owns column tiles 2 w, 2 w + 1 (all eight tile rows: 16 accumulators).
+template <int JB>
+__device__ __forceinline__ bool tg_v_step(const TgArgs& a, const int* cB, int p, TgFollow& f, d4 (&acc)[8][2], double* __restrict__ lds,
+                                          const double* __restrict__ Ag, const double* __restrict__ Bg, int64_t Np) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, n = lane & 15;
+    if (!tg_follow<JB, 2, false>(a, a.ctl + TG_CTL_XSTEP, cB, 8 * (p - 1), f, lds, Ag, Bg, Np)) return false;
+    const double* pa = lds + (2 * (JB & 1)) * TG_SH_PAN + g * PFP + n;
+    const double* pb = pa + TG_SH_PAN + 32 * w;
+    double fa[8][4], nb[2][4];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fa[r][kk] = pa[4 * kk * PFP + 16 * r];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) nb[j][kk] = -pb[4 * kk * PFP + 16 * j];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc[r][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[r][kk], nb[j][kk], acc[r][j], 0, 0, 0);
+    return true;
+}
+
+__device__ __forceinline__ void tg_role_offupd(const TgArgs& a, int off) {
+    double* lds = tg_buf;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), g = lane >> 4, n = lane & 15;
+    const int nP = __builtin_amdgcn_readfirstlane(a.nP), npad = tg_npad(nP);
+    const int64_t Np = (int64_t)uni64((unsigned long long)a.Np);
+    const double* R = uni(a.R);
+    double* S = uni(a.S);
+    int* ctl = uni(a.ctl);
+    int* dd = ctl + TG_CTL_BASE;
+    int* sv = dd + 2 * npad;
+    int* sq = sv + 2 * npad;
+    __builtin_amdgcn_s_setprio(3);
+    off = __builtin_amdgcn_readfirstlane(off);
+    const int* cB = ctl + (off == 1 ? TG_CTL_XSTEP2 : TG_CTL_XSTEP3);
+    for (int p = 1; p + off < nP; ++p) {
+        union { TgTask t; int4 v; } u;
+        u.v = *reinterpret_cast<const int4*>(a.q[0] + p - 1);         // row p's final chunk: [k0, p), ordinal aux
+        u.v.x = __builtin_amdgcn_readfirstlane(u.v.x); u.v.y = __builtin_amdgcn_readfirstlane(u.v.y);
+        u.v.z = __builtin_amdgcn_readfirstlane(u.v.z); u.v.w = __builtin_amdgcn_readfirstlane(u.v.w);
+        const TgTask d = u.t;
+        const int64_t p0 = (int64_t)p * NB, q0 = p0 - NB, j0 = p0 + (int64_t)off * NB;
+        if (!tg_wave_wait_ge(a, sq + p * nP + p + off, d.aux)) return;
+        const __amdgpu_buffer_rsrc_t rs = tg_rsrc(S + p0 * Np + j0, Np);
+        const int vo = (int)((g * Np + n) * 8);
+        d4 acc[8][2];
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[r][j][q] = tg_bload(rs, vo, (int)((((16 * r + 4 * q) * Np) + 32 * w + 16 * j) * 8));
+        // block rows of the final chunk before row p-1 (block row 2 only: its first two chunks are merged): from global memory
+        if (d.k0 < p - 1) {
+            if (!tg_wave_wait_ge(a, sv + 2 * p, p - 1) || !tg_wave_wait_ge(a, sv + 2 * p + 1, p - 1) ||
+                !tg_wave_wait_ge(a, sv + 2 * (p + off), p - 1) || !tg_wave_wait_ge(a, sv + 2 * (p + off) + 1, p - 1)) return;
+            for (int kr = d.k0 * NB; kr < (p - 1) * NB; kr += 4) {
+                const double* Ra = R + (int64_t)(kr + g) * Np + p0 + n;
+                const double* Rb = R + (int64_t)(kr + g) * Np + j0 + 32 * w + n;
+                const double b0 = -ldg<true>(Rb), b1 = -ldg<true>(Rb + 16);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const double ar = ldg<true>(Ra + 16 * r);
+                    acc[r][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, b0, acc[r][0], 0, 0, 0);
+                    acc[r][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, b1, acc[r][1], 0, 0, 0);
+                }
+            }
+        }
+        const double* Ag = R + q0 * Np + p0;          // tile (p-1, p): S1's
+        const double* Bg = R + q0 * Np + j0;          // tile (p-1, p+off): S2's (S3's)
+        TgFollow f;
+        f.avail = 0; f.issued = 0; f.vmi = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f.mark[i] = 0;
+        if (!tg_v_step<0>(a, cB, p, f, acc, lds, Ag, Bg, Np)) return;
+        if (!tg_v_step<1>(a, cB, p, f, acc, lds, Ag, Bg, Np)) return;
+        if (!tg_v_step<2>(a, cB, p, f, acc, lds, Ag, Bg, Np)) return;
+        if (!tg_v_step<3>(a, cB, p, f, acc, lds, Ag, Bg, Np)) return;
+        if (!tg_v_step<4>(a, cB, p, f, acc, lds, Ag, Bg, Np)) return;
+        if (!tg_v_step<5>(a, cB, p, f, acc, lds, Ag, Bg, Np)) return;
+        if (!tg_v_step<6>(a, cB, p, f, acc, lds, Ag, Bg, Np)) return;
+        if (!tg_v_step<7>(a, cB, p, f, acc, lds, Ag, Bg, Np)) return;
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) tg_bstore(rs, vo, (int)((((16 * r + 4 * q) * Np) + 32 * w + 16 * j) * 8), acc[r][j][q]);
+        tg_drain();
+        __syncthreads();
+        if (t == 0) sti(sq + p * nP + p + off, d.aux + 1);
+    }
+}
+__device__ __noinline__ void tg_role_v(const TgArgs& a) { tg_role_offupd(a, 1); }
+__device__ __noinline__ void tg_role_v2(const TgArgs& a) { tg_role_offupd(a, 2); }
+
 
 template <bool DB>
 __device__ __noinline__ void tg_do_upd(const TgArgs& a, int k0, int k1, int I, int J) {
@@ -439,7 +960,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
         tg_role_diag(a);
         return;
     }
-    const bool side = role <= a.nside;
+    if (a.shadow && role <= 7) {     // the shadows of role C
+        if (role == 1) tg_role_s1(a);
+        else if (role == 2) tg_role_s2(a);
+        else if (role == 3) tg_role_s3(a);
+        else if (role == 4) tg_role_u(a);
+        else if (role == 5) tg_role_u0(a);
+        else if (role == 6) tg_role_v(a);
+        else tg_role_v2(a);
+        return;
+    }
+    const bool side = !a.shadow && role <= a.nside;
     long long prof[6] = {0, 0, 0, 0, 0, 0};
     long long tprev = a.trace ? wall_clock64() : 0;
     for (;;) {
@@ -531,7 +1062,7 @@ struct TgTables { std::vector<TgTask> q[2]; };
 // the chunks that end at boundary p + 1, row by row, nearest the pivot first (the final chunk of the diagonal tile
 // (p+1, p+1) as six pieces on the critical list).  (Column-major inside the step -- every update right behind the last
 // solve it needs -- puts long far chunks in front of later solves: 7.8 against 5.5 ms at N = 8192, removed.)
-static void tg_build(int nP, int chunk_code, TgTables& out) {
+static void tg_build(int nP, int chunk_code, TgTables& out, bool shadow = false) {
     std::vector<int> sizes;
     {
         std::vector<int> dg;
@@ -552,11 +1083,25 @@ static void tg_build(int nP, int chunk_code, TgTables& out) {
         t.ord = (int16_t)ord; t.aux = (int16_t)aux; t.rsv = 0;
         out.q[q].push_back(t);
     };
+    // the chunk before the final one of row I, if the final one is the single block row I-1: its first block row, else -1
+    auto u0_start = [&](int I) {
+        const std::vector<int>& b = bnd[I];
+        const int nb = (int)b.size() - 1;
+        return (nb >= 2 && b[nb - 1] == I - 1) ? b[nb - 2] : -1;
+    };
     for (int q = 0; q < 2; ++q) out.q[q].clear();
     for (int p = 0; p < nP; ++p) {
         const int nch = (int)bnd[p].size() - 1;        // chunks of every tile of row p (0 for row 0)
-        for (int J = p + 1; J < nP; ++J)
+        for (int J = p + 1; J < nP; ++J) {
+            if (shadow && J == p + 1) {                // one descriptor per block row, completed below (k0, k1, aux)
+                push(0, TG_SHADOW, p, J, 0, 0, (p == 0) ? 0 : nch, 0);
+                // rsv: where the chunk BEFORE the final one of the diagonal tile (p+1, p+1) starts (role U0's), -1 without one
+                out.q[0].back().rsv = (int16_t)u0_start(p + 1);
+                continue;
+            }
+            if (shadow && J <= p + 3) continue;        // roles S2's and S3's
             for (int h = 0; h < 2; ++h) push(J == p + 1 ? 0 : 1, TG_TRSM, p, J, 0, 0, (p == 0) ? 0 : nch, h);
+        }
         for (int I : ends[p + 1]) {                    // rows ascending: nearest the pivot first
             if (I == 0) continue;
             size_t j = 1;
@@ -564,7 +1109,16 @@ static void tg_build(int nP, int chunk_code, TgTables& out) {
             const int k0 = bnd[I][j - 1], k1 = p + 1, ord = (int)j - 1;
             for (int J = I; J < nP; ++J) {
                 if (I == k1 && J == I) {
+                    if (shadow) {
+                        TgTask& d = out.q[0][(size_t)p];
+                        d.k0 = (int16_t)k0; d.k1 = (int16_t)k1; d.aux = (int16_t)ord;
+                        continue;
+                    }
                     for (int qu = 0; qu < TG_NPIECE; ++qu) push(0, TG_UPDQ, I, I, k0, k1, ord, qu);
+                } else if (shadow && I == k1 && J <= I + 2) {
+                    continue;                              // roles V's and V2's: the final chunks of tiles (I, I+1), (I, I+2)
+                } else if (shadow && J == I && k1 == I - 1 && u0_start(I) == k0) {
+                    continue;                              // role U0's: the chunk before the final one of the diagonal tile
                 } else {
                     push(1, TG_UPD, I, J, k0, k1, ord, 0);
                 }
@@ -578,7 +1132,7 @@ int64_t tg_tasks_copy(int nP, int chunks, int16_t* out, int64_t cap, int64_t* co
     if (nP < 1 || nP > 2047) return -1;
     TgTables tb;
     if (chunks <= 0) chunks = TG_DEFAULT_CHUNKS;
-    tg_build(nP, chunks, tb);
+    tg_build(nP, chunks, tb, true);
     int64_t tot = 0;
     for (int q = 0; q < 2; ++q) { counts[q] = (int64_t)tb.q[q].size(); tot += counts[q]; }
     if (out && cap >= tot) {
@@ -617,7 +1171,7 @@ __global__ __launch_bounds__(64) void k_tg_gate(int* ctl, int nP, int top, long 
 
 
 struct TgCache {                 // per handle (gpx_handle::tg): device copies of the tables and the control block
-    int nP = 0, chunks = 0;
+    int nP = 0, chunks = 0, shadow = -1;
     TgTask* dq = nullptr;
     int64_t cap_q = 0;
     int n[2] = {0, 0};
@@ -650,9 +1204,11 @@ bool launch_cholesky_tg(gpx_handle* h) {
     TgCache* c = static_cast<TgCache*>(h->tg);
     hipStream_t s = h->stream;
     const int chunks = h->tg_chunks > 0 ? h->tg_chunks : TG_DEFAULT_CHUNKS;
-    if (c->nP != nP || c->chunks != chunks || !c->dq) {
+    const bool shadow = h->tg_shadow != 0;
+    static_assert(3 * TG_SH_PAN + 3 * 256 <= GEMM_LDS_F64 && 4 * TG_SH_PAN <= GEMM_LDS_F64, "the shadows' LDS rings fit the tile engine's buffer");
+    if (c->nP != nP || c->chunks != chunks || c->shadow != (int)shadow || !c->dq) {
         TgTables tb;
-        tg_build(nP, chunks, tb);
+        tg_build(nP, chunks, tb, shadow);
         const int64_t tot = (int64_t)tb.q[0].size() + (int64_t)tb.q[1].size() + 2;
         if (tot > c->cap_q) {
             if (c->dq) (void)hipFree(c->dq);
@@ -673,7 +1229,7 @@ bool launch_cholesky_tg(gpx_handle* h) {
             }
             o += c->n[q] + 1;
         }
-        c->nP = nP; c->chunks = chunks;
+        c->nP = nP; c->chunks = chunks; c->shadow = (int)shadow;
     }
     const int64_t nctl = tg_ctl_ints(nP);
     if (nctl > c->cap_ctl) {
@@ -682,7 +1238,7 @@ bool launch_cholesky_tg(gpx_handle* h) {
         if (hipMalloc((void**)&c->dctl, (size_t)nctl * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return false; }
         c->cap_ctl = nctl;
     }
-    const int nside = std::max(1, std::min(h->tg_side > 0 ? h->tg_side : 8, 16));
+    const int nside = shadow ? 7 : std::max(1, std::min(h->tg_side > 0 ? h->tg_side : 8, 16));
     const int64_t nlog = (h->tg_trace >= 2) ? (int64_t)TG_LOG_WGS * TG_LOG_CAP * 4 : 0;
     const int64_t ntrace = 20 * (int64_t)nP + 8 * 1024 + 16 + nlog;
     if (h->tg_trace && ntrace > c->cap_trace) {
@@ -729,6 +1285,7 @@ bool launch_cholesky_tg(gpx_handle* h) {
     a.Np = Np; a.nP = nP; a.dflag = h->dflag; a.ctl = c->dctl;
     for (int q = 0; q < 2; ++q) { a.q[q] = c->dq + c->off[q]; a.n[q] = c->n[q]; }
     a.nside = nside;
+    a.shadow = shadow ? 1 : 0;
     a.isolate = (h->tg_isolate != 0 && grid_is_full) ? 1 : 0;
     a.nap = h->tg_nap > 0 ? h->tg_nap : 16;
     a.trace = h->tg_trace ? c->dtrace : nullptr;

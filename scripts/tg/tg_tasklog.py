@@ -37,8 +37,7 @@ recs = np.array(recs, dtype=np.int64)
 e2 = e
 raw0 = None
 # (crit[p, i] are relative microseconds; the log is raw ticks: align through the first panel-solve record)
-mask = (recs[:, 0] == 1) & (recs[:, 1] == 0) & (recs[:, 2] == 1) & (recs[:, 5] == 0)
-raw0 = recs[mask][0, 7] - crit[0, 0, 1] * 100.0
+raw0 = float(e.last_chol_trace_origin)
 ts = (recs[:, 6] - raw0) / 100.0
 te = (recs[:, 7] - raw0) / 100.0
 typ, I, J, k0, k1, aux = (recs[:, i] for i in range(6))
@@ -91,3 +90,19 @@ nw = int((prof[:, 6] != 0).sum())
 print('busy fraction of %d workgroups per 1/16 of the run:' % nw, ' '.join('%.2f' % (busy[s] / (edges[s + 1] - edges[s]) / nw) for s in range(16)))
 print('diagonal block reached at (us):', ' '.join('%d:%.0f' % (p, diag[p, 1]) for p in range(0, nP, max(nP // 16, 1))))
 e.close()
+
+# the lag-2 chain of the shadows: per block row p, relative to the end of potrf(p): the workers' solve of tile (p, p+3) and the
+# last update of tile (p+1, p+3) (role S2's right-hand side of the NEXT block row), and of tile (p+1, p+1)'s chunk that ends at p
+print()
+print('per block row p, relative to the end of potrf(p) [us]: solve (p,p+3) halves start/end | final update of tile (p+1,p+3) start/end | '
+      'update of (p+2,p+2) ending at block row p+1: start/end')
+rows = {}
+for i in range(len(recs)):
+    rows.setdefault((int(typ[i]), int(I[i]), int(J[i]), int(k1[i])), []).append((ts[i], te[i]))
+for p in range(2, nP - 4):
+    e0 = diag[p, 2]
+    a = rows.get((1, p, p + 3, 0), [])
+    b = rows.get((2, p + 1, p + 3, p + 1), [])
+    c = rows.get((2, p + 2, p + 2, p + 1), [])
+    fmt = lambda L: ' '.join('%+.1f/%+.1f' % (x - e0, y - e0) for x, y in L) if L else '-'
+    print('p=%2d  %s | %s | %s' % (p, fmt(a), fmt(b), fmt(c)))
