@@ -46,7 +46,7 @@
 
 namespace gpx {
 
-enum { TG_TRSM = 1, TG_UPD = 2, TG_UPDQ = 3, TG_SHADOW = 4 };
+enum { TG_TRSM = 1, TG_UPD = 2, TG_UPDQ = 3, TG_SHADOW = 4, TG_TRSMU = 5 };
 struct TgTask { int16_t type, I, J, k0, k1, ord, aux, rsv; };     // 16 bytes; aux = column half (TRSM) / piece (UPDQ)
 
 struct TgArgs {
@@ -75,7 +75,8 @@ constexpr int TG_LOG_CAP = 1024, TG_LOG_WGS = 1024;
 constexpr int TG_NPIECE = 6;          // pieces of the critical update of a diagonal tile
 constexpr int TG_CTL_ABORT = 32, TG_CTL_HEAD = 64, TG_CTL_STEP = 128, TG_CTL_XSTEP = 160, TG_CTL_XSTEP2 = 192, TG_CTL_XSTEP3 = 224, TG_CTL_BASE = 256, TG_CU_KEYS = 4096;
 __host__ __device__ inline int tg_npad(int nP) { return (nP + 31) / 32 * 32; }
-__host__ __device__ inline int tg_ctl_ints(int nP) { return TG_CTL_BASE + 4 * tg_npad(nP) + nP * nP + 2 * TG_CU_KEYS; }
+__host__ __device__ inline int tg_ctl_hf(int nP) { return TG_CTL_BASE + 4 * tg_npad(nP) + nP * nP + 2 * TG_CU_KEYS; }      // half-tile flags [nP * nP * 2], then arrival counts [nP * nP]
+__host__ __device__ inline int tg_ctl_ints(int nP) { return tg_ctl_hf(nP) + 3 * nP * nP; }
 
 __device__ __forceinline__ int ldi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void sti(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -89,6 +90,9 @@ __device__ __forceinline__ bool tg_deps_met(const TgTask& t, const int* dd, cons
     const int s = ldi(sq + I * nP + J);
     if (PRE) return s == t.ord;
     if (t.type == TG_TRSM) return (ldi(dd + I) != 0) && (s == t.ord);
+    // the fused link of a column's chain: its half of tile (I, J) is final (the same half's link of the row above said so);
+    // the diagonal block and everything else are waited for inside the task, behind the loads of the right-hand sides
+    if (t.type == TG_TRSMU) return I == 0 || ldi(dd + tg_ctl_hf(nP) - TG_CTL_BASE + (I * nP + J) * 2 + t.aux) != 0;
     const int s0 = ldi(sv + 2 * I), s1 = ldi(sv + 2 * I + 1), s2 = ldi(sv + 2 * J), s3 = ldi(sv + 2 * J + 1);
     return (s == t.ord) && (min(min(s0, s1), min(s2, s3)) >= t.k1);
 }
@@ -911,6 +915,145 @@ __device__ __noinline__ bool tg_do_updq(const TgArgs& a, int k0, int k1, int I, 
     const int* solved = uni(a.ctl) + TG_CTL_BASE + 2 * tg_npad(__builtin_amdgcn_readfirstlane(a.nP));
     return updq_body(a, uni(a.R), uni(a.S), (int64_t)uni64((unsigned long long)a.Np), k0, k1, I, q, solved);
 }
+// ---- TG_TRSMU: one link of a column's chain in ONE task ----------------------------------------------------------------
+// Below the shadows' band every tile column walks down the block rows alone: the solve of tile (p, J) needs the last update
+// of the same tile, which needs the solve of tile (p-1, J).  As two worker tasks (solve 20 us, one-block update 24 us: each
+// loads its tile, stores it, publishes, is polled for) a link cost 44 us -- more than the 38 us per diagonal block the shadows
+// allow -- and the columns fell behind the diagonal.  Here a link is one task per 64-column half: the solve (panel_solve16_lds's
+// MFMAs in its order), then, with the solved rows still in registers as the B operand, the final chunk of the same half of tile
+// (p+1, J):  S(p+1, J) -= R(p, p+1)^T R(p, J), R(p, p+1) staged whole in LDS (LDS-direct loads; it needs the two k-step images of
+// the one-workgroup-per-CU launch).  Same FMAs per element as the tile engine (accumulators from S, k ascending 4 at a time).
+// The half publishes itself (solved[], a flag for the same half's next link); the second half to arrive counts the tile's chunk.
+__device__ __noinline__ bool tg_do_trsmu(const TgArgs& a, int p, int J, int h, int k0, int ordn) {
+    p = __builtin_amdgcn_readfirstlane(p); J = __builtin_amdgcn_readfirstlane(J); h = __builtin_amdgcn_readfirstlane(h);
+    k0 = __builtin_amdgcn_readfirstlane(k0); ordn = __builtin_amdgcn_readfirstlane(ordn);
+    __builtin_amdgcn_s_setprio(3);
+    double* lds = tg_buf;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), g = lane >> 4, n = lane & 15;
+    const int nP = __builtin_amdgcn_readfirstlane(a.nP), npad = tg_npad(nP);
+    const int64_t Np = (int64_t)uni64((unsigned long long)a.Np);
+    double* R = uni(a.R);
+    double* S = uni(a.S);
+    const double* U = uni(a.U);
+    int* ctl = uni(a.ctl);
+    int* dd = ctl + TG_CTL_BASE;
+    int* sv = dd + 2 * npad;
+    int* sq = sv + 2 * npad;
+    int* hf = ctl + tg_ctl_hf(nP);
+    int* hc = hf + 2 * nP * nP;
+    const int64_t p0 = (int64_t)p * NB, i0 = p0 + NB, j0 = (int64_t)J * NB + 64 * h + 16 * w;
+    const double* Rd = R + p0 * Np + p0;
+    const double* Ud = U + p0 * Np + p0;
+    // (0) the right-hand sides: final when this task was taken
+    const __amdgpu_buffer_rsrc_t rx = tg_rsrc(S + p0 * Np + j0, Np), ro = tg_rsrc(R + p0 * Np + j0, Np);
+    const int vo = (int)((g * Np + n) * 8);
+    d4 X[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) X[r][q] = tg_bload(rx, vo, (int)(((16 * r + 4 * q) * Np) * 8));
+    if (!tg_wave_wait_ge(a, dd + p, 1)) return false;
+    // (1) the factor's diagonal block (36 upper 16-tiles, tile-major) and the eight 16 x 16 inverses: ONE round trip
+    {
+        const __amdgpu_buffer_rsrc_t rs = tg_rsrc(Rd, Np);
+        u4v stage[18];
+        int dst[18];
+#pragma unroll
+        for (int q = 0; q < 18; ++q) {
+            const int e = t + 256 * q;
+            int tile = e >> 7, r = 0;
+            const int piece = e & 127, row = piece >> 3, c2 = piece & 7;
+            int idx = tile;
+            while (idx >= 8 - r) { idx -= 8 - r; ++r; }
+            const int c = r + idx;
+            stage[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((16 * r + row) * Np + 16 * c + 2 * c2) * 8), 0, 16);
+            dst[q] = tile * 256 + row * 16 + 2 * c2;
+        }
+        double ti[8][4];
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) ti[jb][kk] = ldg<true>(Ud + (int64_t)(16 * jb + 4 * kk + g) * Np + 16 * jb + n);
+#pragma unroll
+        for (int q = 0; q < 18; ++q) *reinterpret_cast<u4v*>(lds + dst[q]) = stage[q];
+        __syncthreads();
+        // (2) the substitution
+#pragma unroll
+        for (int jb = 0; jb < 8; ++jb) {
+            d4 x = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) x = __builtin_amdgcn_mfma_f64_16x16x4f64(ti[jb][kk], X[jb][kk], x, 0, 0, 0);
+            X[jb] = x;
+            const d4 xn = -x;
+#pragma unroll
+            for (int i = jb + 1; i < 8; ++i) {
+                const double* tl = lds + 256 * tri_index(jb, i) + g * 16 + n;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) X[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(tl[kk * 64], xn[kk], X[i], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tg_bstore(ro, vo, (int)(((16 * r + 4 * q) * Np) * 8), X[r][q]);
+    // (3) the same half of tile (p+1, J): every earlier chunk applied (long ago, as a rule), then R(p, p+1) whole into LDS
+    if (!tg_wave_wait_ge(a, sq + (p + 1) * nP + J, ordn)) return false;
+    const __amdgpu_buffer_rsrc_t rt = tg_rsrc(S + i0 * Np + j0, Np);
+    d4 acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[r][q] = tg_bload(rt, vo, (int)(((16 * r + 4 * q) * Np) * 8));
+    if (k0 < p) {              // block rows of the chunk before row p (block row 2 only: merged first chunks): from global memory
+        if (!tg_wave_wait_ge(a, sv + 2 * (p + 1), p) || !tg_wave_wait_ge(a, sv + 2 * (p + 1) + 1, p) ||
+            !tg_wave_wait_ge(a, sv + 2 * J + h, p)) return false;
+        for (int kr = k0 * NB; kr < p * NB; kr += 4) {
+            const double* Ra = R + (int64_t)(kr + g) * Np + i0 + n;
+            const double bq = -ldg<true>(R + (int64_t)(kr + g) * Np + j0 + n);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(ldg<true>(Ra + 16 * r), bq, acc[r], 0, 0, 0);
+        }
+    }
+    if (!tg_wave_wait_ge(a, sv + 2 * (p + 1), p + 1) || !tg_wave_wait_ge(a, sv + 2 * (p + 1) + 1, p + 1)) return false;
+    __syncthreads();                               // every wave is through with the diagonal block's image
+    {
+        const double* Ag = R + p0 * Np + i0;       // tile (p, p+1)
+#pragma unroll
+        for (int rr = 0; rr < 32; ++rr)
+            __builtin_amdgcn_global_load_lds(Ag + (int64_t)(32 * w + rr) * Np + 2 * lane, (lds_ptr)(lds + (32 * w + rr) * PFP), 16, 0, 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // (4) acc(i) -= R(p, p+1)[:, tile i]^T x  as  acc(i) += A_i (-x)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) X[r] = -X[r];
+#pragma unroll
+    for (int kt = 0; kt < 8; ++kt) {
+        double af[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) af[i][kk] = lds[(16 * kt + 4 * kk + g) * PFP + 16 * i + n];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i][kk], X[kt][kk], acc[i], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tg_bstore(rt, vo, (int)(((16 * r + 4 * q) * Np) * 8), acc[r][q]);
+    tg_drain();
+    __syncthreads();
+    if (t == 0) {
+        sti(sv + 2 * J + h, p + 1);
+        sti(hf + ((p + 1) * nP + J) * 2 + h, 1);
+        if (atomicAdd(hc + (p + 1) * nP + J, 1) == 1) sti(sq + (p + 1) * nP + J, ordn + 1);
+    }
+    return true;
+}
+
 template <int Q>
 __device__ __noinline__ int tg_take_call(const TgArgs& a, TgTask& out, int lane) {
     return tg_take<Q>(a, out, lane, reinterpret_cast<TgHeld*>(tg_smem + 4));
@@ -995,6 +1138,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
             tg_do_upd<DB>(a, tk.k0, tk.k1, tk.I, tk.J);
         } else if (tk.type == TG_TRSM) {
             if (!tg_do_trsm(a, tk.I, 2 * (tk.J - tk.I - 1) + tk.aux)) break;
+        } else if (tk.type == TG_TRSMU) {
+            if (!tg_do_trsmu(a, tk.I, tk.J, tk.aux, tk.k0, tk.rsv)) break;
         } else {
             if (!tg_do_updq(a, tk.k0, tk.k1, tk.I, tk.aux)) break;
         }
@@ -1016,7 +1161,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
             }
             if (tk.type == TG_UPD) sti(sq + tk.I * nP + tk.J, tk.ord + 1);
             else if (tk.type == TG_TRSM) sti(sv + 2 * tk.J + tk.aux, tk.I + 1);
-            else atomicAdd(qd + tk.I, 1);
+            else if (tk.type == TG_UPDQ) atomicAdd(qd + tk.I, 1);          // (a fused link has published itself)
             if (side && a.trace && (tk.type == TG_UPDQ || (tk.type == TG_TRSM && tk.J == tk.I + 1))) {
                 const int slot = (tk.type == TG_TRSM) ? (8 * tk.I + tk.aux) : (8 * (tk.I - 1) + 2 + tk.aux);
                 a.trace[4 * nP + 2 * slot] = ts;
@@ -1037,7 +1182,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
 
 // chunk boundaries of block row I: k = I - d for the distances d = 0, c1, c1 + c2, ... (chunk sizes counted back from
 // the pivot, the last size repeated), plus 0; a first chunk shorter than 2 blocks is merged into the next one
-static std::vector<int> tg_boundaries(int I, const std::vector<int>& sizes) {
+static std::vector<int> tg_boundaries(int I, const std::vector<int>& sizes, bool merge_first) {
     std::vector<int> b;
     int d = 0;
     size_t i = 0;
@@ -1051,7 +1196,7 @@ static std::vector<int> tg_boundaries(int I, const std::vector<int>& sizes) {
     b.push_back(0);
     std::reverse(b.begin(), b.end());                 // ascending: 0 = b[0] < ... < b[nb] = I
     b.erase(std::unique(b.begin(), b.end()), b.end());
-    while (b.size() > 2 && b[1] - b[0] < 2) b.erase(b.begin() + 1);
+    while (merge_first && b.size() > 2 && b[1] - b[0] < 2) b.erase(b.begin() + 1);
     return b;
 }
 
@@ -1062,7 +1207,7 @@ struct TgTables { std::vector<TgTask> q[2]; };
 // the chunks that end at boundary p + 1, row by row, nearest the pivot first (the final chunk of the diagonal tile
 // (p+1, p+1) as six pieces on the critical list).  (Column-major inside the step -- every update right behind the last
 // solve it needs -- puts long far chunks in front of later solves: 7.8 against 5.5 ms at N = 8192, removed.)
-static void tg_build(int nP, int chunk_code, TgTables& out, bool shadow = false) {
+static void tg_build(int nP, int chunk_code, TgTables& out, bool shadow = false, bool fuse = false) {
     std::vector<int> sizes;
     {
         std::vector<int> dg;
@@ -1074,7 +1219,9 @@ static void tg_build(int nP, int chunk_code, TgTables& out, bool shadow = false)
     std::vector<std::vector<int>> bnd(nP);
     std::vector<std::vector<int>> ends(nP + 1);        // ends[b] = rows with a chunk ending at boundary b
     for (int I = 0; I < nP; ++I) {
-        bnd[I] = tg_boundaries(I, sizes);
+        // (with the shadows every row keeps its single-block chunks next to the pivot -- they apply them 16 rows at a time from
+        //  LDS; a merged chunk would send them through their slow global-memory path for the rows before the followed one)
+        bnd[I] = tg_boundaries(I, sizes, !shadow);
         for (size_t j = 1; j < bnd[I].size(); ++j) ends[bnd[I][j]].push_back(I);
     }
     auto push = [&](int q, int type, int I, int J, int k0, int k1, int ord, int aux) {
@@ -1100,6 +1247,15 @@ static void tg_build(int nP, int chunk_code, TgTables& out, bool shadow = false)
                 continue;
             }
             if (shadow && J <= p + 3) continue;        // roles S2's and S3's
+            if (fuse) {                                // one link of column J's chain: the solve and the final chunk of tile (p+1, J), per half
+                const std::vector<int>& b = bnd[p + 1];
+                const int nb = (int)b.size() - 1;      // the final chunk of row p+1 is [b[nb-1], p+1), its ordinal nb-1
+                for (int h = 0; h < 2; ++h) {
+                    push(1, TG_TRSMU, p, J, b[nb - 1], p + 1, (p == 0) ? 0 : nch, h);
+                    out.q[1].back().rsv = (int16_t)(nb - 1);
+                }
+                continue;
+            }
             for (int h = 0; h < 2; ++h) push(J == p + 1 ? 0 : 1, TG_TRSM, p, J, 0, 0, (p == 0) ? 0 : nch, h);
         }
         for (int I : ends[p + 1]) {                    // rows ascending: nearest the pivot first
@@ -1115,8 +1271,8 @@ static void tg_build(int nP, int chunk_code, TgTables& out, bool shadow = false)
                         continue;
                     }
                     for (int qu = 0; qu < TG_NPIECE; ++qu) push(0, TG_UPDQ, I, I, k0, k1, ord, qu);
-                } else if (shadow && I == k1 && J <= I + 2) {
-                    continue;                              // roles V's and V2's: the final chunks of tiles (I, I+1), (I, I+2)
+                } else if (shadow && I == k1 && (J <= I + 2 || fuse)) {
+                    continue;                              // roles V's and V2's: the final chunks of tiles (I, I+1), (I, I+2); beyond: the fused links'
                 } else if (shadow && J == I && k1 == I - 1 && u0_start(I) == k0) {
                     continue;                              // role U0's: the chunk before the final one of the diagonal tile
                 } else {
@@ -1132,7 +1288,7 @@ int64_t tg_tasks_copy(int nP, int chunks, int16_t* out, int64_t cap, int64_t* co
     if (nP < 1 || nP > 2047) return -1;
     TgTables tb;
     if (chunks <= 0) chunks = TG_DEFAULT_CHUNKS;
-    tg_build(nP, chunks, tb, true);
+    tg_build(nP, chunks, tb, true, true);
     int64_t tot = 0;
     for (int q = 0; q < 2; ++q) { counts[q] = (int64_t)tb.q[q].size(); tot += counts[q]; }
     if (out && cap >= tot) {
@@ -1206,9 +1362,13 @@ bool launch_cholesky_tg(gpx_handle* h) {
     const int chunks = h->tg_chunks > 0 ? h->tg_chunks : TG_DEFAULT_CHUNKS;
     const bool shadow = h->tg_shadow != 0;
     static_assert(3 * TG_SH_PAN + 3 * 256 <= GEMM_LDS_F64 && 4 * TG_SH_PAN <= GEMM_LDS_F64, "the shadows' LDS rings fit the tile engine's buffer");
-    if (c->nP != nP || c->chunks != chunks || c->shadow != (int)shadow || !c->dq) {
+    // (decided here because the lists depend on it) one workgroup per CU with two k-step images of LDS: see below
+    const bool db = (h->tg_db < 0) ? (nP <= h->tg_db_max) : (h->tg_db != 0);
+    const bool fuse = shadow && db && h->tg_fuse != 0;       // a fused link stages a whole 128 x 128 tile in LDS
+    static_assert(NB * PFP <= 2 * GEMM_LDS_F64, "tile (p, p+1) fits the two k-step images");
+    if (c->nP != nP || c->chunks != chunks || c->shadow != (int)shadow * 2 + (int)fuse || !c->dq) {
         TgTables tb;
-        tg_build(nP, chunks, tb, shadow);
+        tg_build(nP, chunks, tb, shadow, fuse);
         const int64_t tot = (int64_t)tb.q[0].size() + (int64_t)tb.q[1].size() + 2;
         if (tot > c->cap_q) {
             if (c->dq) (void)hipFree(c->dq);
@@ -1229,7 +1389,7 @@ bool launch_cholesky_tg(gpx_handle* h) {
             }
             o += c->n[q] + 1;
         }
-        c->nP = nP; c->chunks = chunks; c->shadow = (int)shadow;
+        c->nP = nP; c->chunks = chunks; c->shadow = (int)shadow * 2 + (int)fuse;
     }
     const int64_t nctl = tg_ctl_ints(nP);
     if (nctl > c->cap_ctl) {
@@ -1250,7 +1410,6 @@ bool launch_cholesky_tg(gpx_handle* h) {
     // DB: every workgroup gets two k-step images of LDS (one workgroup per CU by its LDS alone) and the workers run the
     // double-buffered k-loop -- the choice of the sizes that ran one workgroup per CU anyway (up to 72 blocks: latency-bound;
     // option chol_tg_db: -1 auto, 0 / 1 force)
-    const bool db = (h->tg_db < 0) ? (nP <= h->tg_db_max) : (h->tg_db != 0);
     const size_t lds_bytes = (size_t)(TG_CTL_F64 + (db ? 2 : 1) * GEMM_LDS_F64) * sizeof(double);
     int& max_res = db ? c->max_resident_db : c->max_resident;
     if (max_res == 0) {

@@ -8,7 +8,7 @@ import pytest
 
 from pybo_amd import _lib
 
-TRSM, UPD, UPDQ, SHADOW = 1, 2, 3, 4
+TRSM, UPD, UPDQ, SHADOW, TRSMU = 1, 2, 3, 4, 5
 
 
 def tasks(nP, chunks=0):
@@ -37,7 +37,26 @@ def tasks(nP, chunks=0):
                 crit.append((UPD, p + 2, p + 2, r2, p + 1, int(d[p + 1][6]) - 1, 0, 0))
         for piece in range(6):
             crit.append((UPDQ, p + 1, p + 1, k0, k1, aux, piece, 0))
-    return [np.array(crit, dtype=np.int64).reshape(-1, 8), q[1]]
+    # below the shadows' band a column's solve and the final chunk of the tile under it are ONE task per 64-column half
+    # (TG_TRSMU: I = p, J, [k0, k1) = that chunk, aux = half, rsv = its ordinal); the pair of halves stands for two solve halves
+    # and one tile update
+    work = []
+    w = q[1]
+    i = 0
+    while i < len(w):
+        if int(w[i, 0]) != TRSMU:
+            work.append(tuple(int(v) for v in w[i]))
+            i += 1
+            continue
+        a, b = w[i], w[i + 1]
+        assert int(b[0]) == TRSMU and tuple(a[1:6]) == tuple(b[1:6]) and (int(a[6]), int(b[6])) == (0, 1) and a[7] == b[7]
+        typ, I, J, k0, k1, ordn, aux, rsv = (int(v) for v in a)
+        assert J >= I + 4 and k1 == I + 1
+        work.append((TRSM, I, J, 0, 0, ordn, 0, 0))
+        work.append((TRSM, I, J, 0, 0, ordn, 1, 0))
+        work.append((UPD, I + 1, J, k0, k1, rsv, 0, 0))
+        i += 2
+    return [np.array(crit, dtype=np.int64).reshape(-1, 8), np.array(work, dtype=np.int64).reshape(-1, 8)]
 
 
 
@@ -281,9 +300,10 @@ def test_chunks_are_graded_towards_the_pivot():
         sizes = (mine[:, 4] - mine[:, 3])[np.argsort(mine[:, 3])]
         assert sizes[-1] == 1 and sizes.sum() == I
         assert np.all(np.diff(sizes[1:]) <= 0)              # (the first chunk absorbs a short remainder)
-    # generation order inside step p = 3: every solve of block row 3 precedes every chunk that ends at boundary 4
+    # generation order inside step p = 3: every link of block row 3 (solve + the final chunk of the tile below it) precedes
+    # every other chunk that ends at boundary 4
     w = q[1]
-    first_upd = min(i for i in range(len(w)) if w[i, 0] == UPD and w[i, 4] == 4)
+    first_upd = min(i for i in range(len(w)) if w[i, 0] == UPD and w[i, 4] == 4 and w[i, 1] > 4)
     last_trsm = max(i for i in range(len(w)) if w[i, 0] == TRSM and w[i, 1] == 3)
     assert last_trsm < first_upd
 
