@@ -120,7 +120,7 @@ int gpx_version(void);
  *              Both bit-identical, both measured and off by default ("The fit -- round 3").
  *          "chol_tg" = 1 (default): the factorisation runs as ONE persistent kernel that walks its task graph (dedicated
  *              workgroups for the diagonal blocks and the two tiles between consecutive ones, everything else as
- *              throughput work from ONE ticketed, dependency-checked list; kernels_chol_tg.hip) for fits of "chol_tg_min" (default 12) to
+ *              throughput work from ONE ticketed, dependency-checked list; kernels_chol_tg.hip) for fits of "chol_tg_min" (default 2) to
  *              "chol_tg_max" (default 160) 128-blocks; 0: the stream schedule above.  Bit-identical factors either way.  Tuning / diagnostics:
  *              "chol_tg_chunks" (k-chunk sizes counted back from the pivot as decimal digits, default 12499 = 1, 2, 4, 16, 16, ..: the digit 9 stands for 16 blocks),
  *              "chol_tg_nap" (longest pause of a waiting workgroup between two looks at its dependencies, in units of 64

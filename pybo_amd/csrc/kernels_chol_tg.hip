@@ -1005,6 +1005,11 @@ __device__ __noinline__ bool tg_do_trsmu(const TgArgs& a, int p, int J, int h, i
     for (int r = 0; r < 8; ++r)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[r][q] = tg_bload(rt, vo, (int)(((16 * r + 4 * q) * Np) * 8));
+    // the solved rows are announced NOW, not with the update: the workers' chunk of tile (p+2, J) that ends with block row p
+    // takes 24 us and the next link of this column wants it ~12 us after this one ends
+    tg_drain();
+    __syncthreads();                               // (every wave is also through with the diagonal block's image)
+    if (t == 0) sti(sv + 2 * J + h, p + 1);
     if (k0 < p) {              // block rows of the chunk before row p (block row 2 only: merged first chunks): from global memory
         if (!tg_wave_wait_ge(a, sv + 2 * (p + 1), p) || !tg_wave_wait_ge(a, sv + 2 * (p + 1) + 1, p) ||
             !tg_wave_wait_ge(a, sv + 2 * J + h, p)) return false;
@@ -1016,7 +1021,6 @@ __device__ __noinline__ bool tg_do_trsmu(const TgArgs& a, int p, int J, int h, i
         }
     }
     if (!tg_wave_wait_ge(a, sv + 2 * (p + 1), p + 1) || !tg_wave_wait_ge(a, sv + 2 * (p + 1) + 1, p + 1)) return false;
-    __syncthreads();                               // every wave is through with the diagonal block's image
     {
         const double* Ag = R + p0 * Np + i0;       // tile (p, p+1)
 #pragma unroll
@@ -1047,7 +1051,6 @@ __device__ __noinline__ bool tg_do_trsmu(const TgArgs& a, int p, int J, int h, i
     tg_drain();
     __syncthreads();
     if (t == 0) {
-        sti(sv + 2 * J + h, p + 1);
         sti(hf + ((p + 1) * nP + J) * 2 + h, 1);
         if (atomicAdd(hc + (p + 1) * nP + J, 1) == 1) sti(sq + (p + 1) * nP + J, ordn + 1);
     }
@@ -1382,7 +1385,8 @@ bool launch_cholesky_tg(gpx_handle* h) {
             c->off[q] = o;
             c->n[q] = (int)tb.q[q].size();
             if (c->n[q] > 0 &&
-                hipMemcpy(c->dq + o, tb.q[q].data(), tb.q[q].size() * sizeof(TgTask), hipMemcpyHostToDevice) != hipSuccess) {
+                (hipMemcpyAsync(c->dq + o, tb.q[q].data(), tb.q[q].size() * sizeof(TgTask), hipMemcpyHostToDevice, s) != hipSuccess ||
+                 hipStreamSynchronize(s) != hipSuccess)) {
                 (void)hipGetLastError();
                 c->nP = 0;
                 return false;
@@ -1475,7 +1479,9 @@ int tg_abort_code(gpx_handle* h) {
     TgCache* c = static_cast<TgCache*>(h->tg);
     if (!c || !c->dctl) return 0;
     int v = 0;
-    if (hipMemcpy(&v, c->dctl + TG_CTL_ABORT, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 2; }
+    // (never the NULL stream: see gpx_create)
+    if (hipMemcpyAsync(&v, c->dctl + TG_CTL_ABORT, sizeof(int), hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) { (void)hipGetLastError(); return 2; }
     return v;
 }
 
@@ -1486,7 +1492,8 @@ int64_t tg_trace_copy(gpx_handle* h, long long* out, int64_t n) {
     if (!c || !c->dtrace || !h->tg_trace) return 0;
     const int64_t have = std::min<int64_t>(n, std::min<int64_t>(c->cap_trace, 20 * (int64_t)c->nP + 8 * 1024 + 16 + (h->tg_trace >= 2 ? (int64_t)TG_LOG_WGS * TG_LOG_CAP * 4 : 0)));
     if (have <= 0) return 0;
-    if (hipMemcpy(out, c->dtrace, (size_t)have * 8, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (hipMemcpyAsync(out, c->dtrace, (size_t)have * 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return have;
 }
 
