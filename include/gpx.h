@@ -118,17 +118,18 @@ int gpx_version(void);
  *          "chol_fuse" = 1: the diagonal block is factored by every workgroup of the panel solve (one launch per 128-block
  *              instead of two); "chol_graph" = 1: the factorisation's launches are replayed from a captured hipGraph.
  *              Both bit-identical, both measured and off by default ("The fit -- round 3").
- *          "chol_tg" = 1 (default): the factorisation runs as ONE persistent kernel that walks its task graph (dedicated
- *              workgroups for the diagonal blocks and the two tiles between consecutive ones, everything else as
+ *          "chol_tg" = 1 (default): the factorisation runs as ONE persistent kernel that walks its task graph (one workgroup for
+ *              the diagonal blocks, seven that follow it 16 rows at a time with the tiles next to the diagonal, everything else as
  *              throughput work from ONE ticketed, dependency-checked list; kernels_chol_tg.hip) for fits of "chol_tg_min" (default 2) to
  *              "chol_tg_max" (default 160) 128-blocks; 0: the stream schedule above.  Bit-identical factors either way.  Tuning / diagnostics:
- *              "chol_tg_chunks" (k-chunk sizes counted back from the pivot as decimal digits, default 12499 = 1, 2, 4, 16, 16, ..: the digit 9 stands for 16 blocks),
+ *              "chol_tg_chunks" (k-chunk sizes counted back from the pivot as decimal digits, default 11249 = 1, 1, 2, 4, 16, 16, ..: the digit 9 stands for 16 blocks),
  *              "chol_tg_nap" (longest pause of a waiting workgroup between two looks at its dependencies, in units of 64
  *              clocks: 8, 16 (default), 32, 64 or 127),
  *              "chol_tg_db" (-1, default: up to "chol_tg_db_max" = 112 blocks every workgroup has its compute unit to itself with two
  *              k-step images of LDS and the workers run the double-buffered k-loop; 0 / 1: never / always),
- *              "chol_tg_side" (workgroups reserved for the critical tiles, default 8), "chol_tg_grid" (workgroups launched,
- *              0 = by size), "chol_tg_isolate" (1, default: the critical workgroups keep their compute units to themselves),
+ *              "chol_tg_fuse" (1, default: with two k-step images a column's solve and the final chunk of the tile below it are one task),
+ *              "chol_tg_grid" (workgroups launched, 0 = by size), "chol_tg_isolate" (1, default: the critical workgroups keep
+ *              their compute units to themselves),
  *              "chol_tg_tmo_ms" (bound of every spin, default 2000: on expiry the fit re-runs on the stream schedule and
  *              says so on stderr), "chol_tg_trace" = 1 (stamp the critical path, read with gpx_chol_trace).
  *          "x_bg", "x_bg_lds", "x_bg_iters" = DIAGNOSTIC (scripts/chol_bg.py): a synthetic register-only fp64-MFMA kernel of
@@ -355,17 +356,22 @@ int gpx_topk_allgather(gpx_comm *c, int64_t n, int64_t index_offset, int64_t k, 
 int gpx_timers(gpx_handle *h, double *out, int n, int reset);
 /* DIAGNOSTIC (option "chol_tg_trace" = 1): wall-clock stamps (100 MHz ticks) the task-graph factorisation of the last fit
  * took with its own clock: out[4 p + {0, 1, 2}] = the diagonal workgroup started waiting for / started / finished block
- * p (nP = N/128 rounded up blocks), then out[4 nP + 2 (8 p + i) + {0, 1}] = start / end of the critical tasks that follow
- * block p (i = 0, 1: the two halves of the panel solve of tile (p, p+1); 2..7: the pieces of the update of tile
- * (p+1, p+1)).  Returns the number of words written (<= n; 20 nP when complete, followed by up to 1024 x 8 per-workgroup counters: tasks, ticks spent taking / updating / solving /
+ * p (nP = N/128 rounded up blocks), then out[4 nP + 2 (8 p + i) + {0, 1}] = stamps of the shadows of block row p (i = 0: S1
+ * started waiting for its right-hand sides / has them loaded, 1: .. / its last rows are stored; 2, 3: the same for S2; 4: U
+ * started waiting / the tile's earlier chunks are in, 5: the tile is loaded / stored for the diagonal workgroup).  Returns the number of words written (<= n; 20 nP when complete, followed by up to 1024 x 8 per-workgroup counters: tasks, ticks spent taking / updating / solving /
  * publishing, block updates applied, role, exit stamp), 0 without a trace. */
 int64_t gpx_chol_trace(gpx_handle *h, int64_t *out, int64_t n);
 /* The task lists the task-graph factorisation of an nblocks x nblocks block matrix walks (host only, no device needed:
  * what the CPU tests replay to prove that every tile receives every block row once, in order, and that the lists never
- * dead-lock): counts[2] = tasks in the critical list / the workers' list, out (total, 8) int16 = {type (1 panel solve,
- * 2 tile update, 3 piece of a diagonal-tile update), I, J, k0, k1, ordinal, aux, reserved}, the lists back to back.
- * chunks as the option "chol_tg_chunks" (<= 0: default).  Returns the total number of tasks (written only when
- * cap >= total), -1 on bad arguments. */
+ * dead-lock): counts[2] = entries of list 0 / tasks of the workers' list, out (total, 8) int16 = {type, I, J, k0, k1, ordinal,
+ * aux, reserved}, the lists back to back.  Types: 1 = panel solve of the 64-column half aux of tile (I, J); 2 = update of tile
+ * (I, J) with block rows [k0, k1), its chunk number `ordinal`; 5 = a fused link: the solve of half aux of tile (I, J) and the final
+ * chunk [k0, k1 = I+1) (chunk number `reserved`) of the same half of tile (I+1, J); 4 = list 0's descriptor of block row I for the
+ * workgroups that follow the diagonal factorisation (they stand for the solves of tiles (I, I+1 .. I+3), the final chunks of
+ * tiles (I+1, I+1 .. I+3) = [k0, k1) with chunk number aux, and the diagonal tile's chunk before it, which starts at block row
+ * `reserved` if that is >= 0; `ordinal` = chunks of every tile of row I).  The lists are those of a launch with two k-step images
+ * of LDS per workgroup (fused links).  chunks as the option "chol_tg_chunks" (<= 0: default).  Returns the total number of
+ * entries (written only when cap >= total), -1 on bad arguments. */
 int64_t gpx_chol_tasks(int nblocks, int chunks, int16_t *out, int64_t cap, int64_t *counts);
 int gpx_sync(gpx_handle *h);
 

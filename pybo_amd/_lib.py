@@ -708,8 +708,9 @@ class Engine(object):
 
     def chol_trace(self, nblocks, full_log=False):
         """Diagnostic (option chol_tg_trace = 1): the task-graph factorisation's own stamps of the last fit, microseconds
-        from the first one: (diag (nblocks, 3) = wait / start / end per diagonal block, crit (nblocks, 8, 2) = start / end
-        of the two panel-solve halves and the six pieces of the diagonal-tile update that follow each block); None without a trace."""
+        from the first one: (diag (nblocks, 3) = wait / start / end per diagonal block, crit (nblocks, 8, 2) = the stamps of the
+        workgroups that follow block row p -- slots 0, 1: S1 (waiting / right-hand sides loaded, .. / last rows stored), 2, 3: S2,
+        4: U (waiting / earlier chunks in), 5: U (tile loaded / stored) -- see gpx_chol_trace in include/gpx.h); None without a trace."""
         out = np.zeros(20 * nblocks + 8 * 1024 + 16 + (4 << 20 if full_log else 0), dtype=np.int64)
         n = self._lib.gpx_chol_trace(self._h, _ptr(out), out.size)
         if n < 20 * nblocks:

@@ -296,11 +296,11 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             h->chol_w = (int)value;
             return GPX_OK;
         }
-        if (!strcmp(name, "chol_tg") || !strcmp(name, "chol_tg_chunks") || !strcmp(name, "chol_tg_side") ||
+        if (!strcmp(name, "chol_tg") || !strcmp(name, "chol_tg_chunks") ||
             !strcmp(name, "chol_tg_grid") || !strcmp(name, "chol_tg_trace") || !strcmp(name, "chol_tg_tmo_ms") ||
             !strcmp(name, "chol_tg_min") || !strcmp(name, "chol_tg_max") || !strcmp(name, "chol_tg_isolate") ||
             !strcmp(name, "chol_tg_nap") || !strcmp(name, "chol_tg_db") || !strcmp(name, "chol_tg_db_max") ||
-            !strcmp(name, "chol_tg_shadow") || !strcmp(name, "chol_tg_fuse")) {
+            !strcmp(name, "chol_tg_fuse")) {
             if (value < -1 || value > 1000000000) return fail(h, GPX_EARG, "chol_tg*: out of range");
             const char* sub = name + 7;
             if (*sub == 0) { if (value != 0 && value != 1) return fail(h, GPX_EARG, "chol_tg must be 0 or 1"); h->chol_tg = (int)value; }
@@ -308,12 +308,10 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             else if (!strcmp(sub, "_db_max")) h->tg_db_max = (int)std::max<int64_t>(0, value);
             else if (!strcmp(sub, "_nap")) h->tg_nap = (int)std::max<int64_t>(0, std::min<int64_t>(127, value));
             else if (!strcmp(sub, "_chunks")) h->tg_chunks = (int)value;
-            else if (!strcmp(sub, "_side")) h->tg_side = (int)value;
             else if (!strcmp(sub, "_grid")) h->tg_grid = (int)value;
             else if (!strcmp(sub, "_trace")) h->tg_trace = (int)value;
             else if (!strcmp(sub, "_tmo_ms")) h->tg_tmo_ms = (int)value;
             else if (!strcmp(sub, "_isolate")) h->tg_isolate = (int)value;
-            else if (!strcmp(sub, "_shadow")) h->tg_shadow = (value != 0) ? 1 : 0;
             else if (!strcmp(sub, "_fuse")) h->tg_fuse = (value != 0) ? 1 : 0;
             else if (!strcmp(sub, "_max")) h->tg_max = (int)std::max<int64_t>(1, value);
             else h->tg_min = (int)std::max<int64_t>(1, value);

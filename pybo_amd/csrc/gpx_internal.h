@@ -61,9 +61,7 @@ struct gpx_handle {
     int tg_nap = 0;               // longest polling pause of a waiting workgroup in units of 64 clocks (0 = default 16; round 4 until late: 127)
     int tg_db = -1;               // -1 (default): the double-buffered workers (one workgroup per CU, 2 x 72 KB of LDS) up to tg_db_max blocks; 0 / 1: never / always
     int tg_fuse = 1;            // a column's solve and the final chunk of the tile below it as one task (needs the shadows and one workgroup per CU)
-    int tg_shadow = 1;          // role S as one workgroup that follows the diagonal factorisation step by step
     int tg_db_max = 112;          // (N = 12288: 13.04 against 13.38 ms; N = 16384: 27.6 against 27.2: two workgroups per CU win there)
-    int tg_side = 0;              // workgroups reserved for the two critical tiles per block (0 = default 8)
     int tg_grid = 0;              // workgroups launched (0 = by size, bounded by residency)
     int tg_isolate = 1;           // the critical workgroups keep their compute units to themselves (full grids only)
     int tg_trace = 0;             // diagnostic: stamp the critical path with the kernel's own clock (gpx_chol_trace)

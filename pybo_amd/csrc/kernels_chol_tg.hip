@@ -7,32 +7,37 @@
 // the first instruction: the workgroups stay resident, take roles, and hand tiles to each other through agent-scope
 // flags in device memory.
 //
-//   role C (1 workgroup)    POTRF(p), p = 0 .. nP-1: the 16-wide MFMA-blocked diagonal factorisation (potrf16_body).
-//   role S (8 by default)   the two tiles on the critical path between POTRF(p) and POTRF(p+1): the panel solve of tile
-//                           (p, p+1) in two 64-column halves, then the update of the diagonal tile (p+1, p+1) with block
-//                           row p in six 32-column pieces, operands straight from global memory (no LDS staging).
-//   role W (everyone else)  the throughput work, from ONE list: panel solves TRSM(p, J), J >= p+2, and the tile updates
-//                           S_IJ -= sum_{k in [k0,k1)} R_kI^T R_kJ  on the 128 x 128 fp64-MFMA tile engine.
+//   role C (1 workgroup)    POTRF(p), p = 0 .. nP-1: the 16-wide MFMA-blocked diagonal factorisation (potrf16_body), with a
+//                           counter published after each of its eight 16-row steps.
+//   the shadows (7)         dedicated workgroups that FOLLOW role C (and each other) 16 rows at a time instead of waiting for
+//                           whole tiles: the solves of tiles (p, p+1), (p, p+2), (p, p+3) [S1, S2, S3], the last two chunks of
+//                           the next diagonal tile [U0, U], the final chunks of tiles (p+1, p+2), (p+1, p+3) [V, V2] -- see "the
+//                           shadows" below.  Between two diagonal blocks nothing starts from a flag and a cold tile any more.
+//   role W (everyone else)  the throughput work, from ONE list: the links of the column chains right of that band -- the solve of
+//                           tile (p, J) and, fused with it per 64-column half, the final chunk of tile (p+1, J) (tg_do_trsmu;
+//                           two solve halves and a separate update where a workgroup has only one k-step image of LDS) -- and the
+//                           tile updates  S_IJ -= sum_{k in [k0,k1)} R_kI^T R_kJ  on the 128 x 128 fp64-MFMA tile engine.
 //
-// Tile (I, J) receives its I block updates in CHUNKS of consecutive k, graded by distance from the pivot (default 1, 2, 4, 8,
+// Tile (I, J) receives its I block updates in CHUNKS of consecutive k, graded by distance from the pivot (default 1, 1, 2, 4,
 // 16, 16, ... blocks counted back from k = I): far from the pivot a chunk is long (arithmetic intensity), next to it the
-// chunks are single blocks (latency: the final chunk of row I becomes available when block row I-1 is solved and is
-// needed one diagonal block later).  Accumulators start from the S tile and k ascends within and across chunks, so every
+// chunks are single blocks (latency).  Accumulators start from the S tile and k ascends within and across chunks, so every
 // element sees the same sequence of FMAs as in the stream-scheduled kernels: the factor is BIT-IDENTICAL.
 //
-// Scheduling: the task lists are built on the host in the order the tasks become available (a valid topological order): one
-// list for the side-kicks, one for the workers, oldest first.  A workgroup without a task DRAWS the next ticket of its list
-// with one fetch-and-add and waits for THAT task's dependencies with the ticket in hand (bounded polling, 0.4 us between
-// looks): nothing stands between "ready" and "running".  Every ticket is held by a polling workgroup, tickets are drawn in
-// topological order and a task only waits for earlier tasks, so the earliest incomplete task of the graph is always held by
-// a workgroup that will run it: the lists cannot dead-lock as long as the role-C / role-S workgroups and one worker are
+// Scheduling: the workers' list is built on the host in the order the tasks become available (a valid topological order),
+// oldest first.  A workgroup without a task DRAWS the next ticket with one fetch-and-add and waits for THAT task's
+// dependencies with the ticket in hand (bounded polling, 0.4 us between looks): nothing stands between "ready" and "running".
+// Every ticket is held by a polling workgroup, tickets are drawn in topological order and a task only waits for earlier tasks
+// or for the shadows (which wait only for role C, each other and earlier tasks), so the earliest incomplete task of the graph is
+// always held by a workgroup that will run it: the list cannot dead-lock as long as role C, the shadows and one worker are
 // resident, and roles are handed out in order of arrival.  Every spin is bounded (abort code 2 -> the launcher's caller
 // re-runs the stream schedule).  Dependencies are counters: seq[I][J] = chunks applied to tile (I, J), solved[2J + h] =
-// block rows solved in the 64-column half h of block column J, diag[p], and quad[p] = pieces of the diagonal tile p that
-// have received block row p-1.
-// (Measured and removed in round 5 -- the A/B logs are profiles/r04_chol_tg_*_ab.txt: claiming a head by compare-and-swap,
-//  a peek before the draw, priority lists, strided sub-queues, an urgent-only pool, XCD-affine tickets, a fused solve + update
-//  task, column-major lists, the next solve's dependency cone on the side-kicks: every one slower or no faster.)
+// block rows solved in the 64-column half h of block column J, diag[p], quad[p] = the diagonal tile p is ready for role C,
+// the step counters of role C / S1 / S2 / S3, and per half tile a flag "final" for the fused links.
+// (History.  Round 4 had two solve halves and six update pieces per block row on a critical list served by eight side-kick
+//  workgroups -- three hand-offs of 4-5 us between two diagonal blocks, block period 56 us; the A/B against it, before it was
+//  removed: profiles/r05_chol_shadow_ab.txt.  Measured and removed earlier -- profiles/r04_chol_tg_*_ab.txt: claiming a head by
+//  compare-and-swap, a peek before the draw, priority lists, strided sub-queues, an urgent-only pool, XCD-affine tickets,
+//  column-major lists, the next solve's dependency cone on the side-kicks: every one slower or no faster.)
 //
 // Hand-offs follow MI355X_MICROARCH.md ("inter-workgroup visibility"): payloads are stored write-through at agent scope
 // (fit_tiles.h, AG = true), every storing wave drains (s_waitcnt vmcnt(0)), barrier, ONE lane stores the flag; consumers
@@ -46,7 +51,7 @@
 
 namespace gpx {
 
-enum { TG_TRSM = 1, TG_UPD = 2, TG_UPDQ = 3, TG_SHADOW = 4, TG_TRSMU = 5 };
+enum { TG_TRSM = 1, TG_UPD = 2, TG_SHADOW = 4, TG_TRSMU = 5 };      // (3 was the piece of a diagonal tile's update: the shadows' U now)
 struct TgTask { int16_t type, I, J, k0, k1, ord, aux, rsv; };     // 16 bytes; aux = column half (TRSM) / piece (UPDQ)
 
 struct TgArgs {
@@ -57,8 +62,6 @@ struct TgArgs {
     int* ctl;                    // control block (zeroed before every launch), layout below
     const TgTask* q[2];          // 0: critical (role S), 1: the workers' list
     int n[2];
-    int nside;
-    int shadow;                  // role S is three workgroups that follow the diagonal factorisation step by step (tg_role_s1 / s2 / u)
     int isolate;                 // the critical workgroups keep their compute units to themselves
     int nap;                     // longest pause between two looks at a waiting task's dependencies, in units of 64 clocks (8, 16, 32, 64 or 127)
     long long* trace;            // optional: [p][4] critical-path stamps, then [crit task][2]
@@ -72,7 +75,8 @@ struct TgArgs {
 // Default chunks (sweeps in profiles/r04_chol_taskgraph.txt): 1, 2, 4, 8, 16, 16, .. blocks counted back from the pivot.
 constexpr int TG_DEFAULT_CHUNKS = 11249;      // 1, 1, 2, 4, 16, 16, ..: the two chunks next to the pivot are single block rows (the shadows' U0 / U, V / V2)
 constexpr int TG_LOG_CAP = 1024, TG_LOG_WGS = 1024;
-constexpr int TG_NPIECE = 6;          // pieces of the critical update of a diagonal tile
+constexpr int TG_NPIECE = 6;          // what role U stores into quad[p] when the diagonal tile p is ready for role C (the update once came in six pieces)
+constexpr int TG_NSHADOW = 7;         // roles 1 .. 7: S1, S2, S3, U, U0, V, V2 (role 0 is C; workers from 8 on)
 constexpr int TG_CTL_ABORT = 32, TG_CTL_HEAD = 64, TG_CTL_STEP = 128, TG_CTL_XSTEP = 160, TG_CTL_XSTEP2 = 192, TG_CTL_XSTEP3 = 224, TG_CTL_BASE = 256, TG_CU_KEYS = 4096;
 __host__ __device__ inline int tg_npad(int nP) { return (nP + 31) / 32 * 32; }
 __host__ __device__ inline int tg_ctl_hf(int nP) { return TG_CTL_BASE + 4 * tg_npad(nP) + nP * nP + 2 * TG_CU_KEYS; }      // half-tile flags [nP * nP * 2], then arrival counts [nP * nP]
@@ -81,31 +85,27 @@ __host__ __device__ inline int tg_ctl_ints(int nP) { return tg_ctl_hf(nP) + 3 * 
 __device__ __forceinline__ int ldi(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void sti(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// PRE (the critical list): only the dependency on the tile's earlier chunks -- a side-kick takes its task as soon as the
-// tile it will read first is final, starts loading it, and waits for the last dependency (the diagonal block / the two
-// solves) inside the task body: the loads of the S tile are off the critical path.
-template <bool PRE>
+// a worker's task may start: a solve when the diagonal block is factored and its tile has every chunk; an update when the
+// tile's earlier chunks are applied and the block rows it applies are solved in both block columns; a fused link (see
+// tg_do_trsmu) when its half of tile (I, J) is final -- the same half's link of the row above said so; the diagonal block and
+// everything else are waited for inside the task, behind the loads of the right-hand sides
 __device__ __forceinline__ bool tg_deps_met(const TgTask& t, const int* dd, const int* sv, const int* sq, int nP) {
     const int I = t.I, J = t.J;
-    const int s = ldi(sq + I * nP + J);
-    if (PRE) return s == t.ord;
-    if (t.type == TG_TRSM) return (ldi(dd + I) != 0) && (s == t.ord);
-    // the fused link of a column's chain: its half of tile (I, J) is final (the same half's link of the row above said so);
-    // the diagonal block and everything else are waited for inside the task, behind the loads of the right-hand sides
     if (t.type == TG_TRSMU) return I == 0 || ldi(dd + tg_ctl_hf(nP) - TG_CTL_BASE + (I * nP + J) * 2 + t.aux) != 0;
+    const int s = ldi(sq + I * nP + J);
+    if (t.type == TG_TRSM) return (ldi(dd + I) != 0) && (s == t.ord);
     const int s0 = ldi(sv + 2 * I), s1 = ldi(sv + 2 * I + 1), s2 = ldi(sv + 2 * J), s3 = ldi(sv + 2 * J + 1);
     return (s == t.ord) && (min(min(s0, s1), min(s2, s3)) >= t.k1);
 }
 
 struct TgHeld { TgTask t; int have; };     // in LDS, one per workgroup: the ticket in hand (have: 0 none, 1 a task, 2 the list ran out)
 
-// The next task of list Q (0: critical, 1: workers) for this workgroup.  Called by ONE full wave; lane 0 works, the
+// The next task of the workers' list for this workgroup.  Called by ONE full wave; lane 0 works, the
 // result is the same in every lane: 1 (task in `out`), 0 (the list is exhausted) or -1 (abort).
 // A workgroup without a ticket draws one at once (ONE fetch-and-add) and waits for that task's dependencies with the
 // ticket in hand.  (History, profiles/r04_chol_taskgraph.txt: claiming a head with compare-and-swap after checking its
 // dependencies serialised the chip -- 1.3 us per task with 123 workers, 5.9 us with 507, N = 8192 in 107 ms; peeking at the
 // head before drawing made every idle workgroup rush for the one head that had just become ready: 1-2 % slower.)
-template <int Q>
 __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, TgHeld* held) {
     const int nP = a.nP, npad = tg_npad(nP);
     int* ctl = a.ctl;
@@ -113,10 +113,10 @@ __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, T
     const int* sv = dd + 2 * npad;
     const int* sq = sv + 2 * npad;
     const long long t0 = wall_clock64();
-    int nap = 0;                                   // polls since the draw: the pauses grow (Q == 0: stay alert)
-    int* head = ctl + TG_CTL_HEAD + 32 * Q;
-    const int nq = a.n[Q];
-    const TgTask* tq = a.q[Q];
+    int nap = 0;                                   // polls since the draw: the pauses grow
+    int* head = ctl + TG_CTL_HEAD + 32;
+    const int nq = a.n[1];
+    const TgTask* tq = a.q[1];
     for (unsigned spins = 0;; ++spins) {
         if (ldi(ctl + TG_CTL_ABORT) != 0) return -1;
         int code = 0;                              // 1: the held task is ready, 2: the list ran out
@@ -136,7 +136,7 @@ __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, T
                 code = 2;
             } else {
                 u.t = held->t;
-                if (tg_deps_met<Q == 0>(u.t, dd, sv, sq, nP)) {
+                if (tg_deps_met(u.t, dd, sv, sq, nP)) {
                     held->have = 0;
                     code = 1;
                 }
@@ -153,7 +153,7 @@ __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, T
         // pauses between two looks: 256 clocks at first, then a.nap x 64 (default 16: 0.4 us; until late in round 4 the long
         // pause was 127 x 64 clocks = 3.4 us -- half of that, on average, between a dependency's arrival and the task's start:
         // N = 2048 0.945 -> 0.876 ms, 8192 5.30 -> 5.19; profiles/r04_chol_tg_polling_ab.txt)
-        if (Q == 0 || nap < 4) __builtin_amdgcn_s_sleep(4);
+        if (nap < 4) __builtin_amdgcn_s_sleep(4);
         else if (a.nap <= 8) __builtin_amdgcn_s_sleep(8);
         else if (a.nap <= 16) __builtin_amdgcn_s_sleep(16);
         else if (a.nap <= 32) __builtin_amdgcn_s_sleep(32);
@@ -191,53 +191,6 @@ __device__ __forceinline__ bool tg_wait_flags(const TgArgs& a, const int* f0, co
     }
     __syncthreads();
     return code[2] != 0;
-}
-
-// Piece `aux` (0..5) of the update of the diagonal tile (I, I) with block rows [k0, k1): quadrant q = aux >> 1 (0: rows
-// 0-63 x columns 0-63, 1: rows 0-63 x columns 64-127, 2: rows 64-127 x columns 64-127; the lower-left quadrant is never
-// read), column half aux & 1 (32 columns).  One wave = 16 rows x 32 columns = 2 accumulators; fragments straight from
-// global memory in the k-major layout (lane (g, n) <- row 4 kk + g, column n), a whole block row of k (96 loads per
-// lane) in flight at once: ONE round trip per block; no LDS.  The accumulators are loaded BEFORE the task's last
-// dependency (the two solves of tile (I-1, I)) is awaited.  The same FMAs per element as the tile engines: the accumulators
-// start from S, A enters negated, k ascends 4 at a time.  Waves whose two 16-tiles lie below the diagonal do nothing.
-__device__ __forceinline__ bool updq_body(const TgArgs& a, const double* __restrict__ R, double* __restrict__ S, int64_t Np,
-                                          int k0, int k1, int I, int aux, const int* solved) {
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6, g = lane >> 4, n = lane & 15;
-    const int64_t i0 = (int64_t)I * NB;
-    const int q = aux >> 1;
-    const int r0 = (q == 2) ? 64 : 0, c0 = ((q == 0) ? 0 : 64) + 32 * (aux & 1);
-    const bool live = (r0 + 16 * w) <= (c0 + 16);           // tile row <= the piece's last tile column
-    d4 acc[2] = {(d4){0.0, 0.0, 0.0, 0.0}, (d4){0.0, 0.0, 0.0, 0.0}};
-    if (live) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[j][r] = ldg<true>(S + (i0 + r0 + 16 * w + g + 4 * r) * Np + i0 + c0 + 16 * j + n);
-    }
-    if (!tg_wait_flags(a, solved + 2 * I, solved + 2 * I + 1, k1)) return false;
-    if (live) {
-        const double* Ra = R + i0 + r0 + 16 * w + n;
-        const double* Rb = R + i0 + c0 + n;
-        for (int kb = k0 * NB; kb < k1 * NB; kb += NB) {
-            double av[32], bv[32][2];
-#pragma unroll
-            for (int kk = 0; kk < 32; ++kk) {
-                const int64_t row = (int64_t)(kb + 4 * kk + g) * Np;
-                av[kk] = ldg<true>(Ra + row);
-                bv[kk][0] = ldg<true>(Rb + row);
-                bv[kk][1] = ldg<true>(Rb + row + 16);
-            }
-#pragma unroll
-            for (int kk = 0; kk < 32; ++kk)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[kk], bv[kk][j], acc[j], 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) stg<true>(S + (i0 + r0 + 16 * w + g + 4 * r) * Np + i0 + c0 + 16 * j + n, acc[j][r]);
-    }
-    return true;
 }
 
 // The panel solve of fit_tiles.h with the factor's diagonal block staged in LDS.  panel_solve16_body reads its A fragments
@@ -361,8 +314,7 @@ __device__ __noinline__ void tg_role_diag(const TgArgs& a) {
         }
         __syncthreads();
         if (code[0] != 1) break;
-        if (a.shadow) potrf16_body<false, true, true>(a.S, a.R, a.T, a.U, a.Np, p, a.dflag, nullptr, Pn, Ud, sflag, ctl + TG_CTL_STEP, 8 * p);
-        else potrf16_body<false, true>(a.S, a.R, a.T, a.U, a.Np, p, a.dflag, nullptr, Pn, Ud, sflag);
+        potrf16_body<false, true, true>(a.S, a.R, a.T, a.U, a.Np, p, a.dflag, nullptr, Pn, Ud, sflag, ctl + TG_CTL_STEP, 8 * p);
         tg_drain();
         __syncthreads();
         if (sflag) {
@@ -371,28 +323,36 @@ __device__ __noinline__ void tg_role_diag(const TgArgs& a) {
         }
         if (t == 0) {
             sti(dd + p, 1);
-            if (a.shadow) sti(ctl + TG_CTL_STEP, 8 * p + 8);
+            sti(ctl + TG_CTL_STEP, 8 * p + 8);
             if (a.trace) a.trace[4 * p + 2] = wall_clock64();
         }
     }
 }
 
-// ---- the shadows of the diagonal factorisation: roles S1, S2 and U ------------------------------------------------------
+// ---- the shadows of the diagonal factorisation: roles S1, S2, S3, U0, U, V, V2 -------------------------------------------
 // Between POTRF(p) and POTRF(p+1) lie the solve of tile (p, p+1) and the update of the diagonal tile (p+1, p+1) with it.
-// As tasks (two solve halves, six update pieces) they start from nothing when the diagonal block's flag goes up and cost
-// three hand-offs of 4-5 us on the critical path.  The shadows do both WHILE the diagonal block is being factored: role C
-// publishes a counter after each of its eight 16-row steps (potrf16_body, STEP), and three dedicated workgroups follow it:
-//   S1  advances the substitution of tile (p, p+1) by one step per flag -- x_jb = T_d(jb) s_jb, s_i -= R[jb, i]^T x_jb, the
+// As tasks (two solve halves, six update pieces: round 4) they started from nothing when the diagonal block's flag went up and
+// cost three hand-offs of 4-5 us on the critical path: 28 us of diagonal block + 26-28 us of hand-offs per block row.  The
+// shadows do both WHILE the diagonal block is being factored: role C publishes a counter after each of its eight 16-row steps
+// (potrf16_body, STEP), and dedicated workgroups follow it -- and each other -- one step at a time:
+//   S1  advances the substitution of tile (p, p+1) by one step per count -- x_jb = T_d(jb) s_jb, s_i -= R[jb, i]^T x_jb, the
 //       MFMAs of panel_solve16_lds in the same order -- and publishes its own counter per 16 solved rows;
 //   U   applies every 16 rows S1 has solved to the diagonal tile (p+1, p+1) (rank-16 update; k ascends 4 at a time as in the
 //       tile engines: bit-identical) and hands the tile to role C;
-//   S2  does S1's work for tile (p, p+2): the LAST update of tile (p+1, p+2) -- the right-hand side S1 needs one block later --
-//       waits for exactly this solve, and as a worker task it arrived when the next diagonal block was already done.
-// When the last step's flag arrives 7/8 of everything is done; what is left between two diagonal blocks is, per hop, one poll,
-// one 16-row load and a handful of MFMAs.  Operands travel global memory -> LDS without registers (global_load_lds_dwordx4,
-// rings of three 16-row panels, up to two steps ahead of the arithmetic when a shadow starts late and the flags are already
-// up); each wave counts the vector-memory operations it has issued since a panel's loads and waits with the matching vmcnt.
-// Wave w owns 32 columns of a solve (8 x 2 accumulator tiles), in U the diagonal tile's column tiles w and 7 - w (9 tiles).
+//   S2, S3  do S1's work for tiles (p, p+2) and (p, p+3), with counters of their own;
+//   U0  applies block row p-1 to the diagonal tile (p+1, p+1) behind S2 of block row p-1: U finds the tile complete up to its
+//       own block row instead of waiting for a worker's 24-us update that could only start when S2 was done;
+//   V, V2  apply block row p-1 to tiles (p, p+1) and (p, p+2) -- the right-hand sides of S1 and S2 -- behind S1 and S2 (S3) of
+//       block row p-1, for the same reason.
+// What is left between two diagonal blocks when everything is on time: S1's last step (one poll, one 16 x 16 load, 8 MFMAs per
+// wave, its stores), U's last step (one poll, one 16-row load, 36 MFMAs, the tile's store) and role C's load of the tile:
+// 8-9 us (the first block rows of a factorisation run at 37-38 us per block row; measured: profiles/r05_chol_taskgraph.txt).
+// What keeps everything on time is the speed of the column chains right of the band (tg_do_trsmu).
+// Operands travel global memory -> LDS without registers (global_load_lds_dwordx4; rings of 16-row panels, up to three steps
+// ahead of the arithmetic when a shadow starts late and the counts are already up); each wave counts the vector-memory
+// operations it has issued since a panel's loads and waits with the matching vmcnt; all bookkeeping is wave-uniform (SGPRs).
+// Wave w owns 32 columns of a solve (8 x 2 accumulator tiles), in U / U0 the diagonal tile's column tiles w and 7 - w (9
+// tiles), in V / V2 column tiles 2 w, 2 w + 1 (16 tiles).
 __device__ __forceinline__ int tg_peek(const int* f) { return __builtin_amdgcn_readfirstlane(ldi(f)); }
 __device__ __forceinline__ bool tg_wave_wait_ge(const TgArgs& a, const int* f, int need) {
     const long long t0 = wall_clock64();
@@ -908,13 +868,6 @@ __device__ __noinline__ bool tg_do_trsm(const TgArgs& a, int p, int cb) {
     const int* diag = uni(a.ctl) + TG_CTL_BASE;
     return panel_solve16_lds(a, uni(a.U), uni(a.S), uni(a.R), (int64_t)uni64((unsigned long long)a.Np), p, cb, tg_buf, diag);
 }
-__device__ __noinline__ bool tg_do_updq(const TgArgs& a, int k0, int k1, int I, int q) {
-    k0 = __builtin_amdgcn_readfirstlane(k0); k1 = __builtin_amdgcn_readfirstlane(k1);
-    I = __builtin_amdgcn_readfirstlane(I); q = __builtin_amdgcn_readfirstlane(q);
-    __builtin_amdgcn_s_setprio(3);
-    const int* solved = uni(a.ctl) + TG_CTL_BASE + 2 * tg_npad(__builtin_amdgcn_readfirstlane(a.nP));
-    return updq_body(a, uni(a.R), uni(a.S), (int64_t)uni64((unsigned long long)a.Np), k0, k1, I, q, solved);
-}
 // ---- TG_TRSMU: one link of a column's chain in ONE task ----------------------------------------------------------------
 // Below the shadows' band every tile column walks down the block rows alone: the solve of tile (p, J) needs the last update
 // of the same tile, which needs the solve of tile (p-1, J).  As two worker tasks (solve 20 us, one-block update 24 us: each
@@ -1057,9 +1010,8 @@ __device__ __noinline__ bool tg_do_trsmu(const TgArgs& a, int p, int J, int h, i
     return true;
 }
 
-template <int Q>
 __device__ __noinline__ int tg_take_call(const TgArgs& a, TgTask& out, int lane) {
-    return tg_take<Q>(a, out, lane, reinterpret_cast<TgHeld*>(tg_smem + 4));
+    return tg_take(a, out, lane, reinterpret_cast<TgHeld*>(tg_smem + 4));
 }
 
 // DB: the launch gives every workgroup two k-step images of LDS (one workgroup per CU): the workers' tile updates run the
@@ -1076,7 +1028,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
     int* sv = qd + npad;
     int* sq = sv + 2 * npad;
     if (t == 0) {
-        // Roles in order of arrival.  The critical workgroups (role C and the role-S side-kicks) keep their compute unit
+        // Roles in order of arrival.  The critical workgroups (role C and the shadows) keep their compute unit
         // to themselves: next to a worker's matrix phases the diagonal block took 60-80 us instead of 26 and the
         // critical solves twice their time (profiles/r04_chol_taskgraph.txt).  The second workgroup to start on a CU
         // looks up what the first one became and leaves at once if that is a critical role (a grid of two workgroups
@@ -1090,7 +1042,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
         if (a.isolate && atomicAdd(cu_cnt + key, 1) > 0) {
             int first = 0;
             for (unsigned spins = 0; (first = ldi(cu_role + key)) == 0 && spins < 100000; ++spins) __builtin_amdgcn_s_sleep(1);
-            if (first != 0 && first - 1 <= a.nside) r = -2;          // leave
+            if (first != 0 && first - 1 <= TG_NSHADOW) r = -2;          // leave
         }
         if (r != -2) {
             r = atomicAdd(ctl, 1);
@@ -1106,7 +1058,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
         tg_role_diag(a);
         return;
     }
-    if (a.shadow && role <= 7) {     // the shadows of role C
+    if (role <= TG_NSHADOW) {        // the shadows of role C
         if (role == 1) tg_role_s1(a);
         else if (role == 2) tg_role_s2(a);
         else if (role == 3) tg_role_s3(a);
@@ -1116,7 +1068,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
         else tg_role_v2(a);
         return;
     }
-    const bool side = !a.shadow && role <= a.nside;
     long long prof[6] = {0, 0, 0, 0, 0, 0};
     long long tprev = a.trace ? wall_clock64() : 0;
     for (;;) {
@@ -1124,7 +1075,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
             TgTask tk;
             tk.type = 0;
             __builtin_amdgcn_s_setprio(0);
-            const int c = side ? tg_take_call<0>(a, tk, lane) : tg_take_call<1>(a, tk, lane);
+            const int c = tg_take_call(a, tk, lane);
             if (lane == 0) {
                 *cur = tk;
                 code[0] = c;
@@ -1141,10 +1092,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
             tg_do_upd<DB>(a, tk.k0, tk.k1, tk.I, tk.J);
         } else if (tk.type == TG_TRSM) {
             if (!tg_do_trsm(a, tk.I, 2 * (tk.J - tk.I - 1) + tk.aux)) break;
-        } else if (tk.type == TG_TRSMU) {
-            if (!tg_do_trsmu(a, tk.I, tk.J, tk.aux, tk.k0, tk.rsv)) break;
         } else {
-            if (!tg_do_updq(a, tk.k0, tk.k1, tk.I, tk.aux)) break;
+            if (!tg_do_trsmu(a, tk.I, tk.J, tk.aux, tk.k0, tk.rsv)) break;
         }
         tg_drain();
         __syncthreads();
@@ -1163,20 +1112,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
                 if (tk.type == TG_UPD) prof[5] += tk.k1 - tk.k0;
             }
             if (tk.type == TG_UPD) sti(sq + tk.I * nP + tk.J, tk.ord + 1);
-            else if (tk.type == TG_TRSM) sti(sv + 2 * tk.J + tk.aux, tk.I + 1);
-            else if (tk.type == TG_UPDQ) atomicAdd(qd + tk.I, 1);          // (a fused link has published itself)
-            if (side && a.trace && (tk.type == TG_UPDQ || (tk.type == TG_TRSM && tk.J == tk.I + 1))) {
-                const int slot = (tk.type == TG_TRSM) ? (8 * tk.I + tk.aux) : (8 * (tk.I - 1) + 2 + tk.aux);
-                a.trace[4 * nP + 2 * slot] = ts;
-                a.trace[4 * nP + 2 * slot + 1] = wall_clock64();
-            }
+            else if (tk.type == TG_TRSM) sti(sv + 2 * tk.J + tk.aux, tk.I + 1);          // (a fused link has published itself)
             if (a.trace) { tprev = wall_clock64(); prof[4] += tprev - te; }
         }
     }
     if (a.trace && t == 0 && role < 1024) {
         long long* o = a.trace + 20 * (long long)nP + 8 * role;
         for (int i = 0; i < 6; ++i) o[i] = prof[i];
-        o[6] = side ? 1 : 2;
+        o[6] = 2;
         o[7] = wall_clock64();
     }
 }
@@ -1184,8 +1127,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
 // ---- host: the task lists -----------------------------------------------------------------------------------------
 
 // chunk boundaries of block row I: k = I - d for the distances d = 0, c1, c1 + c2, ... (chunk sizes counted back from
-// the pivot, the last size repeated), plus 0; a first chunk shorter than 2 blocks is merged into the next one
-static std::vector<int> tg_boundaries(int I, const std::vector<int>& sizes, bool merge_first) {
+// the pivot, the last size repeated), plus 0
+static std::vector<int> tg_boundaries(int I, const std::vector<int>& sizes) {
     std::vector<int> b;
     int d = 0;
     size_t i = 0;
@@ -1199,18 +1142,21 @@ static std::vector<int> tg_boundaries(int I, const std::vector<int>& sizes, bool
     b.push_back(0);
     std::reverse(b.begin(), b.end());                 // ascending: 0 = b[0] < ... < b[nb] = I
     b.erase(std::unique(b.begin(), b.end()), b.end());
-    while (merge_first && b.size() > 2 && b[1] - b[0] < 2) b.erase(b.begin() + 1);
     return b;
 }
 
 struct TgTables { std::vector<TgTask> q[2]; };
 
-// The two lists, in generation order = a topological order of the graph.  Per step p (the block row that POTRF(p) releases):
-// first ALL solves of block row p (the two halves of tile (p, p+1) on the critical list, the others on the workers'), then
-// the chunks that end at boundary p + 1, row by row, nearest the pivot first (the final chunk of the diagonal tile
-// (p+1, p+1) as six pieces on the critical list).  (Column-major inside the step -- every update right behind the last
-// solve it needs -- puts long far chunks in front of later solves: 7.8 against 5.5 ms at N = 8192, removed.)
-static void tg_build(int nP, int chunk_code, TgTables& out, bool shadow = false, bool fuse = false) {
+// The lists, in generation order = a topological order of the graph.  List 0 is not drawn from: it holds one descriptor per
+// block row p for the shadows -- ord: the chunks of every tile of row p (what a solve of that row waits for); [k0, k1) / aux:
+// the final chunk of row p+1 and its ordinal; rsv: the first block row of the chunk before it on the diagonal tile (p+1, p+1)
+// (role U0's), or -1.  List 1, the workers': per step p (the block row that POTRF(p) releases) first the links of the column
+// chains right of the shadows' band (J >= p+4; fused: solve + final chunk of the tile below per 64-column half; else the two
+// solve halves), then the chunks that end at boundary p + 1, row by row, nearest the pivot first -- without those that belong
+// to the shadows (the final chunks of tiles (I, I .. I+2), the diagonal tile's chunk before its final one) and, with fused
+// links, without any final chunk.  (Column-major inside the step -- every update right behind the last solve it needs -- puts
+// long far chunks in front of later solves: 7.8 against 5.5 ms at N = 8192, removed.)
+static void tg_build(int nP, int chunk_code, TgTables& out, bool fuse) {
     std::vector<int> sizes;
     {
         std::vector<int> dg;
@@ -1222,9 +1168,7 @@ static void tg_build(int nP, int chunk_code, TgTables& out, bool shadow = false,
     std::vector<std::vector<int>> bnd(nP);
     std::vector<std::vector<int>> ends(nP + 1);        // ends[b] = rows with a chunk ending at boundary b
     for (int I = 0; I < nP; ++I) {
-        // (with the shadows every row keeps its single-block chunks next to the pivot -- they apply them 16 rows at a time from
-        //  LDS; a merged chunk would send them through their slow global-memory path for the rows before the followed one)
-        bnd[I] = tg_boundaries(I, sizes, !shadow);
+        bnd[I] = tg_boundaries(I, sizes);
         for (size_t j = 1; j < bnd[I].size(); ++j) ends[bnd[I][j]].push_back(I);
     }
     auto push = [&](int q, int type, int I, int J, int k0, int k1, int ord, int aux) {
@@ -1243,13 +1187,13 @@ static void tg_build(int nP, int chunk_code, TgTables& out, bool shadow = false,
     for (int p = 0; p < nP; ++p) {
         const int nch = (int)bnd[p].size() - 1;        // chunks of every tile of row p (0 for row 0)
         for (int J = p + 1; J < nP; ++J) {
-            if (shadow && J == p + 1) {                // one descriptor per block row, completed below (k0, k1, aux)
+            if (J == p + 1) {                          // one descriptor per block row, completed below (k0, k1, aux)
                 push(0, TG_SHADOW, p, J, 0, 0, (p == 0) ? 0 : nch, 0);
                 // rsv: where the chunk BEFORE the final one of the diagonal tile (p+1, p+1) starts (role U0's), -1 without one
                 out.q[0].back().rsv = (int16_t)u0_start(p + 1);
                 continue;
             }
-            if (shadow && J <= p + 3) continue;        // roles S2's and S3's
+            if (J <= p + 3) continue;                  // roles S2's and S3's
             if (fuse) {                                // one link of column J's chain: the solve and the final chunk of tile (p+1, J), per half
                 const std::vector<int>& b = bnd[p + 1];
                 const int nb = (int)b.size() - 1;      // the final chunk of row p+1 is [b[nb-1], p+1), its ordinal nb-1
@@ -1259,7 +1203,7 @@ static void tg_build(int nP, int chunk_code, TgTables& out, bool shadow = false,
                 }
                 continue;
             }
-            for (int h = 0; h < 2; ++h) push(J == p + 1 ? 0 : 1, TG_TRSM, p, J, 0, 0, (p == 0) ? 0 : nch, h);
+            for (int h = 0; h < 2; ++h) push(1, TG_TRSM, p, J, 0, 0, (p == 0) ? 0 : nch, h);
         }
         for (int I : ends[p + 1]) {                    // rows ascending: nearest the pivot first
             if (I == 0) continue;
@@ -1267,16 +1211,12 @@ static void tg_build(int nP, int chunk_code, TgTables& out, bool shadow = false,
             while (bnd[I][j] != p + 1) ++j;
             const int k0 = bnd[I][j - 1], k1 = p + 1, ord = (int)j - 1;
             for (int J = I; J < nP; ++J) {
-                if (I == k1 && J == I) {
-                    if (shadow) {
-                        TgTask& d = out.q[0][(size_t)p];
-                        d.k0 = (int16_t)k0; d.k1 = (int16_t)k1; d.aux = (int16_t)ord;
-                        continue;
-                    }
-                    for (int qu = 0; qu < TG_NPIECE; ++qu) push(0, TG_UPDQ, I, I, k0, k1, ord, qu);
-                } else if (shadow && I == k1 && (J <= I + 2 || fuse)) {
+                if (I == k1 && J == I) {                   // role U's: the final chunk of the diagonal tile
+                    TgTask& d = out.q[0][(size_t)p];
+                    d.k0 = (int16_t)k0; d.k1 = (int16_t)k1; d.aux = (int16_t)ord;
+                } else if (I == k1 && (J <= I + 2 || fuse)) {
                     continue;                              // roles V's and V2's: the final chunks of tiles (I, I+1), (I, I+2); beyond: the fused links'
-                } else if (shadow && J == I && k1 == I - 1 && u0_start(I) == k0) {
+                } else if (J == I && k1 == I - 1 && u0_start(I) == k0) {
                     continue;                              // role U0's: the chunk before the final one of the diagonal tile
                 } else {
                     push(1, TG_UPD, I, J, k0, k1, ord, 0);
@@ -1291,7 +1231,7 @@ int64_t tg_tasks_copy(int nP, int chunks, int16_t* out, int64_t cap, int64_t* co
     if (nP < 1 || nP > 2047) return -1;
     TgTables tb;
     if (chunks <= 0) chunks = TG_DEFAULT_CHUNKS;
-    tg_build(nP, chunks, tb, true, true);
+    tg_build(nP, chunks, tb, true);
     int64_t tot = 0;
     for (int q = 0; q < 2; ++q) { counts[q] = (int64_t)tb.q[q].size(); tot += counts[q]; }
     if (out && cap >= tot) {
@@ -1330,7 +1270,7 @@ __global__ __launch_bounds__(64) void k_tg_gate(int* ctl, int nP, int top, long 
 
 
 struct TgCache {                 // per handle (gpx_handle::tg): device copies of the tables and the control block
-    int nP = 0, chunks = 0, shadow = -1;
+    int nP = 0, chunks = 0, fuse = -1;
     TgTask* dq = nullptr;
     int64_t cap_q = 0;
     int n[2] = {0, 0};
@@ -1363,15 +1303,14 @@ bool launch_cholesky_tg(gpx_handle* h) {
     TgCache* c = static_cast<TgCache*>(h->tg);
     hipStream_t s = h->stream;
     const int chunks = h->tg_chunks > 0 ? h->tg_chunks : TG_DEFAULT_CHUNKS;
-    const bool shadow = h->tg_shadow != 0;
     static_assert(3 * TG_SH_PAN + 3 * 256 <= GEMM_LDS_F64 && 4 * TG_SH_PAN <= GEMM_LDS_F64, "the shadows' LDS rings fit the tile engine's buffer");
     // (decided here because the lists depend on it) one workgroup per CU with two k-step images of LDS: see below
     const bool db = (h->tg_db < 0) ? (nP <= h->tg_db_max) : (h->tg_db != 0);
-    const bool fuse = shadow && db && h->tg_fuse != 0;       // a fused link stages a whole 128 x 128 tile in LDS
+    const bool fuse = db && h->tg_fuse != 0;       // a fused link stages a whole 128 x 128 tile in LDS
     static_assert(NB * PFP <= 2 * GEMM_LDS_F64, "tile (p, p+1) fits the two k-step images");
-    if (c->nP != nP || c->chunks != chunks || c->shadow != (int)shadow * 2 + (int)fuse || !c->dq) {
+    if (c->nP != nP || c->chunks != chunks || c->fuse != (int)fuse || !c->dq) {
         TgTables tb;
-        tg_build(nP, chunks, tb, shadow, fuse);
+        tg_build(nP, chunks, tb, fuse);
         const int64_t tot = (int64_t)tb.q[0].size() + (int64_t)tb.q[1].size() + 2;
         if (tot > c->cap_q) {
             if (c->dq) (void)hipFree(c->dq);
@@ -1393,7 +1332,7 @@ bool launch_cholesky_tg(gpx_handle* h) {
             }
             o += c->n[q] + 1;
         }
-        c->nP = nP; c->chunks = chunks; c->shadow = (int)shadow * 2 + (int)fuse;
+        c->nP = nP; c->chunks = chunks; c->fuse = (int)fuse;
     }
     const int64_t nctl = tg_ctl_ints(nP);
     if (nctl > c->cap_ctl) {
@@ -1402,7 +1341,7 @@ bool launch_cholesky_tg(gpx_handle* h) {
         if (hipMalloc((void**)&c->dctl, (size_t)nctl * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return false; }
         c->cap_ctl = nctl;
     }
-    const int nside = shadow ? 7 : std::max(1, std::min(h->tg_side > 0 ? h->tg_side : 8, 16));
+    const int nside = TG_NSHADOW;
     const int64_t nlog = (h->tg_trace >= 2) ? (int64_t)TG_LOG_WGS * TG_LOG_CAP * 4 : 0;
     const int64_t ntrace = 20 * (int64_t)nP + 8 * 1024 + 16 + nlog;
     if (h->tg_trace && ntrace > c->cap_trace) {
@@ -1447,8 +1386,6 @@ bool launch_cholesky_tg(gpx_handle* h) {
     a.S = h->dS; a.R = h->dR; a.T = h->dT; a.U = h->dU;
     a.Np = Np; a.nP = nP; a.dflag = h->dflag; a.ctl = c->dctl;
     for (int q = 0; q < 2; ++q) { a.q[q] = c->dq + c->off[q]; a.n[q] = c->n[q]; }
-    a.nside = nside;
-    a.shadow = shadow ? 1 : 0;
     a.isolate = (h->tg_isolate != 0 && grid_is_full) ? 1 : 0;
     a.nap = h->tg_nap > 0 ? h->tg_nap : 16;
     a.trace = h->tg_trace ? c->dtrace : nullptr;

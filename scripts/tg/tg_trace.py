@@ -20,28 +20,19 @@ nP = (N + 127) // 128
 diag, crit = e.chol_trace(nP)
 print('N = %d: cholesky %.3f ms (HIP events); kernel-side span %.1f us' % (N, tm, diag[-1, 2]))
 print('per diagonal block, microseconds (kernel clock): wait = start - ready-to-wait, potrf = end - start;')
-print('trsm / updq = the critical tasks after the block: [start of first .. end of last] relative to potrf end')
 per = np.diff(diag[:, 1])
 print('block period: median %.1f  mean %.1f  min %.1f  max %.1f us' % (np.median(per), per.mean(), per.min(), per.max()))
 print('potrf: median %.1f  max %.1f;  wait before potrf: median %.1f  max %.1f' % (
     np.median(diag[:, 2] - diag[:, 1]), (diag[:, 2] - diag[:, 1]).max(), np.median(diag[1:, 1] - diag[1:, 0]), (diag[1:, 1] - diag[1:, 0]).max()))
 rows = list(range(min(nP - 1, 6))) + list(range(max(6, nP // 2 - 2), min(nP - 1, nP // 2 + 2))) + list(range(max(nP - 5, 6), nP - 1))
-shadow = not any(kv.startswith('chol_tg_shadow=0') for kv in sys.argv[2:])
-if shadow:
-    print('shadows, relative to the end of potrf(p): S1 / S2 = [waiting for the right-hand sides from .. loaded at .. last row stored at], '
-          'U = [waiting from .. earlier chunks in at .. tile loaded at .. stored at]')
+print('the workgroups that follow block row p, relative to the end of potrf(p): S1 / S2 = [waiting for the right-hand sides from .. '
+      'loaded at .. last rows stored at], U = [waiting from .. earlier chunks in at .. tile loaded at .. stored at]')
 for p in rows:
     e0 = diag[p, 2]
-    if shadow:
-        ts = crit[p]
-        print('p=%3d potrf %6.1f..%6.1f (%.1f)  S1 %+6.1f %+6.1f %+6.1f   S2 %+6.1f %+6.1f %+6.1f   U %+6.1f %+6.1f %+6.1f %+6.1f   next potrf start +%.1f' % (
-            p, diag[p, 1], diag[p, 2], diag[p, 2] - diag[p, 1], ts[0, 0] - e0, ts[0, 1] - e0, ts[1, 1] - e0,
-            ts[2, 0] - e0, ts[2, 1] - e0, ts[3, 1] - e0, ts[4, 0] - e0, ts[4, 1] - e0, ts[5, 0] - e0, ts[5, 1] - e0, diag[p + 1, 1] - e0))
-        continue
     ts = crit[p]
-    print('p=%3d potrf %6.1f..%6.1f (%.1f)  trsm start +%.1f/+%.1f end +%.1f/+%.1f  updq start +%s end +%s  next potrf start +%.1f' % (
-        p, diag[p, 1], diag[p, 2], diag[p, 2] - diag[p, 1], ts[0, 0] - e0, ts[1, 0] - e0, ts[0, 1] - e0, ts[1, 1] - e0,
-        '%.1f..%.1f' % (np.nanmin(ts[2:, 0]) - e0, np.nanmax(ts[2:, 0]) - e0), '%.1f..%.1f' % (np.nanmin(ts[2:, 1]) - e0, np.nanmax(ts[2:, 1]) - e0), diag[p + 1, 1] - e0))
+    print('p=%3d potrf %6.1f..%6.1f (%.1f)  S1 %+6.1f %+6.1f %+6.1f   S2 %+6.1f %+6.1f %+6.1f   U %+6.1f %+6.1f %+6.1f %+6.1f   next potrf start +%.1f' % (
+        p, diag[p, 1], diag[p, 2], diag[p, 2] - diag[p, 1], ts[0, 0] - e0, ts[0, 1] - e0, ts[1, 1] - e0,
+        ts[2, 0] - e0, ts[2, 1] - e0, ts[3, 1] - e0, ts[4, 0] - e0, ts[4, 1] - e0, ts[5, 0] - e0, ts[5, 1] - e0, diag[p + 1, 1] - e0))
 prof = e.last_chol_profile
 w = prof[prof[:, 6] == 2]
 if len(w):

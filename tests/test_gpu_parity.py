@@ -93,8 +93,8 @@ def test_factor_does_not_depend_on_the_schedule(N):
                  {'chol_tg': 0, 'chol_merge': 0}, {'chol_tg': 0, 'chol_fuse': 1},
                  {'chol_tg': 0, 'chol_graph': 1}, {'chol_tg': 0, 'chol_graph': 1, 'chol_fuse': 1, 'chol_w': 2},
                  tg, dict(tg, chol_tg_chunks=1124), dict(tg, chol_tg_chunks=14),
-                 dict(tg, chol_tg_chunks=11, chol_tg_grid=40), dict(tg, chol_tg_side=2, chol_tg_isolate=0),
-                 dict(tg, chol_tg_grid=512, chol_tg_chunks=1128), dict(tg, chol_tg_nap=127), dict(tg, chol_tg_side=16, chol_tg_chunks=12489, chol_tg_grid=512)]:
+                 dict(tg, chol_tg_chunks=11, chol_tg_grid=40), dict(tg, chol_tg_fuse=0, chol_tg_isolate=0),
+                 dict(tg, chol_tg_grid=512, chol_tg_chunks=1128), dict(tg, chol_tg_nap=127), dict(tg, chol_tg_fuse=0, chol_tg_chunks=12489, chol_tg_grid=512)]:
         e = _engine(**opts)
         for rep in range(2 if ('chol_graph' in opts or opts.get('chol_tg')) else 1):
             e.fit(X, y, 'matern5', ell, 1.3, 1e-4, 0.1, stage=2)
