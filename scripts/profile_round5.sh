@@ -4,7 +4,7 @@
 #   parity incl. the order of the top-k), the default model at scale (--ensemble 10), the variant ns2, the N > 1 code paths on
 #   the one GPU, rocprofv3 kernel-trace summaries, PMC passes (HBM traffic of the sweep kernel at the N = 8192 and config-B
 #   launch geometries; MFMA busy of the sweep kernel, round-4 and round-5 k-loops; MFMA busy of the factorisation), the
-#   factorisation's own critical-path stamps, the sweep-kernel ablation matrix, profiles/r05_roofline.json.
+#   factorisation's own critical-path stamps, the inversion riding behind it (A/B), the sweep-kernel ablation matrix, profiles/r05_roofline.json.
 # Usage (via gpurun): bash scripts/profile_round5.sh [quick]      then, in the build container: bash scripts/collect_round5.sh
 set -u
 export GPX_ROUND=r05
@@ -59,11 +59,13 @@ done
 cd $R
 # the factorisation by its own clock, sizes, the double-buffered workers against the single-buffer ones
 {
-  for n in 2048 4096 8192 16384; do timeout 200 python scripts/tg/tg_trace.py $n; echo; done
-  for n in 2048 4096 8192 12288 16384; do timeout 300 python scripts/tg/tg_sweep.py $n chol_tg=0 chol_tg=1 chol_tg_db=0 chol_tg_db=1; done
+  for n in 1024 2048 4096 8192 16384; do timeout 200 python scripts/tg/tg_trace.py $n; echo; done
+  for n in 256 512 1024 1536 2048 3001 4096 5000 8192 12288 14336 16384; do timeout 300 python scripts/tg/tg_sweep.py $n chol_tg=0 chol_tg=1 chol_tg_fuse=0 chol_tg_db=0; done
   echo; echo "# PMC (rocprofv3 --pmc, k_chol_tg launches of scripts/tg/tg_sweep.py):"
   for n in 16384 8192; do echo "## N = $n"; cat $O/pmc_chol_$n.txt 2>/dev/null; done
 } > $O/chol_taskgraph.txt 2>&1
+# the inversion's leading part behind the factorisation (option trtri_ahead) against the serial order
+{ for n in 3072 4096 5000 8192 12288; do timeout 300 python scripts/ab/ahead_ab.py $n; done; } > $O/trtri_ahead_ab.txt 2>&1
 # the sweep kernel's ablation matrix (stand-alone probe) and the Thompson kernels
 bash scripts/sweep_phase/run_ablation.sh > /dev/null 2>&1; cp $O/sweep_phase/ablation.log $O/sweep_ablation.log 2>/dev/null; rm -f $O/sweep_phase/*.bin
 timeout 300 python scripts/rff_probe/rff_time.py 1,0 > $O/rff_kernels_ab.txt 2>&1
