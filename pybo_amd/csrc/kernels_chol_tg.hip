@@ -19,7 +19,7 @@
 //                           tile updates  S_IJ -= sum_{k in [k0,k1)} R_kI^T R_kJ  on the 128 x 128 fp64-MFMA tile engine.
 //
 // Tile (I, J) receives its I block updates in CHUNKS of consecutive k, graded by distance from the pivot (default 1, 1, 2, 4,
-// 16, 16, ... blocks counted back from k = I): far from the pivot a chunk is long (arithmetic intensity), next to it the
+// 8, 16, 16, ... blocks counted back from k = I): far from the pivot a chunk is long (arithmetic intensity), next to it the
 // chunks are single blocks (latency).  Accumulators start from the S tile and k ascends within and across chunks, so every
 // element sees the same sequence of FMAs as in the stream-scheduled kernels: the factor is BIT-IDENTICAL.
 //
@@ -73,7 +73,7 @@ struct TgArgs {
 // then diag[nPad], quad[nPad], solved[2 nPad], seq[nP * nP], and per compute unit (key = xcc | se | sh | cu, 12 bits)
 // the number of workgroups that have started there and the role of the first one.
 // Default chunks (sweeps in profiles/r04_chol_taskgraph.txt): 1, 2, 4, 8, 16, 16, .. blocks counted back from the pivot.
-constexpr int TG_DEFAULT_CHUNKS = 11249;      // 1, 1, 2, 4, 16, 16, ..: the two chunks next to the pivot are single block rows (the shadows' U0 / U, V / V2)
+constexpr int TG_DEFAULT_CHUNKS = 112489;     // 1, 1, 2, 4, 8, 16, 16, ..: the two chunks next to the pivot are single block rows (the shadows' U0 / U, V / V2); the step from 4 to 16 cost 10 % at N = 4096 (1.45 -> 1.29 ms) and 6 % at 8192
 constexpr int TG_LOG_CAP = 1024, TG_LOG_WGS = 1024;
 constexpr int TG_NPIECE = 6;          // what role U stores into quad[p] when the diagonal tile p is ready for role C (the update once came in six pieces)
 constexpr int TG_NSHADOW = 7;         // roles 1 .. 7: S1, S2, S3, U, U0, V, V2 (role 0 is C; workers from 8 on)
