@@ -503,7 +503,7 @@ __device__ __forceinline__ void syrk_tile(const double* __restrict__ R, double* 
     d4 acc[4][4];
     double* tile = S + i0 * Np + j0;
     tile128_load<AG>(acc, tile, Np);
-    if constexpr (DB) gemm_tile_128_d<PRIO, true>(acc, R + i0, Np, R + j0, Np, kb0 * NB, kb1 * NB, smem);
+    if constexpr (DB) gemm_tile_128_d<PRIO, true, AG ? 16 : 0>(acc, R + i0, Np, R + j0, Np, kb0 * NB, kb1 * NB, smem);
     else gemm_tile_128_g<PRIO, true>(acc, R + i0, Np, R + j0, Np, kb0 * NB, kb1 * NB, smem);
     tile128_store<AG>(acc, tile, Np);
 }

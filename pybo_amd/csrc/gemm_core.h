@@ -304,7 +304,9 @@ __device__ __forceinline__ void gemm_tile_128_s(d4 (&acc)[4][4], const double* _
 // t + 1 are written to the other buffer two 16-byte pieces per MFMA group, and each register is refilled at once with its piece
 // of tile t + 2 -- every global load has a whole step to arrive, every LDS write hides behind 16 MFMAs, ONE barrier per step.
 // Same arithmetic in the same order as the other loops: bit-identical results.  smem: 2 x GEMM_LDS_F64 doubles.
-template <int PRIO = 1, bool NEGA = false>
+// AUX: cache policy of the operand loads (16 = sc1: past this CU's L1 -- operands another workgroup of the SAME launch has just
+// stored write-through need no acquire fence then; every element is loaded once per workgroup, the L1 had nothing to give)
+template <int PRIO = 1, bool NEGA = false, int AUX = 0>
 __device__ __forceinline__ void gemm_tile_128_d(d4 (&acc)[4][4], const double* __restrict__ A, int64_t lda,
                                                 const double* __restrict__ B, int64_t ldb, int k_lo, int k_hi,
                                                 double* smem) {
@@ -328,8 +330,8 @@ __device__ __forceinline__ void gemm_tile_128_d(d4 (&acc)[4][4], const double* _
         __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)Bbase, 0, -1, 0x00020000);
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            ra[p] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rA, voA, p * soA, 0));
-            rb[p] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rB, voB, p * soB, 0));
+            ra[p] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rA, voA, p * soA, AUX));
+            rb[p] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rB, voB, p * soB, AUX));
         }
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -343,8 +345,8 @@ __device__ __forceinline__ void gemm_tile_128_d(d4 (&acc)[4][4], const double* _
             __amdgpu_buffer_rsrc_t rB1 = __builtin_amdgcn_make_buffer_rsrc((void*)Bbase, 0, -1, 0x00020000);
 #pragma unroll
             for (int p = 0; p < 8; ++p) {
-                ra[p] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rA1, voA, p * soA, 0));
-                rb[p] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rB1, voB, p * soB, 0));
+                ra[p] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rA1, voA, p * soA, AUX));
+                rb[p] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rB1, voB, p * soB, AUX));
             }
             Abase += (int64_t)BK32 * lda * 8;
             Bbase += (int64_t)BK32 * ldb * 8;
@@ -391,8 +393,8 @@ __device__ __forceinline__ void gemm_tile_128_d(d4 (&acc)[4][4], const double* _
                 __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
             }
             if (W2) {                                               // ... and its registers refilled with tile kt + 2
-                ra[kk] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rA, voA, kk * soA, 0));
-                rb[kk] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rB, voB, kk * soB, 0));
+                ra[kk] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rA, voA, kk * soA, AUX));
+                rb[kk] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rB, voB, kk * soB, AUX));
                 __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
             }
         }
