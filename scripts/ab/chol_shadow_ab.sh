@@ -1,7 +1,9 @@
 #!/bin/bash
 # The shadows of the diagonal factorisation (chol_tg_shadow=1: seven workgroups that follow role C 16 rows at a time) and the fused
 # links of the column chains (chol_tg_fuse=1) against the task version (two solve halves + six update pieces on a critical list,
-# every solve and every final chunk a worker task), same box, same build.  Written before the task version was removed.
+# every solve and every final chunk a worker task), same box, same build.  HISTORICAL: it ran on commit b6970cf (+ the early
+# publication of the fused links), before the task version and the option chol_tg_shadow were removed; its log is
+# profiles/r05_chol_shadow_ab.txt.  On later builds the chol_tg_shadow settings are rejected (unknown option).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 for n in 512 1024 1536 2048 3001 4096 5000 8192; do
