@@ -80,7 +80,7 @@ def test_refit_with_different_sizes_reuses_the_handle():
     e.close()
 
 
-@pytest.mark.parametrize('N', [700, 2304])
+@pytest.mark.parametrize('N', [300, 520, 700, 2304])      # 3, 5, 6 and 18 blocks: the shadows' loops start and end inside the first rows
 def test_factor_does_not_depend_on_the_schedule(N):
     """The factorisation's schedule options (panel width, left- / right-looking in-panel updates, two-panel accumulation
     of the far updates, diagonal block fused into the panel solve, replay from a captured hipGraph) reorder LAUNCHES,
