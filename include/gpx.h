@@ -83,7 +83,7 @@ int gpx_version(void);
  *              stream behind a gate that opens when those rows are final, and runs on the compute units the factorisation's
  *              chain-bound tail leaves idle; the first use then finds only the trailing group and one product left.  Same kernels,
  *              same results bit for bit.  Applies to the task-graph factorisation with one workgroup per compute unit, from
- *              "trtri_ahead_min" (default 24) 128-blocks on.  0: the inversion starts when it is asked for.
+ *              "trtri_ahead_min" (default 8) 128-blocks on.  0: the inversion starts when it is asked for.
  *          "grad_form": the form of gpx_predict / gpx_ensemble_predict WITH gradients.  0 (default) = auto: a call with
  *              M = 1 point -- every call of the reference's single-seed refinement [pybo/solvers/lbfgs.py:56-58] -- takes
  *              ONE pass over the triangular inverse T with 1 + d right-hand sides, ds2/dx_j = -2 (T k).(T dk/dx_j), when

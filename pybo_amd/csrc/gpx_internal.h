@@ -77,7 +77,7 @@ struct gpx_handle {
     int ahead_top = 0;               // != 0: the leading part of the inversion has been enqueued on stream2 behind the factorisation's gate (ev_rest marks its end)
     bool want_ahead = false;         // fit_core -> launch_cholesky_tg: the inverse follows at once (stage 3 / eager_inverse)
     int trtri_ahead = 1;             // option: allow that (task-graph factorisation with one workgroup per CU only)
-    int trtri_ahead_min = 24;        // ... from this many blocks on
+    int trtri_ahead_min = 8;         // ... from this many blocks on (N = 1024: 0.43 -> 0.41 ms factor + inverse, 1536: 0.65 -> 0.58, 2560: 1.17 -> 1.05: below ~24 blocks the factorisation does not fill the chip and the side stream finds free compute units at once)
     bool diag_inv_pending = false;   // the diagonal blocks of T / U hold 16x16 inverses only (k_trtri_diag128 due)
     bool eager_inverse = false;  // option: form the inverse inside the fit (timing experiments)
     int grad_form = 0;           // option: predict-with-gradients form (0 auto: one pass for a single point, 1 two passes, 2 one pass)

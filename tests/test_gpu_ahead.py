@@ -22,7 +22,7 @@ def _problem(N, d=5, seed=3):
     return X, y, ell, 1.3, 1e-3, 0.2
 
 
-@pytest.mark.parametrize('N', [3072, 3200, 4224, 8192])      # 24 (the default minimum), 25, 33 and 64 blocks
+@pytest.mark.parametrize('N', [1024, 1100, 3072, 3200, 4224, 8192])      # 8 (the default minimum), 9, 24, 25, 33 and 64 blocks
 def test_eager_inverse_ahead_is_bit_identical(N):
     X, y, ell, rho, sn2, bias = _problem(N)
     Xq = np.random.RandomState(1).rand(300, X.shape[1])
