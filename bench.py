@@ -1073,7 +1073,7 @@ def main():
         # the fit's two MFMA stages against the same peak (algorithmic N^3/3 flop each), for EVERY workload:
         # the replicated fit is what bounds strong scaling
         fit = {}
-        for stage, label in (('cholesky', 'cholesky (k_chol_tg: persistent task-graph kernel with its seven shadow workgroups; a single 128-block: k_potrf16; option chol_tg = 0: k_potrf16 + k_panel_solve16 + '
+        for stage, label in (('cholesky', 'cholesky (k_chol_tg: persistent task-graph kernel with its nine shadow workgroups; a single 128-block: k_potrf16; option chol_tg = 0: k_potrf16 + k_panel_solve16 + '
                                           'k_row_update64 + k_syrk_update)'),
                              ('trtri', 'triangular inverse (k_trtri_gemm1/2)')):
             if tm[stage] > 0:

@@ -119,7 +119,7 @@ int gpx_version(void);
  *              instead of two); "chol_graph" = 1: the factorisation's launches are replayed from a captured hipGraph.
  *              Both bit-identical, both measured and off by default ("The fit -- round 3").
  *          "chol_tg" = 1 (default): the factorisation runs as ONE persistent kernel that walks its task graph (one workgroup for
- *              the diagonal blocks, seven that follow it 16 rows at a time with the tiles next to the diagonal, everything else as
+ *              the diagonal blocks, nine that follow it 16 rows at a time with the tiles next to the diagonal, everything else as
  *              throughput work from ONE ticketed, dependency-checked list; kernels_chol_tg.hip) for fits of "chol_tg_min" (default 2) to
  *              "chol_tg_max" (default 160) 128-blocks; 0: the stream schedule above.  Bit-identical factors either way.  Tuning / diagnostics:
  *              "chol_tg_chunks" (k-chunk sizes counted back from the pivot as decimal digits, default 112489 = 1, 1, 2, 4, 8, 16, 16, ..: the digit 9 stands for 16 blocks),

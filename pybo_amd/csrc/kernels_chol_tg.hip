@@ -9,9 +9,9 @@
 //
 //   role C (1 workgroup)    POTRF(p), p = 0 .. nP-1: the 16-wide MFMA-blocked diagonal factorisation (potrf16_body), with a
 //                           counter published after each of its eight 16-row steps.
-//   the shadows (7)         dedicated workgroups that FOLLOW role C (and each other) 16 rows at a time instead of waiting for
+//   the shadows (9)         dedicated workgroups that FOLLOW role C (and each other) 16 rows at a time instead of waiting for
 //                           whole tiles: the solves of tiles (p, p+1), (p, p+2), (p, p+3) [S1, S2, S3], the last two chunks of
-//                           the next diagonal tile [U0, U], the final chunks of tiles (p+1, p+2), (p+1, p+3) [V, V2] -- see "the
+//                           the next diagonal tile [U0, U], the final chunks of tiles (p+1, p+2), (p+1, p+3) [V, V2: two workgroups each] -- see "the
 //                           shadows" below.  Between two diagonal blocks nothing starts from a flag and a cold tile any more.
 //   role W (everyone else)  the throughput work, from ONE list: the links of the column chains right of that band -- the solve of
 //                           tile (p, J) and, fused with it per 64-column half, the final chunk of tile (p+1, J) (tg_do_trsmu;
@@ -76,7 +76,7 @@ struct TgArgs {
 constexpr int TG_DEFAULT_CHUNKS = 112489;     // 1, 1, 2, 4, 8, 16, 16, ..: the two chunks next to the pivot are single block rows (the shadows' U0 / U, V / V2); the step from 4 to 16 cost 10 % at N = 4096 (1.45 -> 1.29 ms) and 6 % at 8192
 constexpr int TG_LOG_CAP = 1024, TG_LOG_WGS = 1024;
 constexpr int TG_NPIECE = 6;          // what role U stores into quad[p] when the diagonal tile p is ready for role C (the update once came in six pieces)
-constexpr int TG_NSHADOW = 7;         // roles 1 .. 7: S1, S2, S3, U, U0, V, V2 (role 0 is C; workers from 8 on)
+constexpr int TG_NSHADOW = 9;         // roles 1 .. 9: S1, S2, S3, U, U0, V (two column halves), V2 (two) -- role 0 is C; workers from 10 on
 constexpr int TG_CTL_ABORT = 32, TG_CTL_HEAD = 64, TG_CTL_STEP = 128, TG_CTL_XSTEP = 160, TG_CTL_XSTEP2 = 192, TG_CTL_XSTEP3 = 224, TG_CTL_BASE = 256, TG_CU_KEYS = 4096;
 __host__ __device__ inline int tg_npad(int nP) { return (nP + 31) / 32 * 32; }
 __host__ __device__ inline int tg_ctl_hf(int nP) { return TG_CTL_BASE + 4 * tg_npad(nP) + nP * nP + 2 * TG_CU_KEYS; }      // half-tile flags [nP * nP * 2], then arrival counts [nP * nP]
@@ -352,7 +352,7 @@ __device__ __noinline__ void tg_role_diag(const TgArgs& a) {
 // ahead of the arithmetic when a shadow starts late and the counts are already up); each wave counts the vector-memory
 // operations it has issued since a panel's loads and waits with the matching vmcnt; all bookkeeping is wave-uniform (SGPRs).
 // Wave w owns 32 columns of a solve (8 x 2 accumulator tiles), in U / U0 the diagonal tile's column tiles w and 7 - w (9
-// tiles), in V / V2 column tiles 2 w, 2 w + 1 (16 tiles).
+// tiles), in a V / V2 workgroup 16 columns of its 64-column half (8 tiles).
 __device__ __forceinline__ int tg_peek(const int* f) { return __builtin_amdgcn_readfirstlane(ldi(f)); }
 __device__ __forceinline__ bool tg_wave_wait_ge(const TgArgs& a, const int* f, int need) {
     const long long t0 = wall_clock64();
@@ -448,10 +448,12 @@ __device__ __forceinline__ void tg_u_issue(int jb, const double* __restrict__ Xg
 // DRAIN: this wave's earlier stores are complete as well before the barrier (S1 publishes the previous step behind it).
 // (Steps are issued in order, so the step to issue is always one of JB, JB + 1, JB + 2: compile-time slots of `mark`.)
 // V role: the 16 rows S1 and S2 solved in step jb of the PREVIOUS block row (tiles (p-1, p) and (p-1, p+1)): two panels
+// (RM + 1 = pairs of panels in the ring: 2 with one k-step image of LDS, 4 with two)
+template <int RM>
 __device__ __forceinline__ void tg_v_issue(int jb, const double* __restrict__ Ag, const double* __restrict__ Bg, int64_t Np,
                                            double* __restrict__ lds, TgFollow& f) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double* pa = lds + (2 * (jb & 1)) * TG_SH_PAN;
+    double* pa = lds + (2 * (jb & RM)) * TG_SH_PAN;
     double* pb = pa + TG_SH_PAN;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -462,14 +464,15 @@ __device__ __forceinline__ void tg_v_issue(int jb, const double* __restrict__ Ag
     f.mark[jb] = f.vmi;
 }
 
-// KIND: 0 = a solve shadow (tg_s_issue), 1 = U (tg_u_issue), 2 = V (tg_v_issue)
+// KIND: 0 = a solve shadow (tg_s_issue), 1 = U (tg_u_issue), 2 / 3 = V with a ring of 2 / 4 panel pairs (tg_v_issue)
 template <int J, int KIND>
 __device__ __forceinline__ void tg_issue(TgFollow& f, double* __restrict__ lds, const double* __restrict__ A0,
                                          const double* __restrict__ A1, int64_t Np) {
     if constexpr (J < 8) {
         if constexpr (KIND == 0) tg_s_issue(J, A0, A1, Np, lds, f);
         else if constexpr (KIND == 1) tg_u_issue(J, A0, Np, lds, f);
-        else tg_v_issue(J, A0, A1, Np, lds, f);
+        else if constexpr (KIND == 2) tg_v_issue<1>(J, A0, A1, Np, lds, f);
+        else tg_v_issue<3>(J, A0, A1, Np, lds, f);
         f.issued = J + 1;
     }
 }
@@ -501,7 +504,7 @@ __device__ __forceinline__ bool tg_follow(const TgArgs& a, const int* counter, c
     if constexpr (DRAIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else tg_vmcnt_le(f.vmi - __builtin_amdgcn_readfirstlane(f.mark[JB]));
     __syncthreads();
-    constexpr int ahead = (KIND == 0) ? 2 : (KIND == 1 ? 3 : 1);     // rings of 3 (S: panel + inverse), 4 (U) and 2 x 2 (V) buffers
+    constexpr int ahead = (KIND == 0) ? 2 : (KIND == 2 ? 1 : 3);     // rings of 3 (S: panel + inverse), 4 (U), 2 or 4 pairs (V) buffers
     constexpr int lim = (JB + 1 + ahead < 8) ? JB + 1 + ahead : 8;
     if (f.issued < lim) {
         if (f.avail < lim) f.avail = max(f.avail, min(8, tg_peek2(counter, counter2) - base));
@@ -742,7 +745,6 @@ __device__ __forceinline__ void tg_role_diagupd(const TgArgs& a) {
                 long long* o = a.trace + 4 * nP + 2 * 8 * p;
                 o[8] = ts0; o[9] = tsq;            // slots 4, 5 (U): waiting for the tile's earlier chunks; loaded .. stored
                 o[10] = ts1; o[11] = te;
-                for (int k = 6; k < 8; ++k) { o[2 * k] = ts1; o[2 * k + 1] = te; }
             }
         }
     }
@@ -753,33 +755,33 @@ __device__ __noinline__ void tg_role_u0(const TgArgs& a) { tg_role_diagupd<false
 
 // V (off = 1) / V2 (off = 2): the final chunk of tile (p, p + off) -- block row p-1, 16 rows at a time behind S1 and S2 (S3) of
 // the previous block row -- so that the right-hand sides of S1 (S2) are complete a few microseconds after those two are, not
-// one worker task (24 us) later.  Wave w owns column tiles 2 w, 2 w + 1 (all eight tile rows: 16 accumulators).
-template <int JB>
-__device__ __forceinline__ bool tg_v_step(const TgArgs& a, const int* cB, int p, TgFollow& f, d4 (&acc)[8][2], double* __restrict__ lds,
+// one worker task (24 us) later.  A full 128 x 128 x 128 update is 13.7 us of ONE compute unit's matrix pipe -- too long a link of
+// that chain (measured: V took 24 us per tile and S1 started 19 us into its diagonal block) -- so each of the two is TWO
+// workgroups, one per 64-column half (wave w: 16 columns, all eight tile rows: 8 accumulators); the second half to finish counts
+// the tile's chunk.
+template <int JB, bool DB>
+__device__ __forceinline__ bool tg_v_step(const TgArgs& a, const int* cB, int p, int half, TgFollow& f, d4 (&acc)[8], double* __restrict__ lds,
                                           const double* __restrict__ Ag, const double* __restrict__ Bg, int64_t Np) {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), g = lane >> 4, n = lane & 15;
-    if (!tg_follow<JB, 2, false>(a, a.ctl + TG_CTL_XSTEP, cB, 8 * (p - 1), f, lds, Ag, Bg, Np)) return false;
-    const double* pa = lds + (2 * (JB & 1)) * TG_SH_PAN + g * PFP + n;
-    const double* pb = pa + TG_SH_PAN + 32 * w;
-    double fa[8][4], nb[2][4];
+    if (!tg_follow<JB, DB ? 3 : 2, false>(a, a.ctl + TG_CTL_XSTEP, cB, 8 * (p - 1), f, lds, Ag, Bg, Np)) return false;
+    const double* pa = lds + (2 * (JB & (DB ? 3 : 1))) * TG_SH_PAN + g * PFP + n;
+    const double* pb = pa + TG_SH_PAN + 64 * half + 16 * w;
+    double fa[8][4], nb[4];
 #pragma unroll
     for (int r = 0; r < 8; ++r)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) fa[r][kk] = pa[4 * kk * PFP + 16 * r];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) nb[j][kk] = -pb[4 * kk * PFP + 16 * j];
+    for (int kk = 0; kk < 4; ++kk) nb[kk] = -pb[4 * kk * PFP];
 #pragma unroll
     for (int r = 0; r < 8; ++r)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc[r][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[r][kk], nb[j][kk], acc[r][j], 0, 0, 0);
+        for (int kk = 0; kk < 4; ++kk) acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[r][kk], nb[kk], acc[r], 0, 0, 0);
     return true;
 }
 
-__device__ __forceinline__ void tg_role_offupd(const TgArgs& a, int off) {
+template <bool DB>
+__device__ __forceinline__ void tg_role_offupd(const TgArgs& a, int off, int half) {
     double* lds = tg_buf;
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), g = lane >> 4, n = lane & 15;
     const int nP = __builtin_amdgcn_readfirstlane(a.nP), npad = tg_npad(nP);
@@ -791,7 +793,8 @@ __device__ __forceinline__ void tg_role_offupd(const TgArgs& a, int off) {
     int* sv = dd + 2 * npad;
     int* sq = sv + 2 * npad;
     __builtin_amdgcn_s_setprio(3);
-    off = __builtin_amdgcn_readfirstlane(off);
+    off = __builtin_amdgcn_readfirstlane(off); half = __builtin_amdgcn_readfirstlane(half);
+    int* hc = ctl + tg_ctl_hf(nP) + 2 * nP * nP;
     const int* cB = ctl + (off == 1 ? TG_CTL_XSTEP2 : TG_CTL_XSTEP3);
     for (int p = 1; p + off < nP; ++p) {
         union { TgTask t; int4 v; } u;
@@ -800,30 +803,27 @@ __device__ __forceinline__ void tg_role_offupd(const TgArgs& a, int off) {
         u.v.z = __builtin_amdgcn_readfirstlane(u.v.z); u.v.w = __builtin_amdgcn_readfirstlane(u.v.w);
         const TgTask d = u.t;
         const int64_t p0 = (int64_t)p * NB, q0 = p0 - NB, j0 = p0 + (int64_t)off * NB;
+        long long ts0 = 0, ts1 = 0;
+        if (a.trace && t == 0) ts0 = wall_clock64();
         if (!tg_wave_wait_ge(a, sq + p * nP + p + off, d.aux)) return;
+        if (a.trace && t == 0) ts1 = wall_clock64();
         const __amdgpu_buffer_rsrc_t rs = tg_rsrc(S + p0 * Np + j0, Np);
         const int vo = (int)((g * Np + n) * 8);
-        d4 acc[8][2];
+        const int co = 64 * half + 16 * w;            // this wave's 16 columns of the tile
+        d4 acc[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[r][j][q] = tg_bload(rs, vo, (int)((((16 * r + 4 * q) * Np) + 32 * w + 16 * j) * 8));
+            for (int q = 0; q < 4; ++q) acc[r][q] = tg_bload(rs, vo, (int)((((16 * r + 4 * q) * Np) + co) * 8));
         // block rows of the final chunk before row p-1 (block row 2 only: its first two chunks are merged): from global memory
         if (d.k0 < p - 1) {
             if (!tg_wave_wait_ge(a, sv + 2 * p, p - 1) || !tg_wave_wait_ge(a, sv + 2 * p + 1, p - 1) ||
                 !tg_wave_wait_ge(a, sv + 2 * (p + off), p - 1) || !tg_wave_wait_ge(a, sv + 2 * (p + off) + 1, p - 1)) return;
             for (int kr = d.k0 * NB; kr < (p - 1) * NB; kr += 4) {
                 const double* Ra = R + (int64_t)(kr + g) * Np + p0 + n;
-                const double* Rb = R + (int64_t)(kr + g) * Np + j0 + 32 * w + n;
-                const double b0 = -ldg<true>(Rb), b1 = -ldg<true>(Rb + 16);
+                const double b0 = -ldg<true>(R + (int64_t)(kr + g) * Np + j0 + co + n);
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const double ar = ldg<true>(Ra + 16 * r);
-                    acc[r][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, b0, acc[r][0], 0, 0, 0);
-                    acc[r][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(ar, b1, acc[r][1], 0, 0, 0);
-                }
+                for (int r = 0; r < 8; ++r) acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(ldg<true>(Ra + 16 * r), b0, acc[r], 0, 0, 0);
             }
         }
         const double* Ag = R + q0 * Np + p0;          // tile (p-1, p): S1's
@@ -832,27 +832,31 @@ __device__ __forceinline__ void tg_role_offupd(const TgArgs& a, int off) {
         f.avail = 0; f.issued = 0; f.vmi = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) f.mark[i] = 0;
-        if (!tg_v_step<0>(a, cB, p, f, acc, lds, Ag, Bg, Np)) return;
-        if (!tg_v_step<1>(a, cB, p, f, acc, lds, Ag, Bg, Np)) return;
-        if (!tg_v_step<2>(a, cB, p, f, acc, lds, Ag, Bg, Np)) return;
-        if (!tg_v_step<3>(a, cB, p, f, acc, lds, Ag, Bg, Np)) return;
-        if (!tg_v_step<4>(a, cB, p, f, acc, lds, Ag, Bg, Np)) return;
-        if (!tg_v_step<5>(a, cB, p, f, acc, lds, Ag, Bg, Np)) return;
-        if (!tg_v_step<6>(a, cB, p, f, acc, lds, Ag, Bg, Np)) return;
-        if (!tg_v_step<7>(a, cB, p, f, acc, lds, Ag, Bg, Np)) return;
+        if (!tg_v_step<0, DB>(a, cB, p, half, f, acc, lds, Ag, Bg, Np)) return;
+        if (!tg_v_step<1, DB>(a, cB, p, half, f, acc, lds, Ag, Bg, Np)) return;
+        if (!tg_v_step<2, DB>(a, cB, p, half, f, acc, lds, Ag, Bg, Np)) return;
+        if (!tg_v_step<3, DB>(a, cB, p, half, f, acc, lds, Ag, Bg, Np)) return;
+        if (!tg_v_step<4, DB>(a, cB, p, half, f, acc, lds, Ag, Bg, Np)) return;
+        if (!tg_v_step<5, DB>(a, cB, p, half, f, acc, lds, Ag, Bg, Np)) return;
+        if (!tg_v_step<6, DB>(a, cB, p, half, f, acc, lds, Ag, Bg, Np)) return;
+        if (!tg_v_step<7, DB>(a, cB, p, half, f, acc, lds, Ag, Bg, Np)) return;
 #pragma unroll
         for (int r = 0; r < 8; ++r)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) tg_bstore(rs, vo, (int)((((16 * r + 4 * q) * Np) + 32 * w + 16 * j) * 8), acc[r][j][q]);
+            for (int q = 0; q < 4; ++q) tg_bstore(rs, vo, (int)((((16 * r + 4 * q) * Np) + co) * 8), acc[r][q]);
         tg_drain();
         __syncthreads();
-        if (t == 0) sti(sq + p * nP + p + off, d.aux + 1);
+        if (t == 0) {
+            if (atomicAdd(hc + p * nP + p + off, 1) == 1) sti(sq + p * nP + p + off, d.aux + 1);     // the second half to arrive counts the chunk
+            if (a.trace && off == 1 && half == 0) {         // slots 6, 7 of the block row it follows: V waiting from / its tile's earlier chunks in at, .. / stored at
+                long long* o = a.trace + 4 * nP + 2 * 8 * (p - 1) + 12;
+                o[0] = ts0; o[1] = ts1; o[2] = ts1; o[3] = wall_clock64();
+            }
+        }
     }
 }
-__device__ __noinline__ void tg_role_v(const TgArgs& a) { tg_role_offupd(a, 1); }
-__device__ __noinline__ void tg_role_v2(const TgArgs& a) { tg_role_offupd(a, 2); }
+template <bool DB> __device__ __noinline__ void tg_role_v(const TgArgs& a, int half) { tg_role_offupd<DB>(a, 1, half); }
+template <bool DB> __device__ __noinline__ void tg_role_v2(const TgArgs& a, int half) { tg_role_offupd<DB>(a, 2, half); }
 
 
 template <bool DB>
@@ -1064,8 +1068,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
         else if (role == 3) tg_role_s3(a);
         else if (role == 4) tg_role_u(a);
         else if (role == 5) tg_role_u0(a);
-        else if (role == 6) tg_role_v(a);
-        else tg_role_v2(a);
+        else if (role <= 7) tg_role_v<DB>(a, role - 6);
+        else tg_role_v2<DB>(a, role - 8);
         return;
     }
     long long prof[6] = {0, 0, 0, 0, 0, 0};
@@ -1304,7 +1308,7 @@ bool launch_cholesky_tg(gpx_handle* h) {
     TgCache* c = static_cast<TgCache*>(h->tg);
     hipStream_t s = h->stream;
     const int chunks = h->tg_chunks > 0 ? h->tg_chunks : TG_DEFAULT_CHUNKS;
-    static_assert(3 * TG_SH_PAN + 3 * 256 <= GEMM_LDS_F64 && 4 * TG_SH_PAN <= GEMM_LDS_F64, "the shadows' LDS rings fit the tile engine's buffer");
+    static_assert(3 * TG_SH_PAN + 3 * 256 <= GEMM_LDS_F64 && 4 * TG_SH_PAN <= GEMM_LDS_F64 && 8 * TG_SH_PAN <= 2 * GEMM_LDS_F64, "the shadows' LDS rings fit the tile engine's buffer(s)");
     // (decided here because the lists depend on it) one workgroup per CU with two k-step images of LDS: see below
     const bool db = (h->tg_db < 0) ? (nP <= h->tg_db_max) : (h->tg_db != 0);
     const bool fuse = db && h->tg_fuse != 0;       // a fused link stages a whole 128 x 128 tile in LDS

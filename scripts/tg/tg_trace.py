@@ -26,13 +26,15 @@ print('potrf: median %.1f  max %.1f;  wait before potrf: median %.1f  max %.1f' 
     np.median(diag[:, 2] - diag[:, 1]), (diag[:, 2] - diag[:, 1]).max(), np.median(diag[1:, 1] - diag[1:, 0]), (diag[1:, 1] - diag[1:, 0]).max()))
 rows = list(range(min(nP - 1, 6))) + list(range(max(6, nP // 2 - 2), min(nP - 1, nP // 2 + 2))) + list(range(max(nP - 5, 6), nP - 1))
 print('the workgroups that follow block row p, relative to the end of potrf(p): S1 / S2 = [waiting for the right-hand sides from .. '
-      'loaded at .. last rows stored at], U = [waiting from .. earlier chunks in at .. tile loaded at .. stored at]')
+      'loaded at .. last rows stored at], U = [waiting from .. earlier chunks in at .. tile loaded at .. stored at], '
+      'V (tile (p+1, p+2), S1\'s right-hand sides of the NEXT block row) = [waiting from .. earlier chunks in at .. stored at]')
 for p in rows:
     e0 = diag[p, 2]
     ts = crit[p]
-    print('p=%3d potrf %6.1f..%6.1f (%.1f)  S1 %+6.1f %+6.1f %+6.1f   S2 %+6.1f %+6.1f %+6.1f   U %+6.1f %+6.1f %+6.1f %+6.1f   next potrf start +%.1f' % (
+    print('p=%3d potrf %6.1f..%6.1f (%.1f)  S1 %+6.1f %+6.1f %+6.1f   S2 %+6.1f %+6.1f %+6.1f   U %+6.1f %+6.1f %+6.1f %+6.1f   V %+6.1f %+6.1f %+6.1f   next potrf start +%.1f' % (
         p, diag[p, 1], diag[p, 2], diag[p, 2] - diag[p, 1], ts[0, 0] - e0, ts[0, 1] - e0, ts[1, 1] - e0,
-        ts[2, 0] - e0, ts[2, 1] - e0, ts[3, 1] - e0, ts[4, 0] - e0, ts[4, 1] - e0, ts[5, 0] - e0, ts[5, 1] - e0, diag[p + 1, 1] - e0))
+        ts[2, 0] - e0, ts[2, 1] - e0, ts[3, 1] - e0, ts[4, 0] - e0, ts[4, 1] - e0, ts[5, 0] - e0, ts[5, 1] - e0,
+        ts[6, 0] - e0, ts[6, 1] - e0, ts[7, 1] - e0, diag[p + 1, 1] - e0))
 prof = e.last_chol_profile
 w = prof[prof[:, 6] == 2]
 if len(w):

@@ -12,13 +12,13 @@ TRSM, UPD, UPDQ, SHADOW, TRSMU = 1, 2, 3, 4, 5
 
 
 def tasks(nP, chunks=0):
-    """The lists as the replay understands them.  On the device the tiles next to the diagonal belong to seven dedicated
+    """The lists as the replay understands them.  On the device the tiles next to the diagonal belong to nine dedicated
     workgroups that FOLLOW the diagonal factorisation instead of drawing tasks (kernels_chol_tg.hip, "the shadows"): the first
     list holds one descriptor per block row p -- ord: chunks of every tile of row p (what a solve of that row waits for);
     [k0, k1) / aux: the final chunk of row p+1 and its ordinal; rsv: the first block row of the chunk before it on the diagonal
     tile (p+1, p+1), or -1.  Expanded here into the tasks those workgroups stand for, in an order a single critical list could
     run them: per block row the solves of tiles (p, p+1 .. p+3) [S1, S2, S3], the final chunks of tiles (p+1, p+2), (p+1, p+3)
-    [V, V2], the diagonal tile (p+2, p+2)'s chunk before its final one [U0], the diagonal tile (p+1, p+1)'s final chunk [U]."""
+    [V, V2: two workgroups each], the diagonal tile (p+2, p+2)'s chunk before its final one [U0], the diagonal tile (p+1, p+1)'s final chunk [U]."""
     q = _lib.chol_tasks(nP, chunks)
     d = q[0]
     assert len(d) == max(nP - 1, 0) and (len(d) == 0 or np.all(d[:, 0] == SHADOW))
