@@ -64,6 +64,8 @@ cd $R
   echo; echo "# PMC (rocprofv3 --pmc, k_chol_tg launches of scripts/tg/tg_sweep.py):"
   for n in 16384 8192; do echo "## N = $n"; cat $O/pmc_chol_$n.txt 2>/dev/null; done
 } > $O/chol_taskgraph.txt 2>&1
+# the factorisation's soak: random sizes and many repetitions, every factor compared bit for bit
+{ timeout 700 python scripts/tg/tg_fuzz_sizes.py 80 1; timeout 700 python scripts/tg/tg_soak.py 600; } > $O/chol_soak.txt 2>&1
 # the inversion's leading part behind the factorisation (option trtri_ahead) against the serial order
 { for n in 3072 4096 5000 8192 12288; do timeout 300 python scripts/ab/ahead_ab.py $n; done; } > $O/trtri_ahead_ab.txt 2>&1
 # the sweep kernel's ablation matrix (stand-alone probe) and the Thompson kernels

@@ -116,3 +116,22 @@ def test_odd_sizes_through_the_multi_panel_factorisation(N):
     mr, sr = ref.predict(Z)
     assert np.all(np.abs(mu - mr) <= mu_tol(mr, rho)) and np.all(np.abs(s2 - sr) <= s2_tol(sr, rho))
     e.close()
+
+
+def test_task_graph_factor_is_the_stream_schedules_at_random_sizes():
+    """The persistent kernel's roles start and stop inside the first and last block rows in a different way at every size: the
+    factor must be the stream schedule's bit for bit at all of them (scripts/tg/tg_fuzz_sizes.py runs 90 sizes)."""
+    from pybo_amd._lib import Engine
+    rng = np.random.RandomState(11)
+    a, b = Engine(0), Engine(0)
+    b.set_option('chol_tg', 0)
+    for N in [129, 256, 257, 385, 513, 1025] + list(rng.randint(130, 3300, size=12)):
+        N = int(N)
+        d = int(rng.randint(1, 7))
+        X = rng.rand(N, d); y = np.sin(X.sum(1)) + 1e-3 * rng.randn(N)
+        ell = 0.3 * np.ones(d)
+        for e in (a, a, b):
+            e.fit(X, y, 'matern5', ell, 1.1, 1e-4, 0.0, stage=2)
+        assert np.array_equal(a.get_matrix('L'), b.get_matrix('L')), N
+    assert a.timers(reset=True)['chol_fallbacks'] == 0
+    a.close(); b.close()
