@@ -1267,7 +1267,10 @@ static int loglik_batch_chunk(gpx_handle* h, int64_t B, const double* hyp, doubl
     bool big = h->chol_tg && nP >= 16 && nP >= h->tg_min && nP <= h->tg_max;
     if (big) {
         double *sS = h->dS, *sR = h->dR, *sT = h->dT, *sU = h->dU;
+        // (the handle's own model may have the leading part of its inversion still riding on the side stream: that state is the
+        //  model's, not these factorisations' -- launch_cholesky_tg clears it)
         const bool s_pending = h->diag_inv_pending, s_launched = h->tg_launched, s_want = h->want_ahead;
+        const int s_ahead = h->ahead_top;
         h->want_ahead = false;
         for (int64_t b = 0; b < B && big; ++b) {
             h->dS = bS + b * bs; h->dR = bR + b * bs; h->dT = nullptr; h->dU = bS + b * bs;
@@ -1276,7 +1279,7 @@ static int loglik_batch_chunk(gpx_handle* h, int64_t B, const double* hyp, doubl
             if (!ok || hipStreamSynchronize(s) != hipSuccess || tg_abort_code(h) == 2) big = false;
         }
         h->dS = sS; h->dR = sR; h->dT = sT; h->dU = sU;
-        h->diag_inv_pending = s_pending; h->tg_launched = s_launched; h->want_ahead = s_want;
+        h->diag_inv_pending = s_pending; h->tg_launched = s_launched; h->want_ahead = s_want; h->ahead_top = s_ahead;
         if (!big) {
             (void)hipGetLastError();
             (void)hipMemsetAsync(bflag, 0, (size_t)B * sizeof(int), s);

@@ -81,3 +81,26 @@ def test_ahead_next_to_a_factor_that_fails():
     a, b = e.predict(Xq), ref.predict(Xq)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     e.close(); ref.close()
+
+
+def test_batched_likelihoods_between_a_fit_and_its_inverse_leave_the_riding_inversion_alone():
+    """gpx_loglik_batch at this size runs task-graph factorisations of its own on the handle (lent buffers): the handle's model
+    may still have the leading part of its inversion on the side stream -- that state must survive."""
+    N = 3000
+    X, y, ell, rho, sn2, bias = _problem(N)
+    Xq = np.random.RandomState(5).rand(40, X.shape[1])
+    ref = _engine(trtri_ahead=0)
+    ref.fit(X, y, 'se', ell, rho, sn2, bias)
+    want = ref.predict(Xq)
+    e = _engine()
+    e.fit(X, y, 'se', ell, rho, sn2, bias)
+    e.predict(Xq)                                              # the inverse was used: the next fit speculates
+    e.fit(X, y, 'se', ell, rho, sn2, bias)
+    hyp = np.array([[sn2, rho] + list(ell) + [bias], [2 * sn2, 0.9 * rho] + list(1.1 * ell) + [bias]])
+    ll = e.loglik_batch(hyp)
+    got = e.predict(Xq)
+    tm = e.timers(reset=True)
+    assert tm['trtri_ahead'] == 1 and tm['chol_fallbacks'] == 0
+    assert np.all(np.isfinite(ll)) and abs(ll[0] - ref.loglik()) <= 1e-8 * abs(ll[0])
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    e.close(); ref.close()
