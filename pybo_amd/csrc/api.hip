@@ -118,7 +118,7 @@ static void harvest(gpx_handle* h) {
 }
 
 // ---- lifetime ---------------------------------------------------------------------------------
-extern "C" int gpx_version(void) { return 500; }   // round * 100: 300 added gpx_predict_mean, gpx_var_at_obs, gpx_capacity, gpx_append_begin; 400 gpx_chol_trace, gpx_chol_tasks, GPX_OPTIONS; 500: gpx_chol_tasks lost its `split` argument (two lists), timers slot 16
+extern "C" int gpx_version(void) { return 510; }   // round * 100: 300 added gpx_predict_mean, gpx_var_at_obs, gpx_capacity, gpx_append_begin; 400 gpx_chol_trace, gpx_chol_tasks, GPX_OPTIONS; 500: gpx_chol_tasks lost its `split` argument (two lists), timers slot 16; 510: timers slots 17, 18, the entries of gpx_chol_tasks / gpx_chol_trace describe the shadows, options trtri_ahead*, chol_tg_fuse (chol_tg_side gone)
 
 extern "C" const char* gpx_last_error(const gpx_handle* h) {
     return h ? h->err.c_str() : g_create_err.c_str();
