@@ -581,14 +581,15 @@ static int fit_core(gpx_handle* h, const double* dX, int64_t N, int64_t d, const
             const bool tg = h->chol_tg && h->x_skip == 0 && h->x_bg <= 0 && h->Np / NB >= h->tg_min && h->Np / NB <= h->tg_max && launch_cholesky_tg(h);
             if (!tg) launch_cholesky(h);
         }
-        int flag = 0;
-        HIPCHK(h, hipMemcpyAsync(&flag, h->dflag, sizeof(int), hipMemcpyDeviceToHost, s));
+        int flag2[2] = {0, 0};       // [0] failing pivot + 1, [1] the task-graph kernel's "a spin gave up" (2): one copy for both
+        HIPCHK(h, hipMemcpyAsync(flag2, h->dflag, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipStreamSynchronize(s));
+        int flag = flag2[0];
         if (h->ahead_top != 0 && flag != 0) {      // not positive definite: what the side stream is doing is of no use
             (void)hipStreamSynchronize(h->stream2);
             h->ahead_top = 0;
         }
-        if (h->tg_launched && flag == 0 && tg_abort_code(h) == 2) {
+        if (h->tg_launched && flag == 0 && flag2[1] == 2) {
             // a spin of the persistent kernel gave up (the device is shared with something that kept its workgroups from
             // becoming resident): S is half-consumed -- rebuild it and run the stream schedule.  Loud, and counted.
             ++h->tg_fallbacks;

@@ -55,7 +55,7 @@ struct gpx_handle {
     int chol_w = 0;               // outer panel width of the factorisation in 128-blocks (2..8; 0 = by size)
     // the factorisation as ONE persistent task-graph kernel (kernels_chol_tg.hip)
     int chol_tg = 1;              // 1 (default): task-graph kernel for fits of >= tg_min blocks; 0: the stream schedule
-    int tg_min = 2;               // smallest number of 128-blocks the task-graph kernel is used for (round 5, with the shadows: it wins from two blocks on -- N = 256: 0.082 against 0.091 ms, 1024: 0.33 against 0.43, 1280: 0.42 against 0.81)
+    int tg_min = 2;               // smallest number of 128-blocks the task-graph kernel is used for (round 5, with the shadows: it wins from two blocks on, by the kernel's clock -- N = 256: 0.082 against 0.091 ms -- and, since the abort word travels with the pivot flag in ONE copy, by the host's: fit up to the factor 0.172 against 0.184 ms at N = 200, 0.213 against 0.236 at 300, 0.25 against 0.29 at 500, 0.41 against 0.54 at 1000)
     int tg_max = 160;             // ... and the largest (from N = 24576 on the stream schedule is 1-2 % faster: both throughput-bound)
     int tg_chunks = 0;            // chunk sizes counted back from the pivot, as decimal digits (0 = default 12499: 1, 2, 4, 16, 16, ..)
     int tg_nap = 0;               // longest polling pause of a waiting workgroup in units of 64 clocks (0 = default 16; round 4 until late: 127)

@@ -161,7 +161,7 @@ __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, T
         else __builtin_amdgcn_s_sleep(127);
         ++nap;
         if ((spins & 63) == 63 && wall_clock64() - t0 > a.tmo) {
-            if (lane == 0) sti(ctl + TG_CTL_ABORT, 2);
+            if (lane == 0) { sti(ctl + TG_CTL_ABORT, 2); sti(a.dflag + 1, 2); }
             return -1;
         }
     }
@@ -185,7 +185,7 @@ __device__ __forceinline__ bool tg_wait_flags(const TgArgs& a, const int* f0, co
         for (unsigned spins = 0; min(ldi(f0), ldi(f1)) < need; ++spins) {
             if (ldi(a.ctl + TG_CTL_ABORT) != 0) { ok = 0; break; }
             __builtin_amdgcn_s_sleep(1);
-            if ((spins & 255) == 255 && wall_clock64() - t0 > a.tmo) { sti(a.ctl + TG_CTL_ABORT, 2); ok = 0; break; }
+            if ((spins & 255) == 255 && wall_clock64() - t0 > a.tmo) { sti(a.ctl + TG_CTL_ABORT, 2); sti(a.dflag + 1, 2); ok = 0; break; }
         }
         code[2] = ok;
     }
@@ -306,7 +306,7 @@ __device__ __noinline__ void tg_role_diag(const TgArgs& a) {
                 for (unsigned spins = 0; ldi(qd + p) != TG_NPIECE; ++spins) {
                     if (ldi(ctl + TG_CTL_ABORT) != 0) { c = -1; break; }
                     __builtin_amdgcn_s_sleep(2);
-                    if ((spins & 255) == 255 && wall_clock64() - t0 > a.tmo) { sti(ctl + TG_CTL_ABORT, 2); c = -1; break; }
+                    if ((spins & 255) == 255 && wall_clock64() - t0 > a.tmo) { sti(ctl + TG_CTL_ABORT, 2); sti(a.dflag + 1, 2); c = -1; break; }
                 }
             }
             code[0] = c;
@@ -359,7 +359,7 @@ __device__ __forceinline__ bool tg_wave_wait_ge(const TgArgs& a, const int* f, i
     for (unsigned spins = 0; tg_peek(f) < need; ++spins) {
         if (tg_peek(a.ctl + TG_CTL_ABORT) != 0) return false;
         __builtin_amdgcn_s_sleep(1);
-        if ((spins & 255) == 255 && wall_clock64() - t0 > a.tmo) { sti(a.ctl + TG_CTL_ABORT, 2); return false; }
+        if ((spins & 255) == 255 && wall_clock64() - t0 > a.tmo) { sti(a.ctl + TG_CTL_ABORT, 2); sti(a.dflag + 1, 2); return false; }
     }
     return true;
 }
@@ -1254,7 +1254,7 @@ int64_t tg_tasks_copy(int nP, int chunks, int16_t* out, int64_t cap, int64_t* co
 // its right -- i.e. when everything the kernels queued behind it read has been stored (write-through) by the running
 // factorisation.  An abort ends it at once (the caller discards what follows); its own time-out raises the abort word, so that a
 // gate that gave up can never let kernels through onto a factor that is not there yet.
-__global__ __launch_bounds__(64) void k_tg_gate(int* ctl, int nP, int top, long long tmo) {
+__global__ __launch_bounds__(64) void k_tg_gate(int* ctl, int* dflag, int nP, int top, long long tmo) {
     const int npad = tg_npad(nP);
     const int* dd = ctl + TG_CTL_BASE;
     const int* sv = dd + 2 * npad;
@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(64) void k_tg_gate(int* ctl, int nP, int top, long 
         if (__all(ok)) return;
         __builtin_amdgcn_s_sleep(64);
         if ((spins & 63) == 63 && wall_clock64() - t0 > tmo) {
-            if (lane == 0) sti(ctl + TG_CTL_ABORT, 2);
+            if (lane == 0) { sti(ctl + TG_CTL_ABORT, 2); sti(dflag + 1, 2); }
             return;
         }
     }
@@ -1373,7 +1373,7 @@ bool launch_cholesky_tg(gpx_handle* h) {
         }
         max_res = nb * prop.multiProcessorCount;
     }
-    (void)hipMemsetAsync(h->dflag, 0, sizeof(int), s);
+    (void)hipMemsetAsync(h->dflag, 0, 2 * sizeof(int), s);      // [0] failing pivot + 1, [1] 2 = a spin gave up (what tg_abort_code reads, next to the flag)
     (void)hipMemsetAsync(c->dctl, 0, (size_t)nctl * sizeof(int), s);
     if (h->tg_trace) (void)hipMemsetAsync(c->dtrace, 0, (size_t)ntrace * 8, s);
     hipLaunchKernelGGL(k_zero_diag_lower, dim3((unsigned)nP), dim3(256), 0, s, h->dR, Np);
@@ -1408,7 +1408,7 @@ bool launch_cholesky_tg(gpx_handle* h) {
     h->ahead_top = 0;
     if (ahead) {
         (void)hipStreamWaitEvent(h->stream2, h->ev_far, 0);        // the control block is zeroed
-        hipLaunchKernelGGL(k_tg_gate, dim3(1), dim3(64), 0, h->stream2, c->dctl, nP, top, a.tmo);
+        hipLaunchKernelGGL(k_tg_gate, dim3(1), dim3(64), 0, h->stream2, c->dctl, h->dflag, nP, top, a.tmo);
         launch_trtri_ahead(h, h->stream2, top);
         (void)hipEventRecord(h->ev_rest, h->stream2);
         h->ahead_top = top;
