@@ -67,7 +67,7 @@ int gpx_create(int device, void *stream, gpx_handle **out);
 int gpx_destroy(gpx_handle *h);
 const char *gpx_last_error(const gpx_handle *h);
 int gpx_version(void);
-/* options: "chunk" = candidate columns per sweep chunk (multiple of 128);
+/* options: "chunk" = candidate columns per sweep chunk (multiple of 128; default by size: 65536, 131072 up to N = 4096);
  *          "tile_order" = sweep-kernel schedule: bits 0-1 blockIdx->tile map (0 linear heavy-first,
  *              1 per-XCD candidate slices, 2 per-XCD 8x8 super-tiles, 3 the same with every workgroup
  *              computing the PAIR of tiles (nP-1-i, nt), (i, nt): equal work per workgroup), bits 2-4 k-loop schedule

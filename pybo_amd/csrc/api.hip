@@ -953,7 +953,8 @@ static int sweep_core(gpx_handle* h, int acq_id, const double* params, int npara
     hipStream_t s = h->stream;
     const int64_t Np = h->Np;
     const int nP = (int)(Np / NB);
-    const int64_t chunk = std::min<int64_t>(h->chunk, (M + TBH - 1) / TBH * TBH);
+    const int64_t chunk_opt = h->chunk > 0 ? h->chunk : (Np <= 4096 ? 131072 : 65536);
+    const int64_t chunk = std::min<int64_t>(chunk_opt, (M + TBH - 1) / TBH * TBH);
     if ((rc = ensure(h, h->dKs, h->cap_ks, Np * chunk))) return rc;
     if ((rc = ensure(h, h->dQp, h->cap_part, (int64_t)nP * chunk * 2))) return rc;
     h->dPp = h->dQp + (int64_t)nP * chunk;

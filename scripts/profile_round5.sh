@@ -44,7 +44,7 @@ done
 f1=$(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); f2=$(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
 if [ -n "$f1" ] && [ -n "$f2" ]; then python $R/scripts/pmc_traffic.py $f1 $f2 8192 65536 > $O/pmc_traffic.json; grep "k_sweep_trmm\|k_cross_gram" $f1 > $O/pmc_fetch_size.csv; grep "k_sweep_trmm\|k_cross_gram" $f2 > $O/pmc_write_size.csv; fi
 f1=$(find $O/pmcb_FETCH_SIZE -name "*counter_collection.csv" | head -1); f2=$(find $O/pmcb_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-if [ -n "$f1" ] && [ -n "$f2" ]; then python $R/scripts/pmc_traffic.py $f1 $f2 2048 65536 > $O/pmc_traffic_b.json; fi
+if [ -n "$f1" ] && [ -n "$f2" ]; then python $R/scripts/pmc_traffic.py $f1 $f2 2048 131072 > $O/pmc_traffic_b.json; fi
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmcb_FETCH_SIZE $O/pmcb_WRITE_SIZE
 # PMC: MFMA busy of the sweep kernel (round-4 k-loop = tile_order 23, round 5 = 27)
 cd $R; bash scripts/sweep_phase/pmc_sq.sh > $O/pmc_sq_summary.txt 2>&1
