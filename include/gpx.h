@@ -122,7 +122,7 @@ int gpx_version(void);
  *              the diagonal blocks, nine that follow it 16 rows at a time with the tiles next to the diagonal, everything else as
  *              throughput work from ONE ticketed, dependency-checked list; kernels_chol_tg.hip) for fits of "chol_tg_min" (default 2) to
  *              "chol_tg_max" (default 160) 128-blocks; 0: the stream schedule above.  Bit-identical factors either way.  Tuning / diagnostics:
- *              "chol_tg_chunks" (k-chunk sizes counted back from the pivot as decimal digits, default 112489 = 1, 1, 2, 4, 8, 16, 16, ..: the digit 9 stands for 16 blocks),
+ *              "chol_tg_chunks" (k-chunk sizes counted back from the pivot as decimal digits, default 112489 = 1, 1, 2, 4, 8, 16, 16, .. and up to 36 blocks 11112489: the digit 9 stands for 16 blocks),
  *              "chol_tg_nap" (longest pause of a waiting workgroup between two looks at its dependencies, in units of 64
  *              clocks: 8, 16 (default), 32, 64 or 127),
  *              "chol_tg_db" (-1, default: up to "chol_tg_db_max" = 112 blocks every workgroup has its compute unit to itself with two

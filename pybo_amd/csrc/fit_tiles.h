@@ -180,19 +180,15 @@ __device__ __forceinline__ int factor16(d4& D, d4& I, int g, int n) {
         const double a22 = readlane_f64(ds, 32 + 4 * s + 2), a23 = readlane_f64(ds, 32 + 4 * s + 3);
         const double a33 = readlane_f64(ds, 48 + 4 * s + 3);
         // 4x4 Cholesky A44 = R44^T R44 (upper R44), i_k = 1 / R44[k][k]
-        if (bad < 0 && (!(a00 > 0.0) || !(a00 < 1.0e300))) bad = 4 * s;
         const double i0 = rsqrt_pf(a00);
         const double r01 = a01 * i0, r02 = a02 * i0, r03 = a03 * i0;
         const double p1 = fma(-r01, r01, a11);
-        if (bad < 0 && (!(p1 > 0.0) || !(p1 < 1.0e300))) bad = 4 * s + 1;
         const double i1 = rsqrt_pf(p1);
         const double r12 = fma(-r01, r02, a12) * i1, r13 = fma(-r01, r03, a13) * i1;
         const double p2 = fma(-r12, r12, fma(-r02, r02, a22));
-        if (bad < 0 && (!(p2 > 0.0) || !(p2 < 1.0e300))) bad = 4 * s + 2;
         const double i2 = rsqrt_pf(p2);
         const double r23 = fma(-r12, r13, fma(-r02, r03, a23)) * i2;
         const double p3 = fma(-r23, r23, fma(-r13, r13, fma(-r03, r03, a33)));
-        if (bad < 0 && (!(p3 > 0.0) || !(p3 < 1.0e300))) bad = 4 * s + 3;
         const double i3 = rsqrt_pf(p3);
         // T44 = R44^-T (lower): forward substitution on the columns of the identity
         const double t10 = -(r01 * i0) * i1;
@@ -200,11 +196,15 @@ __device__ __forceinline__ int factor16(d4& D, d4& I, int g, int n) {
         const double t30 = -fma(r23, t20, fma(r13, t10, r03 * i0)) * i3;
         const double t31 = -fma(r23, t21, r13 * i1) * i3, t32 = -(r23 * i2) * i3;
         // A operand of the pivot-row products: A[m][k] = T44[m][k] for m < 4 (lane: m = n, k = g), else 0
-        double ta = 0.0;
-        if (n == 0) ta = (g == 0) ? i0 : 0.0;
-        else if (n == 1) ta = (g == 0) ? t10 : ((g == 1) ? i1 : 0.0);
-        else if (n == 2) ta = (g == 0) ? t20 : ((g == 1) ? t21 : ((g == 2) ? i2 : 0.0));
-        else if (n == 3) ta = (g == 0) ? t30 : ((g == 1) ? t31 : ((g == 2) ? t32 : i3));
+        // (flat selects: written as an if / else-if chain over the lane's column the compiler emitted ten exec-mask branches here,
+        //  in the middle of the block's longest dependent chain)
+        const bool g0 = g == 0, g1 = g == 1, g2 = g == 2;
+        const double q0 = g0 ? i0 : 0.0;
+        const double q1 = g0 ? t10 : (g1 ? i1 : 0.0);
+        const double q2 = g0 ? t20 : (g1 ? t21 : (g2 ? i2 : 0.0));
+        const double q3 = g0 ? t30 : (g1 ? t31 : (g2 ? t32 : i3));
+        const double q01 = (n == 0) ? q0 : q1, q23 = (n == 2) ? q2 : q3;
+        const double ta = (n < 2) ? q01 : ((n < 4) ? q23 : 0.0);
         const d4 zero = (d4){0.0, 0.0, 0.0, 0.0};
         const d4 pr = __builtin_amdgcn_mfma_f64_16x16x4f64(ta, ds, zero, 0, 0, 0);
         const d4 pt = __builtin_amdgcn_mfma_f64_16x16x4f64(ta, I[s], zero, 0, 0, 0);
@@ -218,6 +218,12 @@ __device__ __forceinline__ int factor16(d4& D, d4& I, int g, int n) {
             D = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, rrow, D, 0, 0, 0);
             I = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, trow, I, 0, 0, 0);
         }
+        // the pivot checks AFTER the block's arithmetic is on its way: the pivots are wave-uniform, so each check is a scalar
+        // compare-and-branch that waits for its pivot -- between the four dependent rsqrt chains they cost the chain their latency
+        // (a bad pivot's garbage travels on harmlessly: the block is abandoned through `bad`)
+        const double pv[4] = {a00, p1, p2, p3};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bad = (bad < 0 && (!(pv[k] > 0.0) || !(pv[k] < 1.0e300))) ? 4 * s + k : bad;
     }
     return bad;
 }

@@ -57,7 +57,7 @@ struct gpx_handle {
     int chol_tg = 1;              // 1 (default): task-graph kernel for fits of >= tg_min blocks; 0: the stream schedule
     int tg_min = 2;               // smallest number of 128-blocks the task-graph kernel is used for (round 5, with the shadows: it wins from two blocks on, by the kernel's clock -- N = 256: 0.082 against 0.091 ms -- and, since the abort word travels with the pivot flag in ONE copy, by the host's: fit up to the factor 0.172 against 0.184 ms at N = 200, 0.213 against 0.236 at 300, 0.25 against 0.29 at 500, 0.41 against 0.54 at 1000)
     int tg_max = 160;             // ... and the largest (from N = 24576 on the stream schedule is 1-2 % faster: both throughput-bound)
-    int tg_chunks = 0;            // chunk sizes counted back from the pivot, as decimal digits (0 = default 112489: 1, 1, 2, 4, 8, 16, 16, ..)
+    int tg_chunks = 0;            // chunk sizes counted back from the pivot, as decimal digits (0 = default by size: 112489 = 1, 1, 2, 4, 8, 16, 16, .., up to 36 blocks 11112489)
     int tg_nap = 0;               // longest polling pause of a waiting workgroup in units of 64 clocks (0 = default 16; round 4 until late: 127)
     int tg_db = -1;               // -1 (default): the double-buffered workers (one workgroup per CU, 2 x 72 KB of LDS) up to tg_db_max blocks; 0 / 1: never / always
     int tg_fuse = 1;            // a column's solve and the final chunk of the tile below it as one task (needs the shadows and one workgroup per CU)

@@ -74,6 +74,9 @@ struct TgArgs {
 // the number of workgroups that have started there and the role of the first one.
 // Default chunks (sweeps in profiles/r04_chol_taskgraph.txt): 1, 2, 4, 8, 16, 16, .. blocks counted back from the pivot.
 constexpr int TG_DEFAULT_CHUNKS = 112489;     // 1, 1, 2, 4, 8, 16, 16, ..: the two chunks next to the pivot are single block rows (the shadows' U0 / U, V / V2); the step from 4 to 16 cost 10 % at N = 4096 (1.45 -> 1.29 ms) and 6 % at 8192
+constexpr int TG_NEAR_CHUNKS = 11112489;     // ... and up to TG_NEAR_MAX blocks 1, 1, 1, 1, 2, 4, 8, 16, ..: at the chain-bound sizes every multi-block chunk next to the
+constexpr int TG_NEAR_MAX = 36;              // pivot is a 40-us worker task in front of a shadow (N = 2048 0.589 -> 0.548 ms, 4096 1.22 -> 1.155; from N = 5000 on it is neutral, at 8192 it costs 2 %)
+inline int tg_default_chunks(int nP) { return nP <= TG_NEAR_MAX ? TG_NEAR_CHUNKS : TG_DEFAULT_CHUNKS; }
 constexpr int TG_LOG_CAP = 1024, TG_LOG_WGS = 1024;
 constexpr int TG_NPIECE = 6;          // what role U stores into quad[p] when the diagonal tile p is ready for role C (the update once came in six pieces)
 constexpr int TG_NSHADOW = 9;         // roles 1 .. 9: S1, S2, S3, U, U0, V (two column halves), V2 (two) -- role 0 is C; workers from 10 on
@@ -1235,7 +1238,7 @@ static void tg_build(int nP, int chunk_code, TgTables& out, bool fuse) {
 int64_t tg_tasks_copy(int nP, int chunks, int16_t* out, int64_t cap, int64_t* counts) {
     if (nP < 1 || nP > 2047) return -1;
     TgTables tb;
-    if (chunks <= 0) chunks = TG_DEFAULT_CHUNKS;
+    if (chunks <= 0) chunks = tg_default_chunks(nP);
     tg_build(nP, chunks, tb, true);
     int64_t tot = 0;
     for (int q = 0; q < 2; ++q) { counts[q] = (int64_t)tb.q[q].size(); tot += counts[q]; }
@@ -1307,7 +1310,7 @@ bool launch_cholesky_tg(gpx_handle* h) {
     if (!h->tg) h->tg = new TgCache();
     TgCache* c = static_cast<TgCache*>(h->tg);
     hipStream_t s = h->stream;
-    const int chunks = h->tg_chunks > 0 ? h->tg_chunks : TG_DEFAULT_CHUNKS;
+    const int chunks = h->tg_chunks > 0 ? h->tg_chunks : tg_default_chunks(nP);
     static_assert(3 * TG_SH_PAN + 3 * 256 <= GEMM_LDS_F64 && 4 * TG_SH_PAN <= GEMM_LDS_F64 && 8 * TG_SH_PAN <= 2 * GEMM_LDS_F64, "the shadows' LDS rings fit the tile engine's buffer(s)");
     // (decided here because the lists depend on it) one workgroup per CU with two k-step images of LDS: see below
     const bool db = (h->tg_db < 0) ? (nP <= h->tg_db_max) : (h->tg_db != 0);
