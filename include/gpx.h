@@ -71,10 +71,11 @@ int gpx_version(void);
  *          "tile_order" = sweep-kernel schedule: bits 0-1 blockIdx->tile map (0 linear heavy-first,
  *              1 per-XCD candidate slices, 2 per-XCD 8x8 super-tiles, 3 the same with every workgroup
  *              computing the PAIR of tiles (nP-1-i, nt), (i, nt): equal work per workgroup), bits 2-4 k-loop schedule
- *              (6 = k-step 32 through a single LDS buffer with buffer loads, a second fragment set and the wave further
- *              into its matrix phase at the higher priority, the default; 5 = the same k-step without those; 2 = k-step 16
- *              through a 2-deep LDS ring -- both kept as independently scheduled witnesses).  Default 27 = paired
- *              super-tiles + schedule 6.  Every setting produces bit-identical results.
+ *              (4 = the default: operands travel global memory -> LDS by DMA, k-step 32 through a single LDS buffer, two
+ *              workgroups per CU, the all-zero quarter-rows of T's diagonal block skipped; 3 = the same without the skip;
+ *              7 = k-step 16, three workgroups per CU; 6 / 5 / 2 = the register-staged schedules of rounds 5 / 2 / 1 --
+ *              all kept as independently scheduled witnesses).  Default 19 = paired super-tiles + schedule 4.
+ *              Every setting produces bit-identical results.
  *          "super_m" = rows of the XCD super-tile of 64 workgroups (8 -> 8x8 default, 4 -> 4x16, ...).
  *          "eager_inverse" = 1: form the triangular inverse inside gpx_fit instead of on first use.
  *          "trtri_ahead" = 1 (default): when the inverse is certain or likely to follow a fit -- "eager_inverse", gpx_fit_stage

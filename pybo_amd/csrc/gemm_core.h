@@ -54,7 +54,8 @@ __device__ __forceinline__ void acc_zero(d4 (&acc)[4][4]) {
 // (Round 1 also carried a write-at-end ring, a register-double-buffered fragment pipeline and an LDS-DMA
 // staging variant; all tied or lost against the two schedules kept here -- DESIGN.md section 4 -- and were
 // removed.  This one stays as the second, independently scheduled witness of the bit-identity test.)
-template <bool PRIO>
+// ILV (all loops): row block i of a wave is tile rows (2 i + wm) * 16 .. + 15 instead of (4 wm + i) * 16 .. (acc_row_ilv)
+template <bool PRIO, bool ILV = false>
 __device__ __forceinline__ void gemm_tile_128_b(d4 (&acc)[4][4], const double* __restrict__ A, int64_t lda,
                                                 const double* __restrict__ B, int64_t ldb, int k_lo,
                                                 int k_hi, double* smem) {
@@ -98,7 +99,7 @@ __device__ __forceinline__ void gemm_tile_128_b(d4 (&acc)[4][4], const double* _
             swrite(buf ^ 1);                 // tile kt+1 (loaded during step kt-1)
             if (kt + 2 < nk) gload();        // tile kt+2, consumed at the top of step kt+1
         }
-        const double* as = As + buf * BK * LDT + wm * 64 + fr;
+        const double* as = As + buf * BK * LDT + (ILV ? wm * 16 : wm * 64) + fr;
         const double* bs = Bs + buf * BK * LDT + wn * 64 + fr;
         if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -107,7 +108,7 @@ __device__ __forceinline__ void gemm_tile_128_b(d4 (&acc)[4][4], const double* _
             double a[4], b[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                a[i] = as[kr * LDT + i * 16];
+                a[i] = as[kr * LDT + i * (ILV ? 32 : 16)];
                 b[i] = bs[kr * LDT + i * 16];
             }
 #pragma unroll
@@ -133,7 +134,7 @@ constexpr int BK32 = 32;
 // NEGA: the A operand is negated on its way into LDS, i.e. acc += -(A^T-panel) * B: the symmetric updates start
 // their accumulators from the S tile they update (loaded while the first k-steps are in flight) and store
 // S - sum A B directly, instead of a dependent read-modify-write round trip after the k-loop.
-template <int PRIO, bool NEGA = false>
+template <int PRIO, bool NEGA = false, bool ILV = false>
 __device__ __forceinline__ void gemm_tile_128_g(d4 (&acc)[4][4], const double* __restrict__ A, int64_t lda,
                                                 const double* __restrict__ B, int64_t ldb, int k_lo,
                                                 int k_hi, double* smem) {
@@ -173,7 +174,7 @@ __device__ __forceinline__ void gemm_tile_128_g(d4 (&acc)[4][4], const double* _
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + 1 < nk) gload();
-        const double* as = As + wm * 64 + fr;
+        const double* as = As + (ILV ? wm * 16 : wm * 64) + fr;
         const double* bs = Bs + wn * 64 + fr;
         if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
 #pragma unroll
@@ -182,7 +183,7 @@ __device__ __forceinline__ void gemm_tile_128_g(d4 (&acc)[4][4], const double* _
             double a[4], b[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                a[i] = as[kr * LDT + i * 16];
+                a[i] = as[kr * LDT + i * (ILV ? 32 : 16)];
                 b[i] = bs[kr * LDT + i * 16];
             }
 #pragma unroll
@@ -216,7 +217,7 @@ __device__ __forceinline__ void gemm_tile_128_g(d4 (&acc)[4][4], const double* _
 // 61.8 -> 59.7 ms per 65536-column launch at N = 8192 (0.905 -> 0.937 of the fp64-MFMA peak), profiles/r05_sweep_idle_attribution.txt.
 // PRIO / NEGA as in gemm_tile_128_g (PRIO = 0: no priority changes at all; otherwise PRIO for the first half of a step's
 // MFMAs, PRIO + 1 for the second half and while the loads are issued, PRIO - 1 outside the matrix phase).
-template <int PRIO = 1, bool NEGA = false>
+template <int PRIO = 1, bool NEGA = false, bool ILV = false>
 __device__ __forceinline__ void gemm_tile_128_s(d4 (&acc)[4][4], const double* __restrict__ A, int64_t lda,
                                                 const double* __restrict__ B, int64_t ldb, int k_lo, int k_hi,
                                                 double* smem) {
@@ -255,7 +256,8 @@ __device__ __forceinline__ void gemm_tile_128_s(d4 (&acc)[4][4], const double* _
         }
     };
     const int fr = lane & 15, fk = lane >> 4;
-    const double* as = As + wm * 64 + fr;
+    constexpr int IST = ILV ? 32 : 16;
+    const double* as = As + (ILV ? wm * 16 : wm * 64) + fr;
     const double* bs = Bs + wn * 64 + fr;
     gload();
     swrite();
@@ -267,7 +269,7 @@ __device__ __forceinline__ void gemm_tile_128_s(d4 (&acc)[4][4], const double* _
         double a[2][4], b[2][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            a[0][i] = as[fk * LDT + i * 16];
+            a[0][i] = as[fk * LDT + i * IST];
             b[0][i] = bs[fk * LDT + i * 16];
         }
 #pragma unroll
@@ -276,7 +278,7 @@ __device__ __forceinline__ void gemm_tile_128_s(d4 (&acc)[4][4], const double* _
             if (kk + 1 < BK32 / 4) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    a[(kk + 1) & 1][i] = as[((kk + 1) * 4 + fk) * LDT + i * 16];
+                    a[(kk + 1) & 1][i] = as[((kk + 1) * 4 + fk) * LDT + i * IST];
                     b[(kk + 1) & 1][i] = bs[((kk + 1) * 4 + fk) * LDT + i * 16];
                 }
             }
@@ -409,6 +411,113 @@ __device__ __forceinline__ void gemm_tile_128_d(d4 (&acc)[4][4], const double* _
     if (kt + 1 < nk) { step(kt, std::true_type{}, std::false_type{}); ++kt; }
     step(kt, std::false_type{}, std::false_type{});
     if (PRIO) __builtin_amdgcn_s_setprio(PRIO - 1);
+}
+
+// The sweep's k-loop for THREE workgroups per compute unit (round 6).  What the round-5 stamps left standing: the matrix
+// pipe of a SIMD serves one wave's matrix phase at a time, and a lone streaming wave leaves ~3 % of the pipe's issue slots
+// empty (its own LDS reads, waits and priority changes); the partner cannot fill them because it is staging or parked
+// behind a barrier.  A third resident wave per SIMD can -- but 3 x 73.7 KB of LDS and 3 x 248 VGPRs do not exist.  Here
+// the operands travel global memory -> LDS WITHOUT registers (buffer_load_dwordx4 ... lds: every wave instruction lands
+// one 1 KiB k-row, the row pitch of 144 doubles is set per instruction through M0), the k-step is BKL rows through ONE LDS
+// buffer (BKL = 16: 36,864 B -> three workgroups per CU; BKL = 32: 73,728 B -> two), and with no staging registers the
+// wave fits in 168 VGPRs (3 x 168 = 504 of a SIMD's 512).  The step: wait for the own loads, barrier (everyone's rows are
+// in LDS), BKL / 4 groups of 16 MFMAs with the next group's fragments requested ahead, barrier (everyone has read), issue
+// the next step's loads.  The load latency stands exposed inside a workgroup and is covered by the other workgroups of
+// the CU -- the same bet as the single-buffer loop above, with no ds_write phase left to cover.
+// Same arithmetic in the same order as every other loop here: bit-identical results.
+typedef __attribute__((address_space(3))) void* gemm_lds_ptr;
+template <int BKL>
+constexpr int gemm_l_lds_f64() { return 2 * BKL * LDT; }
+
+// TRI (needs ILV): A's last 128 k-rows [k_hi - 128, k_hi) are a lower-triangular block (A(m, k) = 0 for k > m, m and k
+//      counted inside the block).  In its j-th 32-row quarter the row blocks 2 i + wm < 2 j hold only zeros for BOTH waves
+//      when i < j: their MFMAs are skipped (an exact no-op: the skipped products are +0).  The interleaved rows are what
+//      makes the skip worth it: both wave rows lose the same share (1.5 of the block's 4 quarters).
+template <int BKL, int PRIO = 1, int NSET = 2, bool ILV = false, bool TRI = false>
+__device__ __forceinline__ void gemm_tile_128_l(d4 (&acc)[4][4], const double* __restrict__ A, int64_t lda,
+                                                const double* __restrict__ B, int64_t ldb, int k_lo, int k_hi,
+                                                double* smem) {
+    static_assert(!TRI || ILV, "TRI needs the interleaved row blocks");
+    constexpr int G = BKL / 4;         // MFMA groups per step
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    double* As = smem;                 // [BKL][LDT]
+    double* Bs = smem + BKL * LDT;     // [BKL][LDT]
+    const int nk = (k_hi - k_lo) / BKL;
+    if (nk <= 0) return;
+    const char* Abase = reinterpret_cast<const char*>(A + (int64_t)k_lo * lda);
+    const char* Bbase = reinterpret_cast<const char*>(B + (int64_t)k_lo * ldb);
+    const int voA = (int)(((int64_t)w * lda + 2 * lane) * 8), voB = (int)(((int64_t)w * ldb + 2 * lane) * 8);
+    const int soA = (int)(4 * lda * 8), soB = (int)(4 * ldb * 8);      // four rows on: the SGPR offset of load p is p * so
+    auto issue = [&]() {
+        __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)Abase, 0, -1, 0x00020000);
+        __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)Bbase, 0, -1, 0x00020000);
+#pragma unroll
+        for (int p = 0; p < BKL / 4; ++p) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (gemm_lds_ptr)(As + (w + 4 * p) * LDT), 16, voA, p * soA, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (gemm_lds_ptr)(Bs + (w + 4 * p) * LDT), 16, voB, p * soB, 0, 0);
+        }
+        Abase += (int64_t)BKL * lda * 8;
+        Bbase += (int64_t)BKL * ldb * 8;
+    };
+    const int fr = lane & 15, fk = lane >> 4;
+    constexpr int IST = ILV ? 32 : 16;                                  // row-block stride of a wave's A fragments
+    const double* as = As + (ILV ? wm * 16 : wm * 64) + fr + fk * LDT;
+    const double* bs = Bs + wn * 64 + fr + fk * LDT;
+    // one k-step; I0: row blocks i < I0 are skipped (TRI); more: there is a next step whose loads go out at the end
+    auto step = [&](auto i0c, bool more) {
+        constexpr int I0 = decltype(i0c)::value;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // every wave's rows of this step are in LDS
+        asm volatile("" ::: "memory");
+        if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
+        double a[NSET][4], b[NSET][4];
+        auto frag = [&](int set, int g) {
+#pragma unroll
+            for (int i = I0; i < 4; ++i) a[set][i] = as[g * 4 * LDT + i * IST];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[set][j] = bs[g * 4 * LDT + j * 16];
+        };
+        frag(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < G; ++kk) {
+            if (PRIO && kk == G / 2) __builtin_amdgcn_s_setprio(PRIO + 1);
+            if (NSET == 2 && kk + 1 < G) {
+                frag((kk + 1) & 1, kk + 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 8 - I0, 0);      // the LDS reads of group kk + 1 first,
+            }
+#pragma unroll
+            for (int i = I0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk % NSET][i], b[kk % NSET][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * (4 - I0), 0);    // then the MFMAs of group kk
+            if (NSET == 1 && kk + 1 < G) frag(0, kk + 1);
+        }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // everyone has finished reading the buffer
+        if (more) issue();
+    };
+    issue();
+    if (!TRI) {
+        for (int kt = 0; kt < nk; ++kt) step(std::integral_constant<int, 0>{}, kt + 1 < nk);
+    } else {
+        // the triangular block's quarters: its first (lowest k) is full; BKL = 16 takes each quarter in two steps
+        constexpr int Q = 32 / BKL;                     // steps per quarter
+        const int nd = nk - 3 * Q;                      // steps that multiply all four row blocks
+        for (int kt = 0; kt < nd; ++kt) step(std::integral_constant<int, 0>{}, true);
+        for (int q = 0; q < Q; ++q) step(std::integral_constant<int, 1>{}, true);
+        for (int q = 0; q < Q; ++q) step(std::integral_constant<int, 2>{}, true);
+        for (int q = 0; q < Q; ++q) step(std::integral_constant<int, 3>{}, q + 1 < Q);
+    }
+}
+
+// tile row of accumulator register acc[i][.][r] under the interleaved row blocks (ILV)
+__device__ __forceinline__ int acc_row_ilv(int i, int r) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    return (2 * i + (w >> 1)) * 16 + (lane >> 4) + 4 * r;
 }
 
 // element coordinates of accumulator register acc[i][j][r] inside the 128x128 tile

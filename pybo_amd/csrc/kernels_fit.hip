@@ -1271,6 +1271,9 @@ static int loglik_batch_chunk(gpx_handle* h, int64_t B, const double* hyp, doubl
         //  model's, not these factorisations' -- launch_cholesky_tg clears it)
         const bool s_pending = h->diag_inv_pending, s_launched = h->tg_launched, s_want = h->want_ahead;
         const int s_ahead = h->ahead_top;
+        // ... but it polls the handle's control block and reads the handle's pivot flag, both of which the factorisations below
+        // reuse: let it finish first (its results stay the model's)
+        if (s_ahead != 0 && h->stream2) (void)hipStreamSynchronize(h->stream2);
         h->want_ahead = false;
         for (int64_t b = 0; b < B && big; ++b) {
             h->dS = bS + b * bs; h->dR = bR + b * bs; h->dT = nullptr; h->dU = bS + b * bs;
@@ -1280,6 +1283,9 @@ static int loglik_batch_chunk(gpx_handle* h, int64_t B, const double* hyp, doubl
         }
         h->dS = sS; h->dR = sR; h->dT = sT; h->dU = sU;
         h->diag_inv_pending = s_pending; h->tg_launched = s_launched; h->want_ahead = s_want; h->ahead_top = s_ahead;
+        // the pivot flag is the model's again: a fitted model's flag is clear, whatever the last vector of this batch left in it
+        // (the model's lazy inverse starts with `if (*flag != 0) return`)
+        (void)hipMemsetAsync(h->dflag, 0, 2 * sizeof(int), s);
         if (!big) {
             (void)hipGetLastError();
             (void)hipMemsetAsync(bflag, 0, (size_t)B * sizeof(int), s);

@@ -131,6 +131,110 @@ void launch_cross_gram(hipStream_t s, const double* Xs, int64_t Np, int64_t N, i
 // Tile (mt, nt): 128 observed rows x 128 candidates, K-extent (mt+1)*128 (T is lower triangular),
 // N^2 * M flop in total.  Heavy tiles (large mt) are dispatched first.
 // ------------------------------------------------------------------------------------------------
+// blockIdx -> tile(s) of the launch.  Returns false when the block has nothing to do; mt2 >= 0: the workgroup also
+// computes tile (mt2, nt) afterwards.  RES = workgroups resident per XCD (32 CUs x workgroups per CU): the size of a super-tile.
+template <int RES>
+__device__ __forceinline__ bool sweep_tile_of(int b, int order, int sm, int NT, int nP, int& mt, int& nt, int& mt2) {
+    mt2 = -1;
+    if (order == 1) {
+        // XCD-aware: block b runs on XCD b%8 (observed, speed only).  Give each XCD its own
+        // contiguous slice of candidate tiles so the tiles resident on one XCD walk the
+        // SAME mt (shared T rows in that XCD's L2) over neighbouring nt.
+        const int x = b & 7, q = b >> 3;          // q-th block of XCD x
+        const int per = (NT + 7) / 8;             // candidate tiles per XCD
+        const int lm = q / per, ln = q - lm * per;
+        mt = nP - 1 - lm;
+        nt = x * per + ln;
+        return !(nt >= NT || mt < 0);
+    }
+    if (order == 2 || order == 3) {
+        // XCD-aware 2-D super-tiles: the RES workgroups resident on one XCD form an sm (mt) x SN (nt) patch, so every
+        // T row-panel and every Ks column-panel fetched into that XCD's L2 is used by several tiles.
+        // order 3: PAIRED tiles on the super-tile map: the workgroup computes (nP-1-i, nt) and then (i, nt), so every
+        // workgroup of the launch does the same (nP+1)*128 of K.  Equal durations keep the workgroups
+        // of a super-tile in step for the whole launch: tiles that share a Ks column panel (same nt,
+        // different mt) walk k together instead of drifting apart by their K-extent difference.
+        const int x = b & 7, q = b >> 3;
+        const int SN = RES / sm;                  // super-tile = sm (mt) x SN (nt) = RES workgroups
+        const int per = (NT + 7) / 8;             // candidate tiles per XCD (contiguous slice)
+        const int hper = (per + SN - 1) / SN;     // n-groups per XCD
+        const int s = q / RES, r = q - s * RES;
+        const int G = s / hper, H = s - G * hper;
+        const int i = G * sm + r / SN;
+        const int ln = H * SN + (r - (r / SN) * SN);
+        nt = x * per + ln;
+        mt = nP - 1 - i;
+        if (order == 2) return !(ln >= per || nt >= NT || mt < 0);
+        if (ln >= per || nt >= NT || i > mt) return false;
+        if (i < mt) mt2 = i;
+        return true;
+    }
+    mt = nP - 1 - b / NT;
+    nt = b - (b / NT) * NT;
+    return true;
+}
+
+template <int RES>
+static unsigned sweep_grid(int order, int super_m, int NT, int nP) {
+    const int per = (NT + 7) / 8;
+    if (order == 1) return (unsigned)(8 * per * nP);
+    if (order == 2 || order == 3) {
+        const int SN = RES / super_m;
+        const int hper = (per + SN - 1) / SN;
+        const int rows = (order == 3) ? (nP + 1) / 2 : nP;
+        const int gm = (rows + super_m - 1) / super_m;
+        return (unsigned)(8 * RES * hper * gm);
+    }
+    return (unsigned)(NT * nP);
+}
+
+// epilogue of a tile: column sums of V^2 and V*a over its 128 rows -> Qp / Pp[mt][n0 ..] (red: 512 doubles of LDS, free)
+template <bool ILV = false>
+__device__ __forceinline__ void sweep_epilogue(const d4 (&acc)[4][4], const double* __restrict__ avec, int64_t m0,
+                                               double* __restrict__ Qrow, double* __restrict__ Prow, double* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    double qs[4] = {0.0, 0.0, 0.0, 0.0}, ps[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double av[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) av[r] = avec[m0 + (ILV ? (2 * i + wm) * 16 : wm * 64 + i * 16) + (lane >> 4) + 4 * r];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = acc[i][j][r];
+                qs[j] = fma(v, v, qs[j]);
+                ps[j] = fma(v, av[r], ps[j]);
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        double q = qs[j], p = ps[j];
+        q += __shfl_xor(q, 16);
+        p += __shfl_xor(p, 16);
+        q += __shfl_xor(q, 32);
+        p += __shfl_xor(p, 32);
+        qs[j] = q;
+        ps[j] = p;
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = wn * 64 + j * 16 + lane;
+            red[(wm * TB + c) * 2 + 0] = qs[j];
+            red[(wm * TB + c) * 2 + 1] = ps[j];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < TB) {
+        const int c = threadIdx.x;
+        Qrow[c] = red[c * 2] + red[(TB + c) * 2];
+        Prow[c] = red[c * 2 + 1] + red[(TB + c) * 2 + 1];
+    }
+}
+
 template <int VAR>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __restrict__ U, int64_t Np,
                                                                 const double* __restrict__ Ks,
@@ -146,55 +250,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __
     const unsigned long long clk_c0 = __builtin_readcyclecounter();
     const unsigned long long clk_r0 = wall_clock64();
     const int nP = (int)(Np / TB);
-    int mt, nt, mt2 = -1;      // mt2 >= 0: this workgroup also computes tile (mt2, nt) afterwards
-    {
-        const int b = blockIdx.x;
-        if (order == 1) {
-            // XCD-aware: block b runs on XCD b%8 (observed, speed only).  Give each XCD its own
-            // contiguous slice of candidate tiles so the 64 tiles resident on one XCD walk the
-            // SAME mt (shared T rows in that XCD's L2) over neighbouring nt.
-            const int x = b & 7, q = b >> 3;          // q-th block of XCD x
-            const int per = (NT + 7) / 8;             // candidate tiles per XCD
-            const int lm = q / per, ln = q - lm * per;
-            mt = nP - 1 - lm;
-            nt = x * per + ln;
-            if (nt >= NT || mt < 0) return;
-        } else if (order == 2) {
-            // XCD-aware 2-D super-tiles: the 64 workgroups resident on one XCD (32 CUs x 2) form an
-            // 8 (mt) x 8 (nt) patch, so every T row-panel and every Ks column-panel fetched into that
-            // XCD's L2 is used by 8 tiles -> ~4x less fabric/HBM traffic than one-panel-per-tile.
-            const int x = b & 7, q = b >> 3;
-            const int SN = 64 / sm;                   // super-tile = sm (mt) x SN (nt) = 64 workgroups
-            const int per = (NT + 7) / 8;             // candidate tiles per XCD (contiguous slice)
-            const int hper = (per + SN - 1) / SN;     // n-groups per XCD
-            const int s = q >> 6, r = q & 63;
-            const int G = s / hper, H = s - G * hper;
-            mt = nP - 1 - (G * sm + r / SN);
-            const int ln = H * SN + (r - (r / SN) * SN);
-            nt = x * per + ln;
-            if (ln >= per || nt >= NT || mt < 0) return;
-        } else if (order == 3) {
-            // PAIRED tiles on the super-tile map: the workgroup computes (nP-1-i, nt) and then (i, nt), so every
-            // workgroup of the launch does the same (nP+1)*128 of K.  Equal durations keep the 64 workgroups
-            // of a super-tile in step for the whole launch: tiles that share a Ks column panel (same nt,
-            // different mt) walk k together instead of drifting apart by their K-extent difference.
-            const int x = b & 7, q = b >> 3;
-            const int SN = 64 / sm;
-            const int per = (NT + 7) / 8;
-            const int hper = (per + SN - 1) / SN;
-            const int s = q >> 6, r = q & 63;
-            const int G = s / hper, H = s - G * hper;
-            const int i = G * sm + r / SN;              // pair row
-            const int ln = H * SN + (r - (r / SN) * SN);
-            nt = x * per + ln;
-            mt = nP - 1 - i;
-            if (ln >= per || nt >= NT || i > mt) return;
-            if (i < mt) mt2 = i;
-        } else {
-            mt = nP - 1 - b / NT;
-            nt = b - (b / NT) * NT;
-        }
-    }
+    int mt, nt, mt2;
+    if (!sweep_tile_of<64>(blockIdx.x, order, sm, NT, nP, mt, nt, mt2)) return;
 #pragma unroll 1
   for (int ph = 0; ph < 2; ++ph) {
     if (ph == 1) {
@@ -205,53 +262,47 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __
     const int64_t m0 = (int64_t)mt * TB, n0 = (int64_t)nt * TB;
     d4 acc[4][4];
     acc_zero(acc);
-    if (VAR == 2) gemm_tile_128_b<true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
-    else if (VAR == 5) gemm_tile_128_g<true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
-    else gemm_tile_128_s<1>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
-
-    // epilogue: column sums of V^2 and V*a over this tile's 128 rows
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int wm = w >> 1, wn = w & 1;
-    double av[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) av[i][r] = avec[m0 + wm * 64 + i * 16 + (lane >> 4) + 4 * r];
-    double qs[4], ps[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        double q = 0.0, p = 0.0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double v = acc[i][j][r];
-                q = fma(v, v, q);
-                p = fma(v, av[i][r], p);
-            }
-        q += __shfl_xor(q, 16);
-        p += __shfl_xor(p, 16);
-        q += __shfl_xor(q, 32);
-        p += __shfl_xor(p, 32);
-        qs[j] = q;
-        ps[j] = p;
-    }
-    double* red = smem;  // [2][128][2]; the k-loop ended on a barrier, LDS is free
-    if (lane < 16) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = wn * 64 + j * 16 + lane;
-            red[(wm * TB + c) * 2 + 0] = qs[j];
-            red[(wm * TB + c) * 2 + 1] = ps[j];
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < TB) {
-        const int c = threadIdx.x;
-        Qp[(int64_t)mt * ldp + n0 + c] = red[c * 2] + red[(TB + c) * 2];
-        Pp[(int64_t)mt * ldp + n0 + c] = red[c * 2 + 1] + red[(TB + c) * 2 + 1];
-    }
+    // (interleaved row blocks in every schedule: the column sums then add a tile's rows in the same order everywhere)
+    if (VAR == 2) gemm_tile_128_b<true, true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
+    else if (VAR == 5) gemm_tile_128_g<1, false, true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
+    else gemm_tile_128_s<1, false, true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
+    // the k-loop ended on a barrier, LDS is free
+    sweep_epilogue<true>(acc, avec, m0, Qp + (int64_t)mt * ldp + n0, Pp + (int64_t)mt * ldp + n0, smem);
   }
+    if (clk && threadIdx.x == 0) {
+        atomicAdd(clk, (unsigned long long)__builtin_readcyclecounter() - clk_c0);
+        atomicAdd(clk + 1, (unsigned long long)wall_clock64() - clk_r0);
+    }
+}
+
+// The same tiles through the register-free k-loop (gemm_tile_128_l): WGS workgroups per compute unit.
+// TRI: the all-zero quarter-rows of T's diagonal block are skipped (1.5 of 4 k-steps of every tile).
+template <int BKL, int WGS, int PRIO, int NSET, bool TRI>
+__global__ __launch_bounds__(GEMM_THREADS, WGS) void k_sweep_trmm_l(const double* __restrict__ U, int64_t Np,
+                                                                    const double* __restrict__ Ks, int64_t ldk, int NT,
+                                                                    const double* __restrict__ avec,
+                                                                    double* __restrict__ Qp, double* __restrict__ Pp,
+                                                                    int64_t ldp, int order, int sm,
+                                                                    unsigned long long* clk) {
+    __shared__ __attribute__((aligned(16))) double smem[gemm_l_lds_f64<BKL>()];
+    const unsigned long long clk_c0 = __builtin_readcyclecounter();
+    const unsigned long long clk_r0 = wall_clock64();
+    const int nP = (int)(Np / TB);
+    int mt, nt, mt2;
+    if (!sweep_tile_of<32 * WGS>(blockIdx.x, order, sm, NT, nP, mt, nt, mt2)) return;
+#pragma unroll 1
+    for (int ph = 0; ph < 2; ++ph) {
+        if (ph == 1) {
+            if (mt2 < 0) break;
+            mt = mt2;
+            __syncthreads();               // the epilogue's LDS reads are done before the next tile's rows land
+        }
+        const int64_t m0 = (int64_t)mt * TB, n0 = (int64_t)nt * TB;
+        d4 acc[4][4];
+        acc_zero(acc);
+        gemm_tile_128_l<BKL, PRIO, NSET, true, TRI>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
+        sweep_epilogue<true>(acc, avec, m0, Qp + (int64_t)mt * ldp + n0, Pp + (int64_t)mt * ldp + n0, smem);
+    }
     if (clk && threadIdx.x == 0) {
         atomicAdd(clk, (unsigned long long)__builtin_readcyclecounter() - clk_c0);
         atomicAdd(clk + 1, (unsigned long long)wall_clock64() - clk_r0);
@@ -263,35 +314,25 @@ void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double*
                        int tile_order, int super_m, unsigned long long* clk) {
     const int NT = (int)(cols / TB);
     const int nP = (int)(Np / TB);
-    unsigned nblk;
-    if ((tile_order & 3) == 1) {
-        const int per = (NT + 7) / 8;
-        nblk = (unsigned)(8 * per * nP);
-    } else if ((tile_order & 3) == 2) {
-        const int SN = 64 / super_m;
-        const int per = (NT + 7) / 8;
-        const int hper = (per + SN - 1) / SN;
-        const int gm = (nP + super_m - 1) / super_m;
-        nblk = (unsigned)(8 * 64 * hper * gm);
-    } else if ((tile_order & 3) == 3) {
-        const int SN = 64 / super_m;
-        const int per = (NT + 7) / 8;
-        const int hper = (per + SN - 1) / SN;
-        const int gm = ((nP + 1) / 2 + super_m - 1) / super_m;
-        nblk = (unsigned)(8 * 64 * hper * gm);
+    // bits 0-1: tile map, bits 2-4: k-loop (4 = default: operands by LDS-DMA, k-step 32, two workgroups per CU, the zero rows of
+    // T's diagonal block skipped; 3: the same without the skip; 7: k-step 16, three workgroups per CU; 6, 5, 2: the
+    // register-staged schedules of rounds 5, 2, 1 -- all kept as independently scheduled witnesses of the bit-identity test)
+    const int order = tile_order & 3, var = (tile_order >> 2) & 7;
+#define GPX_SW(K) hipLaunchKernelGGL(K, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp, ldp, order, super_m, clk)
+    if (var == 7) {                // three workgroups per CU, k-step 16
+        const unsigned nblk = sweep_grid<96>(order, super_m, NT, nP);
+        GPX_SW((k_sweep_trmm_l<16, 3, 1, 2, false>));
+    } else if (var == 4 || var == 3) {   // two workgroups per CU, k-step 32; 4: with the diagonal block's zero rows skipped
+        const unsigned nblk = sweep_grid<64>(order, super_m, NT, nP);
+        if (var == 4) GPX_SW((k_sweep_trmm_l<32, 2, 1, 2, true>));
+        else GPX_SW((k_sweep_trmm_l<32, 2, 1, 2, false>));
     } else {
-        nblk = (unsigned)(NT * nP);
+        const unsigned nblk = sweep_grid<64>(order, super_m, NT, nP);
+        if (var == 2) GPX_SW(k_sweep_trmm<2>);
+        else if (var == 6) GPX_SW(k_sweep_trmm<6>);
+        else GPX_SW(k_sweep_trmm<5>);
     }
-    const int order = tile_order & 3, var = tile_order >> 2;   // bits 0-1: tile map, bits 2-4: k-loop (6 = default; 5, 2: the earlier schedules, kept as witnesses)
-    if (var == 2)
-        hipLaunchKernelGGL(k_sweep_trmm<2>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
-                           ldp, order, super_m, clk);
-    else if (var == 6)
-        hipLaunchKernelGGL(k_sweep_trmm<6>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
-                           ldp, order, super_m, clk);
-    else
-        hipLaunchKernelGGL(k_sweep_trmm<5>, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp,
-                           ldp, order, super_m, clk);
+#undef GPX_SW
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,87 @@
+// sweep_ab.hip -- stand-alone A/B of the library's sweep kernel schedules (launch_sweep_trmm, kernels_sweep.hip is compiled
+// INTO this binary: what is timed is the library's code).  Synthetic operands; every variant must give the same checksum.
+// Usage: sweep_ab.bin N cols reps tile_order[:super_m] [tile_order[:super_m] ...]
+#include "../../pybo_amd/csrc/kernels_sweep.hip"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+#include <math.h>
+using namespace gpx;
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+__global__ void k_fill(double* p, size_t n, unsigned seed, double scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long x = (i + 1) * 0x9E3779B97F4A7C15ull + seed * 0xD1B54A32D192ED03ull;
+        x ^= x >> 31; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 29;
+        p[i] = scale * ((double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5);
+    }
+}
+// zero the strictly-upper part of T = U^T per 128-block as the library's inverse leaves it: U[k][m] = 0 for k > m
+__global__ void k_tri(double* U, int64_t Np) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)(Np * Np); i += (size_t)gridDim.x * blockDim.x) {
+        const int64_t k = i / Np, m = i - k * Np;
+        if (k > m) U[i] = 0.0;
+    }
+}
+
+int main(int argc, char** argv) {
+    if (argc < 5) { fprintf(stderr, "usage: N cols reps tile_order[:super_m] ...\n"); return 1; }
+    const int64_t N = atoll(argv[1]), cols = atoll(argv[2]);
+    const int reps = atoi(argv[3]);
+    const int64_t Np = (N + 127) / 128 * 128;
+    const int nP = (int)(Np / 128);
+    double *U, *Ks, *a, *Qp, *Pp;
+    unsigned long long* clk;
+    CK(hipMalloc(&U, Np * Np * 8));
+    CK(hipMalloc(&Ks, cols * Np * 8));
+    CK(hipMalloc(&a, Np * 8));
+    CK(hipMalloc(&Qp, (size_t)nP * cols * 8));
+    CK(hipMalloc(&Pp, (size_t)nP * cols * 8));
+    CK(hipMalloc(&clk, 16));
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, U, (size_t)(Np * Np), 1u, 1.0);
+    hipLaunchKernelGGL(k_tri, dim3(4096), dim3(256), 0, 0, U, Np);
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, Ks, (size_t)(cols * Np), 2u, 1.0);
+    hipLaunchKernelGGL(k_fill, dim3(64), dim3(256), 0, 0, a, (size_t)Np, 3u, 1.0);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    std::vector<double> rq, rp;      // the first variant's results: the reference of the others
+    for (int v = 4; v < argc; ++v) {
+        int to = atoi(argv[v]), sm = 8;
+        if (const char* c = strchr(argv[v], ':')) sm = atoi(c + 1);
+        std::vector<float> ms_all;
+        CK(hipMemset(Qp, 0xff, (size_t)nP * cols * 8));
+        CK(hipMemset(Pp, 0xff, (size_t)nP * cols * 8));
+        double mhz = 0;
+        for (int rep = 0; rep < reps + 2; ++rep) {
+            CK(hipMemsetAsync(clk, 0, 16, 0));
+            hipEventRecord(e0);
+            launch_sweep_trmm(0, U, Np, Ks, Np, cols, a, Qp, Pp, cols, to, sm, clk);
+            hipEventRecord(e1);
+            CK(hipEventSynchronize(e1));
+            CK(hipGetLastError());
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            if (rep >= 2) ms_all.push_back(ms);
+            unsigned long long h[2]; CK(hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost));
+            mhz = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+        }
+        std::sort(ms_all.begin(), ms_all.end());
+        const double med = ms_all[ms_all.size() / 2];
+        std::vector<double> hq((size_t)nP * cols), hp((size_t)nP * cols);
+        CK(hipMemcpy(hq.data(), Qp, hq.size() * 8, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hp.data(), Pp, hp.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long x = 0;
+        for (size_t i = 0; i < hq.size(); ++i) { unsigned long long b; memcpy(&b, &hq[i], 8); x = x * 1099511628211ull ^ b; memcpy(&b, &hp[i], 8); x = x * 1099511628211ull ^ b; }
+        double dq = 0, dp = 0, sq = 0, sp = 0;
+        if (rq.empty()) { rq = hq; rp = hp; }
+        for (size_t i = 0; i < hq.size(); ++i) {
+            dq = std::max(dq, fabs(hq[i] - rq[i])); sq = std::max(sq, fabs(rq[i]));
+            dp = std::max(dp, fabs(hp[i] - rp[i])); sp = std::max(sp, fabs(rp[i]));
+        }
+        printf("RESULT tile_order %d super_m %d N %lld cols %lld: min %.3f median %.3f ms  %.2f TFLOP/s  frac %.4f  sclk %.0f MHz  checksum %016llx  maxdiff/scale q %.2e p %.2e\n",
+               to, sm, (long long)N, (long long)cols, ms_all[0], med, (double)N * N * cols / med / 1e9, (double)N * N * cols / med / 1e9 / 78.6, mhz, x, dq / sq, dp / sp);
+        fflush(stdout);
+    }
+    return 0;
+}

@@ -150,6 +150,30 @@ def test_batched_loglik_of_a_large_factor_uses_the_task_graph_and_a_blocked_subs
     assert np.isfinite(out[0]) and out[1] == -np.inf and out[2] == out[0]
 
 
+def test_a_trailing_non_pd_vector_of_a_large_batch_leaves_the_model_usable():
+    """The large-factor path of gpx_loglik_batch lends the handle's pivot flag to its factorisations; a LAST vector that is not
+    positive definite must not leave that flag set: the model's triangular inverse (formed lazily, on the first prediction after
+    the batch) starts with `if (*flag) return` and would silently skip its diagonal blocks."""
+    from pybo_amd import models
+    N, d = 2200, 3
+    X, y, ell = synth_problem(N, d, seed=9)
+    Xd, yd = np.vstack([X[:2100], X[:3]]), np.hstack([y[:2100], y[:3]])
+    gp = models.make_gp(1e-3, 1.1, ell, 0.1)
+    gp.add_data(Xd, yd)
+    bad = gp.hyper_vector().copy()
+    bad[0] = -800.0                                     # sn2 = 0 with duplicated inputs: not positive definite
+    out = gp.loglik_at(np.array([gp.hyper_vector(), bad]))           # the first device call after the fit: no inverse yet
+    assert np.isfinite(out[0]) and out[1] == -np.inf
+    ref = gp_ref.make_gp(1e-3, 1.1, ell, 0.1)
+    ref.add_data(Xd, yd)
+    Z = np.random.RandomState(3).rand(64, d)
+    mu, s2 = gp.predict(Z)
+    mr, sr = ref.predict(Z)
+    np.testing.assert_allclose(mu, mr, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(s2, sr, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(gp.loglik_at(gp.hyper_vector())[0], ref.loglikelihood(), rtol=1e-9)
+
+
 def test_a_default_run_reuses_its_device_handles(monkeypatch):
     """pybo's default model turns over ~30 member / proposal models per iteration; their handles must come from
     the pool (creating + destroying one costs ~5-15 ms: it was 80 % of a default run before the pool kept up)."""
