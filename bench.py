@@ -33,7 +33,8 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X datasheet fp64 matrix (= fp64 vector) peak, dense
 HBM_PEAK_GBS = 8000.0
-PMC_TRAFFIC_FILES = ('r05_pmc_traffic.json', 'r05_pmc_traffic_b.json')      # (N = 8192 and config B's N = 2048 launch geometries)
+SWEEP_KERNEL = 'k_sweep_trmm_l<32, 2, 1, 2, true>'      # the default schedule (tile_order 19) as rocprofv3 names it
+PMC_TRAFFIC_FILES = ('r06_pmc_traffic.json', 'r06_pmc_traffic_b.json')      # (N = 8192 and config B's N = 2048 launch geometries)
 
 
 def hartmann6(X):
@@ -398,7 +399,7 @@ def ensemble_bench(args):
            'selected': {'index': int(best[1][0]), 'value': float(best[0][0])},
            'stage_ms_per_step_rank0_all_members': {kk: tot[kk] / args.steps for kk in ('gram', 'cholesky', 'trtri', 'alpha', 'cross_gram',
                                                                                    'sweep_trmm', 'acq_topk')},
-           'roofline': {'kernel': 'k_sweep_trmm', 'bound': 'mfma', 'achieved': ach, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+           'roofline': {'kernel': SWEEP_KERNEL, 'bound': 'mfma', 'achieved': ach, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                         'frac': ach / FP64_MFMA_PEAK_TFLOPS, 'traffic': None, 'launches': int(tot['sweep_trmm_launches']),
                         'avg_launch_ms': tot['sweep_trmm'] / max(tot['sweep_trmm_launches'], 1),
                         'flop_per_launch': tot['sweep_trmm_flop'] / max(tot['sweep_trmm_launches'], 1),
@@ -528,6 +529,81 @@ def plugin_step(w, nsteps, k):
     return rec
 
 
+def nontrivial_selection_record(eng, dev, M, k, cpu_candidates):
+    """Workload 'ns2' (the north-star problem with its optimum moved off the grid centre) through the device path -- fit,
+    EI sweep over ALL M candidates, top-k -- and the oracle's verdict on that top-k and on a sample of the grid
+    (parity_record: order of the top-k, nothing in the sample outranks it, moments within the stated tolerance)."""
+    import torch
+    w2 = make_workload('ns2', M)
+    dX2, dy2 = torch.from_numpy(w2['X']).to(dev), torch.from_numpy(w2['y']).to(dev)
+    dZ = torch.from_numpy(w2['Xc']).to(dev)
+    eng.fit_dev(dX2.data_ptr(), w2['N'], w2['d'], dy2.data_ptr(), w2['kernel'], w2['ell'], w2['rho'], w2['sn2'], w2['bias'])
+    param = eng.mean_at_obs()[1]
+    tv, ti = eng.sweep_dev('ei', param, dZ.data_ptr(), M, k)
+    nc = min(cpu_candidates or 4096, 4096, M)
+    _, ref_vals = cpu_baseline(w2, nc, M, [], [int(v) for v in np.asarray(ti).ravel() if v >= 0])
+    sidx = ref_vals['index']
+    dsel = torch.from_numpy(np.ascontiguousarray(w2['Xc'][sidx])).to(dev)
+    buf = torch.empty(3, len(sidx), dtype=torch.float64, device=dev)
+    eng.sweep_dev('ei', param, dsel.data_ptr(), len(sidx), 0, d_acq=buf[0].data_ptr(), d_mu=buf[1].data_ptr(),
+                  d_s2=buf[2].data_ptr())
+    eng.sync()
+    hb = buf.cpu().numpy()
+    rec = parity_record(w2, ref_vals, dict(acq=hb[0], mu=hb[1], s2=hb[2], target=float(param), top_val=np.asarray(tv).ravel(),
+                                           top_idx=np.asarray(ti).ravel(), sample_global_index=sidx))
+    rec['workload'] = w2['desc']
+    rec['selected'] = {'index': int(np.asarray(ti).ravel()[0]), 'value': float(np.asarray(tv).ravel()[0])}
+    rec['timed'] = False
+    return rec
+
+
+def bring_up_gpx_exchange(args, eng, rank, world, dist, dev):
+    """The north-star exchange: libgpx's own RCCL communicator on the engine's stream (gpx_comm_init / gpx_topk_allgather).
+    Returns (Comm, 'gpx') or -- with --exchange auto only -- a string 'torch (fallback: <why>)' after saying so on stderr.
+    Every decision is taken by ALL ranks together (one MIN all-reduce of a status word per phase), and the binding is
+    probed on every rank BEFORE the collective ncclCommInitRank, so that a rank that cannot load librccl does not leave
+    the others blocked inside the rendezvous."""
+    import torch
+    from pybo_amd._lib import Comm
+
+    def agree(ok):
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev if args.backend == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+    def give_up(why):
+        msg = 'bench.py: rank %d: the gpx (device-side RCCL) exchange is NOT in use: %s' % (rank, why)
+        if args.exchange == 'gpx':
+            sys.stderr.write(msg + ' -- --exchange gpx was asked for: FATAL\n')
+            sys.stderr.flush()
+            os._exit(5)
+        sys.stderr.write(msg + ' -- FALLING BACK to the torch.distributed transport\n')
+        sys.stderr.flush()
+        return 'torch (fallback: %s)' % why
+
+    if args.share_device >= 0:
+        return give_up('the ranks share device %d (dry run): RCCL refuses two ranks on one GPU' % args.share_device)
+    why, uid = '', None
+    try:
+        uid = Comm.unique_id()                       # loads + binds librccl in THIS process; no communication
+    except Exception as exc:                         # noqa: BLE001
+        why = 'librccl could not be bound: %s' % exc
+    if not agree(uid is not None):
+        return give_up(why or 'another rank could not bind librccl')
+    box = [uid if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    comm = None
+    try:
+        comm = Comm(eng, rank, world, box[0])        # ncclCommInitRank: collective over all ranks
+    except Exception as exc:                         # noqa: BLE001
+        why = 'gpx_comm_init failed: %s' % exc
+    if not agree(comm is not None):
+        if comm is not None:
+            comm.close()
+        return give_up(why or 'gpx_comm_init failed on another rank')
+    return comm, 'gpx'
+
+
 def self_launch(ngpus):
     """`python bench.py --gpus N` without a launcher (the driver's command shape): start N ranks of this very
     command through torch.distributed.run on a free local port, one GPU per rank; rank 0 prints the ONE JSON line
@@ -611,7 +687,7 @@ def main_sharded(args):
                                      'and sharded contiguously (ShardedDeviceGrid), host merge of the top-k' % P},
            'selected': {'index': int(best[1][0]), 'value': float(best[0][0])},
            'stage_ms_per_step_all_replicas': per,
-           'roofline': {'kernel': 'k_sweep_trmm', 'bound': 'mfma', 'achieved': ach, 'peak': FP64_MFMA_PEAK_TFLOPS,
+           'roofline': {'kernel': SWEEP_KERNEL, 'bound': 'mfma', 'achieved': ach, 'peak': FP64_MFMA_PEAK_TFLOPS,
                         'unit': 'TFLOP/s', 'frac': ach / FP64_MFMA_PEAK_TFLOPS, 'traffic': None,
                         'launches': int(tm['sweep_trmm_launches']), 'of': 'replica 0'}}
     if not args.no_cpu_baseline:
@@ -647,9 +723,12 @@ def main():
     ap.add_argument('--warm-steps', type=int, default=8,
                     help='also time this many WARM iterations (append one observation + re-score the cached '
                          'sweep sums); reported separately as warm_step, never as value; 0 = skip')
-    ap.add_argument('--exchange', default='torch', choices=['torch', 'gpx'],
-                    help="transport of the top-k exchange: torch.distributed (default) or libgpx's own RCCL "
-                         "binding (gpx_topk_allgather; needs one GPU per rank)")
+    ap.add_argument('--exchange', default='auto', choices=['auto', 'torch', 'gpx'],
+                    help="transport of the top-k exchange: gpx = libgpx's own RCCL binding (gpx_topk_allgather: the pairs go "
+                         "device -> xGMI -> device, only the k winners reach the host; needs one GPU per rank), torch = "
+                         "torch.distributed (the pairs travel through host tensors).  auto (default) = gpx, falling through "
+                         "to torch -- loudly, on stderr and in collective.exchange -- only if the RCCL binding cannot be "
+                         "brought up on every rank (or the ranks share one device: dry runs)")
     ap.add_argument('--plugin-steps', type=int, default=12,
                     help='also time this many iterations of pybo_amd.solve_bayesopt THROUGH THE PLUGIN API at the '
                          'workload size (cold + warm; reported separately as plugin_step); 0 = skip')
@@ -774,11 +853,11 @@ def main():
         eng.set_option(name, int(val))
     Ml = hi_i - lo_i
     comm = None
-    if world > 1 and args.exchange == 'gpx':
-        from pybo_amd._lib import Comm
-        box = [Comm.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        comm = Comm(eng, rank, world, box[0])
+    exchange_used = 'torch' if world > 1 else None
+    if world > 1 and args.exchange in ('auto', 'gpx'):
+        exchange_used = bring_up_gpx_exchange(args, eng, rank, world, dist, dev)
+        if isinstance(exchange_used, tuple):
+            comm, exchange_used = exchange_used
 
     thompson = None
     if w['acq'] == 'thompson':
@@ -1018,10 +1097,10 @@ def main():
         if fb:
             out['chol_taskgraph_fallbacks'] = int(fb)        # fits re-run on the stream schedule (should be 0)
         if rccl_info is not None:
-            out['collective'] = dict(rccl_info, exchange=args.exchange)
+            out['collective'] = dict(rccl_info, exchange=exchange_used, exchange_requested=args.exchange)
         # what the 1-GPU stage times predict for this rank count (the replicated fit is the serial term)
         try:
-            one = json.load(open(os.path.join(ROOT, 'profiles', 'r05_bench_%s.json' % w['name'])))
+            one = json.load(open(os.path.join(ROOT, 'profiles', 'r06_bench_%s.json' % w['name'])))
             st1 = one['stage_ms_per_step_rank0']
             if w['acq'] == 'thompson':
                 par = st1.get('rff', 0.0)
@@ -1035,9 +1114,15 @@ def main():
                 units = 'candidates'
                 share = 1.0 / world
             out['scaling_model'] = {'formula': 'serial (replicated fit) + parallel (%s sharded) x share + exchange (~0.1 ms)' % units,
-                                    'from': 'profiles/r05_bench_%s.json (1 GPU)' % w['name'], 'serial_ms': ser,
+                                    'from': 'profiles/r06_bench_%s.json (1 GPU)' % w['name'], 'serial_ms': ser,
                                     'parallel_ms_1gpu': par, 'share': share, 'predicted_ms_per_step': ser + par * share + 0.1,
                                     'measured_ms_per_step': sec * 1e3}
+            if w['name'] == 'd':
+                # the fit is "replicas only" -- at N = 16384 it is most of the step and does not divide by P
+                out['scaling_model']['note'] = (
+                    'config D is fit-dominated and the fit is REPLICATED on every rank (SURVEY 8(e): replicas only): only the '
+                    'Thompson stage (%.1f of %.1f ms) divides by the rank count -- expect about %.2fx at 8 ranks, not 8x'
+                    % (par, ser + par, (ser + par) / (ser + par / 8.0 + 0.1)))
         except Exception:
             pass
         if tm['sweep_trmm'] > 0:
@@ -1055,9 +1140,10 @@ def main():
                 except Exception:
                     continue
             ach = tm['sweep_trmm_flop'] / (tm['sweep_trmm'] * 1e-3) / 1e12
-            out['roofline'] = {'kernel': 'k_sweep_trmm', 'bound': 'mfma', 'achieved': ach,
+            out['roofline'] = {'kernel': SWEEP_KERNEL, 'bound': 'mfma', 'achieved': ach,
                                'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': ach / FP64_MFMA_PEAK_TFLOPS, 'traffic': traffic,
+                               'traffic_measured': False,      # a profile-time constant (see traffic_source), never collected in this run
                                'traffic_unit': 'bytes/launch',
                                'traffic_source': 'profile: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE) of this '
                                                  'launch geometry, committed as profiles/%s -- a profile-time '
@@ -1070,6 +1156,7 @@ def main():
                                if tm.get('sweep_sclk_mhz') else None,
                                'avg_launch_ms': tm['sweep_trmm'] / max(launches, 1),
                                'flop_per_launch': tm['sweep_trmm_flop'] / max(launches, 1)}
+            out['traffic_measured'] = False           # roofline.traffic is read from profiles/, see roofline.traffic_source
         # the fit's two MFMA stages against the same peak (algorithmic N^3/3 flop each), for EVERY workload:
         # the replicated fit is what bounds strong scaling
         fit = {}
@@ -1171,6 +1258,11 @@ def main():
                 dev_vals['top_val'], dev_vals['top_idx'] = np.asarray(best[0]).ravel(), np.asarray(best[1]).ravel()
                 dev_vals['sample_global_index'] = lo_i + sidx
             out['parity'] = parity_record(w, ref_vals, dev_vals)
+            if w['name'] == 'ns':
+                # The headline workload's winner is Sobol' point 1 (the box centre IS the optimum): trivially right.  The same
+                # line therefore carries -- untimed -- the selection record of the variant 'ns2' (optimum off the centre): the
+                # device's top-k over the whole grid against the oracle's order.  The headline and its timing stay 'ns'.
+                out['parity']['nontrivial'] = nontrivial_selection_record(eng, dev, M, k, args.cpu_candidates)
         if args.plugin_steps > 0 and world == 1 and w['acq'] in ('ei', 'ucb'):
             out['plugin_step'] = plugin_step(w, args.plugin_steps, k)
         print(json.dumps(out))

@@ -433,7 +433,9 @@ constexpr int gemm_l_lds_f64() { return 2 * BKL * LDT; }
 //      counted inside the block).  In its j-th 32-row quarter the row blocks 2 i + wm < 2 j hold only zeros for BOTH waves
 //      when i < j: their MFMAs are skipped (an exact no-op: the skipped products are +0).  The interleaved rows are what
 //      makes the skip worth it: both wave rows lose the same share (1.5 of the block's 4 quarters).
-template <int BKL, int PRIO = 1, int NSET = 2, bool ILV = false, bool TRI = false>
+// NEGA: acc += -(A) B through the MFMA's own negation of its A operand (neg:[1,0,0]): the same bits as negating A on its way
+//      into LDS (the register-staged loops), which a DMA cannot do.  AUX: cache policy of the operand loads (see gemm_tile_128_d).
+template <int BKL, int PRIO = 1, int NSET = 2, bool ILV = false, bool TRI = false, bool NEGA = false, int AUX = 0>
 __device__ __forceinline__ void gemm_tile_128_l(d4 (&acc)[4][4], const double* __restrict__ A, int64_t lda,
                                                 const double* __restrict__ B, int64_t ldb, int k_lo, int k_hi,
                                                 double* smem) {
@@ -455,8 +457,8 @@ __device__ __forceinline__ void gemm_tile_128_l(d4 (&acc)[4][4], const double* _
         __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)Bbase, 0, -1, 0x00020000);
 #pragma unroll
         for (int p = 0; p < BKL / 4; ++p) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (gemm_lds_ptr)(As + (w + 4 * p) * LDT), 16, voA, p * soA, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (gemm_lds_ptr)(Bs + (w + 4 * p) * LDT), 16, voB, p * soB, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (gemm_lds_ptr)(As + (w + 4 * p) * LDT), 16, voA, p * soA, 0, AUX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (gemm_lds_ptr)(Bs + (w + 4 * p) * LDT), 16, voB, p * soB, 0, AUX);
         }
         Abase += (int64_t)BKL * lda * 8;
         Bbase += (int64_t)BKL * ldb * 8;
@@ -491,7 +493,7 @@ __device__ __forceinline__ void gemm_tile_128_l(d4 (&acc)[4][4], const double* _
             for (int i = I0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk % NSET][i], b[kk % NSET][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk % NSET][i], b[kk % NSET][j], acc[i][j], 0, 0, NEGA ? 1 : 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 4 * (4 - I0), 0);    // then the MFMAs of group kk
             if (NSET == 1 && kk + 1 < G) frag(0, kk + 1);
         }
@@ -512,6 +514,82 @@ __device__ __forceinline__ void gemm_tile_128_l(d4 (&acc)[4][4], const double* _
         for (int q = 0; q < Q; ++q) step(std::integral_constant<int, 2>{}, true);
         for (int q = 0; q < Q; ++q) step(std::integral_constant<int, 3>{}, q + 1 < Q);
     }
+}
+
+// The register-free loop for a workgroup that has its compute unit to ITSELF (two k-step images of LDS, 2 x 73,728 B): the
+// DMA of step t + 2 goes out at the top of step t + 1 into the image step t has just been read from, so every load has a whole
+// step to land and there is ONE barrier per step -- behind it every wave has finished reading image t & 1 AND every wave's
+// rows of step t + 1 have landed (each wave waits for its own loads first).  Against gemm_tile_128_d (registers, LDS writes
+// behind the MFMA groups): no staging registers, no ds_write, no VALU in the step.  Same arithmetic, same order, same bits.
+template <int PRIO = 1, bool NEGA = false, int AUX = 0, int NSET = 2>
+__device__ __forceinline__ void gemm_tile_128_ld(d4 (&acc)[4][4], const double* __restrict__ A, int64_t lda,
+                                                 const double* __restrict__ B, int64_t ldb, int k_lo, int k_hi,
+                                                 double* smem) {
+    constexpr int G = BK32 / 4;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int nk = (k_hi - k_lo) / BK32;
+    if (nk <= 0) return;
+    const char* Abase = reinterpret_cast<const char*>(A + (int64_t)k_lo * lda);
+    const char* Bbase = reinterpret_cast<const char*>(B + (int64_t)k_lo * ldb);
+    const int voA = (int)(((int64_t)w * lda + 2 * lane) * 8), voB = (int)(((int64_t)w * ldb + 2 * lane) * 8);
+    const int soA = (int)(4 * lda * 8), soB = (int)(4 * ldb * 8);
+    auto issue = [&](int img) {
+        double* As = smem + img * GEMM_LDS_F64;
+        double* Bs = As + BK32 * LDT;
+        __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)Abase, 0, -1, 0x00020000);
+        __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)Bbase, 0, -1, 0x00020000);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (gemm_lds_ptr)(As + (w + 4 * p) * LDT), 16, voA, p * soA, 0, AUX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (gemm_lds_ptr)(Bs + (w + 4 * p) * LDT), 16, voB, p * soB, 0, AUX);
+        }
+        Abase += (int64_t)BK32 * lda * 8;
+        Bbase += (int64_t)BK32 * ldb * 8;
+    };
+    const int fr = lane & 15, fk = lane >> 4;
+    const int aoff = wm * 64 + fr + fk * LDT, boff = BK32 * LDT + wn * 64 + fr + fk * LDT;
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // step 0 has landed (step 1's 16 loads may be in flight)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
+    for (int kt = 0; kt < nk; ++kt) {
+        const double* as = smem + (kt & 1) * GEMM_LDS_F64 + aoff;
+        const double* bs = smem + (kt & 1) * GEMM_LDS_F64 + boff;
+        asm volatile("" ::: "memory");
+        double a[NSET][4], b[NSET][4];
+        auto frag = [&](int set, int g) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[set][i] = as[g * 4 * LDT + i * 16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[set][j] = bs[g * 4 * LDT + j * 16];
+        };
+        frag(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < G; ++kk) {
+            if (kk + 1 < G) {
+                frag((kk + 1) & 1, kk + 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, NEGA ? 1 : 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        }
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nk) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's rows of step kt + 1 (issued a whole step ago)
+            __builtin_amdgcn_s_barrier();                               // image kt & 1 is read, image (kt + 1) & 1 is complete
+            if (kt + 2 < nk) issue(kt & 1);
+        }
+    }
+    if (PRIO) __builtin_amdgcn_s_setprio(PRIO - 1);
+    __builtin_amdgcn_s_barrier();                                       // the caller may reuse LDS
 }
 
 // tile row of accumulator register acc[i][.][r] under the interleaved row blocks (ILV)

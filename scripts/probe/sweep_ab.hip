@@ -26,6 +26,28 @@ __global__ void k_tri(double* U, int64_t Np) {
     }
 }
 
+// ONE workgroup per compute unit (two k-step images of LDS): the loops of the task-graph factorisation's workers on the sweep's
+// tiles.  WHICH 0: gemm_tile_128_d (registers), 1: gemm_tile_128_ld (DMA).  Selected by tile_order 1000 + WHICH.
+template <int WHICH>
+__global__ __launch_bounds__(GEMM_THREADS, 1) void k_lone(const double* __restrict__ U, int64_t Np, const double* __restrict__ Ks,
+                                                          int NT, const double* __restrict__ avec, double* __restrict__ Qp,
+                                                          double* __restrict__ Pp, int64_t ldp, int sm) {
+    extern __shared__ __attribute__((aligned(16))) double dsm[];
+    const int nP = (int)(Np / TB);
+    int mt, nt, mt2;
+    if (!sweep_tile_of<32>(blockIdx.x, 3, sm, NT, nP, mt, nt, mt2)) return;
+#pragma unroll 1
+    for (int ph = 0; ph < 2; ++ph) {
+        if (ph == 1) { if (mt2 < 0) break; mt = mt2; __syncthreads(); }
+        const int64_t m0 = (int64_t)mt * TB, n0 = (int64_t)nt * TB;
+        d4 acc[4][4];
+        acc_zero(acc);
+        if (WHICH == 0) gemm_tile_128_d<1>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, dsm);
+        else gemm_tile_128_ld<1>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, dsm);
+        sweep_epilogue<false>(acc, avec, m0, Qp + (int64_t)mt * ldp + n0, Pp + (int64_t)mt * ldp + n0, dsm);
+    }
+}
+
 int main(int argc, char** argv) {
     if (argc < 5) { fprintf(stderr, "usage: N cols reps tile_order[:super_m] ...\n"); return 1; }
     const int64_t N = atoll(argv[1]), cols = atoll(argv[2]);
@@ -57,6 +79,14 @@ int main(int argc, char** argv) {
         for (int rep = 0; rep < reps + 2; ++rep) {
             CK(hipMemsetAsync(clk, 0, 16, 0));
             hipEventRecord(e0);
+            if (to >= 1000) {
+                const size_t lb = (size_t)2 * GEMM_LDS_F64 * 8;
+                const unsigned nblk = sweep_grid<32>(3, sm, (int)(cols / TB), nP);
+                if (to == 1000) { CK(hipFuncSetAttribute((const void*)k_lone<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
+                    hipLaunchKernelGGL(k_lone<0>, dim3(nblk), dim3(GEMM_THREADS), lb, 0, U, Np, Ks, (int)(cols / TB), a, Qp, Pp, cols, sm); }
+                else { CK(hipFuncSetAttribute((const void*)k_lone<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
+                    hipLaunchKernelGGL(k_lone<1>, dim3(nblk), dim3(GEMM_THREADS), lb, 0, U, Np, Ks, (int)(cols / TB), a, Qp, Pp, cols, sm); }
+            } else
             launch_sweep_trmm(0, U, Np, Ks, Np, cols, a, Qp, Pp, cols, to, sm, clk);
             hipEventRecord(e1);
             CK(hipEventSynchronize(e1));

@@ -222,3 +222,61 @@ def ei_from_moments(mu, s2, target):
     s = np.sqrt(s2)
     z = (mu - target) / s
     return (mu - target) * 0.5 * erfc(-z * 0.70710678118654752440) + s * 0.39894228040143267794 * np.exp(-0.5 * z * z)
+
+
+# ---- the reference's loop over a real GP (tests/golden/make_loop_gp.py -> loop_gp.npz) ---------------------------------
+LOOP_GP_CASES = (
+    # tag, bounds, objective id, GP hyper-parameters (sn2, rho, ell, bias), kernel, solve_bayesopt kwargs, niter
+    ('ei_se_2d', [[0.0, 1.0], [-0.5, 1.0]], 'bumps2', (1e-4, 1.0, [0.3, 0.35], 0.0), 'se',
+     dict(policy='ei', recommender='latent', solver=('lbfgs', {'nbest': 5, 'ngrid': 2000})), 8),
+    ('ucb_matern_3d', [[0.0, 1.0]] * 3, 'quad3', (1e-3, 0.8, [0.4, 0.5, 0.45], -0.1), 'matern5',
+     dict(policy=('ucb', {'xi': 0.3}), recommender='incumbent', solver=('lbfgs', {'nbest': 4, 'ngrid': 3000})), 7),
+    ('ei_xi_se_1d', [[0.0, 4.0]], 'tilted1', (1e-4, 1.5, [0.6], 0.2), 'se',
+     dict(policy=('ei', {'xi': 0.05}), recommender='latent', solver=('lbfgs', {'nbest': 3, 'ngrid': 500})), 9),
+)
+
+
+def loop_gp_objective(kind):
+    if kind == 'bumps2':
+        c1, c2 = np.array([0.75, 0.6]), np.array([0.2, -0.1])
+        return lambda x: float(1.2 * np.exp(-6.0 * np.sum((np.ravel(x) - c1) ** 2)) +
+                               0.9 * np.exp(-9.0 * np.sum((np.ravel(x) - c2) ** 2)))
+    if kind == 'quad3':
+        c = np.array([0.3, 0.7, 0.45])
+        return lambda x: float(-np.sum((np.ravel(x) - c) ** 2 * np.array([1.0, 2.0, 0.5])))
+    if kind == 'tilted1':
+        return lambda x: float(np.sin(3.0 * np.ravel(x)[0]) + 0.5 * np.ravel(x)[0])
+    raise KeyError(kind)
+
+
+class SeenIndex(object):
+    """An acquisition index that notes what the solver's grid stage selects: the `nbest` best grid points in ranking order
+    and the best value -- whether the solver ranks f(xgrid) on the host or asks the index for its device top-k."""
+
+    def __init__(self, f, nbest, log):
+        self._f, self._nbest, self._log = f, nbest, log
+        if hasattr(f, 'topk'):
+            self.topk = self._topk
+
+    def __call__(self, X, grad=False):
+        res = self._f(X, grad=grad)
+        if not grad and np.array(X, ndmin=2).shape[0] > 1:
+            v = np.asarray(res)
+            order = np.lexsort((np.arange(len(v)), -v))[:self._nbest]
+            self._log.append((order.copy(), float(v[order[0]])))
+        return res
+
+    def _topk(self, Z, k):
+        vals, idx = self._f.topk(Z, k)
+        self._log.append((np.asarray(idx, dtype=int).copy(), float(np.asarray(vals)[0])))
+        return vals, idx
+
+    def __getattr__(self, name):
+        return getattr(self._f, name)
+
+
+def recording_solver(solve, log):
+    """`solve` (a solve_lbfgs) behind the solver-plugin signature, its index wrapped in SeenIndex."""
+    def solver(f, bounds, nbest=10, ngrid=10000, xgrid=None, rng=None):
+        return solve(SeenIndex(f, nbest, log), bounds, nbest=nbest, ngrid=ngrid, xgrid=xgrid, rng=rng)
+    return solver

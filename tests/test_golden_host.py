@@ -206,6 +206,39 @@ def test_whole_bo_loop_matches_the_reference_loop(tag, bounds, kw):
     np.testing.assert_allclose(xbest, g[tag + '_final'], rtol=0, atol=1e-12)
 
 
+def _replay_loop_gp(case, make_model, solve):
+    """One case of loop_gp.npz through pybo_amd.solve_bayesopt: returns (trace, per-iteration grid selections, fixture)."""
+    from helpers import loop_gp_objective, recording_solver
+    tag, bounds, okind, hyp, kern, kw, niter = case
+    g = np.load(os.path.join(G, 'loop_gp.npz'))
+    kw = dict(kw)
+    name, skw = kw.pop('solver')
+    log = []
+    model = make_model(hyp[0], hyp[1], np.array(hyp[2]), hyp[3], kern)
+    xbest, final, info = bayesopt.solve_bayesopt(loop_gp_objective(okind), bounds, model=model, niter=niter, rng=11,
+                                                 solver=(recording_solver(solve, log), skw), **kw)
+    per = len(log) // niter
+    assert per * niter == len(log) and per == int(g[tag + '_stages_per_iter'])
+    return (xbest, final, info), log[::per], {k[len(tag) + 1:]: g[k] for k in g.files if k.startswith(tag + '_')}
+
+
+@pytest.mark.parametrize('case', __import__('helpers').LOOP_GP_CASES, ids=lambda c: c[0])
+def test_reference_loop_over_a_real_gp_is_reproduced(case):
+    """loop_gp.npz = the REFERENCE's solve_bayesopt + solve_lbfgs + policies + recommenders (run in the build container by
+    tests/golden/make_loop_gp.py) driving oracle.GPRef.  The same model under pybo_amd's loop, solver, policies and
+    recommenders gives the same trace and the same grid selections: pybo's own glue, end to end over a real GP."""
+    from oracle import gp_ref
+    from pybo_amd import solvers
+    (xbest, final, info), grid, g = _replay_loop_gp(case, gp_ref.make_gp, solvers.solve_lbfgs)
+    assert final.ndata == case[6] + 1
+    np.testing.assert_allclose(info.x, g['x'], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(info.y, g['y'], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(info.xbest, g['xbest'], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(xbest, g['final'], rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(np.array([t[0] for t in grid]), g['grid_top'])
+    np.testing.assert_allclose([t[1] for t in grid], g['grid_best'], rtol=1e-12)
+
+
 @pytest.mark.parametrize('tag,bounds,kw', [('b2', [[0.0, 1.0], [-0.5, 1.0]], {}),
                                            ('b3_n5', [[-5.0, 10.0], [0.0, 15.0], [1.0, 3.0]], {'ninit': 5}),
                                            ('flat', [[0.0, 1.0]], {})])

