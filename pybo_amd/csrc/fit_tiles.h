@@ -509,8 +509,14 @@ __device__ __forceinline__ void syrk_tile(const double* __restrict__ R, double* 
     d4 acc[4][4];
     double* tile = S + i0 * Np + j0;
     tile128_load<AG>(acc, tile, Np);
+#ifdef GPX_TG_REGLOOPS       // A/B builds only: the register-staged k-loops of rounds 2-5
     if constexpr (DB) gemm_tile_128_d<PRIO, true, AG ? 16 : 0>(acc, R + i0, Np, R + j0, Np, kb0 * NB, kb1 * NB, smem);
     else gemm_tile_128_g<PRIO, true>(acc, R + i0, Np, R + j0, Np, kb0 * NB, kb1 * NB, smem);
+#else
+    // operands by LDS-DMA (round 6): no staging registers, no ds_write phase; A is negated by the MFMA itself -- same bits
+    if constexpr (DB) gemm_tile_128_ld<PRIO, true, AG ? 16 : 0>(acc, R + i0, Np, R + j0, Np, kb0 * NB, kb1 * NB, smem);
+    else gemm_tile_128_l<32, (PRIO > 2 ? 2 : PRIO), 2, false, false, true>(acc, R + i0, Np, R + j0, Np, kb0 * NB, kb1 * NB, smem);
+#endif
     tile128_store<AG>(acc, tile, Np);
 }
 

@@ -498,7 +498,9 @@ __device__ __forceinline__ void gemm_tile_128_l(d4 (&acc)[4][4], const double* _
             if (NSET == 1 && kk + 1 < G) frag(0, kk + 1);
         }
         if (PRIO) __builtin_amdgcn_s_setprio(0);
-        asm volatile("" ::: "memory");
+        // (lgkmcnt: the compiler may sink a step's last MFMAs below the barrier and leave their fragment reads in flight above
+        //  it; no LDS read of this wave may still be pending when another wave's DMA starts to overwrite the buffer)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                  // everyone has finished reading the buffer
         if (more) issue();
     };
@@ -516,12 +518,12 @@ __device__ __forceinline__ void gemm_tile_128_l(d4 (&acc)[4][4], const double* _
     }
 }
 
-// The register-free loop for a workgroup that has its compute unit to ITSELF (two k-step images of LDS, 2 x 73,728 B): the
-// DMA of step t + 2 goes out at the top of step t + 1 into the image step t has just been read from, so every load has a whole
-// step to land and there is ONE barrier per step -- behind it every wave has finished reading image t & 1 AND every wave's
-// rows of step t + 1 have landed (each wave waits for its own loads first).  Against gemm_tile_128_d (registers, LDS writes
-// behind the MFMA groups): no staging registers, no ds_write, no VALU in the step.  Same arithmetic, same order, same bits.
-template <int PRIO = 1, bool NEGA = false, int AUX = 0, int NSET = 2>
+// The register-free loop for a workgroup that has its compute unit to ITSELF (two k-step images of LDS, 2 x 73,728 B): while
+// step t is multiplied out of image t & 1, the DMA of step t + 1 fills the other image -- issued four instructions at a time
+// behind the step's first four MFMA groups -- and ONE barrier ends the step: behind it every wave has finished reading image
+// t & 1 AND every wave's rows of step t + 1 have landed (each wave waits for its own loads first).  Against gemm_tile_128_d
+// (registers, LDS writes behind the MFMA groups): no staging registers, no ds_write.  Same arithmetic, same order, same bits.
+template <int PRIO = 1, bool NEGA = false, int AUX = 0>
 __device__ __forceinline__ void gemm_tile_128_ld(d4 (&acc)[4][4], const double* __restrict__ A, int64_t lda,
                                                  const double* __restrict__ B, int64_t ldb, int k_lo, int k_hi,
                                                  double* smem) {
@@ -535,32 +537,42 @@ __device__ __forceinline__ void gemm_tile_128_ld(d4 (&acc)[4][4], const double* 
     const char* Bbase = reinterpret_cast<const char*>(B + (int64_t)k_lo * ldb);
     const int voA = (int)(((int64_t)w * lda + 2 * lane) * 8), voB = (int)(((int64_t)w * ldb + 2 * lane) * 8);
     const int soA = (int)(4 * lda * 8), soB = (int)(4 * ldb * 8);
-    auto issue = [&](int img) {
+    // rows w + 4 p, p = P0 .. P1 - 1, of the step at Abase / Bbase into image img
+    auto issue = [&](int img, auto p0c, auto p1c) {
+        constexpr int P0 = decltype(p0c)::value, P1 = decltype(p1c)::value;
         double* As = smem + img * GEMM_LDS_F64;
         double* Bs = As + BK32 * LDT;
         __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)Abase, 0, -1, 0x00020000);
         __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)Bbase, 0, -1, 0x00020000);
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
+        for (int p = P0; p < P1; ++p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (gemm_lds_ptr)(As + (w + 4 * p) * LDT), 16, voA, p * soA, 0, AUX);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (gemm_lds_ptr)(Bs + (w + 4 * p) * LDT), 16, voB, p * soB, 0, AUX);
         }
+    };
+    auto bump = [&]() {
         Abase += (int64_t)BK32 * lda * 8;
         Bbase += (int64_t)BK32 * ldb * 8;
     };
+    using I0 = std::integral_constant<int, 0>;
+    using I8 = std::integral_constant<int, 8>;
     const int fr = lane & 15, fk = lane >> 4;
     const int aoff = wm * 64 + fr + fk * LDT, boff = BK32 * LDT + wn * 64 + fr + fk * LDT;
-    issue(0);
-    if (nk > 1) issue(1);
-    if (nk > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");     // step 0 has landed (step 1's 16 loads may be in flight)
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue(0, I0{}, I8{});
+    bump();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
-    for (int kt = 0; kt < nk; ++kt) {
+    // One step.  FILL: the loads of the NEXT step go out behind this step's first four MFMA groups, four at a time, into the
+    // image the previous step was read from (the barrier that ended it freed it); they have the step's other four groups
+    // (4096 matrix clocks) to land.
+    auto step = [&](int kt, auto fillc) {
+        constexpr bool FILL = decltype(fillc)::value;
         const double* as = smem + (kt & 1) * GEMM_LDS_F64 + aoff;
         const double* bs = smem + (kt & 1) * GEMM_LDS_F64 + boff;
+        const int img = (kt + 1) & 1;
         asm volatile("" ::: "memory");
-        double a[NSET][4], b[NSET][4];
+        double a[2][4], b[2][4];
         auto frag = [&](int set, int g) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) a[set][i] = as[g * 4 * LDT + i * 16];
@@ -580,14 +592,24 @@ __device__ __forceinline__ void gemm_tile_128_ld(d4 (&acc)[4][4], const double* 
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, NEGA ? 1 : 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            if (FILL && kk < 4) {
+                if (kk == 0) issue(img, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+                if (kk == 1) issue(img, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+                if (kk == 2) issue(img, std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{});
+                if (kk == 3) issue(img, std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{});
+                __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+            }
         }
         asm volatile("" ::: "memory");
-        if (kt + 1 < nk) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's rows of step kt + 1 (issued a whole step ago)
-            __builtin_amdgcn_s_barrier();                               // image kt & 1 is read, image (kt + 1) & 1 is complete
-            if (kt + 2 < nk) issue(kt & 1);
+        if (FILL) {
+            bump();
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's rows of the next step; its LDS reads of this one
+            __builtin_amdgcn_s_barrier();                               // image kt & 1 is read, the other image is complete
         }
-    }
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; ++kt) step(kt, std::true_type{});
+    step(kt, std::false_type{});
     if (PRIO) __builtin_amdgcn_s_setprio(PRIO - 1);
     __builtin_amdgcn_s_barrier();                                       // the caller may reuse LDS
 }

@@ -175,9 +175,21 @@ __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, T
 // diagonal kernel's panels fit inside) or TWO (144 KB: a workgroup alone on its CU runs the double-buffered k-loop,
 // gemm_tile_128_d).  File scope, so that the role bodies below can be separate (non-inlined) functions with their own register
 // allocation and still address it with ds_* instructions: inlined into one kernel body the roles spilled 319 VGPRs.
-constexpr int TG_CTL_F64 = 8;
+constexpr int TG_CTL_F64 = 32;        // control words: [0..1] the task in hand, [2..3] codes, [4..6] the held ticket, [8..15] the dispatcher's trace sums, [16..31] the argument block
 extern __shared__ __attribute__((aligned(16))) double tg_smem[];
 #define tg_buf (tg_smem + TG_CTL_F64)
+// Calls of the role / task bodies must not carry LLVM's `tail` marker (the optimiser sets it on any call that cannot see the
+// caller's frame): a function with a marked call site loses the no-callee-saved-registers treatment and saves ~100 VGPRs to
+// scratch on entry.
+#define TG_BODY __noinline__ __attribute__((not_tail_called))
+
+// The launch's argument block as the role bodies see it: a copy in the workgroup's LDS (written once by the kernel's first
+// instructions).  The role bodies are separate functions; handed the kernel's by-value block by reference they forced a copy of it
+// into SCRATCH memory, and the dispatcher's live registers were spilled around every call (round 5: 672 bytes of scratch per
+// lane, 112 scratch instructions in the dispatcher).  (__builtin_amdgcn_kernarg_segment_ptr() inside a callee folds to a null
+// pointer with this compiler: not an option.)
+static_assert(sizeof(TgArgs) <= 16 * sizeof(double), "TgArgs must fit its LDS slot");
+__device__ __forceinline__ const TgArgs& tg_kargs() { return *reinterpret_cast<const TgArgs*>(tg_smem + 16); }
 
 // The last dependency of a task in hand (every thread calls; thread 0 polls): both flags >= need.  false: abort.
 __device__ __forceinline__ bool tg_wait_flags(const TgArgs& a, const int* f0, const int* f1, int need) {
@@ -224,17 +236,17 @@ __device__ __forceinline__ bool panel_solve16_lds(const TgArgs& a, const double*
     // (1) everything else this workgroup reads, issued back to back
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(Rd), 0, (int)(128 * Np * 8), 0x00020000);
     u4v stage[18];
-    int dst[18];
+    // piece e = t + 256 q of the 36 tiles x 128 16-byte pieces: tile e >> 7 = 2 q + (t >> 7), so its LDS position is
+    // 512 q + (t >> 7) * 256 + row * 16 + 2 c2 -- one register for all 18 pieces (18 of them were spilled to scratch memory)
+    const int piece = t & 127, row = piece >> 3, c2 = piece & 7;
+    const int dst0 = (t >> 7) * 256 + row * 16 + 2 * c2;
 #pragma unroll
     for (int q = 0; q < 18; ++q) {
-        const int e = t + 256 * q;                 // 36 tiles x 128 16-byte pieces
-        int tile = e >> 7, r = 0;
-        const int piece = e & 127, row = piece >> 3, c2 = piece & 7;
-        int idx = tile;
+        int r = 0;
+        int idx = 2 * q + (t >> 7);
         while (idx >= 8 - r) { idx -= 8 - r; ++r; }
         const int c = r + idx;
         stage[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((16 * r + row) * Np + 16 * c + 2 * c2) * 8), 0, 16);
-        dst[q] = tile * 256 + row * 16 + 2 * c2;
     }
     double ti[8][4];                               // A fragments of the eight T_d
 #pragma unroll
@@ -242,7 +254,7 @@ __device__ __forceinline__ bool panel_solve16_lds(const TgArgs& a, const double*
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) ti[jb][kk] = ldg<true>(Ud + (int64_t)(16 * jb + 4 * kk + g) * Np + 16 * jb + n);
 #pragma unroll
-    for (int q = 0; q < 18; ++q) *reinterpret_cast<u4v*>(lds + dst[q]) = stage[q];
+    for (int q = 0; q < 18; ++q) *reinterpret_cast<u4v*>(lds + dst0 + 512 * q) = stage[q];
     __syncthreads();
     // (2) the substitution
 #pragma unroll
@@ -290,7 +302,8 @@ __device__ __forceinline__ T* uni(T* p) { return reinterpret_cast<T*>(uni64(rein
 
 __device__ __forceinline__ void tg_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-__device__ __noinline__ void tg_role_diag(const TgArgs& a) {
+__device__ TG_BODY void tg_role_diag() {
+    const TgArgs& a = tg_kargs();
     double* Pn = tg_buf;                           // 2 x 16 x PFP
     double* Ud = tg_buf + 2 * 16 * PFP;            // 256
     int* code = reinterpret_cast<int*>(tg_smem + 2);
@@ -620,9 +633,9 @@ __device__ __forceinline__ void tg_role_solve(const TgArgs& a, int off) {
         }
     }
 }
-__device__ __noinline__ void tg_role_s1(const TgArgs& a) { tg_role_solve<TG_CTL_XSTEP>(a, 1); }
-__device__ __noinline__ void tg_role_s2(const TgArgs& a) { tg_role_solve<TG_CTL_XSTEP2>(a, 2); }
-__device__ __noinline__ void tg_role_s3(const TgArgs& a) { tg_role_solve<TG_CTL_XSTEP3>(a, 3); }
+__device__ TG_BODY void tg_role_s1() { tg_role_solve<TG_CTL_XSTEP>(tg_kargs(), 1); }
+__device__ TG_BODY void tg_role_s2() { tg_role_solve<TG_CTL_XSTEP2>(tg_kargs(), 2); }
+__device__ TG_BODY void tg_role_s3() { tg_role_solve<TG_CTL_XSTEP3>(tg_kargs(), 3); }
 
 // acc(r, c) -= x_r^T x_c as acc += x_r^T (-x_c): the same products with the same signs as the tile engines' (-A) B
 template <int W>
@@ -753,8 +766,8 @@ __device__ __forceinline__ void tg_role_diagupd(const TgArgs& a) {
     }
 }
 
-__device__ __noinline__ void tg_role_u(const TgArgs& a) { tg_role_diagupd<true>(a); }
-__device__ __noinline__ void tg_role_u0(const TgArgs& a) { tg_role_diagupd<false>(a); }
+__device__ TG_BODY void tg_role_u() { tg_role_diagupd<true>(tg_kargs()); }
+__device__ TG_BODY void tg_role_u0() { tg_role_diagupd<false>(tg_kargs()); }
 
 // V (off = 1) / V2 (off = 2): the final chunk of tile (p, p + off) -- block row p-1, 16 rows at a time behind S1 and S2 (S3) of
 // the previous block row -- so that the right-hand sides of S1 (S2) are complete a few microseconds after those two are, not
@@ -858,18 +871,20 @@ __device__ __forceinline__ void tg_role_offupd(const TgArgs& a, int off, int hal
         }
     }
 }
-template <bool DB> __device__ __noinline__ void tg_role_v(const TgArgs& a, int half) { tg_role_offupd<DB>(a, 1, half); }
-template <bool DB> __device__ __noinline__ void tg_role_v2(const TgArgs& a, int half) { tg_role_offupd<DB>(a, 2, half); }
+template <bool DB> __device__ TG_BODY void tg_role_v(int half) { tg_role_offupd<DB>(tg_kargs(), 1, half); }
+template <bool DB> __device__ TG_BODY void tg_role_v2(int half) { tg_role_offupd<DB>(tg_kargs(), 2, half); }
 
 
 template <bool DB>
-__device__ __noinline__ void tg_do_upd(const TgArgs& a, int k0, int k1, int I, int J) {
+__device__ TG_BODY void tg_do_upd(int k0, int k1, int I, int J) {
+    const TgArgs& a = tg_kargs();
     // (arguments of a non-inlined function travel in VGPRs: tell the compiler they are wave-uniform)
     k0 = __builtin_amdgcn_readfirstlane(k0); k1 = __builtin_amdgcn_readfirstlane(k1);
     I = __builtin_amdgcn_readfirstlane(I); J = __builtin_amdgcn_readfirstlane(J);
     syrk_tile<true, 2, DB>(uni(a.R), uni(a.S), (int64_t)uni64((unsigned long long)a.Np), k0, k1, I, J, tg_buf);
 }
-__device__ __noinline__ bool tg_do_trsm(const TgArgs& a, int p, int cb) {
+__device__ TG_BODY bool tg_do_trsm(int p, int cb) {
+    const TgArgs& a = tg_kargs();
     p = __builtin_amdgcn_readfirstlane(p); cb = __builtin_amdgcn_readfirstlane(cb);
     __builtin_amdgcn_s_setprio(3);
     const int* diag = uni(a.ctl) + TG_CTL_BASE;
@@ -884,7 +899,8 @@ __device__ __noinline__ bool tg_do_trsm(const TgArgs& a, int p, int cb) {
 // (p+1, J):  S(p+1, J) -= R(p, p+1)^T R(p, J), R(p, p+1) staged whole in LDS (LDS-direct loads; it needs the two k-step images of
 // the one-workgroup-per-CU launch).  Same FMAs per element as the tile engine (accumulators from S, k ascending 4 at a time).
 // The half publishes itself (solved[], a flag for the same half's next link); the second half to arrive counts the tile's chunk.
-__device__ __noinline__ bool tg_do_trsmu(const TgArgs& a, int p, int J, int h, int k0, int ordn) {
+__device__ TG_BODY bool tg_do_trsmu(int p, int J, int h, int k0, int ordn) {
+    const TgArgs& a = tg_kargs();
     p = __builtin_amdgcn_readfirstlane(p); J = __builtin_amdgcn_readfirstlane(J); h = __builtin_amdgcn_readfirstlane(h);
     k0 = __builtin_amdgcn_readfirstlane(k0); ordn = __builtin_amdgcn_readfirstlane(ordn);
     __builtin_amdgcn_s_setprio(3);
@@ -917,17 +933,15 @@ __device__ __noinline__ bool tg_do_trsmu(const TgArgs& a, int p, int J, int h, i
     {
         const __amdgpu_buffer_rsrc_t rs = tg_rsrc(Rd, Np);
         u4v stage[18];
-        int dst[18];
+        const int piece = t & 127, row = piece >> 3, c2 = piece & 7;       // (as in panel_solve16_lds: one position register)
+        const int dst0 = (t >> 7) * 256 + row * 16 + 2 * c2;
 #pragma unroll
         for (int q = 0; q < 18; ++q) {
-            const int e = t + 256 * q;
-            int tile = e >> 7, r = 0;
-            const int piece = e & 127, row = piece >> 3, c2 = piece & 7;
-            int idx = tile;
+            int r = 0;
+            int idx = 2 * q + (t >> 7);
             while (idx >= 8 - r) { idx -= 8 - r; ++r; }
             const int c = r + idx;
             stage[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(((16 * r + row) * Np + 16 * c + 2 * c2) * 8), 0, 16);
-            dst[q] = tile * 256 + row * 16 + 2 * c2;
         }
         double ti[8][4];
 #pragma unroll
@@ -935,7 +949,7 @@ __device__ __noinline__ bool tg_do_trsmu(const TgArgs& a, int p, int J, int h, i
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) ti[jb][kk] = ldg<true>(Ud + (int64_t)(16 * jb + 4 * kk + g) * Np + 16 * jb + n);
 #pragma unroll
-        for (int q = 0; q < 18; ++q) *reinterpret_cast<u4v*>(lds + dst[q]) = stage[q];
+        for (int q = 0; q < 18; ++q) *reinterpret_cast<u4v*>(lds + dst0 + 512 * q) = stage[q];
         __syncthreads();
         // (2) the substitution
 #pragma unroll
@@ -1017,8 +1031,14 @@ __device__ __noinline__ bool tg_do_trsmu(const TgArgs& a, int p, int J, int h, i
     return true;
 }
 
-__device__ __noinline__ int tg_take_call(const TgArgs& a, TgTask& out, int lane) {
-    return tg_take(a, out, lane, reinterpret_cast<TgHeld*>(tg_smem + 4));
+// (the task goes to the workgroup's LDS slot, not through a reference to the caller's registers: that was scratch memory too)
+__device__ TG_BODY int tg_take_call(int lane) {
+    const TgArgs& a = tg_kargs();
+    TgTask tk;
+    tk.type = 0;
+    const int c = tg_take(a, tk, lane, reinterpret_cast<TgHeld*>(tg_smem + 4));
+    if (lane == 0) *reinterpret_cast<TgTask*>(tg_smem) = tk;
+    return c;
 }
 
 // DB: the launch gives every workgroup two k-step images of LDS (one workgroup per CU): the workers' tile updates run the
@@ -1028,6 +1048,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
     TgTask* cur = reinterpret_cast<TgTask*>(tg_smem);           // 16 bytes
     int* code = reinterpret_cast<int*>(tg_smem + 2);             // [0] take result / role, [1] potrf's sflag
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t == 0) *reinterpret_cast<TgArgs*>(tg_smem + 16) = a;     // the role bodies' view of the arguments (tg_kargs)
     const int nP = a.nP, npad = tg_npad(nP);
     int* ctl = a.ctl;
     int* dd = ctl + TG_CTL_BASE;
@@ -1062,53 +1083,58 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
     __syncthreads();
     if (role < 0) return;
     if (role == 0) {            // role C: the diagonal blocks, one after the other
-        tg_role_diag(a);
+        tg_role_diag();
         return;
     }
     if (role <= TG_NSHADOW) {        // the shadows of role C
-        if (role == 1) tg_role_s1(a);
-        else if (role == 2) tg_role_s2(a);
-        else if (role == 3) tg_role_s3(a);
-        else if (role == 4) tg_role_u(a);
-        else if (role == 5) tg_role_u0(a);
-        else if (role <= 7) tg_role_v<DB>(a, role - 6);
-        else tg_role_v2<DB>(a, role - 8);
+        if (role == 1) tg_role_s1();
+        else if (role == 2) tg_role_s2();
+        else if (role == 3) tg_role_s3();
+        else if (role == 4) tg_role_u();
+        else if (role == 5) tg_role_u0();
+        else if (role <= 7) tg_role_v<DB>(role - 6);
+        else tg_role_v2<DB>(role - 8);
         return;
     }
-    long long prof[6] = {0, 0, 0, 0, 0, 0};
-    long long tprev = a.trace ? wall_clock64() : 0;
+    // the dispatcher keeps nothing in vector registers across a task (the callee would have to save it): the task is read back
+    // from LDS, the trace sums (thread 0, trace runs only) live in LDS
+    volatile long long* prof = reinterpret_cast<volatile long long*>(tg_smem + 8);      // [0..5] sums, [6] tprev, [7] ts
+    if (t == 0) {
+        for (int i = 0; i < 6; ++i) prof[i] = 0;
+        prof[6] = a.trace ? wall_clock64() : 0;
+    }
+    const volatile TgTask* vc = cur;
     for (;;) {
         if (w == 0) {
-            TgTask tk;
-            tk.type = 0;
             __builtin_amdgcn_s_setprio(0);
-            const int c = tg_take_call(a, tk, lane);
+            const int c = tg_take_call(lane);
             if (lane == 0) {
-                *cur = tk;
                 code[0] = c;
                 // the single-buffer tile engine reads its operand panels with plain 16-byte loads: drop this CU's stale L1 lines
                 // (the double-buffered one loads them sc1, past the L1: no fence, 1.7 us per task)
-                if (!DB && c == 1 && tk.type == TG_UPD) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                if (!DB && c == 1 && vc->type == TG_UPD) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
         }
         __syncthreads();
         if (code[0] != 1) break;
-        const TgTask tk = *cur;
-        long long ts = 0;
-        if (a.trace && t == 0) { ts = wall_clock64(); prof[1] += ts - tprev; }
-        if (tk.type == TG_UPD) {
-            tg_do_upd<DB>(a, tk.k0, tk.k1, tk.I, tk.J);
-        } else if (tk.type == TG_TRSM) {
-            if (!tg_do_trsm(a, tk.I, 2 * (tk.J - tk.I - 1) + tk.aux)) break;
+        const int type = __builtin_amdgcn_readfirstlane(vc->type);
+        if (a.trace && t == 0) { const long long ts = wall_clock64(); prof[7] = ts; prof[1] += ts - prof[6]; }
+        if (type == TG_UPD) {
+            tg_do_upd<DB>(vc->k0, vc->k1, vc->I, vc->J);
+        } else if (type == TG_TRSM) {
+            if (!tg_do_trsm(vc->I, 2 * (vc->J - vc->I - 1) + vc->aux)) break;
         } else {
-            if (!tg_do_trsmu(a, tk.I, tk.J, tk.aux, tk.k0, tk.rsv)) break;
+            if (!tg_do_trsmu(vc->I, vc->J, vc->aux, vc->k0, vc->rsv)) break;
         }
         tg_drain();
         __syncthreads();
         if (t == 0) {
+            TgTask tk;
+            tk.type = vc->type; tk.I = vc->I; tk.J = vc->J; tk.k0 = vc->k0; tk.k1 = vc->k1; tk.ord = vc->ord; tk.aux = vc->aux; tk.rsv = vc->rsv;
             long long te = 0;
             if (a.trace) {
                 te = wall_clock64();
+                const long long ts = prof[7];
                 if (a.tasklog && role < TG_LOG_WGS && prof[0] < TG_LOG_CAP) {
                     long long* rec = a.tasklog + ((long long)role * TG_LOG_CAP + prof[0]) * 4;
                     union { TgTask t; long long w[2]; } u;
@@ -1121,7 +1147,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
             }
             if (tk.type == TG_UPD) sti(sq + tk.I * nP + tk.J, tk.ord + 1);
             else if (tk.type == TG_TRSM) sti(sv + 2 * tk.J + tk.aux, tk.I + 1);          // (a fused link has published itself)
-            if (a.trace) { tprev = wall_clock64(); prof[4] += tprev - te; }
+            if (a.trace) { const long long tp = wall_clock64(); prof[6] = tp; prof[4] += tp - te; }
         }
     }
     if (a.trace && t == 0 && role < 1024) {

@@ -608,7 +608,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trtri_gemm1(const double* _
     const int64_t m0 = r2e + (int64_t)bm * NB, n0 = r1e + (int64_t)bn * NB;
     d4 acc[4][4];
     acc_zero(acc);
-    gemm_tile_128_s<1>(acc, R + r1e * Np + m0, Np, T + r1e * Np + n0, Np, bn * NB, hb * NB, smem);
+    gemm_tile_128_l<32, 1, 2>(acc, R + r1e * Np + m0, Np, T + r1e * Np + n0, Np, bn * NB, hb * NB, smem);      // operands by LDS-DMA (round 6)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -633,14 +633,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trtri_gemm2(const double* _
     d4 acc[4][4];
     acc_zero(acc);
     // A(m,k) = T_22(m,k) = U[r2e+k][m0+m], k <= m  ->  k-blocks [0, bm]
-    gemm_tile_128_s<1>(acc, U + r2e * Np + m0, Np, W + r2e * Np + n0, Np, 0, (bm + 1) * NB, smem);
+    gemm_tile_128_l<32, 1, 2, true, true>(acc, U + r2e * Np + m0, Np, W + r2e * Np + n0, Np, 0, (bm + 1) * NB, smem);      // the last k-block of T_22 is triangular: its all-zero quarter-rows are skipped (interleaved row blocks: acc_row_ilv)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int64_t gm = m0 + acc_row(i, r), gn = n0 + acc_col(j);
+                const int64_t gm = m0 + acc_row_ilv(i, r), gn = n0 + acc_col(j);
                 const double v = -acc[i][j][r];
                 T[gm * Np + gn] = v;
                 U[gn * Np + gm] = v;
@@ -731,13 +731,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trtri_gemm1r(const double* 
     const int64_t m0 = r2e + (int64_t)bm * NB, n0 = r1e + (int64_t)bn * NB;
     d4 acc[4][4];
     acc_zero(acc);
-    gemm_tile_128_s<1>(acc, U + r2e * Np + m0, Np, S + r2e * Np + n0, Np, 0, (bm + 1) * NB, smem);
+    gemm_tile_128_l<32, 1, 2, true, true>(acc, U + r2e * Np + m0, Np, S + r2e * Np + n0, Np, 0, (bm + 1) * NB, smem);      // the last k-block of T_22 is triangular: its all-zero quarter-rows are skipped (interleaved row blocks: acc_row_ilv)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) S[(n0 + acc_col(j)) * Np + m0 + acc_row(i, r)] = acc[i][j][r];     // W'^T, upper position
+            for (int r = 0; r < 4; ++r) S[(n0 + acc_col(j)) * Np + m0 + acc_row_ilv(i, r)] = acc[i][j][r];     // W'^T, upper position
 }
 
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trtri_gemm2r(const double* __restrict__ S, double* __restrict__ T,
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_trtri_gemm2r(const double* 
     const int64_t m0 = r2e + (int64_t)bm * NB, n0 = r1e + (int64_t)bn * NB;
     d4 acc[4][4];
     acc_zero(acc);
-    gemm_tile_128_s<1>(acc, S + r1e * Np + m0, Np, T + r1e * Np + n0, Np, bn * NB, hb * NB, smem);
+    gemm_tile_128_l<32, 1, 2>(acc, S + r1e * Np + m0, Np, T + r1e * Np + n0, Np, bn * NB, hb * NB, smem);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
