@@ -15,11 +15,9 @@
  *     device; they enqueue on the handle's stream and are synchronous on return only where an
  *     output lands in a host buffer (top-k, status).
  *   - a handle is not re-entrant; distinct handles may be driven from distinct threads.
- *   - a handle owns up to four HIP streams (its own or the caller's + three side streams created on first need).  The HIP
- *     runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4): a process that keeps
- *     more than one handle alive should export GPU_MAX_HW_QUEUES=8 (or more) BEFORE its first HIP call, or work that is
- *     meant to overlap inside a handle (gpx_append_begin's pass beside gpx_predict_mean) may share a queue and serialise
- *     (measured: +2.3 ms per warm iteration at N = 8192).  Results never depend on it.
+ *   - a handle owns up to four HIP streams (its own or the caller's + three side streams created on first need); a process
+ *     that keeps several handles alive should export GPU_MAX_HW_QUEUES=8 BEFORE its first HIP call, or work meant to overlap
+ *     inside a handle may share a hardware queue and serialise (+2.3 ms per warm iteration at N = 8192).  Results never depend on it.
  *   - no C++ exception crosses this boundary.
  */
 #ifndef GPX_H
@@ -67,79 +65,37 @@ int gpx_create(int device, void *stream, gpx_handle **out);
 int gpx_destroy(gpx_handle *h);
 const char *gpx_last_error(const gpx_handle *h);
 int gpx_version(void);
-/* options: "chunk" = candidate columns per sweep chunk (multiple of 128; default by size: 65536, 131072 up to N = 4096);
- *          "tile_order" = sweep-kernel schedule: bits 0-1 blockIdx->tile map (0 linear heavy-first,
- *              1 per-XCD candidate slices, 2 per-XCD 8x8 super-tiles, 3 the same with every workgroup
- *              computing the PAIR of tiles (nP-1-i, nt), (i, nt): equal work per workgroup), bits 2-4 k-loop schedule
- *              (4 = the default: operands travel global memory -> LDS by DMA, k-step 32 through a single LDS buffer, two
- *              workgroups per CU, the all-zero quarter-rows of T's diagonal block skipped; 3 = the same without the skip;
- *              7 = k-step 16, three workgroups per CU; 6 / 5 / 2 = the register-staged schedules of rounds 5 / 2 / 1 --
- *              all kept as independently scheduled witnesses).  Default 19 = paired super-tiles + schedule 4.
- *              Every setting produces bit-identical results.
- *          "super_m" = rows of the XCD super-tile of 64 workgroups (8 -> 8x8 default, 4 -> 4x16, ...).
- *          "eager_inverse" = 1: form the triangular inverse inside gpx_fit instead of on first use.
- *          "trtri_ahead" = 1 (default): when the inverse is certain or likely to follow a fit -- "eager_inverse", gpx_fit_stage
- *              with stage 3, or the previous model's inverse was formed -- the part of the inversion that needs only the leading
- *              block rows of the factor (the leading group's whole recursion and the top level's first product) is queued on a side
- *              stream behind a gate that opens when those rows are final, and runs on the compute units the factorisation's
- *              chain-bound tail leaves idle; the first use then finds only the trailing group and one product left.  Same kernels,
- *              same results bit for bit.  Applies to the task-graph factorisation with one workgroup per compute unit, from
- *              "trtri_ahead_min" (default 8) 128-blocks on.  0: the inversion starts when it is asked for.
- *          "grad_form": the form of gpx_predict / gpx_ensemble_predict WITH gradients.  0 (default) = auto: a call with
- *              M = 1 point -- every call of the reference's single-seed refinement [pybo/solvers/lbfgs.py:56-58] -- takes
- *              ONE pass over the triangular inverse T with 1 + d right-hand sides, ds2/dx_j = -2 (T k).(T dk/dx_j), when
- *              1 + d <= 16 (N = 8192, d = 8: 105 us per call instead of 159); calls with more points take two passes
- *              (T, then U = T^T) with one right-hand side per point.  1 = always two passes, 2 = one pass for every M
- *              (floor(16 / (1 + d)) points per pass).  Within a form a point's results do not depend on the batch it
- *              travels in; the two forms agree to rounding, not bit for bit.  gpx_predict_mean with M = 1 likewise runs
- *              as one launch (unless grad_form = 1).
- *          "grad_kernel": the triangular matvec of the two-pass form: -1 (default) = register-blocked (4 rows x all
- *              right-hand sides per wave, column segments) for batches and one wave per row for a single point, 0 / 1 =
- *              always the one / the other.  "grad_rb_cs" (columns per segment, a multiple of 128): experiment.
- *          "trtri_left" = 1: the recursive doubling of the triangular inverse associated as T21 = -(T22 L21) T11 instead of
- *              T21 = -T22 (L21 T11) (default 0).  Built in round 4 on the expectation that it keeps the LEFT residual
- *              T R^T - I at rounding level for the same flop; MEASURED (profiles/r04_illcond_vs_long_double.txt): it does not
- *              -- the rounding error of the OUTER product carries the same factor |T11| |L11| in either order (max |T L - I|
- *              1.9e-11 -> 3.1e-11 on config B at sn2 = 1e-6 rho); the mean improves 1.2-1.9x, the variance does not, and it
- *              costs one transposition pass of the factor.  Kept as an option; "refine_inverse" is what reduces the residual.
- *          "refine_inverse" = 1: one Newton step T <- (2I - T R^T) T on the triangular inverse after it is formed (2 N^3 / 3
- *              more flop, one more Np^2 buffer): squares the LEFT residual T R^T - I, the one the sweep's error is
- *              proportional to -- for hyper-parameters with cond(K) >~ 1e9 (sn2 ~ 1e-6 rho), where the plain inverse is
- *              10-20x less accurate than substitution (still 3.5 orders inside the stated tolerance).  Default 0.
- *          "sweep_cache" = 1: full sweeps keep their candidates and reduced sums for gpx_sweep_update;
- *              0 (default): full sweeps leave an existing cache alone (it stays valid and is still kept current
- *              by gpx_append); -1: drop the cache.
- *          "chol_w" = outer panel width of the blocked factorisation in 128-blocks (2..8; 0 = by size, default).
- *          "chol_rl" = 1 (default): inside an outer panel the rows still to come receive each factored row's contribution
- *              at once (right-looking, K = 128 per launch); 0: left-looking row updates (K = 128..(w-1)*128), round 2's
- *              order.  Bit-identical results either way.
- *          "chol_merge" = n >= 1 (default 1): while at least n block rows lie beyond the next two panels, the far trailing
- *              update of every other panel is deferred and applied together with the next panel's (one pass, twice the K
- *              extent); 0: one far update per panel (round 2).  Bit-identical results either way.
- *          "chol_fuse" = 1: the diagonal block is factored by every workgroup of the panel solve (one launch per 128-block
- *              instead of two); "chol_graph" = 1: the factorisation's launches are replayed from a captured hipGraph.
- *              Both bit-identical, both measured and off by default ("The fit -- round 3").
- *          "chol_tg" = 1 (default): the factorisation runs as ONE persistent kernel that walks its task graph (one workgroup for
- *              the diagonal blocks, nine that follow it 16 rows at a time with the tiles next to the diagonal, everything else as
- *              throughput work from ONE ticketed, dependency-checked list; kernels_chol_tg.hip) for fits of "chol_tg_min" (default 2) to
- *              "chol_tg_max" (default 160) 128-blocks; 0: the stream schedule above.  Bit-identical factors either way.  Tuning / diagnostics:
- *              "chol_tg_chunks" (k-chunk sizes counted back from the pivot as decimal digits, default 112489 = 1, 1, 2, 4, 8, 16, 16, .. and up to 36 blocks 11112489: the digit 9 stands for 16 blocks),
- *              "chol_tg_nap" (longest pause of a waiting workgroup between two looks at its dependencies, in units of 64
- *              clocks: 8, 16 (default), 32, 64 or 127),
- *              "chol_tg_db" (-1, default: up to "chol_tg_db_max" = 112 blocks every workgroup has its compute unit to itself with two
- *              k-step images of LDS and the workers run the double-buffered k-loop; 0 / 1: never / always),
- *              "chol_tg_fuse" (1, default: with two k-step images a column's solve and the final chunk of the tile below it are one task),
- *              "chol_tg_grid" (workgroups launched, 0 = by size), "chol_tg_isolate" (1, default: the critical workgroups keep
- *              their compute units to themselves),
- *              "chol_tg_tmo_ms" (bound of every spin, default 2000: on expiry the fit re-runs on the stream schedule and
- *              says so on stderr), "chol_tg_trace" = 1 (stamp the critical path, read with gpx_chol_trace).
- *          "x_bg", "x_bg_lds", "x_bg_iters" = DIAGNOSTIC (scripts/chol_bg.py): a synthetic register-only fp64-MFMA kernel of
- *              x_bg workgroups (x_bg_lds KB of LDS each, x_bg_iters rounds) runs beside the factorisation.
- *          "x_skip" = DIAGNOSTIC (scripts/chol_parts.py): leave out the far updates (bit 0), the chain kernels
- *              (bit 1) or the near updates (bit 2) of the factorisation to time its parts alone -- the result is
- *              then NOT a factorisation; 0 (default) = everything.
- * Environment: GPX_OPTIONS="name=value,name=value" applies these options to every handle at creation (A/B runs through a
- * plug-in layer whose handles the caller never sees); a bad entry fails gpx_create with GPX_EARG. */
+/* Options (int64 values).  Every option below selects among schedules that give BIT-IDENTICAL results unless it says
+ * otherwise; defaults in brackets.  The measurements behind the defaults: DESIGN.md section 4.
+ *   "chunk"          candidate columns per sweep chunk, a multiple of 128 [by size: 65536; 131072 up to N = 4096]
+ *   "tile_order"     sweep-kernel schedule: bits 0-1 blockIdx->tile map (0 linear heavy-first, 1 per-XCD candidate slices, 2 per-XCD
+ *                    8x8 super-tiles, 3 the same with every workgroup computing the PAIR of tiles (nP-1-i, nt), (i, nt): equal work),
+ *                    bits 2-4 k-loop (4 = operands by LDS-DMA, k-step 32, two workgroups per CU, the all-zero quarter-rows of T's
+ *                    diagonal block skipped; 3 = the same without the skip; 7 = k-step 16, three workgroups per CU; 6 / 5 / 2 = the
+ *                    register-staged loops of rounds 5 / 2 / 1: independently scheduled witnesses) [19 = map 3 + loop 4]
+ *   "super_m"        rows of the XCD super-tile of 64 workgroups: 1, 2, 4, 8, 16 [8 -> 8 x 8]
+ *   "sweep_cache"    1: full sweeps keep candidates and reduced sums for gpx_sweep_update; 0: leave a live cache alone; -1: drop it [0]
+ *   "eager_inverse"  1: form the triangular inverse inside gpx_fit instead of on first use [0]
+ *   "trtri_ahead"    1: when the inverse is certain or likely to follow a fit, its part that needs only the factor's leading block
+ *                    rows runs on a side stream behind the factorisation's tail, from "trtri_ahead_min" (8) blocks on [1]
+ *   "trtri_left"     1: T21 = -(T22 L21) T11 instead of -T22 (L21 T11); agrees to rounding, NOT bit for bit [0]
+ *   "refine_inverse" 1: one Newton step on the inverse, T <- (2I - T R^T) T (squares the left residual; for cond(K) >~ 1e9) [0]
+ *   "grad_form"      gpx_predict WITH gradients: 0 auto (one point: one pass over T with 1 + d right-hand sides; batches: two
+ *                    passes), 1 always two passes, 2 always one; the forms agree to rounding [0]
+ *   "grad_kernel"    triangular matvec of the two-pass form: -1 auto, 0 one wave per row, 1 register-blocked [-1]
+ *   "chol_tg"        1: the factorisation is ONE persistent task-graph kernel for fits of "chol_tg_min" (2) .. "chol_tg_max" (160)
+ *                    128-blocks; 0: the stream schedule (~250 launches over four streams) [1].  "chol_tg_db" -1 / 0 / 1: one workgroup per
+ *                    CU with two k-step images of LDS up to "chol_tg_db_max" (112) blocks / never / always [-1]; "chol_tg_fuse" 1: a
+ *                    column's solve and the final chunk of the tile below it are one task [1]; "chol_tg_tmo_ms": bound of every spin
+ *                    -- on expiry the fit re-runs on the stream schedule and says so on stderr [2000]
+ *   "chol_w", "chol_rl", "chol_merge", "chol_fuse", "chol_graph"   the stream schedule: outer panel width in blocks (2..8, 0 = by
+ *                    size), right- / left-looking in-panel updates [1], far updates of two panels in one pass [1], diagonal block
+ *                    factored inside the panel solve [0], replay from a captured hipGraph [0]
+ * Diagnostic knobs ("chol_tg_chunks", "chol_tg_nap", "chol_tg_grid", "chol_tg_isolate", "chol_tg_trace", "grad_rb_cs", "x_rff",
+ * "x_bg*", "x_skip" -- the last one leaves parts of the factorisation OUT) exist only in a library built with -DGPX_DIAGNOSTICS
+ * (pybo_amd/csrc/libgpx_diag.so; pybo_amd/csrc/gpx_diag.h); the shipping library answers them with GPX_EARG.
+ * Environment: GPX_OPTIONS="name=value,name=value" applies options to every handle at creation (A/B runs through a plug-in layer
+ * whose handles the caller never sees); a bad entry fails gpx_create with GPX_EARG. */
 int gpx_set_option(gpx_handle *h, const char *name, int64_t value);
 
 /* ---- GP fit = model.add_data(X, Y)            [pybo/bayesopt.py:114,258,269] ------------- */
@@ -155,39 +111,28 @@ int gpx_fit_dev(gpx_handle *h, const double *dX, int64_t N, int64_t d, const dou
 /* log marginal likelihood of the fitted model, -1/2 a.a - sum log R_ii - N/2 log 2pi: what a
  * hyper-parameter sampler (reggie.MCMC, pybo/bayesopt.py:115) evaluates once per proposal. */
 int gpx_loglik(gpx_handle *h, double *out);
-/* The same quantity for B hyper-parameter vectors at once on the handle's RESIDENT data (any earlier gpx_fit*
- * put X, y on the device), without touching the handle's own fit: hypers (B, d + 3) row-major
- * [sn2, rho, ell_1..d, bias] (the argument order of reggie.make_gp, pybo/bayesopt.py:105), out (B,);
- * -inf where K + sn2 I is not positive definite.  One batched Gram + Cholesky launch chain and one host
- * synchronisation for the whole batch: the evaluation a hyper-parameter sampler repeats per proposal
- * (reggie.MCMC(model, n=10, burn=100), pybo/bayesopt.py:115).  Any B >= 1 (64 vectors per launch chain). */
+/* The same for B hyper-parameter vectors at once on the handle's RESIDENT data, without touching the handle's own fit: hypers
+ * (B, d + 3) row-major [sn2, rho, ell_1..d, bias] (the argument order of reggie.make_gp, pybo/bayesopt.py:105), out (B,); -inf
+ * where K + sn2 I is not positive definite.  One batched launch chain and one host synchronisation per 64 vectors: what
+ * reggie.MCMC(model, n=10, burn=100) [pybo/bayesopt.py:115] repeats per proposal. */
 int gpx_loglik_batch(gpx_handle *h, int64_t B, const double *hypers, double *out);
-/* Incremental fit: absorb ONE more observation x (d,), y into the current factorisation in O(N^2)
- * (two memory-bound passes over T and U) instead of refitting -- the per-iteration
- * `model.add_data(x, y)` of the BO loop [pybo/bayesopt.py:269].  When the current 128-block has no padding
- * left the factors are re-strided to one more block inside buffers allocated with head-room (a device copy, no
- * refit; a reallocation only when the head-room is used up).  GPX_ENOTPD like
- * gpx_fit.  If a sweep cache is live (below) its per-candidate sums are corrected for the new observation in
- * the same call (one N*M pass). */
+/* Incremental fit: absorb ONE more observation x (d,), y into the current factorisation in O(N^2) (two memory-bound passes over
+ * T and U) instead of refitting -- the per-iteration `model.add_data(x, y)` of the BO loop [pybo/bayesopt.py:269].  A full
+ * 128-block is extended inside buffers allocated with head-room (device copy, no refit).  GPX_ENOTPD like gpx_fit.  A live sweep
+ * cache (below) is corrected for the new observation in the same call (one N*M pass). */
 int gpx_append(gpx_handle *h, const double *x, double y);
-/* ANNOUNCE the next observation's location before its value exists: between `x, _ = solver(index, bounds)` and
- * `y = objective(x)` of the BO loop [pybo/bayesopt.py:265-268] the query point is known and the black box is being
- * evaluated -- the time the reference spends idle.  Everything of the coming gpx_append(h, x, y) that does not depend on
- * y is enqueued now, without a host synchronisation: k(X, x), the two triangular passes, and -- on a side stream -- the
- * N*M covariance evaluations of the sweep-cache correction (the new row v of V over the cached candidates).  A following
- * gpx_append with the bit-identical x then costs the scalars, the scatter and q += v^2, p += v a_new (O(N + M)); with
- * any other x, or after anything else changed the model, the announcement is ignored.  Results are bit-identical to an
- * unannounced append.  GPX_ESTATE (nothing started, not an error) without a live sweep cache or when the next append
- * has to add a 128-block first. */
+/* ANNOUNCE the next observation's location before its value exists (between `x, _ = solver(index, bounds)` and
+ * `y = objective(x)`, pybo/bayesopt.py:265-268: the time the reference spends idle): everything of the coming gpx_append(h, x, y)
+ * that does not depend on y is enqueued now without a host synchronisation -- k(X, x), the two triangular passes and, on a side
+ * stream, the N*M covariance evaluations of the sweep-cache correction.  A following gpx_append with the bit-identical x then costs
+ * O(N + M); any other x, or a model change, and the announcement is ignored.  Results bit-identical to an unannounced append.
+ * GPX_ESTATE (nothing started, not an error) without a live sweep cache or when the next append has to add a 128-block first. */
 int gpx_append_begin(gpx_handle *h, const double *x);
 /* 0-based index of the failing pivot of the last GPX_ENOTPD fit, else -1. */
 int64_t gpx_fail_pivot(const gpx_handle *h);
 
-/* introspection for parity tests (host outputs):
- *   which = 0: L (N,N) lower Cholesky factor, row-major        (K + sn2 I = L L^T)
- *   which = 1: T = L^-1 (N,N) lower, row-major
- *   which = 2: K + sn2 I, upper triangle only (lower part returned as 0); only valid after
- *              gpx_fit_stage(..., stop_after_gram=1) since the factorisation consumes it */
+/* introspection for parity tests (host outputs): which = 0: L (N,N) lower Cholesky factor, row-major (K + sn2 I = L L^T);
+ * 1: T = L^-1 (N,N) lower; 2: K + sn2 I, upper triangle (only after gpx_fit_stage(.., 1): the factorisation consumes it) */
 int gpx_get_matrix(gpx_handle *h, int which, double *out);
 /* a = L^-1 (y - bias) (N,) and alpha = (K + sn2 I)^-1 (y - bias) (N,) */
 int gpx_get_vectors(gpx_handle *h, double *a, double *alpha);
@@ -195,8 +140,7 @@ int gpx_get_vectors(gpx_handle *h, double *a, double *alpha);
 int gpx_fit_stage(gpx_handle *h, const double *X, int64_t N, int64_t d, const double *y,
                   int kernel_id, const double *ell, double rho, double sn2, double bias, int stage);
 
-/* posterior (latent) mean at the N observed points, closed form y - sn2*alpha.
- * = model.predict(X_obs)[0]                     [pybo/policies/simple.py:21,35]            */
+/* posterior (latent) mean at the N observed points, closed form y - sn2*alpha = model.predict(X_obs)[0] [pybo/policies/simple.py:21,35] */
 int gpx_mean_at_obs(gpx_handle *h, double *mu_host, double *mu_max);
 /* posterior (latent) variance at the N observed points, closed form sn2 - sn2^2 [K^-1]_ii with
  * [K^-1]_ii = sum_m U[i][m]^2 (one HBM-read pass over U = R^-1; a sweep over X_obs is an N x N x N product).
@@ -209,9 +153,7 @@ int64_t gpx_capacity(const gpx_handle *h);
 /* ---- posterior moments = model.predict(X, grad) [pybo/policies/simple.py:64] ------------- */
 /* Xc (M,d) -> mu (M,), s2 (M,) latent variance; dmu, ds2 (M,d) optional (NULL to skip).  With gradients a single point
  * (M = 1) is answered in the one-pass form, batches in the two-pass form: option "grad_form" above. */
-int gpx_predict(gpx_handle *h, const double *Xc, int64_t M, double *mu, double *s2, double *dmu,
-                double *ds2);
-
+int gpx_predict(gpx_handle *h, const double *Xc, int64_t M, double *mu, double *s2, double *dmu, double *ds2);
 /* The mean alone, mu (M,) and optionally dmu (M,d) (NULL to skip): mu = bias + k(x, X).alpha reads neither the
  * factor nor its inverse -- what the latent recommender maximises, model.predict(X, True)[0::2]
  * [pybo/recommenders.py:17-24], without the two triangular passes per point the variance costs. */
@@ -230,15 +172,11 @@ int gpx_sweep_dev(gpx_handle *h, int acq_id, const double *params, int nparams, 
                   double *d_mu, double *d_s2);
 
 /* ---- warm BO step: the NEXT iteration's `index(xgrid)` over the SAME grid with the SAME hyper-parameters
- *      [pybo/bayesopt.py:262-269 with a fixed `xgrid=` in pybo/solvers/lbfgs.py:42-50].  The reference pays a
- *      full refit and a full solve again; here, with option "sweep_cache" = 1, a full gpx_sweep* keeps the
- *      candidates and their reduced sums q = colsum(V^2), p = V^T a in HBM (8 (d + 2) M bytes), every
- *      gpx_append adds the one new row of V to them (N*M covariance evaluations; the corrections of up to 8
- *      appended points -- one batch-BO add_data(X, Y) -- are queued and share one pass over the candidates,
- *      made when the queue is full or by the next gpx_sweep_update), and gpx_sweep_update re-scores the whole
- *      grid in O(M): mu = bias + p, s2 = rho - q, acquisition (the target / beta may change from call to
- *      call), top-k.  Outputs as in gpx_sweep / gpx_sweep_dev.  GPX_ESTATE without a valid
- *      cache (never swept, or refitted since: gpx_fit* invalidates it). */
+ *      [pybo/bayesopt.py:262-269 with a fixed `xgrid=` in pybo/solvers/lbfgs.py:42-50].  The reference pays a full refit and a full
+ *      solve again; with option "sweep_cache" = 1 a full gpx_sweep* keeps the candidates and their reduced sums q = colsum(V^2),
+ *      p = V^T a in HBM (8 (d + 2) M bytes), every gpx_append adds the one new row of V to them (N*M covariance evaluations; up to 8
+ *      appended points share one pass), and gpx_sweep_update re-scores the whole grid in O(M) (the target / beta may change from call
+ *      to call) + top-k.  Outputs as in gpx_sweep*.  GPX_ESTATE without a valid cache (never swept, or refitted since). */
 int gpx_sweep_update(gpx_handle *h, int acq_id, const double *params, int nparams, int64_t k, double *top_val,
                      int64_t *top_idx, double *acq_all, double *mu, double *s2);
 int gpx_sweep_update_dev(gpx_handle *h, int acq_id, const double *params, int nparams, int64_t k,
@@ -317,13 +255,11 @@ const double *gpx_grid_data(const gpx_grid *g);     /* device pointer, (M,d) row
 int gpx_grid_rows(gpx_grid *g, const int64_t *idx, int64_t k, double *out);
 int gpx_grid_destroy(gpx_grid *g);
 
-/* ---- multi-GPU exchange: the one collective of the sharded sweep -----------------------------------------
- *      The reference is single-process (its only hint at parallelism is the comment pybo/solvers/lbfgs.py:60);
- *      layout per SURVEY.md 8(e): one process per GPU, candidates sharded contiguously, every rank fits
- *      redundantly (bitwise-identical factor), and each rank's best (value, GLOBAL index) pairs are
- *      all-gathered over RCCL/xGMI and merged with the rule "value descending, then index ascending".
- *      RCCL is bound at run time (dlopen of librccl, override with $GPX_RCCL_LIB): single-GPU use never loads it.
- *      Errors of these calls are read with gpx_comm_last_error() (thread-local). */
+/* ---- multi-GPU exchange: the one collective of the sharded sweep.  The reference is single-process (its only hint at
+ *      parallelism is the comment pybo/solvers/lbfgs.py:60); layout per SURVEY.md 8(e): one process per GPU, candidates sharded
+ *      contiguously, every rank fits redundantly (bitwise-identical factor), each rank's best (value, GLOBAL index) pairs
+ *      all-gathered over RCCL/xGMI and merged "value descending, then index ascending".  RCCL is bound at run time (dlopen of
+ *      librccl, override with $GPX_RCCL_LIB): single-GPU use never loads it.  Errors: gpx_comm_last_error() (thread-local). */
 typedef struct gpx_comm gpx_comm;
 #define GPX_COMM_ID_BYTES 128
 /* rank 0 generates the id (ncclGetUniqueId) and hands its 128 bytes to every rank over any side channel */
@@ -344,36 +280,16 @@ int gpx_topk_allgather(gpx_comm *c, int64_t n, int64_t index_offset, int64_t k, 
                        int64_t *out_idx);
 
 /* ---- measurement ------------------------------------------------------------------------ */
-/* Stage timers in milliseconds accumulated since the last reset (HIP events on the handle's
- * stream): [0] gram [1] cholesky [2] trtri [3] alpha [4] cross_gram [5] sweep_trmm [6] acq_topk
- * [7] rff [8] number of sweep_trmm launches [9] sweep_trmm algorithmic flop [10] h2d/d2h copies
- * [11] append (rank-1 extension of the fit) [12] correction passes over the sweep cache [13] the Thompson sweep kernel
- * alone (part of [7]) [14] its algorithmic double-precision lane operations: S n (d + 20) M per launch [15] fits whose
- * task-graph factorisation gave up and were re-run on the stream schedule [16] the shader clock in MHz sustained by the
- * sweep_trmm launches since the last reset (their workgroups' s_memtime over s_memrealtime ticks; 0 without a launch)
- * [17] the same for the Thompson sweep kernel (k_rff_mfma5: it is power-bound and clocks lower) [18] inversions whose leading
- * part ran behind the factorisation (option "trtri_ahead"): for those [2] holds only what was left after the factor was done.
- * Synchronises the stream.  Returns the number of slots written (<= n). */
+/* Stage timers in milliseconds accumulated since the last reset (HIP events on the handle's stream): [0] gram [1] cholesky
+ * [2] trtri [3] alpha [4] cross_gram [5] sweep_trmm [6] acq_topk [7] rff [8] sweep_trmm launches [9] sweep_trmm algorithmic flop
+ * [10] h2d/d2h copies [11] append [12] correction passes over the sweep cache [13] the Thompson sweep kernel alone (part of [7])
+ * [14] its algorithmic fp64 lane operations, S n (d + 20) M per launch [15] fits whose task-graph factorisation gave up and re-ran on
+ * the stream schedule [16] the shader clock in MHz the sweep_trmm launches sustained (their workgroups' s_memtime over s_memrealtime
+ * ticks) [17] the same for the Thompson sweep kernel [18] inversions whose leading part ran behind the factorisation ("trtri_ahead":
+ * for those [2] holds only what was left after the factor was done).  Synchronises the stream.  Returns the slots written (<= n). */
 int gpx_timers(gpx_handle *h, double *out, int n, int reset);
-/* DIAGNOSTIC (option "chol_tg_trace" = 1): wall-clock stamps (100 MHz ticks) the task-graph factorisation of the last fit
- * took with its own clock: out[4 p + {0, 1, 2}] = the diagonal workgroup started waiting for / started / finished block
- * p (nP = N/128 rounded up blocks), then out[4 nP + 2 (8 p + i) + {0, 1}] = stamps of the shadows of block row p (i = 0: S1
- * started waiting for its right-hand sides / has them loaded, 1: .. / its last rows are stored; 2, 3: the same for S2; 4: U
- * started waiting / the tile's earlier chunks are in, 5: the tile is loaded / stored for the diagonal workgroup).  Returns the number of words written (<= n; 20 nP when complete, followed by up to 1024 x 8 per-workgroup counters: tasks, ticks spent taking / updating / solving /
- * publishing, block updates applied, role, exit stamp), 0 without a trace. */
-int64_t gpx_chol_trace(gpx_handle *h, int64_t *out, int64_t n);
-/* The task lists the task-graph factorisation of an nblocks x nblocks block matrix walks (host only, no device needed:
- * what the CPU tests replay to prove that every tile receives every block row once, in order, and that the lists never
- * dead-lock): counts[2] = entries of list 0 / tasks of the workers' list, out (total, 8) int16 = {type, I, J, k0, k1, ordinal,
- * aux, reserved}, the lists back to back.  Types: 1 = panel solve of the 64-column half aux of tile (I, J); 2 = update of tile
- * (I, J) with block rows [k0, k1), its chunk number `ordinal`; 5 = a fused link: the solve of half aux of tile (I, J) and the final
- * chunk [k0, k1 = I+1) (chunk number `reserved`) of the same half of tile (I+1, J); 4 = list 0's descriptor of block row I for the
- * workgroups that follow the diagonal factorisation (they stand for the solves of tiles (I, I+1 .. I+3), the final chunks of
- * tiles (I+1, I+1 .. I+3) = [k0, k1) with chunk number aux, and the diagonal tile's chunk before it, which starts at block row
- * `reserved` if that is >= 0; `ordinal` = chunks of every tile of row I).  The lists are those of a launch with two k-step images
- * of LDS per workgroup (fused links).  chunks as the option "chol_tg_chunks" (<= 0: default).  Returns the total number of
- * entries (written only when cap >= total), -1 on bad arguments. */
-int64_t gpx_chol_tasks(int nblocks, int chunks, int16_t *out, int64_t cap, int64_t *counts);
+/* 1 when the library was built with -DGPX_DIAGNOSTICS (the diagnostic options above are accepted), else 0 */
+int gpx_diagnostics(void);
 int gpx_sync(gpx_handle *h);
 
 #ifdef __cplusplus

@@ -32,7 +32,10 @@ def hw_queues_hint():
 
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('GPX_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libgpx.so')     # (GPX_LIB_PATH: A/B runs against another build of the same ABI)
+# libgpx.so is the shipping library.  GPX_DIAGNOSTICS=1 selects libgpx_diag.so (the same objects, gpx_set_option also accepts the
+# diagnostic knobs of csrc/gpx_diag.h: what the test-suite and the A/B scripts drive); GPX_LIB_PATH: any other build of the ABI.
+LIB_PATH = os.environ.get('GPX_LIB_PATH') or os.path.join(
+    _HERE, 'csrc', 'libgpx_diag.so' if os.environ.get('GPX_DIAGNOSTICS', '0') not in ('', '0') else 'libgpx.so')
 
 # every symbol include/gpx.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
@@ -40,6 +43,11 @@ _D = C.POINTER(C.c_double)
 _I = C.POINTER(C.c_int64)
 _i64 = C.c_int64
 _dbl = C.c_double
+# every symbol pybo_amd/csrc/gpx_diag.h declares (exported by both builds)
+DIAG_SYMBOLS = {
+    'gpx_chol_trace': (_i64, [_P, _P, _i64]),
+    'gpx_chol_tasks2': (_i64, [C.c_int, C.c_int, _P, _i64, _P]),
+}
 SYMBOLS = {
     'gpx_create': (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
     'gpx_destroy': (C.c_int, [_P]),
@@ -86,9 +94,8 @@ SYMBOLS = {
     'gpx_comm_last_error': (C.c_char_p, []),
     'gpx_topk_allgather': (C.c_int, [_P, _i64, _i64, _i64, _P, _P]),
     'gpx_timers': (C.c_int, [_P, _P, C.c_int, C.c_int]),
-    'gpx_chol_trace': (_i64, [_P, _P, _i64]),
-    'gpx_chol_tasks': (_i64, [C.c_int, C.c_int, _P, _i64, _P]),
     'gpx_sync': (C.c_int, [_P]),
+    'gpx_diagnostics': (C.c_int, []),
 }
 
 GPX_OK, GPX_EARG, GPX_ENOTPD, GPX_EHIP, GPX_EOOM, GPX_ESTATE, GPX_ERCCL = 0, -1, -2, -3, -4, -5, -6
@@ -105,14 +112,14 @@ _lib = None
 
 def chol_tasks(nblocks, chunks=0):
     """The task lists of the task-graph factorisation (host only): two (n, 8) int16 arrays
-    {type, I, J, k0, k1, ordinal, aux, reserved} -- the critical list and the workers' list (include/gpx.h: gpx_chol_tasks)."""
+    {type, I, J, k0, k1, ordinal, aux, reserved} -- the critical list and the workers' list (csrc/gpx_diag.h: gpx_chol_tasks2)."""
     lib = load()
     counts = np.zeros(2, dtype=np.int64)
-    tot = lib.gpx_chol_tasks(nblocks, chunks, None, 0, _ptr(counts))
+    tot = lib.gpx_chol_tasks2(nblocks, chunks, None, 0, _ptr(counts))
     if tot < 0:
-        raise ValueError('gpx_chol_tasks: bad arguments')
+        raise ValueError('gpx_chol_tasks2: bad arguments')
     out = np.zeros((max(int(tot), 1), 8), dtype=np.int16)
-    lib.gpx_chol_tasks(nblocks, chunks, _ptr(out), int(tot), _ptr(counts))
+    lib.gpx_chol_tasks2(nblocks, chunks, _ptr(out), int(tot), _ptr(counts))
     o = np.cumsum(np.r_[0, counts])
     return [out[o[q]:o[q + 1]] for q in range(2)]
 
@@ -131,7 +138,7 @@ def load():
             raise ImportError('pybo_amd: %s not found -- build it with `python __graft_entry__.py` '
                               '(or pybo_amd/csrc/build.sh); there is no CPU fallback.' % LIB_PATH)
         lib = C.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
+        for name, (res, args) in list(SYMBOLS.items()) + list(DIAG_SYMBOLS.items()):
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
@@ -710,7 +717,7 @@ class Engine(object):
         """Diagnostic (option chol_tg_trace = 1): the task-graph factorisation's own stamps of the last fit, microseconds
         from the first one: (diag (nblocks, 3) = wait / start / end per diagonal block, crit (nblocks, 8, 2) = the stamps of the
         workgroups that follow block row p -- slots 0, 1: S1 (waiting / right-hand sides loaded, .. / last rows stored), 2, 3: S2,
-        4: U (waiting / earlier chunks in), 5: U (tile loaded / stored) -- see gpx_chol_trace in include/gpx.h); None without a trace."""
+        4: U (waiting / earlier chunks in), 5: U (tile loaded / stored) -- see gpx_chol_trace in csrc/gpx_diag.h); None without a trace."""
         out = np.zeros(20 * nblocks + 8 * 1024 + 16 + (4 << 20 if full_log else 0), dtype=np.int64)
         n = self._lib.gpx_chol_trace(self._h, _ptr(out), out.size)
         if n < 20 * nblocks:

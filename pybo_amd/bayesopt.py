@@ -84,9 +84,18 @@ def safe_load(filename=None):
         from . import dist as pdist
         d = pdist._dist()
         if d is not None and d.get_world_size(_SPMD['group']) > 1:
-            box = [_load_local(filename)] if _spmd_rank() == 0 else [None]
+            box = [None]
+            if _spmd_rank() == 0:
+                # a checkpoint rank 0 cannot read must fail EVERY rank: the others are about to block in the broadcast
+                try:
+                    box = [('ok', _load_local(filename))]
+                except BaseException as exc:      # noqa: BLE001 -- re-raised below, on every rank
+                    box = [('error', '%s: %s' % (type(exc).__name__, exc))]
             d.broadcast_object_list(box, src=0, group=_SPMD['group'])
-            model, info = box[0]
+            status, payload = box[0]
+            if status != 'ok':
+                raise RuntimeError('rank 0 could not load the checkpoint %r: %s' % (filename, payload))
+            model, info = payload
             return model, Info(list(info.x), list(info.y), list(info.xbest))
     return _load_local(filename)
 

@@ -10,6 +10,7 @@
 #include <new>
 
 #include "gpx_internal.h"
+#include "gpx_diag.h"
 
 using namespace gpx;
 
@@ -118,7 +119,14 @@ static void harvest(gpx_handle* h) {
 }
 
 // ---- lifetime ---------------------------------------------------------------------------------
-extern "C" int gpx_version(void) { return 510; }   // round * 100: 300 added gpx_predict_mean, gpx_var_at_obs, gpx_capacity, gpx_append_begin; 400 gpx_chol_trace, gpx_chol_tasks, GPX_OPTIONS; 500: gpx_chol_tasks lost its `split` argument (two lists), timers slot 16; 510: timers slots 17, 18, the entries of gpx_chol_tasks / gpx_chol_trace describe the shadows, options trtri_ahead*, chol_tg_fuse (chol_tg_side gone)
+extern "C" int gpx_version(void) { return 600; }   // round * 100: 300 added gpx_predict_mean, gpx_var_at_obs, gpx_capacity, gpx_append_begin; 400 gpx_chol_trace, gpx_chol_tasks, GPX_OPTIONS; 500: timers slot 16; 510: timers slots 17, 18, options trtri_ahead*, chol_tg_fuse; 600: gpx_diagnostics, gpx_chol_tasks -> gpx_chol_tasks2 (pybo_amd/csrc/gpx_diag.h), the diagnostic options only in a -DGPX_DIAGNOSTICS build, tile_order default 19
+extern "C" int gpx_diagnostics(void) {
+#ifdef GPX_DIAGNOSTICS
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 extern "C" const char* gpx_last_error(const gpx_handle* h) {
     return h ? h->err.c_str() : g_create_err.c_str();
@@ -296,6 +304,13 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             h->chol_w = (int)value;
             return GPX_OK;
         }
+#ifndef GPX_DIAGNOSTICS
+        // the shipping library knows the diagnostic knobs by name only: a consumer of include/gpx.h cannot reach a switch that
+        // leaves parts of a factorisation out (pybo_amd/csrc/gpx_diag.h; libgpx_diag.so accepts them)
+        for (const char* dn : {"chol_tg_chunks", "chol_tg_nap", "chol_tg_grid", "chol_tg_isolate", "chol_tg_trace", "grad_rb_cs", "x_rff",
+                               "x_skip", "x_bg", "x_bg_lds", "x_bg_iters"})
+            if (!strcmp(name, dn)) return fail(h, GPX_EARG, "diagnostic option: only in a library built with -DGPX_DIAGNOSTICS (libgpx_diag.so)");
+#endif
         if (!strcmp(name, "chol_tg") || !strcmp(name, "chol_tg_chunks") ||
             !strcmp(name, "chol_tg_grid") || !strcmp(name, "chol_tg_trace") || !strcmp(name, "chol_tg_tmo_ms") ||
             !strcmp(name, "chol_tg_min") || !strcmp(name, "chol_tg_max") || !strcmp(name, "chol_tg_isolate") ||
@@ -400,7 +415,7 @@ extern "C" int gpx_sync(gpx_handle* h) {
     });
 }
 
-extern "C" int64_t gpx_chol_tasks(int nblocks, int chunks, int16_t* out, int64_t cap, int64_t* counts) {
+extern "C" int64_t gpx_chol_tasks2(int nblocks, int chunks, int16_t* out, int64_t cap, int64_t* counts) {
     if (!counts) return -1;
     try {
         return gpx::tg_tasks_copy(nblocks, chunks, out, cap, counts);

@@ -15,7 +15,7 @@ n=0
 for f in $SRCS; do
   stale=$FORCE
   if [ ! -f $f.o ]; then stale=1; fi
-  for dep in $f.hip gemm_core.h gpx_internal.h gpx_math.h fit_tiles.h ../../include/gpx.h; do
+  for dep in $f.hip gemm_core.h gpx_internal.h gpx_diag.h gpx_math.h fit_tiles.h ../../include/gpx.h; do
     [ $dep -nt $f.o ] && stale=1
   done
   if [ $stale = 1 ]; then
@@ -28,4 +28,11 @@ for p in "${pids[@]}"; do wait $p; done
 OBJS=""
 for f in $SRCS; do OBJS="$OBJS $f.o"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o libgpx.so $OBJS -ldl
-echo "built $(pwd)/libgpx.so ($n of $(echo $SRCS | wc -w) objects compiled)"
+# the diagnostics build: the same objects, api.hip compiled with -DGPX_DIAGNOSTICS (gpx_set_option accepts the diagnostic knobs of
+# gpx_diag.h).  The test-suite drives this one (tests/conftest.py: GPX_DIAGNOSTICS=1); everything else loads libgpx.so.
+stale=$FORCE
+[ ! -f api_diag.o ] && stale=1
+for dep in api.hip gpx_internal.h gpx_diag.h ../../include/gpx.h; do [ $dep -nt api_diag.o ] && stale=1; done
+[ $stale = 1 ] && $HIPCC $FLAGS -DGPX_DIAGNOSTICS -c api.hip -o api_diag.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libgpx_diag.so ${OBJS/api.o/api_diag.o} -ldl
+echo "built $(pwd)/libgpx.so ($n of $(echo $SRCS | wc -w) objects compiled) and libgpx_diag.so"

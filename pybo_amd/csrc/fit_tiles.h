@@ -343,8 +343,12 @@ __device__ __forceinline__ void pf16_trail(d4 (&accA)[8], d4 (&accB)[8], int cA,
     }
     if constexpr (STEP) {
         if (w == OWN_NX) {
+#ifdef GPX_PF16_COUNTED_WAIT      // round 5: leave this wave's stores of the NEXT tile in flight behind the flag (counts them by hand)
             if (Tg) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }

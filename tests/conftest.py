@@ -6,6 +6,10 @@ import pytest
 # the application's choice, made before the HIP runtime starts (pybo_amd itself no longer touches the environment): eight
 # hardware queues keep the streams of several live handles apart
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+# The test-suite drives the DIAGNOSTICS build of the library (pybo_amd/csrc/libgpx_diag.so: the same objects as libgpx.so, but
+# gpx_set_option also accepts the diagnostic knobs of csrc/gpx_diag.h -- chunk lists, grids, traces -- which the bit-identity and
+# fuzz tests use as witnesses).  tests/test_abi.py loads the SHIPPING library as well and checks that it refuses them.
+os.environ.setdefault('GPX_DIAGNOSTICS', '1')
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

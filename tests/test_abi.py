@@ -16,6 +16,12 @@ def _declared():
     return sorted(set(re.findall(r'\b(gpx_[a-z_0-9]+)\s*\(', src)))
 
 
+def _declared_diag():
+    src = open(os.path.join(ROOT, 'pybo_amd', 'csrc', 'gpx_diag.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(gpx_[a-z_0-9]+)\s*\(', src)))
+
+
 def test_library_exports_every_declared_symbol():
     from pybo_amd import _lib
     lib = _lib.load()
@@ -25,6 +31,52 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), 'libgpx.so does not export %s' % n
     # and the binding table covers the header exactly
     assert sorted(_lib.SYMBOLS) == names
+    assert sorted(_lib.DIAG_SYMBOLS) == _declared_diag()
+
+
+def test_shipping_and_diagnostics_builds_export_the_same_abi():
+    """build.sh links two libraries from the same objects (api.hip compiled without / with -DGPX_DIAGNOSTICS): both export every
+    symbol of include/gpx.h and csrc/gpx_diag.h; gpx_diagnostics() tells them apart; the header stays within its size budget."""
+    from pybo_amd import _lib
+    libdir = os.path.join(ROOT, 'pybo_amd', 'csrc')
+    ship, diag = C.CDLL(os.path.join(libdir, 'libgpx.so')), C.CDLL(os.path.join(libdir, 'libgpx_diag.so'))
+    for n in list(_lib.SYMBOLS) + list(_lib.DIAG_SYMBOLS):
+        assert hasattr(ship, n) and hasattr(diag, n), n
+    assert ship.gpx_diagnostics() == 0 and diag.gpx_diagnostics() == 1
+    assert ship.gpx_version() == diag.gpx_version() >= 600
+    assert os.path.basename(_lib.LIB_PATH) == 'libgpx_diag.so'          # what this test session drives (conftest.py)
+    lines = open(os.path.join(ROOT, 'include', 'gpx.h')).read().splitlines()
+    assert len(lines) <= 300 and max(len(ln) for ln in lines) <= 160
+    # no diagnostic option is documented as part of the shipping ABI's option list
+    public = re.sub(r'Diagnostic knobs.*?GPX_EARG\.', '', open(os.path.join(ROOT, 'include', 'gpx.h')).read(), flags=re.S)
+    for name in ('x_skip', 'x_bg', 'chol_tg_chunks', 'chol_tg_nap', 'chol_tg_grid', 'chol_tg_isolate', 'chol_tg_trace', 'grad_rb_cs'):
+        assert '"%s"' % name not in public, name
+
+
+@pytest.mark.gpu
+def test_shipping_library_refuses_the_diagnostic_options():
+    """A handle of the SHIPPING library answers every diagnostic knob with GPX_EARG (and keeps working); the diagnostics build
+    accepts them.  Both libraries live in this process side by side."""
+    from pybo_amd import _lib
+    ship = C.CDLL(os.path.join(ROOT, 'pybo_amd', 'csrc', 'libgpx.so'))
+    ship.gpx_create.argtypes = [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+    ship.gpx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    ship.gpx_last_error.restype = C.c_char_p
+    ship.gpx_last_error.argtypes = [C.c_void_p]
+    ship.gpx_destroy.argtypes = [C.c_void_p]
+    h = C.c_void_p()
+    assert ship.gpx_create(0, None, C.byref(h)) == 0
+    for name, val in (('x_skip', 1), ('x_bg', 4), ('x_bg_lds', 8), ('x_bg_iters', 10), ('chol_tg_chunks', 1248), ('chol_tg_nap', 8),
+                      ('chol_tg_grid', 64), ('chol_tg_isolate', 0), ('chol_tg_trace', 1), ('grad_rb_cs', 128), ('x_rff', 1)):
+        assert ship.gpx_set_option(h, name.encode(), val) == _lib.GPX_EARG, name
+        assert b'GPX_DIAGNOSTICS' in ship.gpx_last_error(h)
+    for name, val in (('chunk', 256), ('tile_order', 27), ('chol_tg', 0), ('chol_tg_min', 3), ('eager_inverse', 1)):
+        assert ship.gpx_set_option(h, name.encode(), val) == 0, name
+    assert ship.gpx_destroy(h) == 0
+    e = _lib.Engine(0)                                   # the diagnostics build (this session's library)
+    for name, val in (('chol_tg_chunks', 1248), ('chol_tg_nap', 8), ('chol_tg_trace', 1), ('x_skip', 0)):
+        e.set_option(name, val)
+    e.close()
 
 
 def test_version_and_loud_failure_without_gpu(gpu_available):

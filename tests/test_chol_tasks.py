@@ -1,5 +1,5 @@
 """CPU tests of the task-graph factorisation's task lists (pybo_amd/csrc/kernels_chol_tg.hip, host part; exported as
-gpx_chol_tasks): replayed under the device's own protocol -- tickets drawn in list order, a task starts when its
+gpx_chol_tasks2): replayed under the device's own protocol -- tickets drawn in list order, a task starts when its
 dependencies are met, tasks complete in any order -- the lists must (1) never dead-lock, (2) apply every block row to every tile exactly once and
 in ascending order (what makes the factor bit-identical to the stream schedule's), (3) BE a Cholesky factorisation when the
 tasks are executed with numpy on a small block size.  Serves `model.add_data` (pybo/bayesopt.py:114,258,269)."""
@@ -309,5 +309,5 @@ def test_chunks_are_graded_towards_the_pivot():
 
 
 def test_bad_arguments():
-    assert _lib.load().gpx_chol_tasks(0, 0, None, 0, _lib._ptr(np.zeros(2, dtype=np.int64))) == -1
-    assert _lib.load().gpx_chol_tasks(4, 0, None, 0, None) == -1
+    assert _lib.load().gpx_chol_tasks2(0, 0, None, 0, _lib._ptr(np.zeros(2, dtype=np.int64))) == -1
+    assert _lib.load().gpx_chol_tasks2(4, 0, None, 0, None) == -1

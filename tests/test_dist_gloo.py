@@ -188,6 +188,21 @@ def _spmd_worker(rank, world, port, q, mode):
                 assert os.path.exists(log)
             dist.barrier()
             kw.update(rng=3, spmd=True, log=log)
+        elif mode == 'corrupt':
+            # rank 0's checkpoint is unreadable: EVERY rank must raise (the others used to block in the broadcast for ever)
+            import tempfile
+            log = os.path.join(tempfile.mkdtemp(prefix='rank%d_' % rank), 'bo.pkl')
+            if rank == 0:
+                with open(log, 'wb') as fh:
+                    fh.write(b'not a pickle')
+            dist.barrier()
+            kw.update(rng=3, spmd=True, log=log)
+            try:
+                pybo_amd.solve_bayesopt(objective, bounds, **kw)
+                q.put((rank, 'no error'))
+            except RuntimeError as exc:
+                q.put((rank, 'raised' if 'could not load the checkpoint' in str(exc) else repr(exc)))
+            return
         elif mode == 'seeded':
             kw.update(rng=3, spmd=True)
         elif mode == 'unseeded':          # rng=None: OS entropy per rank unless the loop broadcasts one seed
@@ -235,6 +250,13 @@ def test_world2_spmd_resume_loads_the_checkpoint_on_rank_0_and_broadcasts_it():
     for a, b in zip(got[0][1:], got[1][1:]):
         np.testing.assert_array_equal(a, b)
     assert len(got[0][2]) == 6                          # box centre + 5 iterations in the trace of BOTH ranks
+
+
+def test_world2_spmd_resume_from_an_unreadable_checkpoint_fails_on_every_rank():
+    """rank 0 loaded the checkpoint BEFORE the broadcast; a corrupt file raised there and left the other
+    ranks blocked in broadcast_object_list.  Now the failure is what is broadcast."""
+    got = _run_spmd('corrupt')
+    assert got[0] == ('raised',) and got[1] == ('raised',)
 
 
 def test_a_process_group_alone_does_not_make_the_loop_collective():

@@ -96,6 +96,48 @@ def test_config_d_fit_and_thompson_full_size():
     e.close()
 
 
+def test_stream_schedule_above_the_task_graph_limit_full_size():
+    """N = 24576 = 192 blocks: above "chol_tg_max" (160) the factorisation runs on the STREAM schedule (kernels_fit.hip: ~250
+    launches over four streams) -- the path every fit took before round 4 and still the fallback of an aborted task-graph
+    launch.  The fit through its defining equations (probed with random vectors, as for config D), then 2048 candidates'
+    moments and the EI ranking against the oracle."""
+    from pybo_amd._lib import Engine
+    N, d = 24576, 8
+    rng = np.random.RandomState(24576)
+    X = rng.rand(N, d)
+    y = -((X - 0.4) ** 2).sum(1) + 1e-3 * rng.randn(N)
+    ell, rho, bias = 0.25 * np.ones(d), float(np.var(y)), float(np.mean(y))
+    sn2 = 1e-4 * rho
+    e = Engine(0)
+    e.fit(X, y, 'se', ell, rho, sn2, bias)
+    assert e.timers()['chol_fallbacks'] == 0                   # not a fallback: the schedule chosen by size
+    K = gp_ref.kernel(gp_ref.SE_ARD, X, X, ell, rho)
+    K[np.diag_indices(N)] += sn2
+    a, alpha = e.get_vectors()
+    r = y - bias
+    res = K @ alpha - r
+    assert np.linalg.norm(res) <= 1e-11 * (np.linalg.norm(K, 'fro') * np.linalg.norm(alpha) + np.linalg.norm(r))
+    L = e.get_matrix('L')
+    P = np.random.RandomState(0).randn(N, 4)
+    assert np.linalg.norm(L @ (L.T @ P) - K @ P) <= 1e-13 * np.linalg.norm(K, 'fro') * np.linalg.norm(P)
+    np.testing.assert_allclose(L @ a, r, rtol=0, atol=1e-11 * np.linalg.norm(r))
+    del K, L
+    ref = gp_ref.make_gp(sn2, rho, ell, bias, 'se')
+    ref.add_data(X, y)
+    Z = np.random.RandomState(1).rand(2048, d)
+    target = float(e.mean_at_obs()[1])
+    assert abs(target - ref.mean_at_obs().max()) <= 1e-9
+    out = e.sweep('ei', target, Z, k=10, want_moments=True)
+    mr, sr = ref.predict(Z)
+    assert np.all(np.abs(out['mu'] - mr) <= mu_tol(mr, rho))
+    assert np.all(np.abs(out['s2'] - sr) <= s2_tol(sr, rho))
+    want = ref.get_improvement(target, Z)
+    big = np.abs(want) > 1e-12 * np.abs(want).max()
+    np.testing.assert_allclose(out['acq'][big], want[big], rtol=1e-6)
+    assert out['top_idx'][0] == int(np.argmax(want))
+    e.close()
+
+
 def test_config_e_batch_of_thompson_recommendations():
     """q = 8 draws on the Matern-5/2 model of config C: eight distinct recommendations, each the argmax of
     its own posterior sample over the grid (checked against the host evaluation of the same sample)."""

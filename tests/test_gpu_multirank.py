@@ -342,6 +342,62 @@ def test_torch_distributed_over_rccl_with_one_rank():
     assert len(got[6]) >= 2
 
 
+def _one_librccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    import datetime
+    import torch
+    import torch.distributed as dist
+    try:
+        from pybo_amd._lib import Engine, Comm
+        from helpers import synth_problem
+
+        def mapped():
+            return sorted(set(ln.split()[-1] for ln in open('/proc/self/maps') if 'librccl' in ln))
+        dev = torch.device('cuda', 0)
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', device_id=dev, timeout=datetime.timedelta(seconds=120))
+        probe = torch.tensor([1.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize(dev)
+        before = mapped()                                   # torch's RCCL is in the process now
+        X, y, ell = synth_problem(300, 3, seed=4)
+        e = Engine(0, torch.cuda.current_stream(dev).cuda_stream)
+        e.fit(X, y, 'se', ell, 1.2, 1e-3, 0.1)
+        c = Comm(e, 0, 1, Comm.unique_id())                 # libgpx binds librccl by soname (comm.hip: dlopen)
+        after = mapped()
+        r = e.sweep('ei', 0.4, np.random.RandomState(3).rand(4000, 3), k=5, want_all=False)
+        tv, ti = c.topk_allgather(5, 100, 5)                # libgpx's communicator ...
+        dist.all_reduce(probe)                              # ... and torch's, interleaved in one process
+        torch.cuda.synchronize(dev)
+        ok = bool(np.array_equal(ti, r['top_idx'] + 100) and np.array_equal(tv, r['top_val']))
+        c.close()
+        e.close()
+        dist.destroy_process_group()
+        q.put(('ok', before, after, ok, float(probe.item())))
+    except BaseException as exc:      # noqa: reported to the parent
+        q.put(('error', repr(exc)))
+
+
+def test_libgpx_binds_the_librccl_torch_has_loaded_one_instance_per_process():
+    """bench.py --gpus N runs torch.distributed's RCCL process group AND libgpx's own communicator (the device-side exchange,
+    the default transport since round 6) in one process.  comm.hip dlopen()s librccl by its soname, which resolves to the copy
+    torch has already mapped: ONE instance of the library (one set of RCCL globals) in /proc/self/maps, and collectives of
+    both communicators interleave."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_librccl_worker, args=(_free_port(), q))
+    p.start()
+    got = q.get(timeout=600)
+    p.join(timeout=120)
+    assert got[0] == 'ok', got
+    before, after = got[1], got[2]
+    assert len(before) == 1, before                     # torch brought exactly one librccl
+    assert after == before, (before, after)             # libgpx did not map a second one
+    assert got[3] and got[4] == 1.0
+
+
 # ---- the whole loop SPMD: rank 0 evaluates the objective, everyone absorbs the same observation --------------------
 def _spmd_loop_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
