@@ -71,7 +71,8 @@ int gpx_version(void);
  *   "tile_order"     sweep-kernel schedule: bits 0-1 blockIdx->tile map (0 linear heavy-first, 1 per-XCD candidate slices, 2 per-XCD
  *                    8x8 super-tiles, 3 the same with every workgroup computing the PAIR of tiles (nP-1-i, nt), (i, nt): equal work),
  *                    bits 2-4 k-loop (4 = operands by LDS-DMA, k-step 32, two workgroups per CU, the all-zero quarter-rows of T's
- *                    diagonal block skipped; 3 = the same without the skip; 7 = k-step 16, three workgroups per CU; 6 / 5 / 2 = the
+ *                    diagonal block skipped; 3 = the same without the skip; 1 = barrier-free, every wave fetching its own operand
+ *                    halves; 7 = k-step 16, three workgroups per CU; 6 / 5 / 2 = the
  *                    register-staged loops of rounds 5 / 2 / 1: independently scheduled witnesses) [19 = map 3 + loop 4]
  *   "super_m"        rows of the XCD super-tile of 64 workgroups: 1, 2, 4, 8, 16 [8 -> 8 x 8]
  *   "sweep_cache"    1: full sweeps keep candidates and reduced sums for gpx_sweep_update; 0: leave a live cache alone; -1: drop it [0]

@@ -288,8 +288,8 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             return GPX_OK;
         }
         if (!strcmp(name, "tile_order")) {
-            if (value < 8 || value > 31)
-                return fail(h, GPX_EARG, "tile_order: bits 0-1 tile map (0..3), bits 2-4 k-loop schedule (2 .. 7)");
+            if (value < 4 || value > 31)
+                return fail(h, GPX_EARG, "tile_order: bits 0-1 tile map (0..3), bits 2-4 k-loop schedule (1 .. 7)");
             h->tile_order = (int)value;
             return GPX_OK;
         }

@@ -614,6 +614,128 @@ __device__ __forceinline__ void gemm_tile_128_ld(d4 (&acc)[4][4], const double* 
     __builtin_amdgcn_s_barrier();                                       // the caller may reuse LDS
 }
 
+// The barrier-free loop: every WAVE keeps its own operands.  Wave (wm, wn) needs the 64 columns wm of A and the 64 columns wn
+// of B of every k-row and nothing else; here it fetches exactly those itself (LDS-DMA) into a private LDS region -- 16 k-rows x
+// (64 + 64) doubles = 16 KB per image -- and therefore never meets another wave at a barrier: it waits for its OWN loads
+// (vmcnt), multiplies, and refills the image it has just read.  The price: each half of A and of B is fetched by the two waves
+// that use it (twice the L2 -> LDS bytes of the shared-image loops).
+//   NIMG = 2 (a workgroup alone on its CU: 128 KB): step t + 1 lands in the other image while step t is multiplied; its loads go
+//            out four at a time behind the four MFMA groups of step t.
+//   NIMG = 1 (two workgroups per CU: 64 KB each): the load latency stands exposed in the wave and is covered by the partner
+//            workgroup's wave on the same SIMD.
+// LDS image of a k-group (4 rows x 64 columns, 2 KB, two DMA instructions of 1 KB): the two rows a half-wave reads together sit
+// 128 B apart inside 256 B lines -- [row r, columns 16 p .. 16 p + 15] at 256 p + 128 (r & 1) + 1024 (r >> 1) -- so a fragment
+// read (lanes (fr, fk) <- row fk, column 16 i + fr) touches 256 contiguous bytes per half-wave: conflict-free without padding.
+// The DMA writes lane-linearly; the permutation is applied to the per-lane GLOBAL address.  Same arithmetic, order and bits.
+constexpr int GEMM_W_IMG_F64 = 2 * 16 * 64;          // one wave's image: A half + B half, 16 k-rows x 64 columns each
+
+template <int NIMG, int PRIO = 1, bool NEGA = false, bool ILV = false, int AUX = 0, bool TRI = false>
+__device__ __forceinline__ void gemm_tile_128_w(d4 (&acc)[4][4], const double* __restrict__ A, int64_t lda,
+                                                const double* __restrict__ B, int64_t ldb, int k_lo, int k_hi,
+                                                double* smem) {
+    constexpr int BKW = 16, G = 4;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int nk = (k_hi - k_lo) / BKW;
+    if (nk <= 0) return;
+    double* mine = smem + w * (NIMG * GEMM_W_IMG_F64);
+    const char* Abase = reinterpret_cast<const char*>(A + (int64_t)k_lo * lda);
+    const char* Bbase = reinterpret_cast<const char*>(B + (int64_t)k_lo * ldb);
+    // lane L supplies 16 bytes at LDS offset 16 L of a 1 KB block: piece p = L >> 4, row-in-pair r = (L >> 3) & 1, column pair L & 7
+    const int lp = lane >> 4, lr = (lane >> 3) & 1, lc = lane & 7;
+    const int colA = (ILV ? (2 * lp + wm) * 16 : wm * 64 + 16 * lp) + 2 * lc, colB = wn * 64 + 16 * lp + 2 * lc;
+    const int voA = (int)(((int64_t)lr * lda + colA) * 8), voB = (int)(((int64_t)lr * ldb + colB) * 8);
+    const int soA = (int)(2 * lda * 8), soB = (int)(2 * ldb * 8);      // a block = two k-rows: block q of the step at q * so
+    // blocks Q0 .. Q1 - 1 (of 8 per operand per step) of the step at Abase / Bbase into image img
+    auto issue = [&](int img, auto q0c, auto q1c) {
+        constexpr int Q0 = decltype(q0c)::value, Q1 = decltype(q1c)::value;
+        double* As = mine + img * GEMM_W_IMG_F64;
+        double* Bs = As + 16 * 64;
+        __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)Abase, 0, -1, 0x00020000);
+        __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)Bbase, 0, -1, 0x00020000);
+#pragma unroll
+        for (int q = Q0; q < Q1; ++q) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (gemm_lds_ptr)(As + q * 128), 16, voA, q * soA, 0, AUX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (gemm_lds_ptr)(Bs + q * 128), 16, voB, q * soB, 0, AUX);
+        }
+    };
+    auto bump = [&]() {
+        Abase += (int64_t)BKW * lda * 8;
+        Bbase += (int64_t)BKW * ldb * 8;
+    };
+    using Q0_ = std::integral_constant<int, 0>;
+    using Q8_ = std::integral_constant<int, 8>;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int foff = (fk >> 1) * 128 + (fk & 1) * 16 + fr;             // + 256 g (group) + 32 i (16-column piece), in doubles
+    issue(0, Q0_{}, Q8_{});
+    bump();
+    if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
+    // I0: row blocks i < I0 are skipped (TRI, as in gemm_tile_128_l)
+    auto step = [&](int kt, auto fillc, auto i0c) {
+        constexpr bool FILL = decltype(fillc)::value;                   // the next step exists: fetch it (NIMG = 2: meanwhile)
+        constexpr int I0 = decltype(i0c)::value;
+        const int cur = (NIMG == 2) ? (kt & 1) : 0, nxt = (NIMG == 2) ? ((kt + 1) & 1) : 0;
+        const double* as = mine + cur * GEMM_W_IMG_F64 + foff;
+        const double* bs = as + 16 * 64;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // this wave's own rows of step kt (and no LDS read pending)
+        double a[2][4], b[2][4];
+        auto frag = [&](int set, int g) {
+#pragma unroll
+            for (int i = I0; i < 4; ++i) a[set][i] = as[g * 256 + i * 32];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[set][j] = bs[g * 256 + j * 32];
+        };
+        frag(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < G; ++kk) {
+            if (kk + 1 < G) {
+                frag((kk + 1) & 1, kk + 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 8 - I0, 0);
+            }
+#pragma unroll
+            for (int i = I0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, NEGA ? 1 : 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * (4 - I0), 0);
+            if (FILL && NIMG == 2) {
+                if (kk == 0) issue(nxt, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+                if (kk == 1) issue(nxt, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+                if (kk == 2) issue(nxt, std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{});
+                if (kk == 3) issue(nxt, std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{});
+                __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+            }
+        }
+        if (FILL) {
+            if (NIMG == 1) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the image is read: refill it
+                issue(0, Q0_{}, Q8_{});
+            }
+            bump();
+        }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    int kt = 0;
+    if (!TRI) {
+        for (; kt + 1 < nk; ++kt) step(kt, T_{}, std::integral_constant<int, 0>{});
+        step(kt, F_{}, std::integral_constant<int, 0>{});
+    } else {
+        // the triangular block = the last eight steps; its quarter j (two steps) skips the row blocks i < j
+        for (; kt < nk - 6; ++kt) step(kt, T_{}, std::integral_constant<int, 0>{});
+        step(kt, T_{}, std::integral_constant<int, 1>{}); ++kt;
+        step(kt, T_{}, std::integral_constant<int, 1>{}); ++kt;
+        step(kt, T_{}, std::integral_constant<int, 2>{}); ++kt;
+        step(kt, T_{}, std::integral_constant<int, 2>{}); ++kt;
+        step(kt, T_{}, std::integral_constant<int, 3>{}); ++kt;
+        step(kt, F_{}, std::integral_constant<int, 3>{});
+    }
+    if (PRIO) __builtin_amdgcn_s_setprio(PRIO - 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                       // the caller may reuse LDS
+}
+
 // tile row of accumulator register acc[i][.][r] under the interleaved row blocks (ILV)
 __device__ __forceinline__ int acc_row_ilv(int i, int r) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;

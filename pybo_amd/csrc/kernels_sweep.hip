@@ -309,19 +309,54 @@ __global__ __launch_bounds__(GEMM_THREADS, WGS) void k_sweep_trmm_l(const double
     }
 }
 
+// The same tiles on the barrier-free loop (gemm_tile_128_w: every wave fetches its own operand halves, one 16-row image per
+// wave, two workgroups per CU), with the diagonal block's zero rows skipped.  Twice the L2 -> LDS bytes of k_sweep_trmm_l.
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm_w(const double* __restrict__ U, int64_t Np,
+                                                                  const double* __restrict__ Ks, int64_t ldk, int NT,
+                                                                  const double* __restrict__ avec, double* __restrict__ Qp,
+                                                                  double* __restrict__ Pp, int64_t ldp, int order, int sm,
+                                                                  unsigned long long* clk) {
+    __shared__ __attribute__((aligned(16))) double smem[4 * GEMM_W_IMG_F64];
+    const unsigned long long clk_c0 = __builtin_readcyclecounter();
+    const unsigned long long clk_r0 = wall_clock64();
+    const int nP = (int)(Np / TB);
+    int mt, nt, mt2;
+    if (!sweep_tile_of<64>(blockIdx.x, order, sm, NT, nP, mt, nt, mt2)) return;
+#pragma unroll 1
+    for (int ph = 0; ph < 2; ++ph) {
+        if (ph == 1) {
+            if (mt2 < 0) break;
+            mt = mt2;
+            __syncthreads();
+        }
+        const int64_t m0 = (int64_t)mt * TB, n0 = (int64_t)nt * TB;
+        d4 acc[4][4];
+        acc_zero(acc);
+        gemm_tile_128_w<1, 1, false, true, 0, true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
+        sweep_epilogue<true>(acc, avec, m0, Qp + (int64_t)mt * ldp + n0, Pp + (int64_t)mt * ldp + n0, smem);
+    }
+    if (clk && threadIdx.x == 0) {
+        atomicAdd(clk, (unsigned long long)__builtin_readcyclecounter() - clk_c0);
+        atomicAdd(clk + 1, (unsigned long long)wall_clock64() - clk_r0);
+    }
+}
+
 void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double* Ks, int64_t ldk,
                        int64_t cols, const double* a, double* Qp, double* Pp, int64_t ldp,
                        int tile_order, int super_m, unsigned long long* clk) {
     const int NT = (int)(cols / TB);
     const int nP = (int)(Np / TB);
     // bits 0-1: tile map, bits 2-4: k-loop (4 = default: operands by LDS-DMA, k-step 32, two workgroups per CU, the zero rows of
-    // T's diagonal block skipped; 3: the same without the skip; 7: k-step 16, three workgroups per CU; 6, 5, 2: the
+    // T's diagonal block skipped; 3: the same without the skip; 1: the barrier-free wave-private loop; 7: k-step 16, three workgroups per CU; 6, 5, 2: the
     // register-staged schedules of rounds 5, 2, 1 -- all kept as independently scheduled witnesses of the bit-identity test)
     const int order = tile_order & 3, var = (tile_order >> 2) & 7;
 #define GPX_SW(K) hipLaunchKernelGGL(K, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp, ldp, order, super_m, clk)
     if (var == 7) {                // three workgroups per CU, k-step 16
         const unsigned nblk = sweep_grid<96>(order, super_m, NT, nP);
         GPX_SW((k_sweep_trmm_l<16, 3, 1, 2, false>));
+    } else if (var == 1) {               // barrier-free: every wave keeps its own operands
+        const unsigned nblk = sweep_grid<64>(order, super_m, NT, nP);
+        GPX_SW(k_sweep_trmm_w);
     } else if (var == 4 || var == 3) {   // two workgroups per CU, k-step 32; 4: with the diagonal block's zero rows skipped
         const unsigned nblk = sweep_grid<64>(order, super_m, NT, nP);
         if (var == 4) GPX_SW((k_sweep_trmm_l<32, 2, 1, 2, true>));

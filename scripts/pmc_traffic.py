@@ -27,7 +27,7 @@ write_b = 1024.0 * sum(tw) / len(tw) / calib
 out = {
     'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only); KiB counters; FETCH_SIZE '
             'doubled (gfx950 wide coalesced reads, MI355X_MICROARCH.md HBM section); WRITE_SIZE calibrated on k_cross_gram',
-    'config': {'N': N, 'Np': Np, 'd': 8, 'cols_per_launch': cols, 'tile_order': 27, 'flop_per_candidate': 'N^2 (algorithmic)'},
+    'config': {'N': N, 'Np': Np, 'd': 8, 'cols_per_launch': cols, 'tile_order': 19, 'flop_per_candidate': 'N^2 (algorithmic)'},
     'k_sweep_trmm': {'launches': len(tf), 'fetch_kib_raw_mean': sum(tf) / len(tf), 'fetch_bytes_corrected': fetch_b,
                      'write_bytes': write_b, 'traffic_bytes_per_launch': fetch_b + write_b,
                      'algorithmic_input_bytes_per_launch': Np * Np * 8 // 2 + Np * cols * 8},

@@ -43,8 +43,29 @@ __global__ __launch_bounds__(GEMM_THREADS, 1) void k_lone(const double* __restri
         d4 acc[4][4];
         acc_zero(acc);
         if (WHICH == 0) gemm_tile_128_d<1>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, dsm);
-        else gemm_tile_128_ld<1>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, dsm);
+        else if (WHICH == 1) gemm_tile_128_ld<1>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, dsm);
+        else gemm_tile_128_w<2, 1>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, dsm);
         sweep_epilogue<false>(acc, avec, m0, Qp + (int64_t)mt * ldp + n0, Pp + (int64_t)mt * ldp + n0, dsm);
+    }
+}
+
+// two workgroups per CU on the wave-private loop (one image per wave): tile_order 2000 (PRIO 1) / 2001 (no priority changes)
+template <int PRIO>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_w(const double* __restrict__ U, int64_t Np, const double* __restrict__ Ks,
+                                                             int NT, const double* __restrict__ avec, double* __restrict__ Qp,
+                                                             double* __restrict__ Pp, int64_t ldp, int sm) {
+    __shared__ __attribute__((aligned(16))) double smem[4 * GEMM_W_IMG_F64];
+    const int nP = (int)(Np / TB);
+    int mt, nt, mt2;
+    if (!sweep_tile_of<64>(blockIdx.x, 3, sm, NT, nP, mt, nt, mt2)) return;
+#pragma unroll 1
+    for (int ph = 0; ph < 2; ++ph) {
+        if (ph == 1) { if (mt2 < 0) break; mt = mt2; __syncthreads(); }
+        const int64_t m0 = (int64_t)mt * TB, n0 = (int64_t)nt * TB;
+        d4 acc[4][4];
+        acc_zero(acc);
+        gemm_tile_128_w<1, 1, false, true, 0, PRIO != 0>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);      // PRIO reused: 1 = with the diagonal-block skip
+        sweep_epilogue<true>(acc, avec, m0, Qp + (int64_t)mt * ldp + n0, Pp + (int64_t)mt * ldp + n0, smem);
     }
 }
 
@@ -79,13 +100,19 @@ int main(int argc, char** argv) {
         for (int rep = 0; rep < reps + 2; ++rep) {
             CK(hipMemsetAsync(clk, 0, 16, 0));
             hipEventRecord(e0);
-            if (to >= 1000) {
+            if (to >= 2000) {
+                const unsigned nblk = sweep_grid<64>(3, sm, (int)(cols / TB), nP);
+                if (to == 2000) hipLaunchKernelGGL(k_sweep_w<1>, dim3(nblk), dim3(GEMM_THREADS), 0, 0, U, Np, Ks, (int)(cols / TB), a, Qp, Pp, cols, sm);
+                else hipLaunchKernelGGL(k_sweep_w<0>, dim3(nblk), dim3(GEMM_THREADS), 0, 0, U, Np, Ks, (int)(cols / TB), a, Qp, Pp, cols, sm);
+            } else if (to >= 1000) {
                 const size_t lb = (size_t)2 * GEMM_LDS_F64 * 8;
                 const unsigned nblk = sweep_grid<32>(3, sm, (int)(cols / TB), nP);
                 if (to == 1000) { CK(hipFuncSetAttribute((const void*)k_lone<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
                     hipLaunchKernelGGL(k_lone<0>, dim3(nblk), dim3(GEMM_THREADS), lb, 0, U, Np, Ks, (int)(cols / TB), a, Qp, Pp, cols, sm); }
-                else { CK(hipFuncSetAttribute((const void*)k_lone<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
+                else if (to == 1001) { CK(hipFuncSetAttribute((const void*)k_lone<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
                     hipLaunchKernelGGL(k_lone<1>, dim3(nblk), dim3(GEMM_THREADS), lb, 0, U, Np, Ks, (int)(cols / TB), a, Qp, Pp, cols, sm); }
+                else { CK(hipFuncSetAttribute((const void*)k_lone<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lb));
+                    hipLaunchKernelGGL(k_lone<2>, dim3(nblk), dim3(GEMM_THREADS), lb, 0, U, Np, Ks, (int)(cols / TB), a, Qp, Pp, cols, sm); }
             } else
             launch_sweep_trmm(0, U, Np, Ks, Np, cols, a, Qp, Pp, cols, to, sm, clk);
             hipEventRecord(e1);

@@ -1,6 +1,6 @@
-"""profiles/r04_roofline.json: kernel -> algorithmic units per launch, average launch duration (rocprofv3 kernel stats of the
+"""profiles/r06_roofline.json: kernel -> algorithmic units per launch, average launch duration (rocprofv3 kernel stats of the
 same bench.py command), achieved rate, peak, fraction -- so that every fraction quoted in DESIGN.md / README.md can be
-recomputed without reading prose.   python scripts/r04_roofline.py gpurun_out/r04 > profiles/r04_roofline.json"""
+recomputed without reading prose.   python scripts/r06_roofline.py gpurun_out/r06 > profiles/r06_roofline.json"""
 import csv, json, os, sys
 
 O = sys.argv[1]
@@ -31,7 +31,7 @@ def load(name):
 
 
 rows = []
-ns, d_, e_ = load('ns'), load('d'), load('e')
+ns, d_, e_, b_, ens_ = load('ns'), load('d'), load('e'), load('b'), load('ns_ens10')
 st = stats('ns')
 N, M, cols = 8192, 1 << 20, 65536
 k, v = pick(st, 'k_sweep_trmm')
@@ -72,6 +72,6 @@ if trt and ns:
 out = {'note': 'avg_ns from rocprofv3 --kernel-trace --stats of `python bench.py [--workload w] --steps 2 --warmup 1` (scripts/trace.sh); '
                'achieved = units_per_launch / avg_ns; peaks: fp64 MFMA 78.6 TFLOP/s, fp64 lanes 39.3 T lane-op/s, HBM 8000 GB/s (datasheet)',
        'kernels': rows,
-       'bench_lines': {w: {kk: b[kk] for kk in ('ms_per_step', 'roofline', 'roofline_fit', 'roofline_rff') if kk in b}
-                       for w, b in (('ns', ns), ('d', d_), ('e', e_)) if b}}
+       'bench_lines': {w: {kk: b[kk] for kk in ('ms_per_step', 'roofline', 'roofline_fit', 'roofline_rff', 'parity') if kk in b}
+                       for w, b in (('ns', ns), ('b', b_), ('d', d_), ('e', e_), ('ns_ens10', ens_)) if b}}
 print(json.dumps(out, indent=1))

@@ -256,6 +256,7 @@ def test_posterior_moments_match_oracle(kernel, N, d, M):
                                   dict(chunk=256, tile_order=24), dict(chunk=384, tile_order=26),
                                   dict(chunk=640, tile_order=27, super_m=4),
                                   dict(chunk=256, tile_order=12), dict(chunk=384, tile_order=15), dict(chunk=128, tile_order=16),
+                                  dict(chunk=256, tile_order=4), dict(chunk=640, tile_order=7, super_m=4),
                                   dict(chunk=512, tile_order=17), dict(chunk=384, tile_order=18),
                                   dict(chunk=640, tile_order=19, super_m=4), dict(chunk=256, tile_order=28),
                                   dict(chunk=384, tile_order=30), dict(chunk=1024, tile_order=31, super_m=2),
@@ -285,7 +286,7 @@ def test_sweep_schedules_agree_bitwise_over_several_block_rows(N):
     mr, sr = ref.predict(Z)
     assert np.all(np.abs(r0['mu'] - mr) <= mu_tol(mr, rho))
     assert np.all(np.abs(r0['s2'] - sr) <= s2_tol(sr, rho))
-    for to in (8 + 3, 12 + 3, 16 + 2, 20 + 3, 24 + 3, 28 + 3):
+    for to in (4 + 3, 8 + 3, 12 + 3, 16 + 2, 20 + 3, 24 + 3, 28 + 3):
         e1 = _engine(tile_order=to, chunk=512)
         e1.fit(X, y, 'se', ell, rho, sn2, bias)
         r1 = e1.sweep('ucb', 2.0, Z, k=10, want_moments=True)
