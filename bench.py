@@ -1210,7 +1210,7 @@ def main():
             warm['rank1_cov_evals_per_s'] = float(N) * Ml * passes / (warm['stage_ms_per_step_rank0']['rank1'] * 1e-3) \
                 if warm['stage_ms_per_step_rank0']['rank1'] > 0 else None
             if warm['rank1_cov_evals_per_s'] and w['kernel'] == 'se' and d == 8 and warm['appends_per_step'] == 1:
-                # what bounds it: 42.4 VALU instructions per evaluation (SQ_INSTS_VALU, profiles/r03_pmc_covariance_kernels.txt:
+                # what bounds it: 42.4 VALU instructions per evaluation (SQ_INSTS_VALU, profiles/history/r03_pmc_covariance_kernels.txt:
                 # a profile-time constant for SE-ARD at d = 8, q = 1) against the chip's 256 CU x 4 SIMD x 16 lanes x 2.4 GHz
                 warm['roofline'] = {'kernel': 'k_sweep_rankq<1, se>', 'bound': 'valu-issue',
                                     'achieved': warm['rank1_cov_evals_per_s'] * 42.4 / 1e12, 'peak': 256 * 4 * 16 * 2.4e9 / 1e12,

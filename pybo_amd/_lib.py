@@ -13,7 +13,7 @@ import numpy as np
 # GPU_MAX_HW_QUEUES hardware queues, 4 by default: with a second live handle (an ensemble, a second model, torch's own
 # streams) two streams of one handle can land on the same queue and what was meant to overlap runs back to back --
 # measured: the warm plug-in iteration 14.0 -> 16.3 ms at N = 8192 merely because another handle existed
-# (profiles/history_r01_r05.md).  Eight queues keep two handles apart.  The variable is read by the HIP runtime when it
+# (profiles/history/).  Eight queues keep two handles apart.  The variable is read by the HIP runtime when it
 # initialises, so it is the APPLICATION's to set (bench.py does, before importing torch): a
 # library import does not change its host's environment -- see hw_queues_hint() below.
 

@@ -214,7 +214,7 @@ __device__ __forceinline__ void gemm_tile_128_g(d4 (&acc)[4][4], const double* _
 //    the attractor, and the waiting wave sits at its first MFMA with its fragments loaded.
 //  * the fragments of MFMA group kk+1 are requested before the MFMAs of group kk (a second fragment set; the buffer loads
 //    freed the registers).
-// 61.8 -> 59.7 ms per 65536-column launch at N = 8192 (0.905 -> 0.937 of the fp64-MFMA peak), profiles/r05_sweep_idle_attribution.txt.
+// 61.8 -> 59.7 ms per 65536-column launch at N = 8192 (0.905 -> 0.937 of the fp64-MFMA peak), profiles/history/r05_sweep_idle_attribution.txt.
 // PRIO / NEGA as in gemm_tile_128_g (PRIO = 0: no priority changes at all; otherwise PRIO for the first half of a step's
 // MFMAs, PRIO + 1 for the second half and while the loads are issued, PRIO - 1 outside the matrix phase).
 template <int PRIO = 1, bool NEGA = false, bool ILV = false>

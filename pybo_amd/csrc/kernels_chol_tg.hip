@@ -3,7 +3,7 @@
 //
 // Why: the stream-scheduled factorisation in kernels_fit.hip launches ~250 kernels over four streams; its serial chain
 // (diagonal block -> panel solve -> row update, per 128-block) is latency-bound, and every chain launch waits ~100 us
-// to START behind the trailing updates' resident tiles (profiles/r03_chol_parts.txt).  Here nothing is launched after
+// to START behind the trailing updates' resident tiles (profiles/history/r03_chol_parts.txt).  Here nothing is launched after
 // the first instruction: the workgroups stay resident, take roles, and hand tiles to each other through agent-scope
 // flags in device memory.
 //
@@ -35,7 +35,7 @@
 // the step counters of role C / S1 / S2 / S3, and per half tile a flag "final" for the fused links.
 // (History.  Round 4 had two solve halves and six update pieces per block row on a critical list served by eight side-kick
 //  workgroups -- three hand-offs of 4-5 us between two diagonal blocks, block period 56 us; the A/B against it, before it was
-//  removed: profiles/r05_chol_shadow_ab.txt.  Measured and removed earlier -- profiles/r04_chol_tg_*_ab.txt: claiming a head by
+//  removed: profiles/history/r05_chol_shadow_ab.txt.  Measured and removed earlier -- profiles/history/r04_chol_tg_*_ab.txt: claiming a head by
 //  compare-and-swap, a peek before the draw, priority lists, strided sub-queues, an urgent-only pool, XCD-affine tickets,
 //  column-major lists, the next solve's dependency cone on the side-kicks: every one slower or no faster.)
 //
@@ -72,7 +72,7 @@ struct TgArgs {
 // control block (ints): [0] arrivals, [32] abort (1 = not positive definite, 2 = a spin gave up), [64 + 32 q] list heads,
 // then diag[nPad], quad[nPad], solved[2 nPad], seq[nP * nP], and per compute unit (key = xcc | se | sh | cu, 12 bits)
 // the number of workgroups that have started there and the role of the first one.
-// Default chunks (sweeps in profiles/r04_chol_taskgraph.txt): 1, 2, 4, 8, 16, 16, .. blocks counted back from the pivot.
+// Default chunks (sweeps in profiles/history/r04_chol_taskgraph.txt): 1, 2, 4, 8, 16, 16, .. blocks counted back from the pivot.
 constexpr int TG_DEFAULT_CHUNKS = 112489;     // 1, 1, 2, 4, 8, 16, 16, ..: the two chunks next to the pivot are single block rows (the shadows' U0 / U, V / V2); the step from 4 to 16 cost 10 % at N = 4096 (1.45 -> 1.29 ms) and 6 % at 8192
 constexpr int TG_NEAR_CHUNKS = 11112489;     // ... and up to TG_NEAR_MAX blocks 1, 1, 1, 1, 2, 4, 8, 16, ..: at the chain-bound sizes every multi-block chunk next to the
 constexpr int TG_NEAR_MAX = 36;              // pivot is a 40-us worker task in front of a shadow (N = 2048 0.589 -> 0.548 ms, 4096 1.22 -> 1.155; from N = 5000 on it is neutral, at 8192 it costs 2 %)
@@ -106,7 +106,7 @@ struct TgHeld { TgTask t; int have; };     // in LDS, one per workgroup: the tic
 // The next task of the workers' list for this workgroup.  Called by ONE full wave; lane 0 works, the
 // result is the same in every lane: 1 (task in `out`), 0 (the list is exhausted) or -1 (abort).
 // A workgroup without a ticket draws one at once (ONE fetch-and-add) and waits for that task's dependencies with the
-// ticket in hand.  (History, profiles/r04_chol_taskgraph.txt: claiming a head with compare-and-swap after checking its
+// ticket in hand.  (History, profiles/history/r04_chol_taskgraph.txt: claiming a head with compare-and-swap after checking its
 // dependencies serialised the chip -- 1.3 us per task with 123 workers, 5.9 us with 507, N = 8192 in 107 ms; peeking at the
 // head before drawing made every idle workgroup rush for the one head that had just become ready: 1-2 % slower.)
 __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, TgHeld* held) {
@@ -155,7 +155,7 @@ __device__ __forceinline__ int tg_take(const TgArgs& a, TgTask& out, int lane, T
         }
         // pauses between two looks: 256 clocks at first, then a.nap x 64 (default 16: 0.4 us; until late in round 4 the long
         // pause was 127 x 64 clocks = 3.4 us -- half of that, on average, between a dependency's arrival and the task's start:
-        // N = 2048 0.945 -> 0.876 ms, 8192 5.30 -> 5.19; profiles/r04_chol_tg_polling_ab.txt)
+        // N = 2048 0.945 -> 0.876 ms, 8192 5.30 -> 5.19; profiles/history/r04_chol_tg_polling_ab.txt)
         if (nap < 4) __builtin_amdgcn_s_sleep(4);
         else if (a.nap <= 8) __builtin_amdgcn_s_sleep(8);
         else if (a.nap <= 16) __builtin_amdgcn_s_sleep(16);
@@ -362,7 +362,7 @@ __device__ TG_BODY void tg_role_diag() {
 //       block row p-1, for the same reason.
 // What is left between two diagonal blocks when everything is on time: S1's last step (one poll, one 16 x 16 load, 8 MFMAs per
 // wave, its stores), U's last step (one poll, one 16-row load, 36 MFMAs, the tile's store) and role C's load of the tile:
-// 8-9 us (the first block rows of a factorisation run at 37-38 us per block row; measured: profiles/r05_chol_taskgraph.txt).
+// 8-9 us (the first block rows of a factorisation run at 37-38 us per block row; measured: profiles/history/r05_chol_taskgraph.txt).
 // What keeps everything on time is the speed of the column chains right of the band (tg_do_trsmu).
 // Operands travel global memory -> LDS without registers (global_load_lds_dwordx4; rings of 16-row panels, up to three steps
 // ahead of the arithmetic when a shadow starts late and the counts are already up); each wave counts the vector-memory
@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_chol_tg(const TgArgs a) {
     if (t == 0) {
         // Roles in order of arrival.  The critical workgroups (role C and the shadows) keep their compute unit
         // to themselves: next to a worker's matrix phases the diagonal block took 60-80 us instead of 26 and the
-        // critical solves twice their time (profiles/r04_chol_taskgraph.txt).  The second workgroup to start on a CU
+        // critical solves twice their time (profiles/history/r04_chol_taskgraph.txt).  The second workgroup to start on a CU
         // looks up what the first one became and leaves at once if that is a critical role (a grid of two workgroups
         // per CU has no third one waiting to take the slot).
         reinterpret_cast<TgHeld*>(tg_smem + 4)->have = 0;

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void k_panel_solve16(const double* __restrict_
 // 128 x 128 diagonal block ITSELF (the same instructions on the same inputs: every copy writes the same bits to R_pp
 // and to the 16 x 16 inverses, then reads its own back through L2) and goes on with its 64 columns.  What this buys is
 // one launch-to-start delay per 128-block instead of two: next to the trailing updates k_potrf16 runs in 29.6 us once
-// it has started but takes 133 us per launch at N = 16384 (profiles/r03_chol_parts.txt, section 6), and the panel
+// it has started but takes 133 us per launch at N = 16384 (profiles/history/r03_chol_parts.txt, section 6), and the panel
 // solve 63 instead of 11.5.  The redundant factorisations are ~30 us of ONE workgroup slot each -- next to a chip
 // full of 175-us trailing tiles.
 __global__ __launch_bounds__(256) void k_potrf_solve16(const double* __restrict__ S, double* __restrict__ R,
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update(const double* _
 // their linear index; in the square grid above (index = row * t + column, the lower half returning at once) a
 // region with t = 0 mod 8 sends whole tile COLUMNS to one XCD, and column J holds J + 1 tiles: at t = 56 the
 // busiest XCD carried 224 tiles against 175 on the idlest and set the launch's duration (the per-launch rate of the
-// trailing updates swung between 33 and 57 TFLOP/s with t mod 8 -- profiles/r02_far_update_launches.txt).
+// trailing updates swung between 33 and 57 TFLOP/s with t mod 8 -- profiles/history/r02_far_update_launches.txt).
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_syrk_update_tri(const double* __restrict__ R,
                                                                      double* __restrict__ S, int64_t Np, int kb0,
                                                                      int kb1, int ib0, int t) {
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(GEMM64_THREADS) void k_trtri_gemm2_64(const double*
 // ---- the same recursion RE-ASSOCIATED (round 4, option trtri_left):  T_21 = - (T_22 L_21) T_11 -------------------------
 // Built on the expectation that this order keeps the LEFT residual (T L - I, the one the sweep's error is proportional to)
 // at rounding level: with T_21 = -T_22 (L_21 T_11) the error d of the inner product enters it as T_22 d L_11, which carries
-// |T_11| |L_11| ~ the conditioning of the leading block.  MEASURED (profiles/r04_illcond_vs_long_double.txt): the left
+// |T_11| |L_11| ~ the conditioning of the leading block.  MEASURED (profiles/history/r04_illcond_vs_long_double.txt): the left
 // residual does not improve (config B, sn2 = 1e-6 rho: 1.9e-11 -> 3.1e-11) -- in this order the OUTER product's rounding
 // error, ~eps |W'| |T_11|, is what gets multiplied by L_11, with the same factor.  Only a triangular SOLVE with L_11
 // (backward stable: error ~eps |T_21| |L_11|) or the Newton step of refine_inverse removes it.  The mean's error is

@@ -27,7 +27,7 @@ __device__ __forceinline__ double cos_cw(double z) {
     // Round 3: reduction by pi (not pi/2) and ONE even polynomial on [-pi/2, pi/2]: cos z = (-1)^n cos r, r = z - n pi.
     // The quadrant form evaluated BOTH fdlibm kernels (sine and cosine on [-pi/4, pi/4]) and selected: 37 VALU
     // instructions per evaluation, and k_rff_mfma is bound by VALU + MFMA issue on the shared double-precision pipe
-    // (profiles/r03_pmc_rff_mfma.txt: 43 % + 37 % of the cycles).
+    // (profiles/history/r03_pmc_rff_mfma.txt: 43 % + 37 % of the cycles).
     // Round 4 (26 -> 20 instructions, 22 -> 18 of them on the double-precision pipe):
     //   * n = round(z / pi) by the magic-number addition t = z / pi + 1.5 * 2^52 (one FMA), n = t - 1.5 * 2^52: the integer
     //     sits in t's low mantissa bits, so the parity of n is bit 0 of t's low word -- no v_rndne, no v_cvt_i32_f64;

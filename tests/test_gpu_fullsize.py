@@ -60,7 +60,7 @@ def test_config_b_full_grid_properties_and_subsample_parity():
     live = host > 1e-9 * host.max()
     np.testing.assert_allclose(ei[live], host[live], rtol=1e-11, atol=0)
     # (2) against the oracle: the north-star's 1e-6 RELATIVE bar, on every compared candidate whose EI is within
-    #     1e-9 of the maximum (z from -5.8 to 0.5 here; measured max 4e-8, profiles/r02_ei_conditioning_config_b.txt)
+    #     1e-9 of the maximum (z from -5.8 to 0.5 here; measured max 4e-8, profiles/history/r02_ei_conditioning_config_b.txt)
     #     -- round 1 checked 2e-5 on a harsher variant of this workload (sn2 = 3.5e-6 rho instead of bench.py's
     #     1e-4 rho); the first-order sensitivity |z| dmu/s + (z^2/2) ds2/s2 explains both numbers --
     #     and within the stated moment tolerances propagated through EI (helpers.ei_tol) everywhere else

@@ -100,7 +100,7 @@ def test_config_b_default_noise_full_grid_properties():
 def test_refine_inverse_option_squares_the_left_residual():
     """Option "refine_inverse" (include/gpx.h): one Newton step T <- (2I - T L) T on the explicit inverse.  The sweep's
     error is (T L - I) V, so the LEFT residual is what counts; the recursive doubling keeps the right one small.
-    Measured against the long-double truth (profiles/r03_illcond_refined.txt): the posterior MEAN gets up to 6x closer
+    Measured against the long-double truth (profiles/history/r03_illcond_refined.txt): the posterior MEAN gets up to 6x closer
     (config B, sn2 = 1e-6: 1.8e-9 -> 3.1e-10 sqrt(rho)); the variance does not move -- its 1e-14 rho is the fp64
     accumulation of the N-term sums q = sum V^2, not the inverse -- which is why the option is off by default."""
     from pybo_amd._lib import Engine
