@@ -3,10 +3,13 @@
 #   build.sh          compile the objects that are older than their sources (incremental: development)
 #   build.sh --force  compile EVERY object from source (what __graft_entry__.build() runs: the driver's build check must
 #                     compile all eight translation units, also on a snapshot that shipped up-to-date .o files)
+# A/B builds (never shipped): EXTRA="-DGPX_TG_REGLOOPS" compiles the factorisation's workers with the register-staged k-loops of rounds
+# 2-5 instead of the LDS-DMA ones; EXTRA="-DGPX_PF16_COUNTED_WAIT" lets the diagonal role publish a step with its next tile's stores in flight
+# (round 5's hand-counted s_waitcnt; 2-5 % faster up to N = 4096, see ADVICE round 5 for why it is off).
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-const-variable"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-const-variable $EXTRA"
 SRCS="kernels_fit kernels_chol_tg kernels_sweep kernels_rff kernels_grad kernels_ens comm api"
 FORCE=0
 [ "$1" = "--force" ] && FORCE=1

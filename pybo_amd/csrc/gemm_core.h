@@ -14,10 +14,17 @@
 // the two 32-lane groups of a ds_read_b64 hit disjoint bank halves -> conflict-free.
 // Result layout (f64 MFMA, NOT the f32 map): D[row = (lane>>4) + 4*r][col = lane&15], r = 0..3.
 //
-// Two k-loop schedules (same arithmetic order, bit-identical results): gemm_tile_128_g steps K 32 at a time
-// through a single LDS buffer (default everywhere), gemm_tile_128_b 16 at a time through a 2-deep ring.
-// fp64 MFMA is 64 cycles/instruction/SIMD: a 32-row k-step is ~8192 matrix cycles per wave against
-// 16 x 16-B global loads and 16 ds_write_b128 per thread.
+// The k-loop schedules of this file perform the same arithmetic in the same order (bit-identical results):
+//   operands by LDS-DMA (round 6; buffer_load_dwordx4 ... lds, no staging registers):
+//     gemm_tile_128_l   k-step 32 (or 16) through ONE LDS image: the sweep (two workgroups per CU), the triangular inverse, the
+//                       factorisation's workers at two workgroups per CU; optional skip of a triangular last k-block (TRI)
+//     gemm_tile_128_ld  two images, the next step's loads behind the first four MFMA groups: a workgroup alone on its CU
+//     gemm_tile_128_w   every WAVE keeps its own operand halves: no barrier at all (a witness of the sweep: it moves twice the bytes)
+//   operands through registers (rounds 1-5; kept as independently scheduled witnesses and for the Gram / RFF products):
+//     gemm_tile_128_s   k-step 32, buffer loads, banded priority, second fragment set (round 5's sweep)
+//     gemm_tile_128_g   k-step 32, flat loads (round 2);  gemm_tile_128_b  k-step 16 through a 2-deep ring (round 1)
+//     gemm_tile_128_d   two images, LDS writes behind the MFMA groups (round 5's lone workgroup)
+// fp64 MFMA is 64 cycles/instruction/SIMD: a 32-row k-step is 8192 matrix cycles per wave.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -8,8 +8,9 @@
 // Per chunk of candidate columns:
 //   1. k_cross_gram   Ks[nt][k][c] = k(x_k, cand_{128 nt + c})    (HBM-write bound; tile-blocked so that every
 //                     128-candidate column panel is one contiguous Np x 128 block)
-//   2. k_sweep_trmm   V = T Ks on fp64 MFMA, tile (mt, nt); V never leaves registers: the epilogue
-//                     reduces colsum(V^2) and V^T a per 128-row block into Qp/Pp[mt][n]
+//   2. k_sweep_trmm*  V = T Ks on fp64 MFMA, tile (mt, nt); V never leaves registers: the epilogue
+//                     reduces colsum(V^2) and V^T a per 128-row block into Qp/Pp[mt][n]   (default: k_sweep_trmm_l -- operands by
+//                     LDS-DMA, the zero rows of T's diagonal block skipped; the other schedules are bit-identical witnesses)
 //   3. k_acq          q = sum_mt Qp, p = sum_mt Pp (fixed order -> deterministic),
 //                     mu = bias + p, s2 = max(rho - q, 1e-100), acquisition value
 // then one block-local + one merge top-k pass over all M values.
@@ -90,14 +91,22 @@ __global__ __launch_bounds__(256, 3) void k_cross_gram(const double* __restrict_
 #pragma unroll 1
             for (int k = 0; k < kc; ++k) dist_step<false>(xo, xc, k, ty, tx, r2);
         }
+        // a tile without padding rows / columns (every tile of the north-star launch) needs no selects: two of the 58 VALU
+        // instructions per entry of a kernel that is bound by their issue (workgroup-uniform branch)
+        const bool full = (k0 + XK <= N) && (m0 + n0 + XN <= M);
 #pragma unroll
         for (int a = 0; a < 8; ++a) {
             const int64_t gk = k0 + ty * 8 + a;
             d4 o;
+            if (full) {
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int64_t gm = m0 + n0 + tx * 4 + b;
-                o[b] = (gk < N && gm < M) ? kern_eval(KID, r2[a][b], rho) : 0.0;
+                for (int b = 0; b < 4; ++b) o[b] = kern_eval(KID, r2[a][b], rho);
+            } else {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int64_t gm = m0 + n0 + tx * 4 + b;
+                    o[b] = (gk < N && gm < M) ? kern_eval(KID, r2[a][b], rho) : 0.0;
+                }
             }
             // tile-blocked layout [nt][k][128]: the 64 x 128 outputs of a row tile are ONE contiguous 64 KB run
             *reinterpret_cast<d4*>(Ks + ((int64_t)blockIdx.y * ldk + gk) * XN + tx * 4) = o;

@@ -76,5 +76,7 @@ export GPX_DIAGNOSTICS=1            # the series below use the diagnostic knobs 
 bash scripts/probe/pmc_fetch.sh 8192 65536 19 18 17 16 19:4 19:16 27 15 7 > $O/sweep_schedules_traffic.txt 2>&1
 timeout 300 python scripts/loglik_rate.py > $O/loglik_rate.txt 2>&1
 unset GPX_DIAGNOSTICS
+# the GPU test-suite of the same tree (the driver runs it again on its own box)
+timeout 1500 python -m pytest tests -q -m gpu < /dev/null > $O/gpu_suite.log 2>&1
 python scripts/r06_roofline.py $O > $O/roofline.json 2> $O/roofline.err
 cut -c1-400 $O/bench_ns.json; echo; cat $O/pmc_traffic.json 2>/dev/null | head -30; tail -5 $O/bench_gpus2_rccl_on_one_gpu.log; head -40 $O/roofline.json
