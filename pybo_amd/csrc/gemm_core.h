@@ -141,7 +141,9 @@ constexpr int BK32 = 32;
 // NEGA: the A operand is negated on its way into LDS, i.e. acc += -(A^T-panel) * B: the symmetric updates start
 // their accumulators from the S tile they update (loaded while the first k-steps are in flight) and store
 // S - sum A B directly, instead of a dependent read-modify-write round trip after the k-loop.
-template <int PRIO, bool NEGA = false, bool ILV = false>
+// REV (the loops that take it): the 32-row k-steps are accumulated in DESCENDING order, the rows inside a step ascending -- a
+// different, fixed summation order; every loop produces the same bits for the same REV (gemm_rev32 gives it to the 16-row loops).
+template <int PRIO, bool NEGA = false, bool ILV = false, bool REV = false>
 __device__ __forceinline__ void gemm_tile_128_g(d4 (&acc)[4][4], const double* __restrict__ A, int64_t lda,
                                                 const double* __restrict__ B, int64_t ldb, int k_lo,
                                                 int k_hi, double* smem) {
@@ -157,16 +159,16 @@ __device__ __forceinline__ void gemm_tile_128_g(d4 (&acc)[4][4], const double* _
     d2 ra[8], rb[8];
     const int nk = (k_hi - k_lo) / BK32;
     if (nk <= 0) return;
-    const double* Ap = A + (int64_t)(k_lo + lrow) * lda + lcol;
-    const double* Bp = B + (int64_t)(k_lo + lrow) * ldb + lcol;
+    const double* Ap = A + (int64_t)((REV ? k_hi - BK32 : k_lo) + lrow) * lda + lcol;
+    const double* Bp = B + (int64_t)((REV ? k_hi - BK32 : k_lo) + lrow) * ldb + lcol;
     auto gload = [&]() {
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
             ra[p] = *reinterpret_cast<const d2*>(Ap + (int64_t)(4 * p) * lda);
             rb[p] = *reinterpret_cast<const d2*>(Bp + (int64_t)(4 * p) * ldb);
         }
-        Ap += (int64_t)BK32 * lda;
-        Bp += (int64_t)BK32 * ldb;
+        Ap += (REV ? -1 : 1) * (int64_t)BK32 * lda;
+        Bp += (REV ? -1 : 1) * (int64_t)BK32 * ldb;
     };
     auto swrite = [&]() {
 #pragma unroll
@@ -224,7 +226,7 @@ __device__ __forceinline__ void gemm_tile_128_g(d4 (&acc)[4][4], const double* _
 // 61.8 -> 59.7 ms per 65536-column launch at N = 8192 (0.905 -> 0.937 of the fp64-MFMA peak), profiles/history/r05_sweep_idle_attribution.txt.
 // PRIO / NEGA as in gemm_tile_128_g (PRIO = 0: no priority changes at all; otherwise PRIO for the first half of a step's
 // MFMAs, PRIO + 1 for the second half and while the loads are issued, PRIO - 1 outside the matrix phase).
-template <int PRIO = 1, bool NEGA = false, bool ILV = false>
+template <int PRIO = 1, bool NEGA = false, bool ILV = false, bool REV = false>
 __device__ __forceinline__ void gemm_tile_128_s(d4 (&acc)[4][4], const double* __restrict__ A, int64_t lda,
                                                 const double* __restrict__ B, int64_t ldb, int k_lo, int k_hi,
                                                 double* smem) {
@@ -239,8 +241,8 @@ __device__ __forceinline__ void gemm_tile_128_s(d4 (&acc)[4][4], const double* _
     d2 ra[8], rb[8];
     const int nk = (k_hi - k_lo) / BK32;
     if (nk <= 0) return;
-    const char* Abase = reinterpret_cast<const char*>(A + (int64_t)k_lo * lda);
-    const char* Bbase = reinterpret_cast<const char*>(B + (int64_t)k_lo * ldb);
+    const char* Abase = reinterpret_cast<const char*>(A + (int64_t)(REV ? k_hi - BK32 : k_lo) * lda);
+    const char* Bbase = reinterpret_cast<const char*>(B + (int64_t)(REV ? k_hi - BK32 : k_lo) * ldb);
     const int voA = (int)(((int64_t)lrow * lda + lcol) * 8), voB = (int)(((int64_t)lrow * ldb + lcol) * 8);
     const int soA = (int)(4 * lda * 8), soB = (int)(4 * ldb * 8);      // four rows on: the SGPR offset of load p is p * so
     auto gload = [&]() {
@@ -252,8 +254,8 @@ __device__ __forceinline__ void gemm_tile_128_s(d4 (&acc)[4][4], const double* _
             ra[p] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rA, voA, p * soA, 0));
             rb[p] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rB, voB, p * soB, 0));
         }
-        Abase += (int64_t)BK32 * lda * 8;
-        Bbase += (int64_t)BK32 * ldb * 8;
+        Abase += (REV ? -1 : 1) * (int64_t)BK32 * lda * 8;
+        Bbase += (REV ? -1 : 1) * (int64_t)BK32 * ldb * 8;
     };
     auto swrite = [&]() {
 #pragma unroll
@@ -442,11 +444,13 @@ constexpr int gemm_l_lds_f64() { return 2 * BKL * LDT; }
 //      makes the skip worth it: both wave rows lose the same share (1.5 of the block's 4 quarters).
 // NEGA: acc += -(A) B through the MFMA's own negation of its A operand (neg:[1,0,0]): the same bits as negating A on its way
 //      into LDS (the register-staged loops), which a DMA cannot do.  AUX: cache policy of the operand loads (see gemm_tile_128_d).
-template <int BKL, int PRIO = 1, int NSET = 2, bool ILV = false, bool TRI = false, bool NEGA = false, int AUX = 0>
+// REV: the 32-row k-steps in DESCENDING order (see gemm_tile_128_g).
+template <int BKL, int PRIO = 1, int NSET = 2, bool ILV = false, bool TRI = false, bool NEGA = false, int AUX = 0, bool REV = false>
 __device__ __forceinline__ void gemm_tile_128_l(d4 (&acc)[4][4], const double* __restrict__ A, int64_t lda,
                                                 const double* __restrict__ B, int64_t ldb, int k_lo, int k_hi,
                                                 double* smem) {
     static_assert(!TRI || ILV, "TRI needs the interleaved row blocks");
+    static_assert(!REV || BKL == 32, "REV is the order of the 32-row steps: gemm_rev32 for other step sizes");
     constexpr int G = BKL / 4;         // MFMA groups per step
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -455,8 +459,9 @@ __device__ __forceinline__ void gemm_tile_128_l(d4 (&acc)[4][4], const double* _
     double* Bs = smem + BKL * LDT;     // [BKL][LDT]
     const int nk = (k_hi - k_lo) / BKL;
     if (nk <= 0) return;
-    const char* Abase = reinterpret_cast<const char*>(A + (int64_t)k_lo * lda);
-    const char* Bbase = reinterpret_cast<const char*>(B + (int64_t)k_lo * ldb);
+    const char* Abase = reinterpret_cast<const char*>(A + (int64_t)(REV ? k_hi - BKL : k_lo) * lda);
+    const char* Bbase = reinterpret_cast<const char*>(B + (int64_t)(REV ? k_hi - BKL : k_lo) * ldb);
+    const int64_t stepA = (REV ? -1 : 1) * (int64_t)BKL * lda * 8, stepB = (REV ? -1 : 1) * (int64_t)BKL * ldb * 8;
     const int voA = (int)(((int64_t)w * lda + 2 * lane) * 8), voB = (int)(((int64_t)w * ldb + 2 * lane) * 8);
     const int soA = (int)(4 * lda * 8), soB = (int)(4 * ldb * 8);      // four rows on: the SGPR offset of load p is p * so
     auto issue = [&]() {
@@ -467,8 +472,8 @@ __device__ __forceinline__ void gemm_tile_128_l(d4 (&acc)[4][4], const double* _
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (gemm_lds_ptr)(As + (w + 4 * p) * LDT), 16, voA, p * soA, 0, AUX);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (gemm_lds_ptr)(Bs + (w + 4 * p) * LDT), 16, voB, p * soB, 0, AUX);
         }
-        Abase += (int64_t)BKL * lda * 8;
-        Bbase += (int64_t)BKL * ldb * 8;
+        Abase += stepA;
+        Bbase += stepB;
     };
     const int fr = lane & 15, fk = lane >> 4;
     constexpr int IST = ILV ? 32 : 16;                                  // row-block stride of a wave's A fragments
@@ -518,10 +523,17 @@ __device__ __forceinline__ void gemm_tile_128_l(d4 (&acc)[4][4], const double* _
         // the triangular block's quarters: its first (lowest k) is full; BKL = 16 takes each quarter in two steps
         constexpr int Q = 32 / BKL;                     // steps per quarter
         const int nd = nk - 3 * Q;                      // steps that multiply all four row blocks
-        for (int kt = 0; kt < nd; ++kt) step(std::integral_constant<int, 0>{}, true);
-        for (int q = 0; q < Q; ++q) step(std::integral_constant<int, 1>{}, true);
-        for (int q = 0; q < Q; ++q) step(std::integral_constant<int, 2>{}, true);
-        for (int q = 0; q < Q; ++q) step(std::integral_constant<int, 3>{}, q + 1 < Q);
+        if (!REV) {
+            for (int kt = 0; kt < nd; ++kt) step(std::integral_constant<int, 0>{}, true);
+            for (int q = 0; q < Q; ++q) step(std::integral_constant<int, 1>{}, true);
+            for (int q = 0; q < Q; ++q) step(std::integral_constant<int, 2>{}, true);
+            for (int q = 0; q < Q; ++q) step(std::integral_constant<int, 3>{}, q + 1 < Q);
+        } else {
+            for (int q = 0; q < Q; ++q) step(std::integral_constant<int, 3>{}, true);
+            for (int q = 0; q < Q; ++q) step(std::integral_constant<int, 2>{}, true);
+            for (int q = 0; q < Q; ++q) step(std::integral_constant<int, 1>{}, true);
+            for (int kt = 0; kt < nd; ++kt) step(std::integral_constant<int, 0>{}, kt + 1 < nd);
+        }
     }
 }
 
@@ -741,6 +753,13 @@ __device__ __forceinline__ void gemm_tile_128_w(d4 (&acc)[4][4], const double* _
     if (PRIO) __builtin_amdgcn_s_setprio(PRIO - 1);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                       // the caller may reuse LDS
+}
+
+// The REV order for a loop that does not take it natively (the 16-row-step witnesses): one call per 32-row step, highest first.
+// Slow (a prologue per step) and exact: the accumulators see the same sequence of MFMAs as in the native loops.
+template <class Loop>
+__device__ __forceinline__ void gemm_rev32(int k_lo, int k_hi, Loop loop) {
+    for (int k = k_hi - BK32; k >= k_lo; k -= BK32) loop(k, k + BK32);
 }
 
 // tile row of accumulator register acc[i][.][r] under the interleaved row blocks (ILV)

@@ -197,6 +197,15 @@ static unsigned sweep_grid(int order, int super_m, int NT, int nP) {
     return (unsigned)(NT * nP);
 }
 
+// The summation order of a tile along k (the SAME in every schedule and every tile map: results stay bit-identical): tiles of the
+// lower half, 2 mt < nP - 1 -- in the paired map exactly the SECOND tile of every pair -- take their 32-row k-steps downwards when
+// the factor has at least 32 block rows.  In the paired map every workgroup of a super-tile then reads the same rows of its Ks
+// panel at the same time in BOTH phases (row t in the first, row (nP + 1) 128 - t in the second, whatever its pair index), which
+// lets an XCD's L2 serve the panel once: L2 -> fabric reads 101 -> 88 GB per launch at N = 8192 and, the kernel being power-bound,
+// 0.8 % more clock on the boxes that sustain 2300 MHz (nothing on those at 2385) -- profiles/r06_sweep_down_probe.txt.  Below 32
+// block rows the second tiles are short and it costs 0.3 %.
+__device__ __forceinline__ bool sweep_tile_rev(int mt, int nP) { return nP >= 32 && 2 * mt < nP - 1; }
+
 // epilogue of a tile: column sums of V^2 and V*a over its 128 rows -> Qp / Pp[mt][n0 ..] (red: 512 doubles of LDS, free)
 template <bool ILV = false>
 __device__ __forceinline__ void sweep_epilogue(const d4 (&acc)[4][4], const double* __restrict__ avec, int64_t m0,
@@ -272,9 +281,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __
     d4 acc[4][4];
     acc_zero(acc);
     // (interleaved row blocks in every schedule: the column sums then add a tile's rows in the same order everywhere)
-    if (VAR == 2) gemm_tile_128_b<true, true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
-    else if (VAR == 5) gemm_tile_128_g<1, false, true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
-    else gemm_tile_128_s<1, false, true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
+    const double* At = U + m0;
+    const double* Bt = Ks + (int64_t)nt * Np * TB;
+    const int kend = (mt + 1) * TB;
+    if (!sweep_tile_rev(mt, nP)) {
+        if (VAR == 2) gemm_tile_128_b<true, true>(acc, At, Np, Bt, TB, 0, kend, smem);
+        else if (VAR == 5) gemm_tile_128_g<1, false, true>(acc, At, Np, Bt, TB, 0, kend, smem);
+        else gemm_tile_128_s<1, false, true>(acc, At, Np, Bt, TB, 0, kend, smem);
+    } else {
+        if (VAR == 2) gemm_rev32(0, kend, [&](int k0, int k1) { gemm_tile_128_b<true, true>(acc, At, Np, Bt, TB, k0, k1, smem); });
+        else if (VAR == 5) gemm_tile_128_g<1, false, true, true>(acc, At, Np, Bt, TB, 0, kend, smem);
+        else gemm_tile_128_s<1, false, true, true>(acc, At, Np, Bt, TB, 0, kend, smem);
+    }
     // the k-loop ended on a barrier, LDS is free
     sweep_epilogue<true>(acc, avec, m0, Qp + (int64_t)mt * ldp + n0, Pp + (int64_t)mt * ldp + n0, smem);
   }
@@ -286,19 +304,20 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm(const double* __
 
 // The same tiles through the register-free k-loop (gemm_tile_128_l): WGS workgroups per compute unit.
 // TRI: the all-zero quarter-rows of T's diagonal block are skipped (1.5 of 4 k-steps of every tile).
-template <int BKL, int WGS, int PRIO, int NSET, bool TRI>
+// DOWN = false: every tile upwards (probe builds only: the A/B of the order rule -- NOT bit-identical with the shipped schedules)
+template <int BKL, int WGS, int PRIO, int NSET, bool TRI, int AUX = 0, bool DOWN = true>
 __global__ __launch_bounds__(GEMM_THREADS, WGS) void k_sweep_trmm_l(const double* __restrict__ U, int64_t Np,
                                                                     const double* __restrict__ Ks, int64_t ldk, int NT,
                                                                     const double* __restrict__ avec,
                                                                     double* __restrict__ Qp, double* __restrict__ Pp,
                                                                     int64_t ldp, int order, int sm,
-                                                                    unsigned long long* clk) {
+                                                                    unsigned long long* clk, int b0) {
     __shared__ __attribute__((aligned(16))) double smem[gemm_l_lds_f64<BKL>()];
     const unsigned long long clk_c0 = __builtin_readcyclecounter();
     const unsigned long long clk_r0 = wall_clock64();
     const int nP = (int)(Np / TB);
     int mt, nt, mt2;
-    if (!sweep_tile_of<32 * WGS>(blockIdx.x, order, sm, NT, nP, mt, nt, mt2)) return;
+    if (!sweep_tile_of<32 * WGS>((int)blockIdx.x + b0, order, sm, NT, nP, mt, nt, mt2)) return;
 #pragma unroll 1
     for (int ph = 0; ph < 2; ++ph) {
         if (ph == 1) {
@@ -309,7 +328,13 @@ __global__ __launch_bounds__(GEMM_THREADS, WGS) void k_sweep_trmm_l(const double
         const int64_t m0 = (int64_t)mt * TB, n0 = (int64_t)nt * TB;
         d4 acc[4][4];
         acc_zero(acc);
-        gemm_tile_128_l<BKL, PRIO, NSET, true, TRI>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
+        const double* At = U + m0;
+        const double* Bt = Ks + (int64_t)nt * Np * TB;
+        const int kend = (mt + 1) * TB;
+        const bool rev = DOWN && sweep_tile_rev(mt, nP);
+        if (!rev) gemm_tile_128_l<BKL, PRIO, NSET, true, TRI, false, AUX>(acc, At, Np, Bt, TB, 0, kend, smem);
+        else if constexpr (BKL == 32) gemm_tile_128_l<32, PRIO, NSET, true, TRI, false, AUX, true>(acc, At, Np, Bt, TB, 0, kend, smem);
+        else gemm_rev32(0, kend, [&](int k0, int k1) { gemm_tile_128_l<BKL, PRIO, NSET, true, false, false, AUX>(acc, At, Np, Bt, TB, k0, k1, smem); });
         sweep_epilogue<true>(acc, avec, m0, Qp + (int64_t)mt * ldp + n0, Pp + (int64_t)mt * ldp + n0, smem);
     }
     if (clk && threadIdx.x == 0) {
@@ -341,7 +366,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_sweep_trmm_w(const double* 
         const int64_t m0 = (int64_t)mt * TB, n0 = (int64_t)nt * TB;
         d4 acc[4][4];
         acc_zero(acc);
-        gemm_tile_128_w<1, 1, false, true, 0, true>(acc, U + m0, Np, Ks + (int64_t)nt * Np * TB, TB, 0, (mt + 1) * TB, smem);
+        const double* At = U + m0;
+        const double* Bt = Ks + (int64_t)nt * Np * TB;
+        const int kend = (mt + 1) * TB;
+        if (!sweep_tile_rev(mt, nP)) gemm_tile_128_w<1, 1, false, true, 0, true>(acc, At, Np, Bt, TB, 0, kend, smem);
+        else gemm_rev32(0, kend, [&](int k0, int k1) { gemm_tile_128_w<1, 1, false, true, 0, false>(acc, At, Np, Bt, TB, k0, k1, smem); });
         sweep_epilogue<true>(acc, avec, m0, Qp + (int64_t)mt * ldp + n0, Pp + (int64_t)mt * ldp + n0, smem);
     }
     if (clk && threadIdx.x == 0) {
@@ -360,16 +389,29 @@ void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double*
     // register-staged schedules of rounds 5, 2, 1 -- all kept as independently scheduled witnesses of the bit-identity test)
     const int order = tile_order & 3, var = (tile_order >> 2) & 7;
 #define GPX_SW(K) hipLaunchKernelGGL(K, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp, ldp, order, super_m, clk)
+#define GPX_SWL(K) hipLaunchKernelGGL(K, dim3(nblk), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a, Qp, Pp, ldp, order, super_m, clk, 0)
     if (var == 7) {                // three workgroups per CU, k-step 16
         const unsigned nblk = sweep_grid<96>(order, super_m, NT, nP);
-        GPX_SW((k_sweep_trmm_l<16, 3, 1, 2, false>));
+        GPX_SWL((k_sweep_trmm_l<16, 3, 1, 2, false>));
     } else if (var == 1) {               // barrier-free: every wave keeps its own operands
         const unsigned nblk = sweep_grid<64>(order, super_m, NT, nP);
         GPX_SW(k_sweep_trmm_w);
     } else if (var == 4 || var == 3) {   // two workgroups per CU, k-step 32; 4: with the diagonal block's zero rows skipped
         const unsigned nblk = sweep_grid<64>(order, super_m, NT, nP);
-        if (var == 4) GPX_SW((k_sweep_trmm_l<32, 2, 1, 2, true>));
-        else GPX_SW((k_sweep_trmm_l<32, 2, 1, 2, false>));
+        const int aux = tile_order >> 5;         // (probe builds only: cache policy of the operand loads; gpx_set_option admits 0)
+        if (var == 4 && aux == 1) GPX_SWL((k_sweep_trmm_l<32, 2, 1, 2, true, 1>));
+        else if (var == 4 && aux == 2) GPX_SWL((k_sweep_trmm_l<32, 2, 1, 2, true, 2>));
+        else if (var == 4 && aux == 3) GPX_SWL((k_sweep_trmm_l<32, 2, 1, 2, true, 16>));
+        else if (var == 4 && aux == 4) GPX_SWL((k_sweep_trmm_l<32, 2, 1, 2, true, 17>));
+        else if (var == 4 && aux == 5) GPX_SWL((k_sweep_trmm_l<32, 2, 1, 2, true, 3>));
+        else if (var == 4 && aux == 6) GPX_SWL((k_sweep_trmm_l<32, 2, 1, 2, true, 0, false>));      // every tile upwards (round 6's first form)
+        else if (var == 4 && aux == 7) {        // probe: one launch per generation of 512 workgroups (every generation starts aligned)
+            for (unsigned g0 = 0; g0 < nblk; g0 += 512)
+                hipLaunchKernelGGL((k_sweep_trmm_l<32, 2, 1, 2, true>), dim3(nblk - g0 < 512 ? nblk - g0 : 512), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a,
+                                   Qp, Pp, ldp, order, super_m, clk, (int)g0);
+        }
+        else if (var == 4) GPX_SWL((k_sweep_trmm_l<32, 2, 1, 2, true>));
+        else GPX_SWL((k_sweep_trmm_l<32, 2, 1, 2, false>));
     } else {
         const unsigned nblk = sweep_grid<64>(order, super_m, NT, nP);
         if (var == 2) GPX_SW(k_sweep_trmm<2>);
@@ -377,6 +419,7 @@ void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double*
         else GPX_SW(k_sweep_trmm<5>);
     }
 #undef GPX_SW
+#undef GPX_SWL
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -275,11 +275,12 @@ def test_chunking_and_tile_order_do_not_change_results(opts):
     e1.close()
 
 
-@pytest.mark.parametrize('N', [128, 257, 1000, 1536])
+@pytest.mark.parametrize('N', [128, 257, 1000, 1536, 4096, 4100])
 def test_sweep_schedules_agree_bitwise_over_several_block_rows(N):
     """Every k-loop schedule of the sweep kernel (tile_order bits 2-4: LDS-DMA with and without the diagonal-block skip, three
     workgroups per CU, the register-staged schedules of earlier rounds) gives the same bits, also when tiles have several
-    block rows of K before their triangular block, and the values are the oracle's."""
+    block rows of K before their triangular block, and the values are the oracle's.  From 32 block rows on (N = 4096, 4100) the
+    tiles of the lower half accumulate their 32-row k-steps downwards (kernels_sweep.hip: sweep_tile_rev) -- in every schedule."""
     e0, ref, (X, y, ell, rho, sn2, bias) = _pair(N, 4, 'se', seed=N)
     Z = np.random.RandomState(N + 1).rand(1500, 4)
     r0 = e0.sweep('ucb', 2.0, Z, k=10, want_moments=True)
