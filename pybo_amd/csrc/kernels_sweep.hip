@@ -202,7 +202,7 @@ static unsigned sweep_grid(int order, int super_m, int NT, int nP) {
 // the factor has at least 32 block rows.  In the paired map every workgroup of a super-tile then reads the same rows of its Ks
 // panel at the same time in BOTH phases (row t in the first, row (nP + 1) 128 - t in the second, whatever its pair index), which
 // lets an XCD's L2 serve the panel once: L2 -> fabric reads 101 -> 88 GB per launch at N = 8192 and, the kernel being power-bound,
-// 0.8 % more clock on the boxes that sustain 2300 MHz (nothing on those at 2385) -- profiles/r06_sweep_down_probe.txt.  Below 32
+// 0.8 % more clock on the boxes that sustain 2300 MHz (nothing on those at 2385) -- profiles/r06_sweep_power_probes.txt.  Below 32
 // block rows the second tiles are short and it costs 0.3 %.
 __device__ __forceinline__ bool sweep_tile_rev(int mt, int nP) { return nP >= 32 && 2 * mt < nP - 1; }
 

@@ -24,6 +24,7 @@ done
 timeout 1200 python bench.py --ensemble 10 --steps 2 --warmup 1 < /dev/null > $O/bench_ns_ens10.json 2> $O/bench_ns_ens10.err
 # the per-rank share of an 8-GPU run on one GPU (2^17 candidates): what the replicated fit costs there
 timeout 600 python bench.py --candidates 131072 --steps 5 --warmup 1 --no-cpu-baseline --plugin-steps 0 --no-refine --warm-steps 0 < /dev/null > $O/bench_ns_share8.json 2> $O/bench_ns_share8.err
+mkdir -p $R/profiles; for wl in ns b c d e; do [ -s $O/bench_$wl.json ] && cp $O/bench_$wl.json $R/profiles/r06_bench_$wl.json; done      # (what the N > 1 lines' scaling_model reads)
 # N > 1 code paths, dry runs on the one GPU (gloo transport, every rank on device 0; the RCCL launch must fail fast and loudly)
 timeout 600 python bench.py --gpus 2 --backend gloo --share-device 0 --steps 3 --warmup 1 --no-refine --plugin-steps 0 --cpu-candidates 8192 < /dev/null > $O/bench_ns_2ranks_gloo_shared_gpu.json 2> $O/bench_ns_2ranks.err
 timeout 600 python bench.py --gpus 2 --backend gloo --share-device 0 --workload d --steps 2 --warmup 1 --cpu-candidates 8192 < /dev/null > $O/bench_d_2ranks_gloo_shared_gpu.json 2> $O/bench_d_2ranks.err
