@@ -914,7 +914,9 @@ def main():
             if w['acq'] == 'thompson':
                 # one (value, index) pair per draw, draws sharded over ranks: ONE all-gather, no merge
                 # (the q recommendations are w['Xc'][indices])
-                res = comm.topk_allgather(len(tv), 0, 0) if comm is not None else pdist.gather_pairs(tv, ti)
+                # (the device-side all-gather moves the same number of pairs from every rank: uneven draw counts go through torch)
+                even = (S % world == 0)
+                res = comm.topk_allgather(len(tv), 0, 0) if (comm is not None and even) else pdist.gather_pairs(tv, ti)
             elif comm is not None:                   # libgpx's own RCCL binding: device -> xGMI -> device merge
                 res = comm.topk_allgather(k, lo_i, k)
             else:

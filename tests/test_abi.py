@@ -130,3 +130,27 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
                            '-L', libdir, '-lgpx', '-Wl,-rpath,' + libdir, '-Wl,-rpath,/opt/rocm/lib'])
     out = subprocess.check_output([str(exe)]).decode().split()
     assert int(out[0]) >= 100 and out[1] == '1'
+
+
+def test_every_reference_citation_of_the_headers_points_at_an_existing_line():
+    """include/gpx.h and the host modules cite the pybo call site each entry point replaces as `pybo/<file>.py:<line>[-<line>]`.
+    Where the reference is present (the build container) every cited file exists and every cited line is inside it."""
+    ref = '/root/reference'
+    if not os.path.isdir(os.path.join(ref, 'pybo')):
+        pytest.skip('the reference is not on this host (GPU box)')
+    cited = set()
+    files = [os.path.join(ROOT, 'include', 'gpx.h'), os.path.join(ROOT, 'DESIGN.md'), os.path.join(ROOT, 'INTEGRATION.md')]
+    for dp, _, fs in os.walk(os.path.join(ROOT, 'pybo_amd')):
+        files += [os.path.join(dp, f) for f in fs if f.endswith(('.py', '.hip', '.h'))]
+    for path in files:
+        txt = open(path, encoding='utf-8', errors='replace').read()
+        for m in re.finditer(r'pybo/([a-z_/]+\.py):(\d+)(?:-(\d+))?((?:,\d+(?:-\d+)?)*)', txt):
+            nums = [int(m.group(2))] + ([int(m.group(3))] if m.group(3) else [])
+            nums += [int(v) for v in re.findall(r'\d+', m.group(4) or '')]
+            cited.add((m.group(1), max(nums)))
+    assert len(cited) >= 20
+    for rel, last in sorted(cited):
+        path = os.path.join(ref, 'pybo', rel)
+        assert os.path.exists(path), rel
+        n = len(open(path, encoding='utf-8', errors='replace').read().splitlines())
+        assert last <= n, '%s has %d lines, cited line %d' % (rel, n, last)
