@@ -33,7 +33,8 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6     # MI355X datasheet fp64 matrix (= fp64 vector) peak, dense
 HBM_PEAK_GBS = 8000.0
-SWEEP_KERNEL = 'k_sweep_trmm_l<32, 2, 1, 2, true>'      # the default schedule (tile_order 19) as rocprofv3 names it
+SWEEP_KERNEL = 'k_sweep_trmm_l<32, 2, 1, 2, true>'      # the default schedule from 32 block rows on (tile_order 19) as rocprofv3 names it
+SWEEP_KERNEL_SHORT = 'k_sweep_trmm_w'                    # ... and below (tile_order 7: config B)
 PMC_TRAFFIC_FILES = ('r06_pmc_traffic.json', 'r06_pmc_traffic_b.json')      # (N = 8192 and config B's N = 2048 launch geometries)
 
 
@@ -1142,7 +1143,7 @@ def main():
                 except Exception:
                     continue
             ach = tm['sweep_trmm_flop'] / (tm['sweep_trmm'] * 1e-3) / 1e12
-            out['roofline'] = {'kernel': SWEEP_KERNEL, 'bound': 'mfma', 'achieved': ach,
+            out['roofline'] = {'kernel': SWEEP_KERNEL if Np_ >= 4096 else SWEEP_KERNEL_SHORT, 'bound': 'mfma', 'achieved': ach,
                                'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': ach / FP64_MFMA_PEAK_TFLOPS, 'traffic': traffic,
                                'traffic_measured': False,      # a profile-time constant (see traffic_source), never collected in this run

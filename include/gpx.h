@@ -73,7 +73,7 @@ int gpx_version(void);
  *                    bits 2-4 k-loop (4 = operands by LDS-DMA, k-step 32, two workgroups per CU, the all-zero quarter-rows of T's
  *                    diagonal block skipped; 3 = the same without the skip; 1 = barrier-free, every wave fetching its own operand
  *                    halves; 7 = k-step 16, three workgroups per CU; 6 / 5 / 2 = the
- *                    register-staged loops of rounds 5 / 2 / 1: independently scheduled witnesses) [19 = map 3 + loop 4]
+ *                    register-staged loops of rounds 5 / 2 / 1: independently scheduled witnesses) [-1 = by size: 7 below 32 block rows, else 19]
  *   "super_m"        rows of the XCD super-tile of 64 workgroups: 1, 2, 4, 8, 16 [8 -> 8 x 8]
  *   "sweep_cache"    1: full sweeps keep candidates and reduced sums for gpx_sweep_update; 0: leave a live cache alone; -1: drop it [0]
  *   "eager_inverse"  1: form the triangular inverse inside gpx_fit instead of on first use [0]

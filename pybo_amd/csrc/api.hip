@@ -119,7 +119,7 @@ static void harvest(gpx_handle* h) {
 }
 
 // ---- lifetime ---------------------------------------------------------------------------------
-extern "C" int gpx_version(void) { return 600; }   // round * 100: 300 added gpx_predict_mean, gpx_var_at_obs, gpx_capacity, gpx_append_begin; 400 gpx_chol_trace, gpx_chol_tasks, GPX_OPTIONS; 500: timers slot 16; 510: timers slots 17, 18, options trtri_ahead*, chol_tg_fuse; 600: gpx_diagnostics, gpx_chol_tasks -> gpx_chol_tasks2 (pybo_amd/csrc/gpx_diag.h), the diagnostic options only in a -DGPX_DIAGNOSTICS build, tile_order default 19
+extern "C" int gpx_version(void) { return 600; }   // round * 100: 300 added gpx_predict_mean, gpx_var_at_obs, gpx_capacity, gpx_append_begin; 400 gpx_chol_trace, gpx_chol_tasks, GPX_OPTIONS; 500: timers slot 16; 510: timers slots 17, 18, options trtri_ahead*, chol_tg_fuse; 600: gpx_diagnostics, gpx_chol_tasks -> gpx_chol_tasks2 (pybo_amd/csrc/gpx_diag.h), the diagnostic options only in a -DGPX_DIAGNOSTICS build, tile_order default by size (7 below 32 block rows, 19 from there on)
 extern "C" int gpx_diagnostics(void) {
 #ifdef GPX_DIAGNOSTICS
     return 1;
@@ -288,8 +288,8 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
             return GPX_OK;
         }
         if (!strcmp(name, "tile_order")) {
-            if (value < 4 || value > 31)
-                return fail(h, GPX_EARG, "tile_order: bits 0-1 tile map (0..3), bits 2-4 k-loop schedule (1 .. 7)");
+            if (value != -1 && (value < 4 || value > 31))
+                return fail(h, GPX_EARG, "tile_order: -1 (by size) or bits 0-1 tile map (0..3), bits 2-4 k-loop schedule (1 .. 7)");
             h->tile_order = (int)value;
             return GPX_OK;
         }
@@ -1004,7 +1004,9 @@ static int sweep_core(gpx_handle* h, int acq_id, const double* params, int npara
         {
             Span sp(h, T_TRMM);
             launch_sweep_trmm(s, h->dU, Np, h->dKs, chunk, cols, h->da, h->dQp, h->dPp, chunk,
-                              h->tile_order, h->super_m, h->dclk);
+                              // by size: short tiles (fewer than 32 block rows) on the barrier-free loop, long ones on the shared-image loop
+                              // (crossover measured: profiles/r06_sweep_power_probes.txt, section 6)
+                              h->tile_order >= 0 ? h->tile_order : (Np / NB < 32 ? 7 : 19), h->super_m, h->dclk);
         }
         h->tacc[T_NLAUNCH] += 1.0;
         // ALGORITHMIC work of this launch: N^2 flop per candidate (N^2/2 multiply-adds of the

@@ -119,7 +119,7 @@ struct gpx_handle {
     // sweep workspace
     int64_t chunk = 0;        // option: candidate columns per chunk (multiple of 128); 0 = by size: 65536, 131072 up to N = 4096 (half the launches: config B 68.4 -> 68.0 ms)
     int super_m = 8;          // rows (mt) of an XCD super-tile of 64 workgroups: 8 -> 8x8, 4 -> 4x16, 2 -> 2x32
-    int tile_order = 19;      // bits 0-1 tile map (3 = XCD 8x8 super-tiles of PAIRED tiles), bits 2-4 k-loop schedule (launch_sweep_trmm: 4 = LDS-DMA, k-step 32, diagonal-block skip)
+    int tile_order = -1;      // -1: by size (7 below 32 block rows, 19 from there on); else bits 0-1 tile map (3 = XCD 8x8 super-tiles of PAIRED tiles), bits 2-4 k-loop schedule (launch_sweep_trmm)
     int64_t cap_ks = 0;       // elements of dKs
     double* dKs = nullptr;    // cross-Gram chunk, tile-blocked [chunk/128][Np][128]
     double* dQp = nullptr;    // (Np/128, chunk) per-row-block partials of colsum(V^2)
