@@ -398,6 +398,7 @@ void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double*
         GPX_SW(k_sweep_trmm_w);
     } else if (var == 4 || var == 3) {   // two workgroups per CU, k-step 32; 4: with the diagonal block's zero rows skipped
         const unsigned nblk = sweep_grid<64>(order, super_m, NT, nP);
+#ifdef GPX_SWEEP_PROBES          // scripts/probe/sweep_ab.hip only: variants that are NOT schedules of the library (profiles/r06_sweep_power_probes.txt)
         const int aux = tile_order >> 5;         // (probe builds only: cache policy of the operand loads; gpx_set_option admits 0)
         if (var == 4 && aux == 1) GPX_SWL((k_sweep_trmm_l<32, 2, 1, 2, true, 1>));
         else if (var == 4 && aux == 2) GPX_SWL((k_sweep_trmm_l<32, 2, 1, 2, true, 2>));
@@ -410,7 +411,9 @@ void launch_sweep_trmm(hipStream_t s, const double* U, int64_t Np, const double*
                 hipLaunchKernelGGL((k_sweep_trmm_l<32, 2, 1, 2, true>), dim3(nblk - g0 < 512 ? nblk - g0 : 512), dim3(GEMM_THREADS), 0, s, U, Np, Ks, ldk, NT, a,
                                    Qp, Pp, ldp, order, super_m, clk, (int)g0);
         }
-        else if (var == 4) GPX_SWL((k_sweep_trmm_l<32, 2, 1, 2, true>));
+        else
+#endif
+        if (var == 4) GPX_SWL((k_sweep_trmm_l<32, 2, 1, 2, true>));
         else GPX_SWL((k_sweep_trmm_l<32, 2, 1, 2, false>));
     } else {
         const unsigned nblk = sweep_grid<64>(order, super_m, NT, nP);

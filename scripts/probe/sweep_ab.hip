@@ -1,6 +1,10 @@
 // sweep_ab.hip -- stand-alone A/B of the library's sweep kernel schedules (launch_sweep_trmm, kernels_sweep.hip is compiled
 // INTO this binary: what is timed is the library's code).  Synthetic operands; every variant must give the same checksum.
-// Usage: sweep_ab.bin N cols reps tile_order[:super_m] [tile_order[:super_m] ...]
+// Usage: sweep_ab.bin N cols reps tile_order[:super_m] [tile_order[:super_m] ...]        (build: scripts/probe/build.sh, -DGPX_SWEEP_PROBES)
+//   tile_order < 32: the library's schedules (include/gpx.h).  Probe-only codes: 19 + 32 c -- c = 1 .. 5 cache policy of the DMA loads
+//   (sc0, nt, sc1, sc0 sc1, sc0 nt), 6 every tile upwards, 7 one launch per generation of 512 workgroups; 1000 / 1001 / 1002: ONE
+//   workgroup per CU on gemm_tile_128_d / _ld / _w<2> (the factorisation's worker loops); 2000 / 2001: the wave-private loop with /
+//   without the diagonal-block skip, every tile upwards.  bash scripts/probe/pmc_fetch.sh adds the L2 -> fabric read bytes.
 #include "../../pybo_amd/csrc/kernels_sweep.hip"
 #include <stdio.h>
 #include <stdlib.h>
