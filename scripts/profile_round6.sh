@@ -15,6 +15,20 @@ mkdir -p $O
 cd $R
 QUICK=${1:-}
 CPU=""; [ "$QUICK" = "quick" ] && CPU="--cpu-candidates 8192"
+# FIRST, because the bench lines quote it (roofline.traffic is a profile-time constant):
+# PMC: L2 -> fabric traffic of the sweep kernel (separate passes, --kernel-trace only): N = 8192 and config B's geometry
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 420 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o p -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --warm-steps 0 --plugin-steps 0 --no-refine --candidates 131072 < /dev/null > $O/pmc_$c.log 2>&1
+  timeout 420 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmcb_$c -o p -- python $R/bench.py --workload b --steps 1 --warmup 0 --no-cpu-baseline --warm-steps 0 --plugin-steps 0 --no-refine --candidates 131072 < /dev/null > $O/pmcb_$c.log 2>&1
+done
+f1=$(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); f2=$(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+if [ -n "$f1" ] && [ -n "$f2" ]; then python $R/scripts/pmc_traffic.py $f1 $f2 8192 65536 > $O/pmc_traffic.json; grep "k_sweep_trmm\|k_cross_gram" $f1 > $O/pmc_fetch_size.csv; grep "k_sweep_trmm\|k_cross_gram" $f2 > $O/pmc_write_size.csv; fi
+f1=$(find $O/pmcb_FETCH_SIZE -name "*counter_collection.csv" | head -1); f2=$(find $O/pmcb_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+if [ -n "$f1" ] && [ -n "$f2" ]; then python $R/scripts/pmc_traffic.py $f1 $f2 2048 131072 > $O/pmc_traffic_b.json; fi
+rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmcb_FETCH_SIZE $O/pmcb_WRITE_SIZE
+mkdir -p $R/profiles; for f in pmc_traffic.json pmc_traffic_b.json; do [ -s $O/$f ] && cp $O/$f $R/profiles/r06_$f; done      # roofline.traffic of the bench lines below reads these
+cd $R
 timeout 1200 python bench.py --steps 5 --warmup 1 $CPU < /dev/null > $O/bench_ns.json 2> $O/bench_ns.err
 timeout 900 python bench.py --workload b --steps 5 --warmup 1 $CPU < /dev/null > $O/bench_b.json 2> $O/bench_b.err
 timeout 900 python bench.py --workload c --steps 3 --warmup 1 $CPU < /dev/null > $O/bench_c.json 2> $O/bench_c.err
@@ -34,18 +48,8 @@ TOPN=24 timeout 420 bash scripts/trace.sh ns --steps 2 --warmup 1 --warm-steps 2
 TOPN=24 timeout 420 bash scripts/trace.sh b --workload b --steps 2 --warmup 1 --warm-steps 0 --plugin-steps 0 < /dev/null > $O/trace_b.txt 2>&1
 TOPN=24 timeout 420 bash scripts/trace.sh d --workload d --steps 2 --warmup 1 < /dev/null > $O/trace_d.txt 2>&1
 TOPN=24 timeout 420 bash scripts/trace.sh e --workload e --steps 2 --warmup 1 < /dev/null > $O/trace_e.txt 2>&1
-# PMC: L2 -> fabric traffic of the sweep kernel (separate passes, --kernel-trace only): N = 8192 and config B's geometry
-cd /tmp && export TMPDIR=/tmp
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 420 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -o p -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --warm-steps 0 --plugin-steps 0 --no-refine --candidates 131072 < /dev/null > $O/pmc_$c.log 2>&1
-  timeout 420 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmcb_$c -o p -- python $R/bench.py --workload b --steps 1 --warmup 0 --no-cpu-baseline --warm-steps 0 --plugin-steps 0 --no-refine --candidates 131072 < /dev/null > $O/pmcb_$c.log 2>&1
-done
-f1=$(find $O/pmc_FETCH_SIZE -name "*counter_collection.csv" | head -1); f2=$(find $O/pmc_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-if [ -n "$f1" ] && [ -n "$f2" ]; then python $R/scripts/pmc_traffic.py $f1 $f2 8192 65536 > $O/pmc_traffic.json; grep "k_sweep_trmm\|k_cross_gram" $f1 > $O/pmc_fetch_size.csv; grep "k_sweep_trmm\|k_cross_gram" $f2 > $O/pmc_write_size.csv; fi
-f1=$(find $O/pmcb_FETCH_SIZE -name "*counter_collection.csv" | head -1); f2=$(find $O/pmcb_WRITE_SIZE -name "*counter_collection.csv" | head -1)
-if [ -n "$f1" ] && [ -n "$f2" ]; then python $R/scripts/pmc_traffic.py $f1 $f2 2048 131072 > $O/pmc_traffic_b.json; fi
-rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmcb_FETCH_SIZE $O/pmcb_WRITE_SIZE
 # PMC: MFMA busy of the sweep kernel: round 5's schedule (tile_order 27) and round 6's (19)
+cd /tmp && export TMPDIR=/tmp
 mkdir -p $O/pmc_sq
 for v in 27 19; do
   timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq/v$v -o p -- python $R/scripts/pmc_sweep.py $v < /dev/null > $O/pmc_sq/v$v.log 2>&1
