@@ -121,7 +121,7 @@ void launch_cross_gram(hipStream_t s, const double* Xs, int64_t Np, int64_t N, i
     // row tiles per workgroup: the SE kernel at small d is bound by its 8 B/evaluation of stores (one tile per
     // workgroup interleaves them best: 3.5 vs 4.3 ms per 2^31 evaluations), the others by their VALU work (the
     // candidates staged once per 8 tiles: Matern-5/2 4.35 vs 4.85 ms); non-temporal stores change nothing
-    const int XRTa = (kernel_id == GPX_KERN_SE_ARD && d <= XDC) ? 1 : XRT;
+    const int XRTa = (kernel_id == GPX_KERN_SE_ARD && d <= XDC) ? 1 : XRT;       // (re-measured in round 6: SE 14.3 / 15.5 / 17.5 ms per 2^20 candidates with 1 / 2 / 4 tiles)
     const int XRTv = XRTa;
     dim3 grid((unsigned)((tiles + XRTa - 1) / XRTa), (unsigned)(cols / XN));   // x: row groups of one candidate tile = one contiguous run of Ks
 #define GPX_CG(KID) \
