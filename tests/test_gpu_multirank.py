@@ -398,6 +398,47 @@ def test_libgpx_binds_the_librccl_torch_has_loaded_one_instance_per_process():
     assert got[3] and got[4] == 1.0
 
 
+def _exchange_fallback_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import argparse
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import bench
+        from pybo_amd._lib import Engine
+        e = Engine(0)
+        args = argparse.Namespace(exchange='auto', share_device=-1, backend='gloo')      # as if every rank had a GPU of its own
+        got = bench.bring_up_gpx_exchange(args, e, rank, world, dist, torch.device('cuda', 0))
+        q.put((rank, got if isinstance(got, str) else 'gpx'))
+        e.close()
+    except BaseException as exc:      # noqa: reported to the parent
+        q.put((rank, 'error: %r' % (exc,)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_device_side_exchange_falls_through_together_when_rccl_refuses_the_communicator():
+    """bench.py's default transport is libgpx's own RCCL communicator.  Here two ranks (gloo process group) sit on ONE GPU without
+    saying so: the binding loads on both, ncclCommInitRank refuses the duplicate device on both, and BOTH ranks come back with the
+    torch transport and the reason -- nobody hangs in a rendezvous, nobody is left alone on the other transport."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_fallback_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+    assert set(got) == {0, 1}
+    for r in (0, 1):
+        assert got[r].startswith('torch (fallback: gpx_comm_init failed'), got
+
+
 # ---- the whole loop SPMD: rank 0 evaluates the objective, everyone absorbs the same observation --------------------
 def _spmd_loop_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
