@@ -9,7 +9,7 @@
  *   "chol_tg_chunks"  k-chunk sizes of the task-graph factorisation counted back from the pivot as decimal digits (9 = 16 blocks)
  *                     [0 = by size: 112489 = 1, 1, 2, 4, 8, 16, 16, ..; up to 36 blocks 11112489]
  *   "chol_tg_nap"     longest pause of a waiting workgroup between two looks at its dependencies, x 64 clocks: 8, 16, 32, 64, 127 [16]
- *   "chol_tg_grid"    workgroups launched [0 = by size];  "chol_tg_isolate" 1: the critical workgroups keep their CUs to themselves [1]
+ *   "chol_tg_grid"    workgroups launched [0 = by size];  "chol_tg_isolate" 1: the critical workgroups keep their CUs to themselves [-1: up to 112 blocks]
  *   "chol_tg_trace"   1: stamp the critical path (gpx_chol_trace); 2: also a per-workgroup task log
  *   "grad_rb_cs"      columns per segment of the register-blocked triangular matvec, a multiple of 128 [0 = default]
  *   "x_rff"           1: the round-3 Thompson sweep kernel instead of the default (process-wide; A/B and witness of the tests)

@@ -63,7 +63,7 @@ struct gpx_handle {
     int tg_fuse = 1;            // a column's solve and the final chunk of the tile below it as one task (needs the shadows and one workgroup per CU)
     int tg_db_max = 112;          // (N = 12288: 13.04 against 13.38 ms; N = 16384: 27.6 against 27.2: two workgroups per CU win there)
     int tg_grid = 0;              // workgroups launched (0 = by size, bounded by residency)
-    int tg_isolate = 1;           // the critical workgroups keep their compute units to themselves (full grids only)
+    int tg_isolate = -1;          // the critical workgroups keep their compute units to themselves (full grids only): -1 by size (up to 112 blocks), 0 / 1
     int tg_trace = 0;             // diagnostic: stamp the critical path with the kernel's own clock (gpx_chol_trace)
     int tg_tmo_ms = 0;            // bound of every spin in milliseconds (0 = default 2000)
     bool tg_launched = false;     // the last factorisation ran on the task-graph kernel

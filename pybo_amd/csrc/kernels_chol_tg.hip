@@ -1420,7 +1420,11 @@ bool launch_cholesky_tg(gpx_handle* h) {
     a.S = h->dS; a.R = h->dR; a.T = h->dT; a.U = h->dU;
     a.Np = Np; a.nP = nP; a.dflag = h->dflag; a.ctl = c->dctl;
     for (int q = 0; q < 2; ++q) { a.q[q] = c->dq + c->off[q]; a.n[q] = c->n[q]; }
-    a.isolate = (h->tg_isolate != 0 && grid_is_full) ? 1 : 0;
+    // -1 = by size: where two workgroups per CU are the default (more than 112 blocks) the diagonal waits for its inputs anyway
+    // (150 us per block at N = 16384) and ten more CUs of workers are worth more than a faster critical path: 24.8 -> 24.45 ms at
+    // N = 16384, 46.0 -> 45.3 at 20480; below (chol_tg_db = 0 forced) the critical workgroups keep their CUs
+    const bool iso = h->tg_isolate < 0 ? nP <= 112 : h->tg_isolate != 0;
+    a.isolate = (iso && grid_is_full) ? 1 : 0;
     a.nap = h->tg_nap > 0 ? h->tg_nap : 16;
     a.trace = h->tg_trace ? c->dtrace : nullptr;
     a.tasklog = nlog ? c->dtrace + 20 * (int64_t)nP + 8 * 1024 + 16 : nullptr;
